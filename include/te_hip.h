@@ -1,0 +1,167 @@
+/* te_hip.h — C ABI of the MI355X-native GMG V-cycle path (libte_hip.so).
+ *
+ * Drop-in boundary for GEM3D/pressurePoissonSolver's src/Thunderegg GMG hot path. Every entry
+ * point names the reference interface it stands behind (paths relative to the reference
+ * root). Plain pointers, sizes and opaque handles only; no C++ or torch types. All functions
+ * return TE_OK (0) or a negative TE_E* code; te_last_error() gives the message. The C++
+ * adaptors in pressurepoissonsolver_amd/thunderegg/ turn a non-zero status into the
+ * reference's own error convention (`throw 3;`, e.g. GMG/InterLevelComm.h:175).
+ *
+ * Vector layout on the host side of upload/download is the reference's: patch-major, x-fastest,
+ * interior cells only, patch p at offset p*n^dim (src/Thunderegg/PetscVector.h:70-98), with
+ * patches in THIS library's local order (te_hier_level_ids gives the tree node id of each).
+ */
+#ifndef TE_HIP_H
+#define TE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TE_OK 0
+#define TE_EINVAL -1   /* bad argument / shape mismatch */
+#define TE_EHIP -2     /* HIP runtime error (no device, launch failure, OOM) */
+#define TE_ESTATE -3   /* call not valid in the object's current state */
+#define TE_EIO -4      /* mesh file unreadable */
+#define TE_EUNSUPPORTED -5
+
+typedef struct te_mesh te_mesh; /* octree / quadtree              (OctTree.h:34 Tree<D>) */
+typedef struct te_hier te_hier; /* host level tables, one rank    (ThundereggDomGen.h:95-222 + Domain.h) */
+typedef struct te_gmg  te_gmg;  /* device-resident level stack    (GMG/CycleFactory3d.cpp:69-134 product) */
+typedef struct te_vec  te_vec;  /* device vector on one level     (Vector.h:179 Vector<D>, PetscVector.h:59) */
+
+const char *te_last_error(void);
+const char *te_version(void);
+
+/* ---------------------------------------------------------------- mesh (host only, no GPU) */
+/* Tree<D>::Tree(std::string) OctTree.h:90-118 */
+int te_mesh_read(const char *path, int dim, te_mesh **out);
+/* one root node on the unit box (what a 1-node mesh file such as apps/3d/meshes/1uni.bin holds) */
+int te_mesh_unit_root(int dim, te_mesh **out);
+/* Tree<D>::refineLeaves OctTree.h:119-179 (== one unit of the drivers' --divide) */
+int te_mesh_refine_leaves(te_mesh *m);
+int te_mesh_num_nodes(const te_mesh *m);
+int te_mesh_num_levels(const te_mesh *m);
+int te_mesh_dim(const te_mesh *m);
+/* node table in ascending id order; any pointer may be NULL.
+ * ilp[N][3] = id, level, parent; lengths/starts [N][dim]; nbr [N][2*dim]; child [N][2^dim] */
+int  te_mesh_get_nodes(const te_mesh *m, int32_t *ilp, double *lengths, double *starts,
+                       int32_t *nbr, int32_t *child);
+void te_mesh_destroy(te_mesh *m);
+
+/* ----------------------------------------------------- level hierarchy (host only, no GPU) */
+/* ThundereggDomGen<D>(t, ns, neumann) + the level loop of CycleFactory3d::getCycle
+ * (CycleFactory3d.cpp:98-127; max_levels / patches_per_proc from GMG/CycleOpts.h:55-63).
+ * The Zoltan partition is replaced by contiguous Morton ranges over `nranks`. */
+int te_hier_build(const te_mesh *m, int n, int neumann, int max_levels, double patches_per_proc,
+                  int rank, int nranks, te_hier **out);
+int te_hier_num_levels(const te_hier *h);
+int te_hier_dim(const te_hier *h);
+int te_hier_n(const te_hier *h);
+/* level 0 = finest. P_local = this rank's patches, P_global = all ranks'. */
+int te_hier_level_sizes(const te_hier *h, int level, int *P_local, int *P_global);
+/* Global tables of one level (Morton order); any pointer may be NULL.
+ * id[P] rank[P] local[P] starts[P][dim] lengths[P][dim] nbr_kind[P][2dim] (0 none, 1 normal,
+ * 2 coarse, 3 fine) nbr[P][2dim][4] nbr_orth[P][2dim] parent[P] orth_on_parent[P] */
+int te_hier_level_tables(const te_hier *h, int level, int32_t *id, int32_t *rank, int32_t *local,
+                         double *starts, double *lengths, int32_t *nbr_kind, int32_t *nbr,
+                         int32_t *nbr_orth, int32_t *parent, int32_t *orth_on_parent);
+/* local -> global patch index of this rank's patches */
+int  te_hier_level_l2g(const te_hier *h, int level, int32_t *l2g);
+void te_hier_destroy(te_hier *h);
+
+/* ------------------------------------------------------------------------ device objects */
+typedef struct {
+	int32_t pre_sweeps, post_sweeps, coarse_sweeps, mid_sweeps; /* GMG/CycleOpts.h:64-79 */
+	int32_t cycle_type; /* 0 "V" (VCycle.h), 1 "W" (WCycle.h) */
+	int32_t smoother;   /* TE_SMOOTH_* */
+	double  omega;      /* Jacobi weight */
+	int32_t exact_coarse; /* pointwise smoothers: exact patch solve on a 1-patch coarsest level */
+	int32_t fuse;         /* 1: use fused residual+restrict / zero-guess kernels inside te_vcycle */
+} te_cycle_opts;
+
+#define TE_SMOOTH_PATCH_SOLVE 0 /* reference: FFTBlockJacobiSmoother.h:55-58 (block Jacobi, exact patch solves) */
+#define TE_SMOOTH_JACOBI 1      /* weighted point Jacobi */
+#define TE_SMOOTH_RBGS 2        /* patch-local red-black Gauss-Seidel, neighbour ghosts frozen */
+
+void te_cycle_opts_default(te_cycle_opts *o);
+
+/* Creates the HIP stream, uploads every level's tables, allocates all scratch. Fails with
+ * TE_EHIP when no gfx950 device is usable — there is no CPU fallback.
+ * device < 0 selects the current device. */
+int  te_gmg_create(const te_hier *h, int device, te_gmg **out);
+void te_gmg_destroy(te_gmg *g);
+int  te_gmg_num_levels(const te_gmg *g);
+int  te_gmg_sync(te_gmg *g);            /* hipStreamSynchronize on the solver stream */
+void *te_gmg_stream(te_gmg *g);         /* hipStream_t, for event timing by the caller */
+
+/* VectorGenerator<D>::getNewVector (Vector.h:323-327; DomainVG Domain.h:415-429): zero-filled */
+int    te_vec_create(te_gmg *g, int level, te_vec **out);
+void   te_vec_destroy(te_vec *v);
+size_t te_vec_size(const te_vec *v);                 /* doubles (local patches * n^dim) */
+int    te_vec_upload(te_vec *v, const double *host); /* Vector<D>::getLocalData write path */
+int    te_vec_download(const te_vec *v, double *host);
+void  *te_vec_device_ptr(te_vec *v);
+
+/* Vector<D> BLAS-1 virtuals, Vector.h:190-321 (same names, same argument order) */
+int te_vec_set(te_vec *v, double alpha);
+int te_vec_scale(te_vec *v, double alpha);
+int te_vec_shift(te_vec *v, double delta);
+int te_vec_copy(te_vec *v, const te_vec *b);
+int te_vec_add(te_vec *v, const te_vec *b);
+int te_vec_add_scaled(te_vec *v, double alpha, const te_vec *b);
+int te_vec_add_scaled2(te_vec *v, double alpha, const te_vec *a, double beta, const te_vec *b);
+int te_vec_scale_then_add(te_vec *v, double alpha, const te_vec *b);
+int te_vec_scale_then_add_scaled(te_vec *v, double alpha, double beta, const te_vec *b);
+int te_vec_scale_then_add_scaled2(te_vec *v, double alpha, double beta, const te_vec *b,
+                                  double gamma, const te_vec *c);
+/* local (this rank's) partial results; the caller all-reduces (Vector.h:294,306,319) */
+int te_vec_two_norm_sq(const te_vec *v, double *out);
+int te_vec_inf_norm(const te_vec *v, double *out);
+int te_vec_dot(const te_vec *v, const te_vec *b, double *out);
+
+/* Operator<D>::apply (Operators/Operator.h:37) as SchurDomainOp / DomainWrapOp implement it:
+ * f = A u through SchurHelper::apply (SchurHelper.h:360-376) */
+int te_apply(te_gmg *g, int level, const te_vec *u, te_vec *f);
+/* r = f - A u  (Cycle.h:60-61 fused: apply + scaleThenAdd(-1, f)) */
+int te_residual(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *r);
+/* GMG::Smoother<D>::smooth(f, u) (GMG/Smoother.h:39), `sweeps` times */
+int te_smooth(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega,
+              int sweeps);
+/* GMG::Restrictor<D>::restrict(coarse, fine) (GMG/Restrictor.h:39) == AvgRstr.h:78-113.
+ * `fine_level` is the level of `fine`; coarse lives on fine_level+1. */
+int te_restrict(te_gmg *g, int fine_level, const te_vec *fine, te_vec *coarse);
+/* GMG::Interpolator<D>::interpolate(coarse, fine) (GMG/Interpolator.h:39) == DrctIntp.h:80-113 */
+int te_prolong_add(te_gmg *g, int fine_level, const te_vec *coarse, te_vec *fine);
+/* GMG::Cycle<D>::apply(f, u) (GMG/Cycle.h:116-126) on level 0 */
+int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u);
+/* BiCGStab<D>::solve(vg, A, x, b, Mr, max_it, tol) (BiCGStab.h:45-106). Mr = te_vcycle when
+ * `o` is non-NULL. Single-rank only (multi-rank callers drive te_vec_* themselves). */
+int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, int max_it,
+                double tol, int *iterations, double *rel_resid);
+
+/* ------------------------------------------------------------ multi-rank ghost exchange */
+/* The library never talks to the network itself. When a level has off-rank neighbours, it
+ * packs the needed face layers into one send buffer, calls `exchange`, and reads the receive
+ * buffer. `exchange` must move, for every peer r: send[send_off[r] .. +send_cnt[r]) to rank r
+ * and fill recv[recv_off[r] .. +recv_cnt[r]) from rank r (counts in doubles, device
+ * pointers), ordered on `stream` (hipStream_t). This replaces the PETSc VecScatter of
+ * SchurHelper.h:123-150 and GMG/InterLevelComm.h:169-189; the Python host binds it to
+ * torch.distributed (RCCL) batch_isend_irecv. */
+typedef int (*te_exchange_fn)(void *user, int tag, const double *send, double *recv, int npeers,
+                              const int32_t *peers, const int64_t *send_off,
+                              const int64_t *send_cnt, const int64_t *recv_off,
+                              const int64_t *recv_cnt, void *stream);
+int te_gmg_set_exchange(te_gmg *g, te_exchange_fn fn, void *user);
+
+/* kernel timing hooks for bench.py: HIP-event time of the last te_vcycle's dominant kernel */
+int te_gmg_profile(te_gmg *g, int enable);
+/* name[i] (<=63 chars), calls[i], total_ms[i]; returns number of rows written (<= max_rows) */
+int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *calls, double *total_ms);
+int te_gmg_profile_reset(te_gmg *g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,728 @@
+// TEST INFRASTRUCTURE — NOT PRODUCT CODE. See te_oracle.h for scope, citations and the
+// pinning status of every function. Plain scalar C++ (OpenMP over patches only), written to
+// follow the reference's arithmetic order, not to be fast.
+#include "te_oracle.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace
+{
+int g_threads = 1;
+
+inline int ipow(int b, int e)
+{
+	int r = 1;
+	while (e-- > 0) r *= b;
+	return r;
+}
+struct Geo {
+	int dim, n, nsides, nc, nf; // cells per patch, cells per face
+	int stride[3];
+	explicit Geo(const orc_level *L)
+	{
+		dim       = L->dim;
+		n         = L->n;
+		nsides    = 2 * dim;
+		nc        = ipow(n, dim);
+		nf        = ipow(n, dim - 1);
+		stride[0] = 1;
+		stride[1] = n;
+		stride[2] = n * n;
+	}
+	// offset of face cell (a,b) of side s, `off` layers in from the face
+	// (Vector.h:152-177 getSliceOnSidePriv)
+	inline int faceCell(int s, int a, int b, int off) const
+	{
+		int ax  = s / 2;
+		int pos = (s & 1) ? (n - 1 - off) : off;
+		int fa[2], k = 0;
+		for (int i = 0; i < dim; i++)
+			if (i != ax) fa[k++] = i;
+		int idx = pos * stride[ax] + a * stride[fa[0]];
+		if (dim == 3) idx += b * stride[fa[1]];
+		return idx;
+	}
+};
+
+// Interface numbering: SchurInfo.h:141-150 (normal), :229-237 (coarse), :322-331 (fine);
+// dense local indices in first-seen order as SchurHelper.h:377-397 assigns them.
+struct Ifaces {
+	std::vector<int> own;    // [P*nsides] index of the interface on (p,s) or -1
+	std::vector<int> other;  // [P*nsides*4] coarse: [0] = coarse patch's iface; fine: 4 fine ifaces
+	int              count = 0;
+};
+Ifaces buildIfaces(const orc_level *L)
+{
+	Geo                G(L);
+	Ifaces             I;
+	std::map<int, int> rev;
+	auto               get = [&](int id) {
+        auto it = rev.find(id);
+        if (it != rev.end()) return it->second;
+        int v   = I.count++;
+        rev[id] = v;
+        return v;
+	};
+	const int NS = G.nsides;
+	I.own.assign((size_t) L->P * NS, -1);
+	I.other.assign((size_t) L->P * NS * 4, -1);
+	for (int p = 0; p < L->P; p++) {
+		for (int s = 0; s < NS; s++) {
+			size_t f    = (size_t) p * NS + s;
+			int    kind = L->nbr_kind[f];
+			if (kind == 1) {
+				int id = (s & 1) ? L->id[L->nbr[f * 4]] * NS + (s ^ 1) : L->id[p] * NS + s;
+				I.own[f] = get(id);
+			} else if (kind == 2) {
+				I.own[f]       = get(L->id[p] * NS + s);
+				I.other[f * 4] = get(L->id[L->nbr[f * 4]] * NS + (s ^ 1));
+			} else if (kind == 3) {
+				I.own[f] = get(L->id[p] * NS + s);
+				for (int q = 0; q < (1 << (G.dim - 1)); q++)
+					I.other[f * 4 + q] = get(L->id[L->nbr[f * 4 + q]] * NS + (s ^ 1));
+			}
+		}
+	}
+	return I;
+}
+
+// ---- a6: one patch's contributions -----------------------------------------------------
+void interpPatch(const orc_level *L, const Geo &G, const Ifaces &I, int p, const double *u,
+                 double *gamma)
+{
+	const int     n  = G.n;
+	const double *up = u + (size_t) p * G.nc;
+	for (int s = 0; s < G.nsides; s++) {
+		size_t f    = (size_t) p * G.nsides + s;
+		int    kind = L->nbr_kind[f];
+		if (kind == 0) continue;
+		auto sl = [&](int a, int b) { return up[G.faceCell(s, a, b, 0)]; };
+		if (G.dim == 3) {
+			auto at = [&](int iface, int a, int b) -> double & {
+				return gamma[(size_t) iface * G.nf + a + n * b];
+			};
+			if (kind == 1) { // normal, TriLinInterp.cpp:78-84
+				for (int b = 0; b < n; b++)
+					for (int a = 0; a < n; a++) at(I.own[f], a, b) += 0.5 * sl(a, b);
+			} else if (kind == 2) {
+				// fine_to_fine, TriLinInterp.cpp:85-98
+				for (int b = 0; b < n / 2; b++)
+					for (int a = 0; a < n / 2; a++) {
+						double va = sl(2 * a, 2 * b), vb = sl(2 * a + 1, 2 * b);
+						double vc = sl(2 * a, 2 * b + 1), vd = sl(2 * a + 1, 2 * b + 1);
+						at(I.own[f], 2 * a, 2 * b) += (11 * va - vb - vc - vd) / 12.0;
+						at(I.own[f], 2 * a + 1, 2 * b) += (-va + 11 * vb - vc - vd) / 12.0;
+						at(I.own[f], 2 * a, 2 * b + 1) += (-va - vb + 11 * vc - vd) / 12.0;
+						at(I.own[f], 2 * a + 1, 2 * b + 1) += (-va - vb - vc + 11 * vd) / 12.0;
+					}
+				// fine_to_coarse, TriLinInterp.cpp:138-170
+				int q = L->nbr_orth[f], oa = (q & 1) ? n : 0, ob = (q & 2) ? n : 0;
+				for (int b = 0; b < n; b++)
+					for (int a = 0; a < n; a++)
+						at(I.other[f * 4], (a + oa) / 2, (b + ob) / 2) += 1.0 / 6.0 * sl(a, b);
+			} else {
+				// coarse_to_coarse, TriLinInterp.cpp:131-137
+				for (int b = 0; b < n; b++)
+					for (int a = 0; a < n; a++) at(I.own[f], a, b) += 2.0 / 6.0 * sl(a, b);
+				// coarse_to_fine, TriLinInterp.cpp:99-130
+				for (int q = 0; q < 4; q++) {
+					int oa = (q & 1) ? n : 0, ob = (q & 2) ? n : 0;
+					for (int b = 0; b < n; b++)
+						for (int a = 0; a < n; a++)
+							at(I.other[f * 4 + q], a, b) += 4.0 * sl((a + oa) / 2, (b + ob) / 2) / 12.0;
+				}
+			}
+		} else {
+			auto at = [&](int iface, int a) -> double & { return gamma[(size_t) iface * G.nf + a]; };
+			if (kind == 1) { // BilinearInterpolator.cpp:71-75
+				for (int a = 0; a < n; a++) at(I.own[f], a) += 0.5 * sl(a, 0);
+			} else if (kind == 2) {
+				// fine_to_fine :95-103
+				for (int a = 0; a < n; a += 2) at(I.own[f], a) += 5.0 / 6 * sl(a, 0) - 1.0 / 6 * sl(a + 1, 0);
+				for (int a = 1; a < n; a += 2) at(I.own[f], a) += 5.0 / 6 * sl(a, 0) - 1.0 / 6 * sl(a - 1, 0);
+				// fine_to_coarse :82-94
+				int oa = (L->nbr_orth[f] & 1) ? n : 0;
+				for (int a = 0; a < n; a += 2)
+					at(I.other[f * 4], (oa + a) / 2) += 1.0 / 3 * sl(a, 0) + 1.0 / 3 * sl(a + 1, 0);
+			} else {
+				for (int a = 0; a < n; a++) at(I.own[f], a) += 1.0 / 3 * sl(a, 0); // :76-81
+				for (int q = 0; q < 2; q++) {                                       // :104-115
+					int oa = q ? n : 0;
+					for (int a = 0; a < n; a++) at(I.other[f * 4 + q], a) += 2.0 / 6 * sl((oa + a) / 2, 0);
+				}
+			}
+		}
+	}
+}
+
+// ---- a3 / a4: one patch ----------------------------------------------------------------
+// with_gamma = false reproduces StarPatchOp::apply (neighbour faces treated as Dirichlet).
+void applyPatch(const orc_level *L, const Geo &G, const Ifaces *I, int p, const double *u,
+                const double *gamma, double *f, bool with_gamma)
+{
+	const int     n  = G.n;
+	const double *up = u + (size_t) p * G.nc;
+	double       *fp = f + (size_t) p * G.nc;
+	const int     nz = (G.dim == 3) ? n : 1;
+	for (int ax = 0; ax < G.dim; ax++) {
+		double    h2 = L->h[(size_t) p * G.dim + ax];
+		h2 *= h2;
+		const int st = G.stride[ax];
+		const int sl = 2 * ax, su = 2 * ax + 1;
+		const int kl = L->nbr_kind[(size_t) p * G.nsides + sl], ku = L->nbr_kind[(size_t) p * G.nsides + su];
+		const bool nl = (L->neumann[p] >> sl) & 1, nu = (L->neumann[p] >> su) & 1;
+		for (int z = 0; z < nz; z++)
+			for (int y = 0; y < n; y++)
+				for (int x = 0; x < n; x++) {
+					int c[3] = {x, y, z};
+					int idx  = x + n * y + n * n * z;
+					// face coordinates = remaining axes in order
+					int a = 0, b = 0;
+					{
+						int k = 0, fa[2] = {0, 0};
+						for (int i = 0; i < G.dim; i++)
+							if (i != ax) fa[k++] = c[i];
+						a = fa[0];
+						b = (G.dim == 3) ? fa[1] : 0;
+					}
+					double val;
+					double mid = up[idx];
+					if (c[ax] == 0) {
+						double upper = up[idx + st];
+						if (with_gamma && kl != 0) {
+							double bnd = gamma[(size_t) I->own[(size_t) p * G.nsides + sl] * G.nf + a + n * b];
+							val        = (2 * bnd - 3 * mid + upper) / h2;
+						} else if (nl && (kl == 0 || !with_gamma)) {
+							val = (-mid + upper) / h2;
+						} else {
+							val = (-3 * mid + upper) / h2;
+						}
+					} else if (c[ax] == n - 1) {
+						double lower = up[idx - st];
+						if (with_gamma && ku != 0) {
+							double bnd = gamma[(size_t) I->own[(size_t) p * G.nsides + su] * G.nf + a + n * b];
+							val        = (lower - 3 * mid + 2 * bnd) / h2;
+						} else if (nu && (ku == 0 || !with_gamma)) {
+							val = (lower - mid) / h2;
+						} else {
+							val = (lower - 3 * mid) / h2;
+						}
+					} else {
+						double lower = up[idx - st], upper = up[idx + st];
+						val = (lower - 2 * mid + upper) / h2;
+					}
+					if (ax == 0)
+						fp[idx] = val;
+					else
+						fp[idx] += val;
+				}
+	}
+}
+
+// ---- a9: dense DST/DCT patch solve -------------------------------------------------------
+enum DftType { DCT_II, DCT_III, DCT_IV, DST_II, DST_III, DST_IV };
+// DftPatchSolver.h:237-289; returned row-major M with y_i = sum_j M[i*n+j] x_j
+std::vector<double> transformMatrix(DftType t, int n)
+{
+	std::vector<double> m((size_t) n * n, 0.0);
+	switch (t) {
+		case DCT_II:
+			for (int j = 0; j < n; j++)
+				for (int i = 0; i < n; i++) m[i * n + j] = cos(M_PI / n * (i * (j + 0.5)));
+			break;
+		case DCT_III:
+			for (int i = 0; i < n; i++) m[i * n] = 0.5;
+			for (int j = 1; j < n; j++)
+				for (int i = 0; i < n; i++) m[i * n + j] = cos(M_PI / n * ((i + 0.5) * j));
+			break;
+		case DCT_IV:
+			for (int j = 0; j < n; j++)
+				for (int i = 0; i < n; i++) m[i * n + j] = cos(M_PI / n * ((i + 0.5) * (j + 0.5)));
+			break;
+		case DST_II:
+			for (int i = 0; i < n; i++)
+				for (int j = 0; j < n; j++) m[i * n + j] = sin(M_PI / n * ((i + 1) * (j + 0.5)));
+			break;
+		case DST_III:
+			for (int i = 0; i < n; i += 2) m[i * n + n - 1] = 0.5;
+			for (int i = 1; i < n; i += 2) m[i * n + n - 1] = -0.5;
+			for (int i = 0; i < n; i++)
+				for (int j = 0; j < n - 1; j++) m[i * n + j] = sin(M_PI / n * ((i + 0.5) * (j + 1)));
+			break;
+		case DST_IV:
+			for (int j = 0; j < n; j++)
+				for (int i = 0; i < n; i++) m[i * n + j] = sin(M_PI / n * ((i + 0.5) * (j + 0.5)));
+			break;
+	}
+	return m;
+}
+// out = transform of `in` along axis ax (DftPatchSolver.h:295-347: one dgemv per line)
+void transformAxis(const Geo &G, const std::vector<double> &M, int ax, const double *in, double *out)
+{
+	const int n = G.n, st = G.stride[ax];
+	// transposed copy so the inner loop runs over contiguous outputs
+	const int outer = G.nc / (n * st); // blocks above the axis
+	for (int o = 0; o < outer; o++) {
+		for (int i = 0; i < n; i++) {
+			double *dst = out + (size_t) o * n * st + (size_t) i * st;
+			for (int x = 0; x < st; x++) dst[x] = 0;
+			for (int j = 0; j < n; j++) {
+				const double  w   = M[i * n + j];
+				const double *src = in + (size_t) o * n * st + (size_t) j * st;
+				for (int x = 0; x < st; x++) dst[x] += w * src[x];
+			}
+		}
+	}
+}
+struct SolvePlan {
+	std::vector<double> fwd[3], inv[3], eig;
+};
+SolvePlan makePlan(const orc_level *L, const Geo &G, int p)
+{
+	SolvePlan pl;
+	const int n   = G.n;
+	const int neu = L->neumann[p];
+	// a side is Neumann for the solver only if it is a physical boundary with the bit set
+	auto isNeu = [&](int s) { return ((neu >> s) & 1) && L->nbr_kind[(size_t) p * G.nsides + s] == 0; };
+	pl.eig.assign(G.nc, 0.0);
+	const double h = L->h[(size_t) p * G.dim]; // DftPatchSolver.h:148 uses spacings[0]
+	for (int ax = 0; ax < G.dim; ax++) {
+		bool lo = isNeu(2 * ax), hi = isNeu(2 * ax + 1);
+		DftType f, i;
+		if (lo && hi) {
+			f = DCT_II;
+			i = DCT_III;
+		} else if (lo) {
+			f = i = DCT_IV;
+		} else if (hi) {
+			f = i = DST_IV;
+		} else {
+			f = DST_II;
+			i = DST_III;
+		}
+		pl.fwd[ax] = transformMatrix(f, n);
+		pl.inv[ax] = transformMatrix(i, n);
+		// eigenvalues, FftwPatchSolver.h:143-168 == DftPatchSolver.h:150-166
+		for (int c = 0; c < G.nc; c++) {
+			int    xi = (c / G.stride[ax]) % n;
+			double v;
+			if (lo && hi)
+				v = 4 / (h * h) * pow(sin(xi * M_PI / (2 * n)), 2);
+			else if (lo || hi)
+				v = 4 / (h * h) * pow(sin((xi + 0.5) * M_PI / (2 * n)), 2);
+			else
+				v = 4 / (h * h) * pow(sin((xi + 1) * M_PI / (2 * n)), 2);
+			pl.eig[c] -= v;
+		}
+	}
+	return pl;
+}
+void solvePatch(const orc_level *L, const Geo &G, const Ifaces &I, int p, const double *gamma,
+                const double *f, double *u)
+{
+	const int           n = G.n;
+	std::vector<double> a(f + (size_t) p * G.nc, f + (size_t) (p + 1) * G.nc), b(G.nc);
+	// f_copy -= 2/h^2 * gamma on every face that has a neighbour (DftPatchSolver.h:190-202)
+	for (int s = 0; s < G.nsides; s++) {
+		size_t fidx = (size_t) p * G.nsides + s;
+		if (L->nbr_kind[fidx] == 0) continue;
+		double h2 = pow(L->h[(size_t) p * G.dim + s / 2], 2);
+		for (int bb = 0; bb < (G.dim == 3 ? n : 1); bb++)
+			for (int aa = 0; aa < n; aa++)
+				a[G.faceCell(s, aa, bb, 0)] -= 2.0 / h2 * gamma[(size_t) I.own[fidx] * G.nf + aa + n * bb];
+	}
+	SolvePlan pl = makePlan(L, G, p);
+	double   *src = a.data(), *dst = b.data();
+	for (int ax = 0; ax < G.dim; ax++) {
+		transformAxis(G, pl.fwd[ax], ax, src, dst);
+		std::swap(src, dst);
+	}
+	for (int c = 0; c < G.nc; c++) src[c] /= pl.eig[c];
+	bool all_neu = true;
+	for (int s = 0; s < G.nsides; s++)
+		if (!(((L->neumann[p] >> s) & 1) && L->nbr_kind[(size_t) p * G.nsides + s] == 0)) all_neu = false;
+	// reference tests neumann.all() (DftPatchSolver.h:208); identical for a 1-patch domain
+	if (all_neu) src[0] = 0;
+	for (int ax = 0; ax < G.dim; ax++) {
+		transformAxis(G, pl.inv[ax], ax, src, dst);
+		std::swap(src, dst);
+	}
+	double scale = pow(2.0 / n, G.dim);
+	double *up   = u + (size_t) p * G.nc;
+	for (int c = 0; c < G.nc; c++) up[c] = src[c] * scale;
+}
+
+// diagonal of the assembled operator seen from cell c of patch p (used by the product's
+// pointwise smoothers only)
+inline double faceDiagCoef(int kind, bool neu)
+{
+	switch (kind) {
+		case 1: return 2.0;
+		case 2: return 0; // filled by caller (dim dependent)
+		case 3: return 0;
+		default: return neu ? 1.0 : 3.0;
+	}
+}
+} // namespace
+
+extern "C" {
+void orc_set_threads(int nthreads) { g_threads = nthreads < 1 ? 1 : nthreads; }
+
+int orc_num_ifaces(const orc_level *L) { return buildIfaces(L).count; }
+
+void orc_iface_index(const orc_level *L, int32_t *iface_index)
+{
+	Ifaces I = buildIfaces(L);
+	for (size_t i = 0; i < I.own.size(); i++) iface_index[i] = I.own[i];
+}
+
+void orc_interp(const orc_level *L, const double *u, double *gamma)
+{
+	Geo    G(L);
+	Ifaces I = buildIfaces(L);
+	memset(gamma, 0, sizeof(double) * (size_t) I.count * G.nf);
+	for (int p = 0; p < L->P; p++) interpPatch(L, G, I, p, u, gamma);
+}
+
+void orc_apply_with_gamma(const orc_level *L, const double *u, const double *gamma, double *f)
+{
+	Geo    G(L);
+	Ifaces I = buildIfaces(L);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+	for (int p = 0; p < L->P; p++) applyPatch(L, G, &I, p, u, gamma, f, true);
+}
+
+void orc_apply(const orc_level *L, const double *u, double *f)
+{
+	Geo                 G(L);
+	Ifaces              I = buildIfaces(L);
+	std::vector<double> gamma((size_t) I.count * G.nf, 0.0);
+	for (int p = 0; p < L->P; p++) interpPatch(L, G, I, p, u, gamma.data());
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+	for (int p = 0; p < L->P; p++) applyPatch(L, G, &I, p, u, gamma.data(), f, true);
+}
+
+void orc_patch_apply(const orc_level *L, const double *u, double *f)
+{
+	Geo G(L);
+	for (int p = 0; p < L->P; p++) applyPatch(L, G, nullptr, p, u, nullptr, f, false);
+}
+
+void orc_add_iface_rhs(const orc_level *L, const double *gamma, double *f)
+{
+	Geo    G(L);
+	Ifaces I = buildIfaces(L);
+	for (int p = 0; p < L->P; p++)
+		for (int s = 0; s < G.nsides; s++) {
+			size_t fidx = (size_t) p * G.nsides + s;
+			if (L->nbr_kind[fidx] == 0) continue;
+			// StarPatchOp.h:195 takes spacings[s.axis()] where axis() returns bool (Side.h:105);
+			// identical for the cubic cells every config uses. We use the true axis.
+			double h2 = pow(L->h[(size_t) p * G.dim + s / 2], 2);
+			for (int b = 0; b < (G.dim == 3 ? G.n : 1); b++)
+				for (int a = 0; a < G.n; a++)
+					f[(size_t) p * G.nc + G.faceCell(s, a, b, 0)]
+					-= 2.0 / h2 * gamma[(size_t) I.own[fidx] * G.nf + a + G.n * b];
+		}
+}
+
+void orc_patch_solve(const orc_level *L, const double *gamma, const double *f, double *u)
+{
+	Geo    G(L);
+	Ifaces I = buildIfaces(L);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic)
+	for (int p = 0; p < L->P; p++) solvePatch(L, G, I, p, gamma, f, u);
+}
+
+void orc_smooth(const orc_level *L, const double *f, double *u)
+{
+	Geo                 G(L);
+	Ifaces              I = buildIfaces(L);
+	std::vector<double> gamma((size_t) I.count * G.nf, 0.0);
+	for (int p = 0; p < L->P; p++) interpPatch(L, G, I, p, u, gamma.data());
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic)
+	for (int p = 0; p < L->P; p++) solvePatch(L, G, I, p, gamma.data(), f, u);
+}
+
+void orc_restrict(const orc_level *fine, const orc_level *coarse, const double *fv, double *cv)
+{
+	Geo       G(fine);
+	const int n = G.n, nz = (G.dim == 3) ? n : 1;
+	memset(cv, 0, sizeof(double) * (size_t) coarse->P * G.nc);
+	// fine patches in ascending id order (std::set<ILCFineToCoarseMetadata>, InterLevelComm.h:47-50)
+	std::vector<std::pair<int, int>> order;
+	for (int p = 0; p < fine->P; p++) order.emplace_back(fine->id[p], p);
+	std::sort(order.begin(), order.end());
+	for (auto &op : order) {
+		int           p  = op.second;
+		const double *fp = fv + (size_t) p * G.nc;
+		double       *cp = cv + (size_t) fine->parent[p] * G.nc;
+		int           o  = fine->orth_on_parent[p];
+		if (o >= 0) {
+			int st[3] = {(o & 1) ? n : 0, (o & 2) ? n : 0, (o & 4) ? n : 0};
+			for (int z = 0; z < nz; z++)
+				for (int y = 0; y < n; y++)
+					for (int x = 0; x < n; x++) {
+						int ci = (x + st[0]) / 2 + n * ((y + st[1]) / 2);
+						if (G.dim == 3) ci += n * n * ((z + st[2]) / 2);
+						cp[ci] += fp[x + n * y + n * n * z] / (1 << G.dim);
+					}
+		} else {
+			for (int c = 0; c < G.nc; c++) cp[c] += fp[c];
+		}
+	}
+}
+
+void orc_prolong_add(const orc_level *fine, const orc_level *coarse, const double *cv, double *fv)
+{
+	(void) coarse;
+	Geo       G(fine);
+	const int n = G.n, nz = (G.dim == 3) ? n : 1;
+	for (int p = 0; p < fine->P; p++) {
+		double       *fp = fv + (size_t) p * G.nc;
+		const double *cp = cv + (size_t) fine->parent[p] * G.nc;
+		int           o  = fine->orth_on_parent[p];
+		if (o >= 0) {
+			int st[3] = {(o & 1) ? n : 0, (o & 2) ? n : 0, (o & 4) ? n : 0};
+			for (int z = 0; z < nz; z++)
+				for (int y = 0; y < n; y++)
+					for (int x = 0; x < n; x++) {
+						int ci = (x + st[0]) / 2 + n * ((y + st[1]) / 2);
+						if (G.dim == 3) ci += n * n * ((z + st[2]) / 2);
+						fp[x + n * y + n * n * z] += cp[ci];
+					}
+		} else {
+			for (int c = 0; c < G.nc; c++) fp[c] += cp[c];
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// Product smoothers restated (not reference functions).
+// Ghost value on a neighbour face = 2*gamma - own face cell.
+// ------------------------------------------------------------------------------------------
+static void cellCoefs(const orc_level *L, const Geo &G, int p, int x, int y, int z, double *diag,
+                      const double *up, const double *ghost /*[nsides][nf]*/, double *offsum)
+{
+	// returns diag = sum_a k_a / h_a^2 (positive), offsum = sum_a (lo + hi)/h_a^2 excluding
+	// the cell itself and physical-boundary ghosts
+	const int n  = G.n;
+	int       c[3] = {x, y, z};
+	double    d = 0, o = 0;
+	for (int ax = 0; ax < G.dim; ax++) {
+		double h2 = L->h[(size_t) p * G.dim + ax];
+		h2 *= h2;
+		double k   = 2.0;
+		int    idx = x + n * y + n * n * z;
+		int    fa[2] = {0, 0}, kk = 0;
+		for (int i = 0; i < G.dim; i++)
+			if (i != ax) fa[kk++] = c[i];
+		for (int side = 0; side < 2; side++) {
+			int  s      = 2 * ax + side;
+			bool atface = side ? (c[ax] == n - 1) : (c[ax] == 0);
+			if (!atface) {
+				o += up[idx + (side ? G.stride[ax] : -G.stride[ax])] / h2;
+			} else {
+				int kind = L->nbr_kind[(size_t) p * G.nsides + s];
+				if (kind == 0) {
+					k += ((L->neumann[p] >> s) & 1) ? -1.0 : 1.0;
+				} else {
+					o += ghost[(size_t) s * G.nf + fa[0] + n * fa[1]] / h2;
+				}
+			}
+		}
+		d += k / h2;
+	}
+	*diag   = d;
+	*offsum = o;
+}
+
+static void ghostsFromGamma(const orc_level *L, const Geo &G, const Ifaces &I, int p,
+                            const double *u, const double *gamma, double *ghost)
+{
+	const int n = G.n;
+	for (int s = 0; s < G.nsides; s++) {
+		size_t f = (size_t) p * G.nsides + s;
+		if (L->nbr_kind[f] == 0) continue;
+		for (int b = 0; b < (G.dim == 3 ? n : 1); b++)
+			for (int a = 0; a < n; a++)
+				ghost[(size_t) s * G.nf + a + n * b]
+				= 2 * gamma[(size_t) I.own[f] * G.nf + a + n * b] - u[(size_t) p * G.nc + G.faceCell(s, a, b, 0)];
+	}
+}
+
+void orc_jacobi(const orc_level *L, const double *f, double *u, double omega)
+{
+	// u <- u + omega * D^-1 (f - A u), D = diagonal of the assembled operator. On coarse/fine
+	// faces the ghost depends on the cell itself: fine side d(ghost)/d(cell) = 5/6 (3D) or 5/6
+	// (2D: 2*5/6-1 = 2/3), coarse side -1/3; folded into the diagonal below.
+	Geo                 G(L);
+	Ifaces              I = buildIfaces(L);
+	std::vector<double> au((size_t) L->P * G.nc);
+	orc_apply(L, u, au.data());
+	const int n = G.n, nz = (G.dim == 3) ? n : 1;
+	for (int p = 0; p < L->P; p++) {
+		for (int z = 0; z < nz; z++)
+			for (int y = 0; y < n; y++)
+				for (int x = 0; x < n; x++) {
+					int    c[3] = {x, y, z};
+					double d    = 0;
+					for (int ax = 0; ax < G.dim; ax++) {
+						double h2 = L->h[(size_t) p * G.dim + ax];
+						h2 *= h2;
+						double k = 2.0;
+						for (int side = 0; side < 2; side++) {
+							int  s      = 2 * ax + side;
+							bool atface = side ? (c[ax] == n - 1) : (c[ax] == 0);
+							if (!atface) continue;
+							int kind = L->nbr_kind[(size_t) p * G.nsides + s];
+							if (kind == 0)
+								k += ((L->neumann[p] >> s) & 1) ? -1.0 : 1.0;
+							else if (kind == 2)
+								k -= (G.dim == 3) ? 5.0 / 6.0 : 2.0 / 3.0;
+							else if (kind == 3)
+								k += 1.0 / 3.0;
+						}
+						d += k / h2;
+					}
+					size_t i = (size_t) p * G.nc + x + n * y + n * n * z;
+					// A's diagonal is -d
+					u[i] += omega * (f[i] - au[i]) / (-d);
+				}
+	}
+}
+
+void orc_patch_rbgs(const orc_level *L, const double *f, double *u)
+{
+	Geo                 G(L);
+	Ifaces              I = buildIfaces(L);
+	std::vector<double> gamma((size_t) I.count * G.nf, 0.0);
+	for (int p = 0; p < L->P; p++) interpPatch(L, G, I, p, u, gamma.data());
+	const int n = G.n, nz = (G.dim == 3) ? n : 1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+	for (int p = 0; p < L->P; p++) {
+		std::vector<double> ghost((size_t) G.nsides * G.nf, 0.0);
+		ghostsFromGamma(L, G, I, p, u, gamma.data(), ghost.data());
+		double *up = u + (size_t) p * G.nc;
+		for (int colour = 0; colour < 2; colour++)
+			for (int z = 0; z < nz; z++)
+				for (int y = 0; y < n; y++)
+					for (int x = 0; x < n; x++) {
+						if (((x + y + z) & 1) != colour) continue;
+						double d, o;
+						cellCoefs(L, G, p, x, y, z, &d, up, ghost.data(), &o);
+						int i = x + n * y + n * n * z;
+						up[i] = (o - f[(size_t) p * G.nc + i]) / d;
+					}
+	}
+}
+
+// ---- a1 ------------------------------------------------------------------------------------
+static void smoothLevel(const orc_level *L, const orc_cycle_opts *o, bool coarsest,
+                        const double *f, double *u)
+{
+	if (o->smoother == 0 || (coarsest && o->exact_coarse && L->P == 1))
+		orc_smooth(L, f, u);
+	else if (o->smoother == 1)
+		orc_jacobi(L, f, u, o->omega);
+	else
+		orc_patch_rbgs(L, f, u);
+}
+static void visit(const orc_level *levels, int nlevels, int l, const orc_cycle_opts *o,
+                  const double *f, double *u)
+{
+	const orc_level *L = &levels[l];
+	Geo              G(L);
+	size_t           N        = (size_t) L->P * G.nc;
+	bool             coarsest = (l == nlevels - 1);
+	if (coarsest) {
+		for (int i = 0; i < o->coarse_sweeps; i++) smoothLevel(L, o, true, f, u);
+		return;
+	}
+	auto descend = [&]() {
+		// prepCoarser, Cycle.h:56-68
+		std::vector<double> r(N);
+		orc_apply(L, u, r.data());
+		for (size_t i = 0; i < N; i++) r[i] = -1 * r[i] + f[i];
+		size_t              Nc = (size_t) levels[l + 1].P * G.nc;
+		std::vector<double> cu(Nc, 0.0), cf(Nc, 0.0);
+		orc_restrict(L, &levels[l + 1], r.data(), cf.data());
+		visit(levels, nlevels, l + 1, o, cf.data(), cu.data());
+		// prepFiner, Cycle.h:74-80
+		orc_prolong_add(L, &levels[l + 1], cu.data(), u);
+	};
+	for (int i = 0; i < o->pre_sweeps; i++) smoothLevel(L, o, false, f, u);
+	descend();
+	if (o->cycle_type == 1) {
+		for (int i = 0; i < o->mid_sweeps; i++) smoothLevel(L, o, false, f, u);
+		descend();
+	}
+	for (int i = 0; i < o->post_sweeps; i++) smoothLevel(L, o, false, f, u);
+}
+void orc_cycle(const orc_level *levels, int nlevels, const orc_cycle_opts *o, const double *f,
+               double *u)
+{
+	Geo    G(&levels[0]);
+	size_t N = (size_t) levels[0].P * G.nc;
+	memset(u, 0, sizeof(double) * N); // Cycle.h:118
+	visit(levels, nlevels, 0, o, f, u);
+}
+
+int orc_bicgstab(const orc_level *levels, int nlevels, const orc_cycle_opts *o, int use_prec,
+                 const double *b, double *x, int max_it, double tol, double *final_rel_resid)
+{
+	const orc_level *L = &levels[0];
+	Geo              G(L);
+	const size_t     N = (size_t) L->P * G.nc;
+	auto dot  = [&](const std::vector<double> &a, const std::vector<double> &c) {
+        double s = 0;
+        for (size_t i = 0; i < N; i++) s += a[i] * c[i];
+        return s;
+	};
+	auto norm = [&](const std::vector<double> &a) { return sqrt(dot(a, a)); };
+	std::vector<double> resid(N), ms(N), mp(N), rhat, p, ap(N), as(N), s(N);
+	// BiCGStab.h:57-69
+	orc_apply(L, x, resid.data());
+	for (size_t i = 0; i < N; i++) resid[i] = -1 * resid[i] + b[i];
+	double r0_norm = norm(resid);
+	rhat           = resid;
+	p              = resid;
+	double rho     = dot(rhat, resid);
+	int    num_its = 0;
+	while (norm(resid) / r0_norm > tol && num_its < max_it) {
+		if (use_prec) {
+			orc_cycle(levels, nlevels, o, p.data(), mp.data());
+			orc_apply(L, mp.data(), ap.data());
+		} else {
+			orc_apply(L, p.data(), ap.data());
+		}
+		double alpha = rho / dot(rhat, ap);
+		for (size_t i = 0; i < N; i++) s[i] = resid[i] + ap[i] * -alpha;
+		if (use_prec) {
+			orc_cycle(levels, nlevels, o, s.data(), ms.data());
+			orc_apply(L, ms.data(), as.data());
+		} else {
+			orc_apply(L, s.data(), as.data());
+		}
+		double omega = dot(as, s) / dot(as, as);
+		const std::vector<double> &dp = use_prec ? mp : p, &ds = use_prec ? ms : s;
+		for (size_t i = 0; i < N; i++) x[i] += dp[i] * alpha + ds[i] * omega;
+		for (size_t i = 0; i < N; i++) resid[i] += ap[i] * -alpha + as[i] * -omega;
+		double rho_new = dot(resid, rhat);
+		double beta    = rho_new * alpha / (rho * omega);
+		for (size_t i = 0; i < N; i++) p[i] += ap[i] * -omega;
+		for (size_t i = 0; i < N; i++) p[i] = beta * p[i] + resid[i];
+		num_its++;
+		rho = rho_new;
+	}
+	if (final_rel_resid) *final_rel_resid = norm(resid) / r0_norm;
+	return num_its;
+}
+} // extern "C"

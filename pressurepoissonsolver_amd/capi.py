@@ -1,0 +1,371 @@
+"""ctypes binding of include/te_hip.h (libte_hip.so) — plumbing only.
+
+The shared library is the product; this module adds nothing numerical. It fails loudly when the
+library is missing (`TeLibraryMissing`): there is no Python / torch / CPU fallback for any
+operation.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libte_hip.so")
+
+
+class TeError(RuntimeError):
+    """Non-zero status from the C ABI (the reference's convention is `throw 3;`)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"te_hip error {code}: {msg}")
+        self.code = code
+
+
+class TeLibraryMissing(ImportError):
+    pass
+
+
+TE_OK, TE_EINVAL, TE_EHIP, TE_ESTATE, TE_EIO, TE_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+SMOOTH_PATCH_SOLVE, SMOOTH_JACOBI, SMOOTH_RBGS = 0, 1, 2
+
+
+class CycleOpts(C.Structure):
+    """GMG/CycleOpts.h:51-79 + the smoother selection of this build."""
+
+    _fields_ = [("pre_sweeps", C.c_int32), ("post_sweeps", C.c_int32), ("coarse_sweeps", C.c_int32),
+                ("mid_sweeps", C.c_int32), ("cycle_type", C.c_int32), ("smoother", C.c_int32),
+                ("omega", C.c_double), ("exact_coarse", C.c_int32), ("fuse", C.c_int32)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                          C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                          C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p)
+
+# every symbol include/te_hip.h declares: (restype, argtypes)
+_P = C.c_void_p
+_D = C.c_double
+_I = C.c_int
+_PI32 = C.POINTER(C.c_int32)
+_PD = C.POINTER(C.c_double)
+SYMBOLS = {
+    "te_last_error": (C.c_char_p, []),
+    "te_version": (C.c_char_p, []),
+    "te_mesh_read": (_I, [C.c_char_p, _I, C.POINTER(_P)]),
+    "te_mesh_unit_root": (_I, [_I, C.POINTER(_P)]),
+    "te_mesh_refine_leaves": (_I, [_P]),
+    "te_mesh_num_nodes": (_I, [_P]),
+    "te_mesh_num_levels": (_I, [_P]),
+    "te_mesh_dim": (_I, [_P]),
+    "te_mesh_get_nodes": (_I, [_P, _P, _P, _P, _P, _P]),
+    "te_mesh_destroy": (None, [_P]),
+    "te_hier_build": (_I, [_P, _I, _I, _I, _D, _I, _I, C.POINTER(_P)]),
+    "te_hier_num_levels": (_I, [_P]),
+    "te_hier_dim": (_I, [_P]),
+    "te_hier_n": (_I, [_P]),
+    "te_hier_level_sizes": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "te_hier_level_tables": (_I, [_P, _I] + [_P] * 10),
+    "te_hier_level_l2g": (_I, [_P, _I, _P]),
+    "te_hier_destroy": (None, [_P]),
+    "te_cycle_opts_default": (None, [C.POINTER(CycleOpts)]),
+    "te_gmg_create": (_I, [_P, _I, C.POINTER(_P)]),
+    "te_gmg_destroy": (None, [_P]),
+    "te_gmg_num_levels": (_I, [_P]),
+    "te_gmg_sync": (_I, [_P]),
+    "te_gmg_stream": (_P, [_P]),
+    "te_vec_create": (_I, [_P, _I, C.POINTER(_P)]),
+    "te_vec_destroy": (None, [_P]),
+    "te_vec_size": (C.c_size_t, [_P]),
+    "te_vec_upload": (_I, [_P, _P]),
+    "te_vec_download": (_I, [_P, _P]),
+    "te_vec_device_ptr": (_P, [_P]),
+    "te_vec_set": (_I, [_P, _D]),
+    "te_vec_scale": (_I, [_P, _D]),
+    "te_vec_shift": (_I, [_P, _D]),
+    "te_vec_copy": (_I, [_P, _P]),
+    "te_vec_add": (_I, [_P, _P]),
+    "te_vec_add_scaled": (_I, [_P, _D, _P]),
+    "te_vec_add_scaled2": (_I, [_P, _D, _P, _D, _P]),
+    "te_vec_scale_then_add": (_I, [_P, _D, _P]),
+    "te_vec_scale_then_add_scaled": (_I, [_P, _D, _D, _P]),
+    "te_vec_scale_then_add_scaled2": (_I, [_P, _D, _D, _P, _D, _P]),
+    "te_vec_two_norm_sq": (_I, [_P, _PD]),
+    "te_vec_inf_norm": (_I, [_P, _PD]),
+    "te_vec_dot": (_I, [_P, _P, _PD]),
+    "te_apply": (_I, [_P, _I, _P, _P]),
+    "te_residual": (_I, [_P, _I, _P, _P, _P]),
+    "te_smooth": (_I, [_P, _I, _P, _P, _I, _D, _I]),
+    "te_restrict": (_I, [_P, _I, _P, _P]),
+    "te_prolong_add": (_I, [_P, _I, _P, _P]),
+    "te_vcycle": (_I, [_P, C.POINTER(CycleOpts), _P, _P]),
+    "te_bicgstab": (_I, [_P, C.POINTER(CycleOpts), _P, _P, _I, _D, C.POINTER(_I), _PD]),
+    "te_gmg_set_exchange": (_I, [_P, EXCHANGE_FN, _P]),
+    "te_gmg_profile": (_I, [_P, _I]),
+    "te_gmg_profile_rows": (_I, [_P, _I, _P, _P, _P]),
+    "te_gmg_profile_reset": (_I, [_P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libte_hip.so (once). Raises TeLibraryMissing if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TeLibraryMissing(
+                f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no fallback implementation.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != TE_OK:
+        raise TeError(rc, lib().te_last_error().decode())
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Mesh:
+    """Tree<D> (src/Thunderegg/OctTree.h:34)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def read(cls, path, dim=3):
+        h = C.c_void_p()
+        check(lib().te_mesh_read(os.fsencode(path), dim, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def unit_root(cls, dim=3):
+        h = C.c_void_p()
+        check(lib().te_mesh_unit_root(dim, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def uniform(cls, dim, divides):
+        """1-node tree refined `divides` times: 2^(dim*divides) leaves."""
+        m = cls.unit_root(dim)
+        for _ in range(divides):
+            m.refine_leaves()
+        return m
+
+    def refine_leaves(self):
+        check(lib().te_mesh_refine_leaves(self.h))
+
+    @property
+    def dim(self):
+        return lib().te_mesh_dim(self.h)
+
+    @property
+    def num_nodes(self):
+        return lib().te_mesh_num_nodes(self.h)
+
+    @property
+    def num_levels(self):
+        return lib().te_mesh_num_levels(self.h)
+
+    def nodes(self):
+        n, d = self.num_nodes, self.dim
+        out = dict(ilp=np.zeros((n, 3), np.int32), lengths=np.zeros((n, d)), starts=np.zeros((n, d)),
+                   nbr=np.zeros((n, 2 * d), np.int32), child=np.zeros((n, 1 << d), np.int32))
+        check(lib().te_mesh_get_nodes(self.h, _ptr(out["ilp"]), _ptr(out["lengths"]), _ptr(out["starts"]),
+                                      _ptr(out["nbr"]), _ptr(out["child"])))
+        return out
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.te_mesh_destroy(self.h)
+            self.h = None
+
+
+class Hierarchy:
+    """DomainGenerator + the CycleFactory level loop (ThundereggDomGen.h, CycleFactory3d.cpp:98-127)."""
+
+    def __init__(self, mesh, n, neumann=False, max_levels=0, patches_per_proc=0.0, rank=0, nranks=1):
+        self.h = C.c_void_p()
+        check(lib().te_hier_build(mesh.h, n, int(neumann), max_levels, float(patches_per_proc), rank, nranks,
+                                  C.byref(self.h)))
+        self.n = n
+        self.neumann = bool(neumann)
+        self.dim = lib().te_hier_dim(self.h)
+        self.num_levels = lib().te_hier_num_levels(self.h)
+        self.rank, self.nranks = rank, nranks
+
+    def sizes(self, level):
+        a, b = C.c_int(), C.c_int()
+        check(lib().te_hier_level_sizes(self.h, level, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def tables(self, level):
+        P = self.sizes(level)[1]
+        d, ns = self.dim, 2 * self.dim
+        t = dict(id=np.zeros(P, np.int32), rank=np.zeros(P, np.int32), local=np.zeros(P, np.int32),
+                 starts=np.zeros((P, d)), lengths=np.zeros((P, d)), nbr_kind=np.zeros((P, ns), np.int32),
+                 nbr=np.zeros((P, ns, 4), np.int32), nbr_orth=np.zeros((P, ns), np.int32),
+                 parent=np.zeros(P, np.int32), orth_on_parent=np.zeros(P, np.int32))
+        check(lib().te_hier_level_tables(self.h, level, *[_ptr(t[k]) for k in (
+            "id", "rank", "local", "starts", "lengths", "nbr_kind", "nbr", "nbr_orth", "parent",
+            "orth_on_parent")]))
+        return t
+
+    def l2g(self, level):
+        out = np.zeros(self.sizes(level)[0], np.int32)
+        check(lib().te_hier_level_l2g(self.h, level, _ptr(out)))
+        return out
+
+    def cells(self, level):
+        return self.sizes(level)[0] * self.n ** self.dim
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.te_hier_destroy(self.h)
+            self.h = None
+
+
+class Vec:
+    """Vector<D> on the device (Vector.h:179-321); method names follow the reference."""
+
+    def __init__(self, gmg, level=0, data=None):
+        self.gmg, self.level = gmg, level
+        self.h = C.c_void_p()
+        check(lib().te_vec_create(gmg.h, level, C.byref(self.h)))
+        if data is not None:
+            self.upload(data)
+
+    @property
+    def size(self):
+        return lib().te_vec_size(self.h)
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+        if a.size != self.size:
+            raise ValueError(f"upload: {a.size} values for a vector of {self.size}")
+        check(lib().te_vec_upload(self.h, _ptr(a)))
+
+    def download(self):
+        out = np.empty(self.size, np.float64)
+        check(lib().te_vec_download(self.h, _ptr(out)))
+        return out
+
+    def device_ptr(self):
+        return lib().te_vec_device_ptr(self.h)
+
+    def set(self, alpha): check(lib().te_vec_set(self.h, alpha))
+    def scale(self, alpha): check(lib().te_vec_scale(self.h, alpha))
+    def shift(self, delta): check(lib().te_vec_shift(self.h, delta))
+    def copy(self, b): check(lib().te_vec_copy(self.h, b.h))
+    def add(self, b): check(lib().te_vec_add(self.h, b.h))
+
+    def addScaled(self, alpha, a, beta=None, b=None):
+        if b is None:
+            check(lib().te_vec_add_scaled(self.h, alpha, a.h))
+        else:
+            check(lib().te_vec_add_scaled2(self.h, alpha, a.h, beta, b.h))
+
+    def scaleThenAdd(self, alpha, b): check(lib().te_vec_scale_then_add(self.h, alpha, b.h))
+
+    def scaleThenAddScaled(self, alpha, beta, b, gamma=None, c=None):
+        if c is None:
+            check(lib().te_vec_scale_then_add_scaled(self.h, alpha, beta, b.h))
+        else:
+            check(lib().te_vec_scale_then_add_scaled2(self.h, alpha, beta, b.h, gamma, c.h))
+
+    def twoNormSqLocal(self):
+        out = C.c_double()
+        check(lib().te_vec_two_norm_sq(self.h, C.byref(out)))
+        return out.value
+
+    def twoNorm(self):
+        return float(np.sqrt(self.twoNormSqLocal()))
+
+    def infNorm(self):
+        out = C.c_double()
+        check(lib().te_vec_inf_norm(self.h, C.byref(out)))
+        return out.value
+
+    def dot(self, b):
+        out = C.c_double()
+        check(lib().te_vec_dot(self.h, b.h, C.byref(out)))
+        return out.value
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None and getattr(self.gmg, "h", None):
+            _lib.te_vec_destroy(self.h)
+            self.h = None
+
+
+class GMG:
+    """Device-resident level stack: the product of CycleFactory3d::getCycle (CycleFactory3d.cpp:69-134).
+
+    apply / smooth / restrict / interpolate / cycle carry the reference plugin names
+    (Operator::apply, Smoother::smooth, Restrictor::restrict, Interpolator::interpolate,
+    Cycle::apply)."""
+
+    def __init__(self, hier, device=-1):
+        self.hier = hier
+        self.h = C.c_void_p()
+        check(lib().te_gmg_create(hier.h, device, C.byref(self.h)))
+        self.num_levels = lib().te_gmg_num_levels(self.h)
+        self._cb = None
+
+    @staticmethod
+    def default_opts(**kw):
+        o = CycleOpts()
+        lib().te_cycle_opts_default(C.byref(o))
+        for k, v in kw.items():
+            if not hasattr(o, k):
+                raise AttributeError(k)
+            setattr(o, k, v)
+        return o
+
+    def new_vector(self, level=0, data=None):
+        return Vec(self, level, data)
+
+    def sync(self):
+        check(lib().te_gmg_sync(self.h))
+
+    def stream(self):
+        return lib().te_gmg_stream(self.h)
+
+    def apply(self, u, f, level=0): check(lib().te_apply(self.h, level, u.h, f.h))
+    def residual(self, u, f, r, level=0): check(lib().te_residual(self.h, level, u.h, f.h, r.h))
+
+    def smooth(self, f, u, level=0, smoother=SMOOTH_PATCH_SOLVE, omega=6.0 / 7.0, sweeps=1):
+        check(lib().te_smooth(self.h, level, f.h, u.h, smoother, omega, sweeps))
+
+    def restrict(self, coarse, fine, fine_level=0): check(lib().te_restrict(self.h, fine_level, fine.h, coarse.h))
+    def interpolate(self, coarse, fine, fine_level=0): check(lib().te_prolong_add(self.h, fine_level, coarse.h, fine.h))
+    def cycle(self, opts, f, u): check(lib().te_vcycle(self.h, C.byref(opts), f.h, u.h))
+
+    def bicgstab(self, x, b, opts=None, max_it=1000, tol=1e-12):
+        its, rr = C.c_int(), C.c_double()
+        check(lib().te_bicgstab(self.h, C.byref(opts) if opts is not None else None, x.h, b.h, max_it, tol,
+                                C.byref(its), C.byref(rr)))
+        return its.value, rr.value
+
+    def profile(self, enable=True): check(lib().te_gmg_profile(self.h, int(enable)))
+    def profile_reset(self): check(lib().te_gmg_profile_reset(self.h))
+
+    def profile_rows(self):
+        names = (C.c_char * 64 * 32)()
+        calls = (C.c_int64 * 32)()
+        ms = (C.c_double * 32)()
+        n = lib().te_gmg_profile_rows(self.h, 32, names, calls, ms)
+        if n < 0:
+            check(n)
+        return {bytes(names[i]).split(b"\0")[0].decode(): (calls[i], ms[i]) for i in range(n)}
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.te_gmg_destroy(self.h)
+            self.h = None

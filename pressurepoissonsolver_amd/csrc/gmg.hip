@@ -1,0 +1,891 @@
+// Device half of include/te_hip.h: level stack on the GPU, kernel launches, V/W cycle,
+// BiCGStab. Host C++ + HIP for gfx950 only. There is no CPU fallback anywhere in this file:
+// if HIP cannot give us a device, te_gmg_create fails with TE_EHIP.
+#include "capi_common.hpp"
+#include "kernels3d.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+using namespace te;
+
+#define HIPCHK(expr)                                                                              \
+	do {                                                                                          \
+		hipError_t _e = (expr);                                                                   \
+		if (_e != hipSuccess)                                                                     \
+			return te::fail(TE_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+	} while (0)
+
+struct te_vec {
+	te_gmg *g     = nullptr;
+	int     level = 0;
+	double *d     = nullptr;
+	size_t  n     = 0;
+};
+
+namespace
+{
+enum KClass : int {
+	KC_APPLY, KC_RESID, KC_JACOBI, KC_RBGS, KC_CFGHOST, KC_RESTRICT, KC_PROLONG, KC_PATCH_RHS,
+	KC_DST, KC_VECOP, KC_REDUCE, KC_COUNT
+};
+const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_jacobi", "stencil_rbgs",
+                                    "cf_ghost", "restrict", "prolong_add", "patch_rhs", "dst_axis",
+                                    "vecop", "reduce"};
+
+template <typename T> struct DevBuf {
+	T     *p = nullptr;
+	size_t n = 0;
+	~DevBuf()
+	{
+		if (p) (void) hipFree(p);
+	}
+	int alloc(size_t count)
+	{
+		n = count;
+		if (count == 0) return TE_OK;
+		HIPCHK(hipMalloc(&p, sizeof(T) * count));
+		return TE_OK;
+	}
+	int upload(const std::vector<T> &h)
+	{
+		int rc = alloc(h.size());
+		if (rc) return rc;
+		if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+		return TE_OK;
+	}
+};
+
+struct LevelHost {
+	int    dim = 3, n = 0, P = 0;
+	size_t nc = 0, nf = 0;
+	// stencil tables
+	DevBuf<int32_t> face_kind, face_src;
+	DevBuf<double>  face_kadj, rh2, ghost;
+	int             nslots = 0;
+	// coarse/fine faces
+	int             ncf = 0;
+	DevBuf<int32_t> cf_desc, cf_slots;
+	// transfer to level+1
+	int             Pc = 0;
+	DevBuf<int32_t> parent, orth, child, copy;
+	// patch solve
+	DevBuf<int32_t> plan, zero_mode;
+	DevBuf<double>  mats, lam;
+	// scratch
+	std::unique_ptr<te_vec> u, f, r, t;
+
+	LevelDev dev() const
+	{
+		LevelDev L;
+		L.P         = P;
+		L.face_kind = face_kind.p;
+		L.face_src  = face_src.p;
+		L.face_kadj = face_kadj.p;
+		L.rh2       = rh2.p;
+		L.ghost     = ghost.p;
+		return L;
+	}
+};
+
+struct EventPair {
+	hipEvent_t a, b;
+	int        kc;
+};
+} // namespace
+
+struct te_gmg {
+	int                                     device = 0;
+	hipStream_t                             stream = nullptr;
+	int                                     dim = 3, n = 0;
+	std::vector<std::unique_ptr<LevelHost>> levels;
+	DevBuf<double>                          partial, result;
+	double                                 *result_host = nullptr; // pinned
+	int                                     red_blocks  = 1024;
+	te_exchange_fn                          exchange    = nullptr;
+	void                                   *exchange_user = nullptr;
+	// profiling
+	bool                   profiling = false;
+	std::vector<EventPair> ev_pool;
+	size_t                 ev_used = 0;
+	int64_t                calls[KC_COUNT];
+	double                 total_ms[KC_COUNT];
+};
+
+namespace
+{
+struct Timed {
+	te_gmg *g;
+	int     idx = -1;
+	Timed(te_gmg *g_, int kc) : g(g_)
+	{
+		if (!g->profiling) return;
+		if (g->ev_used == g->ev_pool.size()) {
+			EventPair e;
+			if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+			g->ev_pool.push_back(e);
+		}
+		idx                  = (int) g->ev_used++;
+		g->ev_pool[idx].kc   = kc;
+		(void) hipEventRecord(g->ev_pool[idx].a, g->stream);
+	}
+	~Timed()
+	{
+		if (idx >= 0) (void) hipEventRecord(g->ev_pool[idx].b, g->stream);
+	}
+};
+void drainEvents(te_gmg *g)
+{
+	if (g->ev_used == 0) return;
+	(void) hipStreamSynchronize(g->stream);
+	for (size_t i = 0; i < g->ev_used; i++) {
+		float ms = 0;
+		if (hipEventElapsedTime(&ms, g->ev_pool[i].a, g->ev_pool[i].b) == hipSuccess) {
+			g->calls[g->ev_pool[i].kc]++;
+			g->total_ms[g->ev_pool[i].kc] += ms;
+		}
+	}
+	g->ev_used = 0;
+}
+
+inline int gridFor(size_t work_items, int tpb, int cap = 4096)
+{
+	size_t b = (work_items + tpb - 1) / tpb;
+	if (b < 1) b = 1;
+	if (b > (size_t) cap) b = cap;
+	return (int) b;
+}
+
+// DftPatchSolver.h:237-289 (row-major: y_i = sum_j M[i*n+j] x_j)
+void transformMatrix(int type, int n, double *m)
+{
+	for (int i = 0; i < n * n; i++) m[i] = 0.0;
+	switch (type) {
+		case 0: // DCT-II
+			for (int i = 0; i < n; i++)
+				for (int j = 0; j < n; j++) m[i * n + j] = cos(M_PI / n * (i * (j + 0.5)));
+			break;
+		case 1: // DCT-III
+			for (int i = 0; i < n; i++) {
+				m[i * n] = 0.5;
+				for (int j = 1; j < n; j++) m[i * n + j] = cos(M_PI / n * ((i + 0.5) * j));
+			}
+			break;
+		case 2: // DCT-IV
+			for (int i = 0; i < n; i++)
+				for (int j = 0; j < n; j++) m[i * n + j] = cos(M_PI / n * ((i + 0.5) * (j + 0.5)));
+			break;
+		case 3: // DST-II
+			for (int i = 0; i < n; i++)
+				for (int j = 0; j < n; j++) m[i * n + j] = sin(M_PI / n * ((i + 1) * (j + 0.5)));
+			break;
+		case 4: // DST-III
+			for (int i = 0; i < n; i++) {
+				for (int j = 0; j < n - 1; j++) m[i * n + j] = sin(M_PI / n * ((i + 0.5) * (j + 1)));
+				m[i * n + n - 1] = (i & 1) ? -0.5 : 0.5;
+			}
+			break;
+		default: // DST-IV
+			for (int i = 0; i < n; i++)
+				for (int j = 0; j < n; j++) m[i * n + j] = sin(M_PI / n * ((i + 0.5) * (j + 0.5)));
+			break;
+	}
+}
+
+int buildLevel(te_gmg *g, const Hierarchy &H, int li)
+{
+	const Level &lv = H.levels[li];
+	if (H.nranks != 1) return te::fail(TE_EUNSUPPORTED, "te_gmg_create: multi-rank levels not built yet");
+	if (lv.dim != 3) return te::fail(TE_EUNSUPPORTED, "te_gmg_create: only dim == 3 has device kernels");
+	const int n = lv.n;
+	if (n != 4 && n != 8 && n != 16 && n != 32)
+		return te::fail(TE_EUNSUPPORTED, "te_gmg_create: n must be 4, 8, 16 or 32");
+	auto L = std::make_unique<LevelHost>();
+	L->dim = lv.dim;
+	L->n   = n;
+	L->P   = lv.P;
+	L->nc  = (size_t) n * n * n;
+	L->nf  = (size_t) n * n;
+	const int P = lv.P, NS = 6;
+
+	std::vector<int32_t> fk(P * NS), fs(P * NS, -1), cfd, cfs, plan(P, 0);
+	std::vector<double>  kadj(P * NS, 0.0), rh2(P * 3);
+	std::map<int, int>   plan_of_key;
+	std::vector<int>     keys;
+	int                  nslots = 0;
+	for (int p = 0; p < P; p++) {
+		const int gp  = lv.l2g[p];
+		int       key = 0;
+		for (int a = 0; a < 3; a++) {
+			double h       = lv.g_lengths[(size_t) gp * 3 + a] / n;
+			rh2[p * 3 + a] = 1.0 / (h * h);
+		}
+		for (int s = 0; s < NS; s++) {
+			const size_t gf   = (size_t) gp * NS + s;
+			const int    kind = lv.g_nbr_kind[gf];
+			if (kind == NBR_NONE) {
+				fk[p * NS + s]   = H.neumann ? FACE_NEUMANN : FACE_DIRICHLET;
+				kadj[p * NS + s] = H.neumann ? -1.0 : 1.0;
+				if (H.neumann) key |= 1 << s;
+			} else if (kind == NBR_NORMAL) {
+				fk[p * NS + s] = FACE_LOCAL;
+				fs[p * NS + s] = lv.g_local[lv.g_nbr[gf * 4]];
+			} else {
+				fk[p * NS + s]   = FACE_GHOST;
+				fs[p * NS + s]   = nslots;
+				kadj[p * NS + s] = (kind == NBR_COARSE) ? -5.0 / 6.0 : 1.0 / 3.0;
+				cfd.push_back(p);
+				cfd.push_back(s);
+				cfd.push_back(kind);
+				cfd.push_back(lv.g_nbr_orth[gf]);
+				for (int q = 0; q < 4; q++) {
+					int nb = lv.g_nbr[gf * 4 + q];
+					cfd.push_back(nb >= 0 ? lv.g_local[nb] : -1);
+				}
+				cfs.push_back(nslots);
+				nslots++;
+			}
+		}
+		auto it = plan_of_key.find(key);
+		if (it == plan_of_key.end()) {
+			plan_of_key[key] = (int) keys.size();
+			plan[p]          = (int) keys.size();
+			keys.push_back(key);
+		} else {
+			plan[p] = it->second;
+		}
+	}
+	L->nslots = nslots;
+	L->ncf    = (int) cfs.size();
+	int rc;
+	if ((rc = L->face_kind.upload(fk)) || (rc = L->face_src.upload(fs)) || (rc = L->face_kadj.upload(kadj))
+	    || (rc = L->rh2.upload(rh2)) || (rc = L->cf_desc.upload(cfd)) || (rc = L->cf_slots.upload(cfs))
+	    || (rc = L->ghost.alloc((size_t) std::max(nslots, 1) * L->nf)))
+		return rc;
+
+	// patch-solve plans (FftwPatchSolver.h:93-172: transform kinds per axis, eigenvalues)
+	{
+		const int            np = (int) keys.size();
+		std::vector<double>  mats((size_t) np * 6 * n * n), lam((size_t) np * 3 * n);
+		std::vector<int32_t> zm(np, 0);
+		for (int k = 0; k < np; k++) {
+			const int key = keys[k];
+			zm[k]         = (key == 63);
+			for (int a = 0; a < 3; a++) {
+				bool lo = (key >> (2 * a)) & 1, hi = (key >> (2 * a + 1)) & 1;
+				int  tf, ti;
+				if (lo && hi) {
+					tf = 0;
+					ti = 1;
+				} else if (lo) {
+					tf = ti = 2;
+				} else if (hi) {
+					tf = ti = 5;
+				} else {
+					tf = 3;
+					ti = 4;
+				}
+				transformMatrix(tf, n, &mats[((size_t) k * 6 + a) * n * n]);
+				transformMatrix(ti, n, &mats[((size_t) k * 6 + 3 + a) * n * n]);
+				for (int i = 0; i < n; i++) {
+					double s;
+					if (lo && hi)
+						s = sin(i * M_PI / (2 * n));
+					else if (lo || hi)
+						s = sin((i + 0.5) * M_PI / (2 * n));
+					else
+						s = sin((i + 1) * M_PI / (2 * n));
+					lam[((size_t) k * 3 + a) * n + i] = 4 * s * s;
+				}
+			}
+		}
+		if ((rc = L->plan.upload(plan)) || (rc = L->mats.upload(mats)) || (rc = L->lam.upload(lam))
+		    || (rc = L->zero_mode.upload(zm)))
+			return rc;
+	}
+
+	// transfers
+	if (li + 1 < (int) H.levels.size()) {
+		const Level         &cv = H.levels[li + 1];
+		std::vector<int32_t> parent(P), orth(P), child((size_t) cv.P * 8, -1), copy(cv.P, 0);
+		for (int p = 0; p < P; p++) {
+			const int gp = lv.l2g[p];
+			const int pc = cv.g_local[lv.g_parent[gp]];
+			parent[p]    = pc;
+			orth[p]      = lv.g_orth_on_parent[gp];
+			if (orth[p] < 0) {
+				copy[pc]                = 1;
+				child[(size_t) pc * 8] = p;
+			} else {
+				child[(size_t) pc * 8 + orth[p]] = p;
+			}
+		}
+		for (int pc = 0; pc < cv.P; pc++) {
+			if (copy[pc]) continue;
+			for (int o = 0; o < 8; o++)
+				if (child[(size_t) pc * 8 + o] < 0)
+					return te::fail(TE_EINVAL, "te_gmg_create: coarse patch with a missing child");
+		}
+		L->Pc = cv.P;
+		if ((rc = L->parent.upload(parent)) || (rc = L->orth.upload(orth)) || (rc = L->child.upload(child))
+		    || (rc = L->copy.upload(copy)))
+			return rc;
+	}
+	g->levels.push_back(std::move(L));
+	return TE_OK;
+}
+
+int newVec(te_gmg *g, int level, te_vec **out)
+{
+	LevelHost &L = *g->levels[level];
+	auto       v = new te_vec;
+	v->g         = g;
+	v->level     = level;
+	v->n         = (size_t) L.P * L.nc;
+	hipError_t e = hipMalloc(&v->d, sizeof(double) * std::max<size_t>(v->n, 2));
+	if (e != hipSuccess) {
+		delete v;
+		return te::fail(TE_EHIP, std::string("hipMalloc(vector): ") + hipGetErrorString(e));
+	}
+	e = hipMemsetAsync(v->d, 0, sizeof(double) * v->n, g->stream);
+	if (e != hipSuccess) {
+		(void) hipFree(v->d);
+		delete v;
+		return te::fail(TE_EHIP, std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+	}
+	*out = v;
+	return TE_OK;
+}
+
+inline bool sameShape(const te_vec *a, const te_vec *b) { return a && b && a->g == b->g && a->level == b->level; }
+
+// ------------------------------------------------------------------------------ launches
+template <int N> int launchCfGhost(te_gmg *g, LevelHost &L, const double *u)
+{
+	if (L.ncf == 0) return TE_OK;
+	Timed t(g, KC_CFGHOST);
+	hipLaunchKernelGGL(k_cf_ghost3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
+	                   L.cf_slots.p, u, L.ghost.p);
+	return TE_OK;
+}
+template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out,
+                                              double omega)
+{
+	int rc = launchCfGhost<N>(g, L, u);
+	if (rc) return rc;
+	Timed     t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : KC_JACOBI));
+	const int tpb = Tile<N>::TPB;
+	// enough workgroups to fill 256 CUs a few times over: split patches into z-slabs when few
+	int zs = 1;
+	if (N >= 8) {
+		while (zs < 4 && (size_t) L.P * zs < 2048 && N / (zs * 2) >= 4) zs *= 2;
+	}
+	auto grid = [&](int z) { return dim3(8 * ((L.P * z + 7) / 8)); };
+	LevelDev D = L.dev();
+	switch (zs) {
+		case 1: hipLaunchKernelGGL((k_stencil3d<N, MODE, 1>), grid(1), dim3(tpb), 0, g->stream, D, u, f, out, omega); break;
+		case 2:
+			if constexpr (N >= 8)
+				hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega);
+			break;
+		default:
+			if constexpr (N >= 16)
+				hipLaunchKernelGGL((k_stencil3d<N, MODE, 4>), grid(4), dim3(tpb), 0, g->stream, D, u, f, out, omega);
+			else if constexpr (N >= 8)
+				hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega);
+			break;
+	}
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega)
+{
+	if (L.P == 0) return TE_OK;
+	switch (L.n) {
+		case 4: return launchStencilN<4, MODE>(g, L, u, f, out, omega);
+		case 8: return launchStencilN<8, MODE>(g, L, u, f, out, omega);
+		case 16: return launchStencilN<16, MODE>(g, L, u, f, out, omega);
+		default: return launchStencilN<32, MODE>(g, L, u, f, out, omega);
+	}
+}
+template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out)
+{
+	int rc = launchCfGhost<N>(g, L, u);
+	if (rc) return rc;
+	Timed t(g, KC_RBGS);
+	hipLaunchKernelGGL(k_rbgs3d<N>, dim3(8 * ((L.P + 7) / 8)), dim3(Tile<N>::TPB), 0, g->stream, L.dev(), u, f, out);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out)
+{
+	if (L.P == 0) return TE_OK;
+	switch (L.n) {
+		case 4: return launchRbgsN<4>(g, L, u, f, out);
+		case 8: return launchRbgsN<8>(g, L, u, f, out);
+		case 16: return launchRbgsN<16>(g, L, u, f, out);
+		default: return launchRbgsN<32>(g, L, u, f, out);
+	}
+}
+template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1)
+{
+	int rc = launchCfGhost<N>(g, L, u);
+	if (rc) return rc;
+	const size_t total = (size_t) L.P * L.nc;
+	{
+		Timed t(g, KC_PATCH_RHS);
+		hipLaunchKernelGGL(k_patch_rhs3d<N>, dim3(gridFor(total, 256)), dim3(256), 0, g->stream, L.dev(), u, f, s0);
+	}
+	constexpr int BPP = (N * N * N + 255) / 256;
+	const dim3    grid(L.P * BPP), blk(256);
+#define TE_DST(STAGE, IN, OUT)                                                                                \
+	{                                                                                                         \
+		Timed t(g, KC_DST);                                                                                   \
+		hipLaunchKernelGGL((k_dst_axis3d<N, STAGE>), grid, blk, 0, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p, \
+		                   L.zero_mode.p, L.rh2.p, IN, OUT);                                                  \
+	}
+	TE_DST(0, s0, s1)
+	TE_DST(1, s1, s0)
+	TE_DST(2, s0, s1)
+	TE_DST(3, s1, s0)
+	TE_DST(4, s0, s1)
+	TE_DST(5, s1, u)
+#undef TE_DST
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+int patchSolve(te_gmg *g, LevelHost &L, const double *f, double *u)
+{
+	if (L.P == 0) return TE_OK;
+	double *s0 = L.r->d, *s1 = L.t->d;
+	switch (L.n) {
+		case 4: return patchSolveN<4>(g, L, f, u, s0, s1);
+		case 8: return patchSolveN<8>(g, L, f, u, s0, s1);
+		case 16: return patchSolveN<16>(g, L, f, u, s0, s1);
+		default: return patchSolveN<32>(g, L, f, u, s0, s1);
+	}
+}
+template <int N> int restrictN(te_gmg *g, LevelHost &L, const double *fine, double *coarse)
+{
+	Timed t(g, KC_RESTRICT);
+	hipLaunchKernelGGL(k_restrict3d<N>, dim3(gridFor((size_t) L.Pc * L.nc, 256)), dim3(256), 0, g->stream, L.Pc,
+	                   L.child.p, L.copy.p, fine, coarse);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+template <int N> int prolongN(te_gmg *g, LevelHost &L, const double *coarse, double *fine)
+{
+	Timed t(g, KC_PROLONG);
+	hipLaunchKernelGGL(k_prolong3d<N>, dim3(gridFor((size_t) L.P * L.nc / 2, 256)), dim3(256), 0, g->stream, L.P,
+	                   L.parent.p, L.orth.p, coarse, fine);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+template <int OP> int vecop(te_vec *v, const te_vec *a, const te_vec *b, double alpha, double beta, double gamma)
+{
+	if (!v || (OP >= VOP_COPY && !sameShape(v, a))
+	    || ((OP == VOP_ADD_SCALED2 || OP == VOP_SCALE_THEN_ADD_SCALED2) && !sameShape(v, b)))
+		return te::fail(TE_EINVAL, "te_vec_*: vectors of different levels");
+	if (v->n == 0) return TE_OK;
+	te_gmg *g = v->g;
+	Timed   t(g, KC_VECOP);
+	hipLaunchKernelGGL(k_vecop<OP>, dim3(gridFor(v->n / 2, 256, 2048)), dim3(256), 0, g->stream, v->n / 2,
+	                   reinterpret_cast<double2 *>(v->d), a ? reinterpret_cast<const double2 *>(a->d) : nullptr,
+	                   b ? reinterpret_cast<const double2 *>(b->d) : nullptr, alpha, beta, gamma);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+template <int OP> int reduce(const te_vec *a, const te_vec *b, double *out)
+{
+	if (!a || !out || (OP == RED_DOT && !sameShape(a, b))) return te::fail(TE_EINVAL, "te_vec reduce: bad argument");
+	te_gmg *g = a->g;
+	if (a->n == 0) {
+		*out = 0.0;
+		return TE_OK;
+	}
+	const int blocks = gridFor(a->n / 2, 256, g->red_blocks);
+	{
+		Timed t(g, KC_REDUCE);
+		hipLaunchKernelGGL(k_reduce<OP>, dim3(blocks), dim3(256), 0, g->stream, a->n / 2,
+		                   reinterpret_cast<const double2 *>(a->d),
+		                   b ? reinterpret_cast<const double2 *>(b->d) : nullptr, g->partial.p);
+		hipLaunchKernelGGL(k_reduce_final<OP>, dim3(1), dim3(256), 0, g->stream, blocks, g->partial.p, g->result.p);
+	}
+	HIPCHK(hipMemcpyAsync(g->result_host, g->result.p, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+	HIPCHK(hipStreamSynchronize(g->stream));
+	*out = g->result_host[0];
+	return TE_OK;
+}
+
+void swapData(te_vec *a, te_vec *b) { std::swap(a->d, b->d); }
+
+int smoothOnce(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega)
+{
+	LevelHost &L = *g->levels[level];
+	int        rc;
+	switch (smoother) {
+		case TE_SMOOTH_PATCH_SOLVE: return patchSolve(g, L, f->d, u->d);
+		case TE_SMOOTH_JACOBI:
+			rc = launchStencil<MODE_JACOBI>(g, L, u->d, f->d, L.t->d, omega);
+			if (rc) return rc;
+			swapData(u, L.t.get());
+			return TE_OK;
+		case TE_SMOOTH_RBGS:
+			rc = launchRbgs(g, L, u->d, f->d, L.t->d);
+			if (rc) return rc;
+			swapData(u, L.t.get());
+			return TE_OK;
+		default: return te::fail(TE_EINVAL, "te_smooth: unknown smoother");
+	}
+}
+int doRestrict(te_gmg *g, int fine_level, const double *fine, double *coarse)
+{
+	LevelHost &L = *g->levels[fine_level];
+	if (L.Pc == 0) return TE_OK;
+	switch (L.n) {
+		case 4: return restrictN<4>(g, L, fine, coarse);
+		case 8: return restrictN<8>(g, L, fine, coarse);
+		case 16: return restrictN<16>(g, L, fine, coarse);
+		default: return restrictN<32>(g, L, fine, coarse);
+	}
+}
+int doProlong(te_gmg *g, int fine_level, const double *coarse, double *fine)
+{
+	LevelHost &L = *g->levels[fine_level];
+	if (L.P == 0) return TE_OK;
+	switch (L.n) {
+		case 4: return prolongN<4>(g, L, coarse, fine);
+		case 8: return prolongN<8>(g, L, coarse, fine);
+		case 16: return prolongN<16>(g, L, coarse, fine);
+		default: return prolongN<32>(g, L, coarse, fine);
+	}
+}
+
+// GMG/VCycle.h:44-62, GMG/WCycle.h:45-68, GMG/Cycle.h:56-90
+int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u)
+{
+	const int  nl       = (int) g->levels.size();
+	const bool coarsest = (l == nl - 1);
+	LevelHost &L        = *g->levels[l];
+	int        rc;
+	auto       smooth = [&](int sweeps, bool at_coarsest) -> int {
+        int sm = o->smoother;
+        if (at_coarsest && o->exact_coarse && L.P == 1) sm = TE_SMOOTH_PATCH_SOLVE;
+        for (int i = 0; i < sweeps; i++) {
+            int r = smoothOnce(g, l, f, u, sm, o->omega);
+            if (r) return r;
+        }
+        return TE_OK;
+	};
+	if (coarsest) return smooth(o->coarse_sweeps, true);
+	LevelHost &C       = *g->levels[l + 1];
+	auto       descend = [&]() -> int {
+        int r = launchStencil<MODE_RESID>(g, L, u->d, f->d, L.r->d, 0.0); // prepCoarser: r = f - A u
+        if (r) return r;
+        if ((r = doRestrict(g, l, L.r->d, C.f->d))) return r;
+        if ((r = vecop<VOP_SET>(C.u.get(), nullptr, nullptr, 0.0, 0.0, 0.0))) return r;
+        if ((r = visit(g, o, l + 1, C.f.get(), C.u.get()))) return r;
+        return doProlong(g, l, C.u->d, u->d); // prepFiner
+	};
+	if ((rc = smooth(o->pre_sweeps, false))) return rc;
+	if ((rc = descend())) return rc;
+	if (o->cycle_type == 1) {
+		if ((rc = smooth(o->mid_sweeps, false))) return rc;
+		if ((rc = descend())) return rc;
+	}
+	return smooth(o->post_sweeps, false);
+}
+} // namespace
+
+extern "C" {
+void te_cycle_opts_default(te_cycle_opts *o)
+{
+	if (!o) return;
+	o->pre_sweeps = o->post_sweeps = o->coarse_sweeps = o->mid_sweeps = 1; // CycleOpts.h:64-79
+	o->cycle_type   = 0;
+	o->smoother     = TE_SMOOTH_PATCH_SOLVE;
+	o->omega        = 6.0 / 7.0;
+	o->exact_coarse = 1;
+	o->fuse         = 0;
+}
+
+int te_gmg_create(const te_hier *h, int device, te_gmg **out)
+{
+	if (!h || !out) return te::fail(TE_EINVAL, "te_gmg_create: null argument");
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+		return te::fail(TE_EHIP, "te_gmg_create: no HIP device visible (this library has no CPU fallback)");
+	if (device < 0) HIPCHK(hipGetDevice(&device));
+	HIPCHK(hipSetDevice(device));
+	auto g    = std::make_unique<te_gmg>();
+	g->device = device;
+	g->dim    = h->h.dim;
+	g->n      = h->h.n;
+	memset(g->calls, 0, sizeof(g->calls));
+	memset(g->total_ms, 0, sizeof(g->total_ms));
+	HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+	int rc;
+	for (int li = 0; li < (int) h->h.levels.size(); li++)
+		if ((rc = buildLevel(g.get(), h->h, li))) return rc;
+	if ((rc = g->partial.alloc(g->red_blocks)) || (rc = g->result.alloc(8))) return rc;
+	HIPCHK(hipHostMalloc((void **) &g->result_host, 8 * sizeof(double), hipHostMallocDefault));
+	for (int li = 0; li < (int) g->levels.size(); li++) {
+		LevelHost &L = *g->levels[li];
+		te_vec    *v;
+		if ((rc = newVec(g.get(), li, &v))) return rc;
+		L.r.reset(v);
+		if ((rc = newVec(g.get(), li, &v))) return rc;
+		L.t.reset(v);
+		if (li > 0) {
+			if ((rc = newVec(g.get(), li, &v))) return rc;
+			L.u.reset(v);
+			if ((rc = newVec(g.get(), li, &v))) return rc;
+			L.f.reset(v);
+		}
+	}
+	HIPCHK(hipStreamSynchronize(g->stream));
+	*out = g.release();
+	return TE_OK;
+}
+void te_gmg_destroy(te_gmg *g)
+{
+	if (!g) return;
+	(void) hipStreamSynchronize(g->stream);
+	for (auto &L : g->levels) {
+		for (te_vec *v : {L->u.get(), L->f.get(), L->r.get(), L->t.get()})
+			if (v && v->d) (void) hipFree(v->d);
+	}
+	for (auto &e : g->ev_pool) {
+		(void) hipEventDestroy(e.a);
+		(void) hipEventDestroy(e.b);
+	}
+	if (g->result_host) (void) hipHostFree(g->result_host);
+	(void) hipStreamDestroy(g->stream);
+	delete g;
+}
+int   te_gmg_num_levels(const te_gmg *g) { return g ? (int) g->levels.size() : TE_EINVAL; }
+int   te_gmg_sync(te_gmg *g)
+{
+	if (!g) return te::fail(TE_EINVAL, "te_gmg_sync: null");
+	HIPCHK(hipStreamSynchronize(g->stream));
+	return TE_OK;
+}
+void *te_gmg_stream(te_gmg *g) { return g ? (void *) g->stream : nullptr; }
+int   te_gmg_set_exchange(te_gmg *g, te_exchange_fn fn, void *user)
+{
+	if (!g) return te::fail(TE_EINVAL, "te_gmg_set_exchange: null");
+	g->exchange      = fn;
+	g->exchange_user = user;
+	return TE_OK;
+}
+
+int te_vec_create(te_gmg *g, int level, te_vec **out)
+{
+	if (!g || !out || level < 0 || level >= (int) g->levels.size())
+		return te::fail(TE_EINVAL, "te_vec_create: bad argument");
+	HIPCHK(hipSetDevice(g->device));
+	return newVec(g, level, out);
+}
+void te_vec_destroy(te_vec *v)
+{
+	if (!v) return;
+	(void) hipStreamSynchronize(v->g->stream);
+	(void) hipFree(v->d);
+	delete v;
+}
+size_t te_vec_size(const te_vec *v) { return v ? v->n : 0; }
+int    te_vec_upload(te_vec *v, const double *host)
+{
+	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_upload: null");
+	HIPCHK(hipMemcpyAsync(v->d, host, sizeof(double) * v->n, hipMemcpyHostToDevice, v->g->stream));
+	HIPCHK(hipStreamSynchronize(v->g->stream));
+	return TE_OK;
+}
+int te_vec_download(const te_vec *v, double *host)
+{
+	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_download: null");
+	HIPCHK(hipMemcpyAsync(host, v->d, sizeof(double) * v->n, hipMemcpyDeviceToHost, v->g->stream));
+	HIPCHK(hipStreamSynchronize(v->g->stream));
+	return TE_OK;
+}
+void *te_vec_device_ptr(te_vec *v) { return v ? v->d : nullptr; }
+
+int te_vec_set(te_vec *v, double a) { return vecop<VOP_SET>(v, nullptr, nullptr, a, 0, 0); }
+int te_vec_scale(te_vec *v, double a) { return vecop<VOP_SCALE>(v, nullptr, nullptr, a, 0, 0); }
+int te_vec_shift(te_vec *v, double d) { return vecop<VOP_SHIFT>(v, nullptr, nullptr, d, 0, 0); }
+int te_vec_copy(te_vec *v, const te_vec *b) { return vecop<VOP_COPY>(v, b, nullptr, 0, 0, 0); }
+int te_vec_add(te_vec *v, const te_vec *b) { return vecop<VOP_ADD>(v, b, nullptr, 0, 0, 0); }
+int te_vec_add_scaled(te_vec *v, double a, const te_vec *b) { return vecop<VOP_ADD_SCALED>(v, b, nullptr, a, 0, 0); }
+int te_vec_add_scaled2(te_vec *v, double alpha, const te_vec *a, double beta, const te_vec *b)
+{
+	return vecop<VOP_ADD_SCALED2>(v, a, b, alpha, beta, 0);
+}
+int te_vec_scale_then_add(te_vec *v, double a, const te_vec *b) { return vecop<VOP_SCALE_THEN_ADD>(v, b, nullptr, a, 0, 0); }
+int te_vec_scale_then_add_scaled(te_vec *v, double a, double be, const te_vec *b)
+{
+	return vecop<VOP_SCALE_THEN_ADD_SCALED>(v, b, nullptr, a, be, 0);
+}
+int te_vec_scale_then_add_scaled2(te_vec *v, double a, double be, const te_vec *b, double ga, const te_vec *c)
+{
+	return vecop<VOP_SCALE_THEN_ADD_SCALED2>(v, b, c, a, be, ga);
+}
+int te_vec_two_norm_sq(const te_vec *v, double *out) { return reduce<RED_SUMSQ>(v, nullptr, out); }
+int te_vec_inf_norm(const te_vec *v, double *out) { return reduce<RED_MAXABS>(v, nullptr, out); }
+int te_vec_dot(const te_vec *v, const te_vec *b, double *out) { return reduce<RED_DOT>(v, b, out); }
+
+static int checkLevelVec(te_gmg *g, int level, const te_vec *v, const char *who)
+{
+	if (!g || !v || level < 0 || level >= (int) g->levels.size() || v->g != g || v->level != level)
+		return te::fail(TE_EINVAL, std::string(who) + ": vector does not belong to this level");
+	return TE_OK;
+}
+int te_apply(te_gmg *g, int level, const te_vec *u, te_vec *f)
+{
+	int rc;
+	if ((rc = checkLevelVec(g, level, u, "te_apply")) || (rc = checkLevelVec(g, level, f, "te_apply"))) return rc;
+	if (u == f) return te::fail(TE_EINVAL, "te_apply: in-place apply is not supported");
+	return launchStencil<MODE_APPLY>(g, *g->levels[level], u->d, nullptr, f->d, 0.0);
+}
+int te_residual(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *r)
+{
+	int rc;
+	if ((rc = checkLevelVec(g, level, u, "te_residual")) || (rc = checkLevelVec(g, level, f, "te_residual"))
+	    || (rc = checkLevelVec(g, level, r, "te_residual")))
+		return rc;
+	if (u == r) return te::fail(TE_EINVAL, "te_residual: r must not alias u");
+	return launchStencil<MODE_RESID>(g, *g->levels[level], u->d, f->d, r->d, 0.0);
+}
+int te_smooth(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega, int sweeps)
+{
+	int rc;
+	if ((rc = checkLevelVec(g, level, u, "te_smooth")) || (rc = checkLevelVec(g, level, f, "te_smooth"))) return rc;
+	for (int i = 0; i < sweeps; i++)
+		if ((rc = smoothOnce(g, level, f, u, smoother, omega))) return rc;
+	return TE_OK;
+}
+int te_restrict(te_gmg *g, int fine_level, const te_vec *fine, te_vec *coarse)
+{
+	int rc;
+	if ((rc = checkLevelVec(g, fine_level, fine, "te_restrict"))
+	    || (rc = checkLevelVec(g, fine_level + 1, coarse, "te_restrict")))
+		return rc;
+	return doRestrict(g, fine_level, fine->d, coarse->d);
+}
+int te_prolong_add(te_gmg *g, int fine_level, const te_vec *coarse, te_vec *fine)
+{
+	int rc;
+	if ((rc = checkLevelVec(g, fine_level, fine, "te_prolong_add"))
+	    || (rc = checkLevelVec(g, fine_level + 1, coarse, "te_prolong_add")))
+		return rc;
+	return doProlong(g, fine_level, coarse->d, fine->d);
+}
+int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u)
+{
+	int rc;
+	if (!o) return te::fail(TE_EINVAL, "te_vcycle: null options");
+	if ((rc = checkLevelVec(g, 0, f, "te_vcycle")) || (rc = checkLevelVec(g, 0, u, "te_vcycle"))) return rc;
+	if ((rc = te_vec_set(u, 0.0))) return rc; // Cycle.h:118
+	return visit(g, o, 0, f, u);
+}
+
+// BiCGStab.h:45-106, statement for statement, on device vectors
+int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, int max_it, double tol,
+                int *iterations, double *rel_resid)
+{
+	int rc;
+	if ((rc = checkLevelVec(g, 0, x, "te_bicgstab")) || (rc = checkLevelVec(g, 0, b, "te_bicgstab"))) return rc;
+	te_vec *w[8] = {nullptr};
+	for (auto &p : w)
+		if ((rc = newVec(g, 0, &p))) return rc;
+	te_vec *resid = w[0], *ms = w[1], *mp = w[2], *rhat = w[3], *p = w[4], *ap = w[5], *as = w[6], *s = w[7];
+	auto    done = [&](int code) {
+        for (auto q : w) te_vec_destroy(q);
+        return code;
+	};
+	double r0sq, rsq, rho, tmp, tmp2;
+#define TE_TRY(x)                \
+	if ((rc = (x))) return done(rc)
+	TE_TRY(te_apply(g, 0, x, resid));
+	TE_TRY(te_vec_scale_then_add(resid, -1, b));
+	TE_TRY(te_vec_two_norm_sq(resid, &r0sq));
+	const double r0_norm = sqrt(r0sq);
+	TE_TRY(te_vec_copy(rhat, resid));
+	TE_TRY(te_vec_copy(p, resid));
+	TE_TRY(te_vec_dot(rhat, resid, &rho));
+	int num_its = 0;
+	rsq         = r0sq;
+	while (sqrt(rsq) / r0_norm > tol && num_its < max_it) {
+		if (o) {
+			TE_TRY(te_vcycle(g, o, p, mp));
+			TE_TRY(te_apply(g, 0, mp, ap));
+		} else {
+			TE_TRY(te_apply(g, 0, p, ap));
+		}
+		TE_TRY(te_vec_dot(rhat, ap, &tmp));
+		const double alpha = rho / tmp;
+		TE_TRY(te_vec_copy(s, resid));
+		TE_TRY(te_vec_add_scaled(s, -alpha, ap));
+		if (o) {
+			TE_TRY(te_vcycle(g, o, s, ms));
+			TE_TRY(te_apply(g, 0, ms, as));
+		} else {
+			TE_TRY(te_apply(g, 0, s, as));
+		}
+		TE_TRY(te_vec_dot(as, s, &tmp));
+		TE_TRY(te_vec_dot(as, as, &tmp2));
+		const double omega = tmp / tmp2;
+		if (o) {
+			TE_TRY(te_vec_add_scaled2(x, alpha, mp, omega, ms));
+		} else {
+			TE_TRY(te_vec_add_scaled2(x, alpha, p, omega, s));
+		}
+		TE_TRY(te_vec_add_scaled2(resid, -alpha, ap, -omega, as));
+		double rho_new;
+		TE_TRY(te_vec_dot(resid, rhat, &rho_new));
+		const double beta = rho_new * alpha / (rho * omega);
+		TE_TRY(te_vec_add_scaled(p, -omega, ap));
+		TE_TRY(te_vec_scale_then_add(p, beta, resid));
+		num_its++;
+		rho = rho_new;
+		TE_TRY(te_vec_two_norm_sq(resid, &rsq));
+	}
+#undef TE_TRY
+	if (iterations) *iterations = num_its;
+	if (rel_resid) *rel_resid = sqrt(rsq) / r0_norm;
+	return done(TE_OK);
+}
+
+int te_gmg_profile(te_gmg *g, int enable)
+{
+	if (!g) return te::fail(TE_EINVAL, "te_gmg_profile: null");
+	drainEvents(g);
+	g->profiling = enable != 0;
+	return TE_OK;
+}
+int te_gmg_profile_reset(te_gmg *g)
+{
+	if (!g) return te::fail(TE_EINVAL, "te_gmg_profile_reset: null");
+	drainEvents(g);
+	memset(g->calls, 0, sizeof(g->calls));
+	memset(g->total_ms, 0, sizeof(g->total_ms));
+	return TE_OK;
+}
+int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *calls, double *total_ms)
+{
+	if (!g || !name || !calls || !total_ms) return te::fail(TE_EINVAL, "te_gmg_profile_rows: null");
+	drainEvents(g);
+	int n = 0;
+	for (int k = 0; k < KC_COUNT && n < max_rows; k++) {
+		if (g->calls[k] == 0) continue;
+		strncpy(name[n], kclassName[k], 63);
+		name[n][63] = 0;
+		calls[n]    = g->calls[k];
+		total_ms[n] = g->total_ms[k];
+		n++;
+	}
+	return n;
+}
+} // extern "C"
