@@ -95,13 +95,13 @@ __global__ __launch_bounds__(Tile<N>::TPB) void k_stencil3d(LevelDev L, const do
 	double       *op = out + (size_t) pid * NNN;
 
 	if (MODE == MODE_JACOBI) {
-		if (tid < 27) {
+		for (int e = tid; e < 27; e += TPB) { // TPB may be < 27 for tiny patches
 			const double *ka = L.face_kadj + (size_t) pid * 6;
-			int           cx = tid % 3, cy = (tid / 3) % 3, cz = tid / 9;
+			int           cx = e % 3, cy = (e / 3) % 3, cz = e / 9;
 			double        kx = 2.0 + (cx == 0 ? ka[0] : 0.0) + (cx == 2 ? ka[1] : 0.0);
 			double        ky = 2.0 + (cy == 0 ? ka[2] : 0.0) + (cy == 2 ? ka[3] : 0.0);
 			double        kz = 2.0 + (cz == 0 ? ka[4] : 0.0) + (cz == 2 ? ka[5] : 0.0);
-			idiag[tid]       = -1.0 / (kx * rhx + ky * rhy + kz * rhz);
+			idiag[e]         = -1.0 / (kx * rhx + ky * rhy + kz * rhz);
 		}
 	}
 
