@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""V-cycle lattice-site updates per second on the 512^3 uniform 3D Poisson problem
+(BASELINE.json metric), MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one GMG V(1,1) cycle (GMG/Cycle.h:116-126 semantics: zero u, pre-smooth, residual,
+restrict, recurse, prolong-add, post-smooth) over the whole 512^3 grid, 16^3 patches of 32^3
+(apps/3d/steady -n 32 --mesh 4uni.bin --divide 1). Inputs are resident in HBM before the timed
+region. N > 1: one rank per GPU (torch.distributed, backend nccl == RCCL); the same 512^3
+problem is sharded by contiguous Morton ranges of patches (strong scaling).
+
+The JSON line carries `roofline` for the dominant kernel (HIP-event timed on the solver stream
+inside the timed region) and `cpu_baseline` (the CPU restatement of the reference algorithm,
+oracle/, timed on this host's cores on a bounded sample; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is achievable
+
+# algorithmic (compulsory) HBM bytes per lattice site per launch, fp64 (DESIGN.md "Kernels")
+ALG_BYTES = {
+    "stencil_rbgs": 24.0,    # read u, f; write u
+    "stencil_jacobi": 24.0,
+    "stencil_resid": 24.0,   # read u, f; write r
+    "stencil_apply": 16.0,
+    "restrict": 9.0,         # read fine (8), write coarse (8/8)
+    "prolong_add": 17.0,     # read+write fine (16), read coarse (8/8)
+    "vecop": 8.0,
+    "patch_rhs": 24.0,
+    "dst_axis": 16.0,
+    "resid_restrict": 17.0,
+}
+
+
+def vcycle_alg_bytes_per_finest_cell(levels_cells, fused=False):
+    """per level V(1,1) 3D unfused = 2*24 + 24 + 9 + 1 + 17 = 99 B/cell,
+    coarsest level 24 B/cell; summed over levels per finest cell."""
+    total = 0.0
+    for i, c in enumerate(levels_cells):
+        total += (24.0 if i == len(levels_cells) - 1 else 99.0) * c
+    return total / levels_cells[0]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=512, help="cells per axis of the uniform grid (multiple of 32)")
+    ap.add_argument("--smoother", default="rbgs", choices=["rbgs", "jacobi", "patch_solve"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=128, help="cells per axis of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(sample, smoother_id):
+    """CPU restatement of the reference V-cycle (reference smoother = block-Jacobi patch solves)
+    on `sample`^3 cells with all host cores; a few cycles, bounded to ~10-30 s."""
+    from oracle import oracle as orc
+    from pressurepoissonsolver_amd import capi, problems
+    cores = os.cpu_count() or 1
+    div = int(round(np.log2(sample // 32)))
+    m = capi.Mesh.uniform(3, div)
+    H = capi.Hierarchy(m, 32)
+    levels = orc.levels_from_hierarchy(H)
+    f = problems.random_rhs(H.tables(0)["id"], 32 ** 3)
+    orc.set_threads(cores)
+    o = orc.cycle_opts(smoother=0)
+    orc.cycle(levels, o, f)  # warm
+    t0, reps = time.time(), 0
+    while reps < 3 or (time.time() - t0 < 10.0 and reps < 50):
+        orc.cycle(levels, o, f)
+        reps += 1
+    dt = (time.time() - t0) / reps
+    return {"value": levels[0].size / dt, "unit": "lattice-site updates/s", "cores": cores, "kind": "port",
+            "sample": f"{sample}^3 uniform, {levels[0].P} patches of 32^3, V(1,1) with the reference's "
+                      f"block-Jacobi patch-solve smoother, {reps} cycles, OpenMP over patches",
+            "ms_per_step": dt * 1e3}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from pressurepoissonsolver_amd import build
+    if rank == 0 or world == 1:
+        build.build_hip()
+    if dist is not None:
+        dist.barrier()
+    from pressurepoissonsolver_amd import capi, problems
+    from pressurepoissonsolver_amd import dist as tedist
+
+    n = 32
+    assert a.size % n == 0 and (a.size // n) & (a.size // n - 1) == 0, "--size must be 32 * 2^k"
+    div = int(round(np.log2(a.size // n)))
+    mesh = capi.Mesh.uniform(3, div)
+    H = capi.Hierarchy(mesh, n, rank=rank, nranks=world)
+    g = capi.GMG(H, device=local_rank)
+    if world > 1:
+        tedist.attach(g, dist)
+    sm = {"rbgs": capi.SMOOTH_RBGS, "jacobi": capi.SMOOTH_JACOBI, "patch_solve": capi.SMOOTH_PATCH_SOLVE}[a.smoother]
+    opts = g.default_opts(smoother=sm)
+
+    t = H.tables(0)
+    ids = t["id"][H.l2g(0)]
+    f = g.new_vector(0, problems.random_rhs(ids, n ** 3))
+    u = g.new_vector(0)
+    cells_global = [H.sizes(l)[1] * n ** 3 for l in range(H.num_levels)]
+
+    def barrier():
+        g.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        g.cycle(opts, f, u)
+    barrier()
+    g.profile(True)
+    g.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        g.cycle(opts, f, u)
+    barrier()
+    dt = time.perf_counter() - t0
+    rows = g.profile_rows()
+    g.profile(False)
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    ms_per_step = dt / a.steps * 1e3
+    value = cells_global[0] / (dt / a.steps)
+
+    # sanity: the cycle must actually reduce the residual (guards against timing a no-op)
+    r = g.new_vector(0)
+    g.residual(u, f, r)
+    rn, fn = r.twoNormSqLocal(), f.twoNormSqLocal()
+    if dist is not None:
+        tt = torch.tensor([rn, fn], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt)
+        rn, fn = tt.tolist()
+    reduction = float(np.sqrt(rn / fn))
+
+    if rank == 0:
+        dom = max(rows.items(), key=lambda kv: kv[1]["ms"])
+        name, st = dom
+        avg_ms = st["ms"] / st["calls"]
+        bytes_per_launch = ALG_BYTES.get(name, 24.0) * st["cells"] / st["calls"]
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(f"{name}:{a.size}:{world}")
+            except Exception:
+                traffic = None
+        b_alg = vcycle_alg_bytes_per_finest_cell(cells_global)
+        out = {
+            "metric": "V-cycle lattice-site updates/sec, 512^3 3D Poisson" if a.size == 512 else
+                      f"V-cycle lattice-site updates/sec, {a.size}^3 3D Poisson",
+            "value": value, "unit": "lattice-site updates/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"apps/3d/steady-equivalent: {a.size}^3 uniform, {cells_global[0] // n ** 3} "
+                                   f"patches of 32^3, {H.num_levels} levels, V(1,1), smoother={a.smoother}, "
+                                   "Dirichlet, f ~ U(-1,1) splitmix64(0x5EED + patch id)",
+                       "parallelism": f"patch-sharded x{world} (Morton ranges)", "levels": H.num_levels,
+                       "smoother": a.smoother, "residual_reduction_per_cycle": reduction},
+            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "avg_launch_ms": avg_ms, "launches": st["calls"],
+                         "alg_bytes_per_site": ALG_BYTES.get(name, 24.0)},
+            "vcycle_hbm": {"alg_bytes_per_finest_site": b_alg,
+                           "achieved_GBs": b_alg * cells_global[0] / (dt / a.steps) / 1e9,
+                           "frac_of_peak": b_alg * cells_global[0] / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world)},
+            "kernels": {k: {"calls": v["calls"], "ms": round(v["ms"], 4),
+                            "GBs": (ALG_BYTES.get(k, 0) * v["cells"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
+                        for k, v in rows.items()},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            build.build_oracle()
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample, sm)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -157,8 +157,10 @@ int te_gmg_set_exchange(te_gmg *g, te_exchange_fn fn, void *user);
 
 /* kernel timing hooks for bench.py: HIP-event time of the last te_vcycle's dominant kernel */
 int te_gmg_profile(te_gmg *g, int enable);
-/* name[i] (<=63 chars), calls[i], total_ms[i]; returns number of rows written (<= max_rows) */
-int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *calls, double *total_ms);
+/* name[i] (<=63 chars), calls[i], total_ms[i] (HIP events on the solver stream), cells[i]
+ * (lattice sites the launches processed); returns number of rows written (<= max_rows) */
+int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *calls, double *total_ms,
+                        int64_t *cells);
 int te_gmg_profile_reset(te_gmg *g);
 
 #ifdef __cplusplus

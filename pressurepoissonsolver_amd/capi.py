@@ -100,7 +100,7 @@ SYMBOLS = {
     "te_bicgstab": (_I, [_P, C.POINTER(CycleOpts), _P, _P, _I, _D, C.POINTER(_I), _PD]),
     "te_gmg_set_exchange": (_I, [_P, EXCHANGE_FN, _P]),
     "te_gmg_profile": (_I, [_P, _I]),
-    "te_gmg_profile_rows": (_I, [_P, _I, _P, _P, _P]),
+    "te_gmg_profile_rows": (_I, [_P, _I, _P, _P, _P, _P]),
     "te_gmg_profile_reset": (_I, [_P]),
 }
 
@@ -360,10 +360,12 @@ class GMG:
         names = (C.c_char * 64 * 32)()
         calls = (C.c_int64 * 32)()
         ms = (C.c_double * 32)()
-        n = lib().te_gmg_profile_rows(self.h, 32, names, calls, ms)
+        cells = (C.c_int64 * 32)()
+        n = lib().te_gmg_profile_rows(self.h, 32, names, calls, ms, cells)
         if n < 0:
             check(n)
-        return {bytes(names[i]).split(b"\0")[0].decode(): (calls[i], ms[i]) for i in range(n)}
+        return {bytes(names[i]).split(b"\0")[0].decode(): dict(calls=calls[i], ms=ms[i], cells=cells[i])
+                for i in range(n)}
 
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None:

@@ -112,6 +112,7 @@ struct te_gmg {
 	std::vector<EventPair> ev_pool;
 	size_t                 ev_used = 0;
 	int64_t                calls[KC_COUNT];
+	int64_t                cells[KC_COUNT]; // lattice sites processed
 	double                 total_ms[KC_COUNT];
 };
 
@@ -120,9 +121,10 @@ namespace
 struct Timed {
 	te_gmg *g;
 	int     idx = -1;
-	Timed(te_gmg *g_, int kc) : g(g_)
+	Timed(te_gmg *g_, int kc, size_t ncells = 0) : g(g_)
 	{
 		if (!g->profiling) return;
+		g->cells[kc] += (int64_t) ncells;
 		if (g->ev_used == g->ev_pool.size()) {
 			EventPair e;
 			if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -366,7 +368,7 @@ inline bool sameShape(const te_vec *a, const te_vec *b) { return a && b && a->g 
 template <int N> int launchCfGhost(te_gmg *g, LevelHost &L, const double *u)
 {
 	if (L.ncf == 0) return TE_OK;
-	Timed t(g, KC_CFGHOST);
+	Timed t(g, KC_CFGHOST, (size_t) L.ncf * L.nf);
 	hipLaunchKernelGGL(k_cf_ghost3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
 	                   L.cf_slots.p, u, L.ghost.p);
 	return TE_OK;
@@ -376,7 +378,7 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 {
 	int rc = launchCfGhost<N>(g, L, u);
 	if (rc) return rc;
-	Timed     t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : KC_JACOBI));
+	Timed     t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : KC_JACOBI), (size_t) L.P * L.nc);
 	const int tpb = Tile<N>::TPB;
 	// enough workgroups to fill 256 CUs a few times over: split patches into z-slabs when few
 	int zs = 1;
@@ -415,7 +417,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 {
 	int rc = launchCfGhost<N>(g, L, u);
 	if (rc) return rc;
-	Timed t(g, KC_RBGS);
+	Timed t(g, KC_RBGS, (size_t) L.P * L.nc);
 	hipLaunchKernelGGL(k_rbgs3d<N>, dim3(8 * ((L.P + 7) / 8)), dim3(Tile<N>::TPB), 0, g->stream, L.dev(), u, f, out);
 	HIPCHK(hipGetLastError());
 	return TE_OK;
@@ -436,14 +438,14 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 	if (rc) return rc;
 	const size_t total = (size_t) L.P * L.nc;
 	{
-		Timed t(g, KC_PATCH_RHS);
+		Timed t(g, KC_PATCH_RHS, total);
 		hipLaunchKernelGGL(k_patch_rhs3d<N>, dim3(gridFor(total, 256)), dim3(256), 0, g->stream, L.dev(), u, f, s0);
 	}
 	constexpr int BPP = (N * N * N + 255) / 256;
 	const dim3    grid(L.P * BPP), blk(256);
 #define TE_DST(STAGE, IN, OUT)                                                                                \
 	{                                                                                                         \
-		Timed t(g, KC_DST);                                                                                   \
+		Timed t(g, KC_DST, total);                                                                                 \
 		hipLaunchKernelGGL((k_dst_axis3d<N, STAGE>), grid, blk, 0, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p, \
 		                   L.zero_mode.p, L.rh2.p, IN, OUT);                                                  \
 	}
@@ -470,7 +472,7 @@ int patchSolve(te_gmg *g, LevelHost &L, const double *f, double *u)
 }
 template <int N> int restrictN(te_gmg *g, LevelHost &L, const double *fine, double *coarse)
 {
-	Timed t(g, KC_RESTRICT);
+	Timed t(g, KC_RESTRICT, (size_t) L.P * L.nc);
 	hipLaunchKernelGGL(k_restrict3d<N>, dim3(gridFor((size_t) L.Pc * L.nc, 256)), dim3(256), 0, g->stream, L.Pc,
 	                   L.child.p, L.copy.p, fine, coarse);
 	HIPCHK(hipGetLastError());
@@ -478,7 +480,7 @@ template <int N> int restrictN(te_gmg *g, LevelHost &L, const double *fine, doub
 }
 template <int N> int prolongN(te_gmg *g, LevelHost &L, const double *coarse, double *fine)
 {
-	Timed t(g, KC_PROLONG);
+	Timed t(g, KC_PROLONG, (size_t) L.P * L.nc);
 	hipLaunchKernelGGL(k_prolong3d<N>, dim3(gridFor((size_t) L.P * L.nc / 2, 256)), dim3(256), 0, g->stream, L.P,
 	                   L.parent.p, L.orth.p, coarse, fine);
 	HIPCHK(hipGetLastError());
@@ -491,7 +493,7 @@ template <int OP> int vecop(te_vec *v, const te_vec *a, const te_vec *b, double 
 		return te::fail(TE_EINVAL, "te_vec_*: vectors of different levels");
 	if (v->n == 0) return TE_OK;
 	te_gmg *g = v->g;
-	Timed   t(g, KC_VECOP);
+	Timed   t(g, KC_VECOP, v->n);
 	hipLaunchKernelGGL(k_vecop<OP>, dim3(gridFor(v->n / 2, 256, 2048)), dim3(256), 0, g->stream, v->n / 2,
 	                   reinterpret_cast<double2 *>(v->d), a ? reinterpret_cast<const double2 *>(a->d) : nullptr,
 	                   b ? reinterpret_cast<const double2 *>(b->d) : nullptr, alpha, beta, gamma);
@@ -508,7 +510,7 @@ template <int OP> int reduce(const te_vec *a, const te_vec *b, double *out)
 	}
 	const int blocks = gridFor(a->n / 2, 256, g->red_blocks);
 	{
-		Timed t(g, KC_REDUCE);
+		Timed t(g, KC_REDUCE, a->n);
 		hipLaunchKernelGGL(k_reduce<OP>, dim3(blocks), dim3(256), 0, g->stream, a->n / 2,
 		                   reinterpret_cast<const double2 *>(a->d),
 		                   b ? reinterpret_cast<const double2 *>(b->d) : nullptr, g->partial.p);
@@ -625,6 +627,7 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 	g->dim    = h->h.dim;
 	g->n      = h->h.n;
 	memset(g->calls, 0, sizeof(g->calls));
+	memset(g->cells, 0, sizeof(g->cells));
 	memset(g->total_ms, 0, sizeof(g->total_ms));
 	HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
 	int rc;
@@ -870,12 +873,14 @@ int te_gmg_profile_reset(te_gmg *g)
 	if (!g) return te::fail(TE_EINVAL, "te_gmg_profile_reset: null");
 	drainEvents(g);
 	memset(g->calls, 0, sizeof(g->calls));
+	memset(g->cells, 0, sizeof(g->cells));
 	memset(g->total_ms, 0, sizeof(g->total_ms));
 	return TE_OK;
 }
-int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *calls, double *total_ms)
+int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *calls, double *total_ms,
+                        int64_t *cells)
 {
-	if (!g || !name || !calls || !total_ms) return te::fail(TE_EINVAL, "te_gmg_profile_rows: null");
+	if (!g || !name || !calls || !total_ms || !cells) return te::fail(TE_EINVAL, "te_gmg_profile_rows: null");
 	drainEvents(g);
 	int n = 0;
 	for (int k = 0; k < KC_COUNT && n < max_rows; k++) {
@@ -884,6 +889,7 @@ int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *call
 		name[n][63] = 0;
 		calls[n]    = g->calls[k];
 		total_ms[n] = g->total_ms[k];
+		cells[n]    = g->cells[k];
 		n++;
 	}
 	return n;
