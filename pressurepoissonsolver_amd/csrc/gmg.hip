@@ -379,11 +379,11 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 	int rc = launchCfGhost<N>(g, L, u);
 	if (rc) return rc;
 	Timed     t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : KC_JACOBI), (size_t) L.P * L.nc);
-	const int tpb = Tile<N>::TPB;
+	const int tpb = Tile2<N>::TPB;
 	// enough workgroups to fill 256 CUs a few times over: split patches into z-slabs when few
 	int zs = 1;
 	if (N >= 8) {
-		while (zs < 4 && (size_t) L.P * zs < 2048 && N / (zs * 2) >= 4) zs *= 2;
+		while (zs < 4 && (getenv("TE_ZS_FORCE") || (size_t) L.P * zs < 2048) && N / (zs * 2) >= 4) zs *= 2;
 	}
 	auto grid = [&](int z) { return dim3(8 * ((L.P * z + 7) / 8)); };
 	LevelDev D = L.dev();
@@ -418,7 +418,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 	int rc = launchCfGhost<N>(g, L, u);
 	if (rc) return rc;
 	Timed t(g, KC_RBGS, (size_t) L.P * L.nc);
-	hipLaunchKernelGGL(k_rbgs3d<N>, dim3(8 * ((L.P + 7) / 8)), dim3(Tile<N>::TPB), 0, g->stream, L.dev(), u, f, out);
+	hipLaunchKernelGGL(k_rbgs3d<N>, dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f, out);
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }

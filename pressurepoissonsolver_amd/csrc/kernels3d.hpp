@@ -41,172 +41,245 @@ template <int N> struct Tile {
 // Blocks b, b+8, b+16, ... share an XCD (observed round-robin dispatch); give every XCD one
 // contiguous run of patches so that x/y/z-neighbour faces are mostly served from that XCD's
 // L2. Speed only; correctness never depends on placement.
+#ifndef TE_XCD_REMAP
+#define TE_XCD_REMAP 1
+#endif
 __device__ __forceinline__ int xcdRemap(int b, int nblocks)
 {
+#if TE_XCD_REMAP
 	int chunk = (nblocks + 7) >> 3;
 	return (b & 7) * chunk + (b >> 3);
+#else
+	return b;
+#endif
 }
 
-// value a cell just outside the patch takes, given the cell just inside (`own`)
+// Workgroup barrier that waits for this wave's LDS traffic only. __syncthreads() also drains
+// vmcnt(0), i.e. every global prefetch issued just before it and every store of the previous
+// plane; keeping those in flight across the barrier is what lets the plane pipeline stream.
+__device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Plane tiling used by the marching kernels: each thread owns CPT pairs of x-adjacent cells
+// (16 B per lane, the widest coalesced access), pair q of a plane = cells 2q, 2q+1.
+template <int N> struct Tile2 {
+	static constexpr int  NP   = N * N / 2;
+	static constexpr int  TPB  = NP < 64 ? 64 : (NP > 256 ? 256 : NP);
+	static constexpr int  CPT  = (NP + TPB - 1) / TPB;
+	static constexpr bool FULL = (NP % TPB == 0);
+	static constexpr int  LW   = N + 4; // [pad, west halo, N cells, east halo, pad]: interior 16-B aligned
+	static constexpr int  LSZ  = LW * (N + 2);
+	static_assert(4 * N <= TPB, "one halo entry per thread");
+};
+
+// A plane just outside the patch in z, as "sign * memory": FACE_LOCAL -> the neighbour's facing
+// plane, FACE_GHOST -> the ghost slot, physical -> +-(own boundary plane) (or 0 when the caller
+// folds the physical closure into the diagonal).
+struct PlaneSrc {
+	const double2 *p;
+	double         s;
+};
 template <int N>
-__device__ __forceinline__ double ghostValue(int kind, int src, double own, const double *__restrict__ u,
-                                             const double *__restrict__ ghost, int nbr_cell, int slot_cell)
+__device__ __forceinline__ PlaneSrc zPlaneSrc(int kind, int src, bool top, const double *u, const double *up,
+                                              const double *ghost, double dir_sign, double neu_sign)
 {
-	switch (kind) {
-		case FACE_DIRICHLET: return -own;
-		case FACE_NEUMANN: return own;
-		case FACE_LOCAL: return u[(size_t) src * (N * N * N) + nbr_cell];
-		default: return ghost[(size_t) src * (N * N) + slot_cell];
+	constexpr int NN = N * N, NNN = N * N * N;
+	PlaneSrc      r;
+	const double *own = up + (top ? (N - 1) * NN : 0);
+	const double *p   = own;
+	r.s               = 1.0;
+	if (kind == FACE_LOCAL) p = u + (size_t) src * NNN + (top ? 0 : (N - 1) * NN);
+	if (kind == FACE_GHOST) p = ghost + (size_t) src * NN;
+	if (kind == FACE_DIRICHLET) r.s = dir_sign;
+	if (kind == FACE_NEUMANN) r.s = neu_sign;
+	r.p = reinterpret_cast<const double2 *>(p);
+	return r;
+}
+// One x/y halo entry per thread (threads >= 4N get a harmless dummy): value(z) = s * p[z*stride].
+struct HaloSrc {
+	const double *p;
+	int           stride;
+	double        s;
+	int           lds; // slot in the LDS tile, -1 = none
+};
+template <int N>
+__device__ __forceinline__ HaloSrc haloSrc(int tid, const int32_t *fk, const int32_t *fs, const double *u,
+                                           const double *up, const double *ghost, double dir_sign, double neu_sign)
+{
+	constexpr int NN = N * N, NNN = N * N * N, LW = Tile2<N>::LW;
+	HaloSrc       h;
+	h.p      = up;
+	h.stride = 0;
+	h.s      = 0.0;
+	h.lds    = -1;
+	if (tid < 4 * N) {
+		const int side = tid / N, t = tid % N;
+		const int kind = fk[side], src = fs[side];
+		int       own, nbr;
+		if (side == 0) { // west: own (0,t), neighbour's (N-1,t)
+			own   = t * N;
+			nbr   = t * N + (N - 1);
+			h.lds = (t + 1) * LW + 1;
+		} else if (side == 1) {
+			own   = t * N + (N - 1);
+			nbr   = t * N;
+			h.lds = (t + 1) * LW + N + 2;
+		} else if (side == 2) { // south: own (t,0), neighbour's (t,N-1)
+			own   = t;
+			nbr   = (N - 1) * N + t;
+			h.lds = t + 2;
+		} else {
+			own   = (N - 1) * N + t;
+			nbr   = t;
+			h.lds = (N + 1) * LW + t + 2;
+		}
+		h.stride = NN;
+		h.s      = 1.0;
+		h.p      = up + own;
+		if (kind == FACE_LOCAL) h.p = u + (size_t) src * NNN + nbr;
+		if (kind == FACE_GHOST) { // ghost plane cell (a,b) = (t, z)
+			h.p      = ghost + (size_t) src * NN + t;
+			h.stride = N;
+		}
+		if (kind == FACE_DIRICHLET) h.s = dir_sign;
+		if (kind == FACE_NEUMANN) h.s = neu_sign;
 	}
+	return h;
 }
 
 // MODE_APPLY : out = A u                     (SchurHelper.h:360-376 + StarPatchOp.h:28-184)
 // MODE_RESID : out = f - A u                 (+ Cycle.h:60-61)
 // MODE_JACOBI: out = u + omega (f - A u)/diag(A)
-// grid: 8*ceil(P*ZS/8) blocks of Tile<N>::TPB threads; ZS z-slabs per patch.
+// grid: 8*ceil(P*ZS/8) blocks of Tile2<N>::TPB threads; ZS z-slabs per patch.
+// The steady-state loop is branch-free: every load of an iteration is issued unconditionally
+// from a (pointer, sign) pair chosen with scalar selects, so the compiler can keep the whole
+// next plane in flight behind the LDS barrier.
 template <int N, int MODE, int ZS>
-__global__ __launch_bounds__(Tile<N>::TPB) void k_stencil3d(LevelDev L, const double *__restrict__ u,
-                                                            const double *__restrict__ f,
-                                                            double *__restrict__ out, double omega)
+__global__ __launch_bounds__(Tile2<N>::TPB) void k_stencil3d(LevelDev L, const double *__restrict__ u,
+                                                             const double *__restrict__ f,
+                                                             double *__restrict__ out, double omega)
 {
-	using T                = Tile<N>;
-	constexpr int TPB      = T::TPB;
-	constexpr int CPT      = T::CPT;
-	constexpr int LW       = T::LW;
-	constexpr int NN       = N * N;
-	constexpr int NNN      = N * N * N;
-	constexpr int ZL       = N / ZS; // planes per slab
-	const int     nblocks  = L.P * ZS;
-	const int     work     = xcdRemap(blockIdx.x, nblocks);
+	using T               = Tile2<N>;
+	constexpr int  TPB    = T::TPB;
+	constexpr int  CPT    = T::CPT;
+	constexpr int  LW     = T::LW;
+	constexpr int  NP     = T::NP;
+	constexpr int  NN     = N * N;
+	constexpr int  NNN    = N * N * N;
+	constexpr int  H      = N / 2;
+	constexpr int  ZL     = N / ZS; // planes per slab
+	constexpr bool FULL   = T::FULL;
+	const int      nblocks = L.P * ZS;
+	const int      work    = xcdRemap(blockIdx.x, nblocks);
 	if (work >= nblocks) return;
 	const int pid = work / ZS;
 	const int z0  = (work % ZS) * ZL;
 	const int tid = threadIdx.x;
 
-	__shared__ double tile[2][T::LSZ];
+	__shared__ __attribute__((aligned(16))) double tile[2][T::LSZ];
 	__shared__ double idiag[27];
 
-	const int32_t *fk = L.face_kind + (size_t) pid * 6;
-	const int32_t *fs = L.face_src + (size_t) pid * 6;
+	const int32_t *fk  = L.face_kind + (size_t) pid * 6;
+	const int32_t *fs  = L.face_src + (size_t) pid * 6;
 	const double   rhx = L.rh2[(size_t) pid * 3], rhy = L.rh2[(size_t) pid * 3 + 1],
 	             rhz = L.rh2[(size_t) pid * 3 + 2];
-	const double *up = u + (size_t) pid * NNN;
-	const double *fp = (MODE != MODE_APPLY) ? f + (size_t) pid * NNN : nullptr;
-	double       *op = out + (size_t) pid * NNN;
+	const double  *up  = u + (size_t) pid * NNN;
+	const double2 *up2 = reinterpret_cast<const double2 *>(up);
+	const double2 *fp2 = reinterpret_cast<const double2 *>((MODE != MODE_APPLY ? f : u) + (size_t) pid * NNN);
+	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
 
 	if (MODE == MODE_JACOBI) {
-		for (int e = tid; e < 27; e += TPB) { // TPB may be < 27 for tiny patches
+		if (tid < 27) {
 			const double *ka = L.face_kadj + (size_t) pid * 6;
-			int           cx = e % 3, cy = (e / 3) % 3, cz = e / 9;
+			int           cx = tid % 3, cy = (tid / 3) % 3, cz = tid / 9;
 			double        kx = 2.0 + (cx == 0 ? ka[0] : 0.0) + (cx == 2 ? ka[1] : 0.0);
 			double        ky = 2.0 + (cy == 0 ? ka[2] : 0.0) + (cy == 2 ? ka[3] : 0.0);
 			double        kz = 2.0 + (cz == 0 ? ka[4] : 0.0) + (cz == 2 ? ka[5] : 0.0);
-			idiag[e]         = -1.0 / (kx * rhx + ky * rhy + kz * rhz);
+			idiag[tid]       = -1.0 / (kx * rhx + ky * rhy + kz * rhz);
 		}
 	}
 
-	// ---- x/y halo ownership: thread h < 4N owns halo entry (side = h/N, t = h%N) ----------
-	const bool has_halo = tid < 4 * N;
-	int        h_kind = 0, h_src = 0, h_own = 0, h_nbr = 0, h_lds = 0, h_slot_mul = 0;
-	if (has_halo) {
-		const int side = tid / N, t = tid % N;
-		h_kind = fk[side];
-		h_src  = fs[side];
-		switch (side) {
-			case 0: // west: own (0,t), neighbour's (N-1,t)
-				h_own = t * N;
-				h_nbr = t * N + (N - 1);
-				h_lds = (t + 1) * LW;
-				break;
-			case 1:
-				h_own = t * N + (N - 1);
-				h_nbr = t * N;
-				h_lds = (t + 1) * LW + N + 1;
-				break;
-			case 2: // south: own (t,0), neighbour's (t,N-1)
-				h_own = t;
-				h_nbr = (N - 1) * N + t;
-				h_lds = t + 1;
-				break;
-			default:
-				h_own = (N - 1) * N + t;
-				h_nbr = t;
-				h_lds = (N + 1) * LW + t + 1;
-				break;
-		}
-		h_slot_mul = t; // ghost plane cell (a,b) = (t, z)
-	}
-	auto haloLoad = [&](int z) -> double {
-		double own = (h_kind <= FACE_NEUMANN) ? up[z * NN + h_own] : 0.0;
-		return ghostValue<N>(h_kind, h_src, own, u, L.ghost, z * NN + h_nbr, h_slot_mul + N * z);
-	};
+	const HaloSrc  hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, -1.0, 1.0);
+	const PlaneSrc bot = zPlaneSrc<N>(fk[4], fs[4], false, u, up, L.ghost, -1.0, 1.0);
+	const PlaneSrc top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, -1.0, 1.0);
 
-	// ---- register pipeline over z ------------------------------------------------------------
-	double um[CPT], uc[CPT], un[CPT], un2[CPT], fc[CPT], fn[CPT];
-	const int kb = fk[4], sb = fs[4], kt = fk[5], st = fs[5];
+	int  q[CPT], lds[CPT];
+	bool act[CPT];
 #pragma unroll
 	for (int k = 0; k < CPT; k++) {
-		const int i = tid + k * TPB;
-		uc[k]       = up[z0 * NN + i];
-		if (z0 == 0)
-			um[k] = ghostValue<N>(kb, sb, uc[k], u, L.ghost, (N - 1) * NN + i, i);
-		else
-			um[k] = up[(z0 - 1) * NN + i];
-		if (z0 + 1 < N)
-			un[k] = up[(z0 + 1) * NN + i];
-		else
-			un[k] = ghostValue<N>(kt, st, uc[k], u, L.ghost, i, i);
-		if (MODE != MODE_APPLY) fc[k] = fp[z0 * NN + i];
+		q[k]   = tid + k * TPB;
+		act[k] = FULL || q[k] < NP;
+		if (!act[k]) q[k] = 0;
+		const int y = q[k] / H, x = 2 * (q[k] % H);
+		lds[k]      = (y + 1) * LW + x + 2;
 	}
-	double hv = has_halo ? haloLoad(z0) : 0.0;
+
+	// ---- register pipeline over z ------------------------------------------------------------
+	double2        um[CPT], uc[CPT], un[CPT], un2[CPT], fc[CPT], fn[CPT];
+	const double2 *pm  = (z0 > 0) ? up2 + (z0 - 1) * NP : bot.p;
+	const double   sm  = (z0 > 0) ? 1.0 : bot.s;
+	const double2 *pn1 = (z0 + 1 < N) ? up2 + (z0 + 1) * NP : top.p;
+	const double   sn1 = (z0 + 1 < N) ? 1.0 : top.s;
+#pragma unroll
+	for (int k = 0; k < CPT; k++) {
+		uc[k]      = up2[z0 * NP + q[k]];
+		double2 a  = pm[q[k]], b = pn1[q[k]];
+		um[k]      = double2{sm * a.x, sm * a.y};
+		un[k]      = double2{sn1 * b.x, sn1 * b.y};
+		if (MODE != MODE_APPLY) fc[k] = fp2[z0 * NP + q[k]];
+	}
+	double hv = hs.s * hs.p[z0 * hs.stride];
 
 #pragma unroll 1
 	for (int zz = 0; zz < ZL; zz++) {
 		const int z = z0 + zz;
-		// prefetch plane z+2 (or the top ghost) and the next halo / rhs plane
+		// issue everything the NEXT iteration needs: plane z+2 (or the top ghost), rhs plane z+1,
+		// halo of plane z+1 (indices clamped on the last iterations: harmless re-reads)
+		const double2 *pn  = (z + 2 < N) ? up2 + (z + 2) * NP : top.p;
+		const double   sn  = (z + 2 < N) ? 1.0 : top.s;
+		const int      zc  = (z + 1 < N) ? z + 1 : N - 1;
 #pragma unroll
 		for (int k = 0; k < CPT; k++) {
-			const int i = tid + k * TPB;
-			if (z + 2 < N)
-				un2[k] = up[(z + 2) * NN + i];
-			else if (z + 2 == N)
-				un2[k] = ghostValue<N>(kt, st, un[k], u, L.ghost, i, i);
-			else
-				un2[k] = 0.0;
-			if (MODE != MODE_APPLY) fn[k] = (zz + 1 < ZL) ? fp[(z + 1) * NN + i] : 0.0;
+			double2 a = pn[q[k]];
+			un2[k]    = double2{sn * a.x, sn * a.y};
+			if (MODE != MODE_APPLY) fn[k] = fp2[zc * NP + q[k]];
 		}
-		double hvn = (has_halo && zz + 1 < ZL) ? haloLoad(z + 1) : 0.0;
+		const double hvn = hs.s * hs.p[zc * hs.stride];
 
 		double *tl = tile[zz & 1];
 #pragma unroll
-		for (int k = 0; k < CPT; k++) {
-			const int i = tid + k * TPB;
-			const int x = i % N, y = i / N;
-			tl[(y + 1) * LW + x + 1] = uc[k];
-		}
-		if (has_halo) tl[h_lds] = hv;
-		__syncthreads();
+		for (int k = 0; k < CPT; k++)
+			if (act[k]) *reinterpret_cast<double2 *>(tl + lds[k]) = uc[k];
+		if (hs.lds >= 0) tl[hs.lds] = hv;
+		ldsBarrier();
 #pragma unroll
 		for (int k = 0; k < CPT; k++) {
-			const int    i = tid + k * TPB;
-			const int    x = i % N, y = i / N;
-			const double c = uc[k];
-			const double *t0 = tl + (y + 1) * LW + x + 1;
-			double lap = (t0[-1] - 2 * c + t0[1]) * rhx;
-			lap += (t0[-LW] - 2 * c + t0[LW]) * rhy;
-			lap += (um[k] - 2 * c + un[k]) * rhz;
-			double r;
+			const double *t0 = tl + lds[k];
+			const double2 c  = uc[k];
+			const double2 ym = *reinterpret_cast<const double2 *>(t0 - LW);
+			const double2 yp = *reinterpret_cast<const double2 *>(t0 + LW);
+			const double  xl = t0[-1], xr = t0[2];
+			double2       lap;
+			lap.x = (xl - 2 * c.x + c.y) * rhx;
+			lap.y = (c.x - 2 * c.y + xr) * rhx;
+			lap.x += (ym.x - 2 * c.x + yp.x) * rhy;
+			lap.y += (ym.y - 2 * c.y + yp.y) * rhy;
+			lap.x += (um[k].x - 2 * c.x + un[k].x) * rhz;
+			lap.y += (um[k].y - 2 * c.y + un[k].y) * rhz;
+			double2 r;
 			if (MODE == MODE_APPLY) {
 				r = lap;
 			} else if (MODE == MODE_RESID) {
-				r = fc[k] - lap;
+				r.x = fc[k].x - lap.x;
+				r.y = fc[k].y - lap.y;
 			} else {
-				const int cx = (x == 0) ? 0 : (x == N - 1 ? 2 : 1);
+				const int y = q[k] / H, x = 2 * (q[k] % H);
 				const int cy = (y == 0) ? 0 : (y == N - 1 ? 2 : 1);
 				const int cz = (z == 0) ? 0 : (z == N - 1 ? 2 : 1);
-				r            = c + omega * (fc[k] - lap) * idiag[cx + 3 * cy + 9 * cz];
+				const int b  = 3 * cy + 9 * cz;
+				r.x = c.x + omega * (fc[k].x - lap.x) * idiag[b + (x == 0 ? 0 : 1)];
+				r.y = c.y + omega * (fc[k].y - lap.y) * idiag[b + (x == N - 2 ? 2 : 1)];
 			}
-			op[z * NN + i] = r;
+			if (act[k]) op2[z * NP + q[k]] = r;
 		}
 #pragma unroll
 		for (int k = 0; k < CPT; k++) {
@@ -219,154 +292,152 @@ __global__ __launch_bounds__(Tile<N>::TPB) void k_stencil3d(LevelDev L, const do
 	}
 }
 
+__device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a : b; }
+
+// relax the cells of colour `colour` of plane z; `cen` holds the plane's pairs (LDS copy in tl)
+template <int N>
+__device__ __forceinline__ void rbgsRelax(double *tl, const double *idiag, int z, int colour,
+                                          const int (&yy)[Tile2<N>::CPT], const int (&xx)[Tile2<N>::CPT],
+                                          const bool (&act)[Tile2<N>::CPT], double rhx, double rhy, double rhz,
+                                          double2 (&cen)[Tile2<N>::CPT], const double2 (&below)[Tile2<N>::CPT],
+                                          const double2 (&above)[Tile2<N>::CPT], const double2 (&rhs)[Tile2<N>::CPT])
+{
+	constexpr int CPT = Tile2<N>::CPT, LW = Tile2<N>::LW;
+	const int     cz  = (z == 0) ? 0 : (z == N - 1 ? 2 : 1);
+#pragma unroll
+	for (int k = 0; k < CPT; k++) {
+		const int    y = yy[k], x = xx[k];
+		const bool   first = ((y + z + colour) & 1) == 0; // the even-x cell of the pair has this colour
+		const int    xc    = first ? x : x + 1;
+		double      *t0    = tl + (y + 1) * LW + xc + 2;
+		// sel() takes values, so no conditional lvalue (= dynamically indexed stack slot) is formed
+		const double2 cv = cen[k], bl = below[k], ab = above[k], rr = rhs[k];
+		const double  side = sel(first, t0[-1], t0[1]); // the x-neighbour outside the pair
+		const double  mate = sel(first, cv.y, cv.x);
+		const double  zb = sel(first, bl.x, bl.y), za = sel(first, ab.x, ab.y);
+		const double  rh = sel(first, rr.x, rr.y);
+		const double  o  = (side + mate) * rhx + (t0[-LW] + t0[LW]) * rhy + (zb + za) * rhz;
+		const int     cx = (xc == 0) ? 0 : (xc == N - 1 ? 2 : 1);
+		const int     cy = (y == 0) ? 0 : (y == N - 1 ? 2 : 1);
+		const double  v  = (o - rh) * idiag[cx + 3 * cy + 9 * cz];
+		cen[k]           = double2{sel(first, v, cv.x), sel(first, cv.y, v)};
+		if (act[k]) *t0 = v;
+	}
+}
+
 // Patch-local red-black Gauss-Seidel sweep with neighbour ghosts frozen at the old iterate
 // (hybrid GS: Gauss-Seidel inside the patch, Jacobi across patch faces), out-of-place:
 // out = S(u, f). Red = (x+y+z) even. Plane z gets its red update from old black values;
 // plane z-1 then gets its black update from new red values, so output lags one plane.
+// In a pair (x even, x+1) exactly one cell has each colour, so every lane relaxes one cell per
+// phase and nothing diverges. Physical faces are folded into the diagonal (k = 3 Dirichlet,
+// 1 Neumann), so their ghost contributes 0 to the off-diagonal sum.
 template <int N>
-__global__ __launch_bounds__(Tile<N>::TPB) void k_rbgs3d(LevelDev L, const double *__restrict__ u,
-                                                         const double *__restrict__ f,
-                                                         double *__restrict__ out)
+__global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const double *__restrict__ u,
+                                                          const double *__restrict__ f,
+                                                          double *__restrict__ out)
 {
-	using T           = Tile<N>;
-	constexpr int TPB = T::TPB;
-	constexpr int CPT = T::CPT;
-	constexpr int LW  = T::LW;
-	constexpr int NN  = N * N;
-	constexpr int NNN = N * N * N;
-	const int     pid = xcdRemap(blockIdx.x, L.P);
+	using T             = Tile2<N>;
+	constexpr int  TPB  = T::TPB;
+	constexpr int  CPT  = T::CPT;
+	constexpr int  LW   = T::LW;
+	constexpr int  NP   = T::NP;
+	constexpr int  NN   = N * N;
+	constexpr int  NNN  = N * N * N;
+	constexpr int  H    = N / 2;
+	constexpr bool FULL = T::FULL;
+	const int      pid  = xcdRemap(blockIdx.x, L.P);
 	if (pid >= L.P) return;
 	const int tid = threadIdx.x;
 
-	__shared__ double tile[3][T::LSZ]; // planes z-1, z, z+1 rotate through three buffers
-	__shared__ double kfac[9]; // per axis: k at lo face, interior, hi face (physical faces change the diagonal)
+	__shared__ __attribute__((aligned(16))) double tile[3][T::LSZ]; // planes z-1, z, z+1 rotate
+	__shared__ double idiag[27]; // 1/diag per (x,y,z) position class
 
-	const int32_t *fk = L.face_kind + (size_t) pid * 6;
-	const int32_t *fs = L.face_src + (size_t) pid * 6;
+	const int32_t *fk  = L.face_kind + (size_t) pid * 6;
+	const int32_t *fs  = L.face_src + (size_t) pid * 6;
 	const double   rhx = L.rh2[(size_t) pid * 3], rhy = L.rh2[(size_t) pid * 3 + 1],
 	             rhz = L.rh2[(size_t) pid * 3 + 2];
-	const double *up = u + (size_t) pid * NNN;
-	const double *fp = f + (size_t) pid * NNN;
-	double       *op = out + (size_t) pid * NNN;
+	const double  *up  = u + (size_t) pid * NNN;
+	const double2 *up2 = reinterpret_cast<const double2 *>(up);
+	const double2 *fp2 = reinterpret_cast<const double2 *>(f + (size_t) pid * NNN);
+	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
 
-	if (tid < 9) {
-		int    ax = tid / 3, c = tid % 3;
-		double k  = 2.0;
-		if (c != 1) {
-			int kind = fk[2 * ax + (c == 2)];
-			if (kind == FACE_DIRICHLET) k = 3.0;
-			if (kind == FACE_NEUMANN) k = 1.0;
+	if (tid < 27) {
+		double kf[3];
+		int    cls[3] = {tid % 3, (tid / 3) % 3, tid / 9};
+#pragma unroll
+		for (int ax = 0; ax < 3; ax++) {
+			kf[ax] = 2.0;
+			if (cls[ax] != 1) {
+				int kind = fk[2 * ax + (cls[ax] == 2)];
+				if (kind == FACE_DIRICHLET) kf[ax] = 3.0;
+				if (kind == FACE_NEUMANN) kf[ax] = 1.0;
+			}
 		}
-		kfac[tid] = k;
+		idiag[tid] = 1.0 / (kf[0] * rhx + kf[1] * rhy + kf[2] * rhz);
 	}
 
-	const bool has_halo = tid < 4 * N;
-	int        h_kind = 0, h_src = 0, h_nbr = 0, h_lds = 0, h_t = 0;
-	if (has_halo) {
-		const int side = tid / N, t = tid % N;
-		h_kind = fk[side];
-		h_src  = fs[side];
-		h_t    = t;
-		switch (side) {
-			case 0:
-				h_nbr = t * N + (N - 1);
-				h_lds = (t + 1) * LW;
-				break;
-			case 1:
-				h_nbr = t * N;
-				h_lds = (t + 1) * LW + N + 1;
-				break;
-			case 2:
-				h_nbr = (N - 1) * N + t;
-				h_lds = t + 1;
-				break;
-			default:
-				h_nbr = t;
-				h_lds = (N + 1) * LW + t + 1;
-				break;
-		}
-	}
-	// physical faces contribute nothing to the off-diagonal sum (their ghost is folded into k)
-	auto haloLoad = [&](int z) -> double {
-		if (h_kind == FACE_LOCAL) return u[(size_t) h_src * NNN + z * NN + h_nbr];
-		if (h_kind == FACE_GHOST) return L.ghost[(size_t) h_src * NN + h_t + N * z];
-		return 0.0;
-	};
-	const int kb = fk[4], sb = fs[4], kt = fk[5], st = fs[5];
-	auto zGhost = [&](int kind, int src, int nbr_cell, int i) -> double {
-		if (kind == FACE_LOCAL) return u[(size_t) src * NNN + nbr_cell];
-		if (kind == FACE_GHOST) return L.ghost[(size_t) src * NN + i];
-		return 0.0;
-	};
+	const HaloSrc  hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, 0.0, 0.0);
+	const PlaneSrc bot = zPlaneSrc<N>(fk[4], fs[4], false, u, up, L.ghost, 0.0, 0.0);
+	const PlaneSrc top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, 0.0, 0.0);
 
-	// planes: umm = z-2, um = z-1, uc = z, un = z+1, un2 = z+2 (values are updated in place)
-	double umm[CPT], um[CPT], uc[CPT], un[CPT], un2[CPT], fm[CPT], fc[CPT], fn[CPT];
+	int  q[CPT], lds[CPT], yy[CPT], xx[CPT];
+	bool act[CPT];
 #pragma unroll
 	for (int k = 0; k < CPT; k++) {
-		const int i = tid + k * TPB;
-		uc[k]       = up[i];
-		um[k]       = zGhost(kb, sb, (N - 1) * NN + i, i);
-		un[k]       = up[NN + i];
-		fc[k]       = fp[i];
-		umm[k]      = 0.0;
-		fm[k]       = 0.0;
+		q[k]   = tid + k * TPB;
+		act[k] = FULL || q[k] < NP;
+		if (!act[k]) q[k] = 0;
+		yy[k]  = q[k] / H;
+		xx[k]  = 2 * (q[k] % H);
+		lds[k] = (yy[k] + 1) * LW + xx[k] + 2;
 	}
-	double hv = has_halo ? haloLoad(0) : 0.0;
-	__syncthreads(); // kfac
 
-	auto relax = [&](double *tl, int z, int colour, double *cen, const double *below, const double *above,
-	                 const double *rhs) {
-		const int cz = (z == 0) ? 0 : (z == N - 1 ? 2 : 1);
+	// planes: umm = z-2, um = z-1, uc = z, un = z+1, un2 = z+2 (values are updated in place)
+	double2 umm[CPT], um[CPT], uc[CPT], un[CPT], un2[CPT], fm[CPT], fc[CPT], fn[CPT];
 #pragma unroll
-		for (int k = 0; k < CPT; k++) {
-			const int i = tid + k * TPB;
-			const int x = i % N, y = i / N;
-			if (((x + y + z) & 1) != colour) continue;
-			const int     cx = (x == 0) ? 0 : (x == N - 1 ? 2 : 1);
-			const int     cy = (y == 0) ? 0 : (y == N - 1 ? 2 : 1);
-			const double *t0 = tl + (y + 1) * LW + x + 1;
-			double        o  = (t0[-1] + t0[1]) * rhx + (t0[-LW] + t0[LW]) * rhy + (below[k] + above[k]) * rhz;
-			double        d  = kfac[cx] * rhx + kfac[3 + cy] * rhy + kfac[6 + cz] * rhz;
-			double        v  = (o - rhs[k]) / d;
-			cen[k]           = v;
-			tl[(y + 1) * LW + x + 1] = v;
-		}
-	};
+	for (int k = 0; k < CPT; k++) {
+		uc[k]     = up2[q[k]];
+		double2 a = bot.p[q[k]];
+		um[k]     = double2{bot.s * a.x, bot.s * a.y};
+		un[k]     = up2[NP + q[k]];
+		fc[k]     = fp2[q[k]];
+		umm[k]    = double2{0.0, 0.0};
+		fm[k]     = double2{0.0, 0.0};
+	}
+	double hv = hs.s * hs.p[0];
+	__syncthreads(); // idiag
 
 #pragma unroll 1
 	for (int z = 0; z <= N; z++) {
-		double hvn = 0.0;
-		if (z < N) {
+		// issue the next iteration's loads (clamped / redirected on the last iterations)
+		const double2 *pn = (z + 2 < N) ? up2 + (z + 2) * NP : top.p;
+		const double   sn = (z + 2 < N) ? 1.0 : top.s;
+		const int      zc = (z + 1 < N) ? z + 1 : N - 1;
 #pragma unroll
-			for (int k = 0; k < CPT; k++) {
-				const int i = tid + k * TPB;
-				if (z + 2 < N)
-					un2[k] = up[(z + 2) * NN + i];
-				else if (z + 2 == N)
-					un2[k] = zGhost(kt, st, i, i);
-				else
-					un2[k] = 0.0;
-				fn[k] = (z + 1 < N) ? fp[(z + 1) * NN + i] : 0.0;
-			}
-			hvn        = (has_halo && z + 1 < N) ? haloLoad(z + 1) : 0.0;
+		for (int k = 0; k < CPT; k++) {
+			double2 a = pn[q[k]];
+			un2[k]    = double2{sn * a.x, sn * a.y};
+			fn[k]     = fp2[zc * NP + q[k]];
+		}
+		const double hvn = hs.s * hs.p[zc * hs.stride];
+		if (z < N) {
 			double *tl = tile[z % 3];
 #pragma unroll
-			for (int k = 0; k < CPT; k++) {
-				const int i = tid + k * TPB;
-				tl[(i / N + 1) * LW + i % N + 1] = uc[k];
-			}
-			if (has_halo) tl[h_lds] = hv;
+			for (int k = 0; k < CPT; k++)
+				if (act[k]) *reinterpret_cast<double2 *>(tl + lds[k]) = uc[k];
+			if (hs.lds >= 0) tl[hs.lds] = hv;
 		}
 		// one barrier per plane: buffer z%3 was last read two iterations ago (black of plane z-3)
-		__syncthreads();
-		if (z < N) relax(tile[z % 3], z, 0, uc, um, un, fc); // red cells of plane z from old black values
+		ldsBarrier();
+		if (z < N) rbgsRelax<N>(tile[z % 3], idiag, z, 0, yy, xx, act, rhx, rhy, rhz, uc, um, un, fc); // red cells of plane z from old black values
 		if (z > 0) {
-			double *tl = tile[(z - 1) % 3];
 			// black cells of plane z-1: x/y neighbours = new red in LDS; z neighbours = umm (new red,
 			// or the frozen bottom ghost) and uc (new red, or the frozen top ghost when z == N)
-			relax(tl, z - 1, 1, um, umm, uc, fm);
+			rbgsRelax<N>(tile[(z - 1) % 3], idiag, z - 1, 1, yy, xx, act, rhx, rhy, rhz, um, umm, uc, fm);
 #pragma unroll
-			for (int k = 0; k < CPT; k++) op[(z - 1) * NN + tid + k * TPB] = um[k];
+			for (int k = 0; k < CPT; k++)
+				if (act[k]) op2[(z - 1) * NP + q[k]] = um[k];
 		}
 #pragma unroll
 		for (int k = 0; k < CPT; k++) {

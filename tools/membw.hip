@@ -1,0 +1,147 @@
+// Device stream-bandwidth probes (tooling, not product): what a 2-read + 1-write fp64 stream can
+// reach on this MI355X with the access shapes our kernels use. hipcc --offload-arch=gfx950.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+template <int NT> __device__ __forceinline__ void st2(double2 *p, double2 v)
+{
+	if (NT) {
+		__builtin_nontemporal_store(v.x, &p->x);
+		__builtin_nontemporal_store(v.y, &p->y);
+	} else
+		*p = v;
+}
+template <int NT> __device__ __forceinline__ double2 ld2(const double2 *p)
+{
+	if (NT) {
+		double2 v;
+		v.x = __builtin_nontemporal_load(&p->x);
+		v.y = __builtin_nontemporal_load(&p->y);
+		return v;
+	}
+	return *p;
+}
+// grid-stride, 16 B per lane
+template <int NT> __global__ __launch_bounds__(256) void fill16(size_t n2, double2 *a)
+{
+	for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t) gridDim.x * 256) st2<NT>(a + i, double2{1.0, 2.0});
+}
+template <int NT> __global__ __launch_bounds__(256) void read16(size_t n2, const double2 *a, double *out)
+{
+	double s = 0;
+	for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t) gridDim.x * 256) {
+		double2 v = ld2<NT>(a + i);
+		s += v.x + v.y;
+	}
+	if (s == 123.456) out[0] = s;
+}
+template <int NT> __global__ __launch_bounds__(256) void triad16(size_t n2, double2 *a, const double2 *b, const double2 *c)
+{
+	for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t) gridDim.x * 256) {
+		double2 x = ld2<NT>(b + i), y = ld2<NT>(c + i);
+		st2<NT>(a + i, double2{x.x + 0.5 * y.x, x.y + 0.5 * y.y});
+	}
+}
+__global__ __launch_bounds__(256) void triad8(size_t n, double *a, const double *b, const double *c)
+{
+	for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256) a[i] = b[i] + 0.5 * c[i];
+}
+// patch-shaped: one workgroup owns a contiguous 32^3 block and walks it plane by plane (8 KiB steps),
+// W = bytes per lane (8 or 16), DEPTH planes in flight
+template <int W, int NT> __global__ __launch_bounds__(256) void triad_patch(int P, double *a, const double *b, const double *c, int stagger = 0, int remap = 1)
+{
+	const int chunk = (P + 7) >> 3;
+	const int pid   = remap ? (blockIdx.x & 7) * chunk + (blockIdx.x >> 3) : blockIdx.x;
+	if (pid >= P) return;
+	const int zoff = (pid * stagger) & 31;
+	const size_t base = (size_t) pid * 32768;
+	if (W == 8) {
+		for (int zz = 0; zz < 32; zz++) {
+			const int z = (zz + zoff) & 31;
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				size_t i = base + z * 1024 + k * 256 + threadIdx.x;
+				a[i]     = b[i] + 0.5 * c[i];
+			}
+		}
+	} else {
+		for (int zz = 0; zz < 32; zz++) {
+			const int z = (zz + zoff) & 31;
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				size_t  i = (base + z * 1024) / 2 + k * 256 + threadIdx.x;
+				double2 x = ld2<NT>((const double2 *) b + i), y = ld2<NT>((const double2 *) c + i);
+				st2<NT>((double2 *) a + i, double2{x.x + 0.5 * y.x, x.y + 0.5 * y.y});
+			}
+		}
+	}
+}
+
+int main(int argc, char **argv)
+{
+	size_t n = (size_t) 512 * 512 * 512;
+	if (argc > 1) n = (size_t) atol(argv[1]);
+	double *a, *b, *c;
+	CK(hipMalloc(&a, n * 8));
+	CK(hipMalloc(&b, n * 8));
+	CK(hipMalloc(&c, n * 8));
+	CK(hipMemset(a, 0, n * 8));
+	CK(hipMemset(b, 0, n * 8));
+	CK(hipMemset(c, 0, n * 8));
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	auto timeit = [&](const char *name, double bytes, auto launch) {
+		for (int i = 0; i < 3; i++) launch();
+		CK(hipDeviceSynchronize());
+		float best = 1e30f, tot = 0;
+		const int reps = 10;
+		for (int i = 0; i < reps; i++) {
+			CK(hipEventRecord(e0));
+			launch();
+			CK(hipEventRecord(e1));
+			CK(hipEventSynchronize(e1));
+			float ms;
+			CK(hipEventElapsedTime(&ms, e0, e1));
+			best = ms < best ? ms : best;
+			tot += ms;
+		}
+		printf("%-44s best %8.1f us  %7.1f GB/s   avg %7.1f GB/s\n", name, best * 1e3, bytes / best / 1e6, bytes / (tot / reps) / 1e6);
+	};
+	const size_t n2 = n / 2;
+	const int    P  = (int) (n / 32768);
+	char         nm[128];
+	timeit("hipMemsetAsync", n * 8.0, [&] { (void) hipMemsetAsync(a, 0, n * 8, 0); });
+	for (int grid : {1024, 2048, 4096, 16384, (int) (n2 / 256)}) {
+		snprintf(nm, sizeof nm, "fill16 grid=%d", grid);
+		timeit(nm, n * 8.0, [&] { hipLaunchKernelGGL(fill16<0>, dim3(grid), dim3(256), 0, 0, n2, (double2 *) a); });
+		snprintf(nm, sizeof nm, "fill16 nt grid=%d", grid);
+		timeit(nm, n * 8.0, [&] { hipLaunchKernelGGL(fill16<1>, dim3(grid), dim3(256), 0, 0, n2, (double2 *) a); });
+	}
+	for (int grid : {2048, 4096, (int) (n2 / 256)}) {
+		snprintf(nm, sizeof nm, "read16 grid=%d", grid);
+		timeit(nm, n * 8.0, [&] { hipLaunchKernelGGL(read16<0>, dim3(grid), dim3(256), 0, 0, n2, (const double2 *) b, a); });
+		snprintf(nm, sizeof nm, "triad16 grid=%d", grid);
+		timeit(nm, n * 24.0, [&] { hipLaunchKernelGGL(triad16<0>, dim3(grid), dim3(256), 0, 0, n2, (double2 *) a, (const double2 *) b, (const double2 *) c); });
+		snprintf(nm, sizeof nm, "triad16 nt grid=%d", grid);
+		timeit(nm, n * 24.0, [&] { hipLaunchKernelGGL(triad16<1>, dim3(grid), dim3(256), 0, 0, n2, (double2 *) a, (const double2 *) b, (const double2 *) c); });
+		snprintf(nm, sizeof nm, "triad8 grid=%d", grid);
+		timeit(nm, n * 24.0, [&] { hipLaunchKernelGGL(triad8, dim3(grid), dim3(256), 0, 0, n, a, b, c); });
+	}
+	const int pg = 8 * ((P + 7) / 8);
+	timeit("triad_patch W=8", n * 24.0, [&] { hipLaunchKernelGGL((triad_patch<8, 0>), dim3(pg), dim3(256), 0, 0, P, a, b, c); });
+	timeit("triad_patch W=16", n * 24.0, [&] { hipLaunchKernelGGL((triad_patch<16, 0>), dim3(pg), dim3(256), 0, 0, P, a, b, c); });
+	timeit("triad_patch W=16 nt", n * 24.0, [&] { hipLaunchKernelGGL((triad_patch<16, 1>), dim3(pg), dim3(256), 0, 0, P, a, b, c); });
+	for (int st : {1, 5, 7, 13})
+		for (int rm : {0, 1}) {
+			snprintf(nm, sizeof nm, "triad_patch W=16 stagger=%d remap=%d", st, rm);
+			timeit(nm, n * 24.0, [&] { hipLaunchKernelGGL((triad_patch<16, 0>), dim3(pg), dim3(256), 0, 0, P, a, b, c, st, rm); });
+		}
+	timeit("triad_patch W=16 stagger=0 remap=0", n * 24.0, [&] { hipLaunchKernelGGL((triad_patch<16, 0>), dim3(pg), dim3(256), 0, 0, P, a, b, c, 0, 0); });
+	timeit("triad_patch W=8 stagger=5 remap=1", n * 24.0, [&] { hipLaunchKernelGGL((triad_patch<8, 0>), dim3(pg), dim3(256), 0, 0, P, a, b, c, 5, 1); });
+	timeit("triad_patch W=16 nt stagger=5 remap=1", n * 24.0, [&] { hipLaunchKernelGGL((triad_patch<16, 1>), dim3(pg), dim3(256), 0, 0, P, a, b, c, 5, 1); });
+	return 0;
+}
