@@ -204,7 +204,8 @@ def main():
                         for k, v in rows.items()},
         }
         if world == 1 and not a.no_cpu_baseline:
-            build.build_oracle()
+            from oracle import build as obuild
+            obuild.build_oracle()
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample, sm)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -1,11 +1,6 @@
-"""Builds the in-tree native libraries.
-
-  libte_hip.so   (pressurepoissonsolver_amd/csrc)  hipcc --offload-arch=gfx950: the product
-  libte_oracle.so (oracle/)                         g++: CPU restatement, test infrastructure
-  oracle/_ref/libte_ref.so                          g++ over /root/reference sources, only when
-                                                    that tree is present (never on the GPU box)
-
-Outputs are git-ignored but travel with the gpurun snapshot.
+"""Builds the product library in-tree: libte_hip.so from pressurepoissonsolver_amd/csrc with
+hipcc --offload-arch=gfx950. The output is git-ignored but travels with the gpurun snapshot.
+(The test-only checker libraries are built by the checker's own build script, not from here.)
 """
 import os
 import shutil
@@ -15,10 +10,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pressurepoissonsolver_amd", "csrc")
 LIB_HIP = os.path.join(ROOT, "pressurepoissonsolver_amd", "libte_hip.so")
-ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_ORACLE = os.path.join(ORACLE_DIR, "libte_oracle.so")
-REF_ROOT = os.environ.get("THUNDEREGG_REF", "/root/reference")
-LIB_REF = os.path.join(ORACLE_DIR, "_ref", "libte_ref.so")
 
 
 def _newer(target, sources):
@@ -52,36 +43,8 @@ def build_hip(force=False):
     return LIB_HIP
 
 
-def build_oracle(force=False):
-    srcs = [os.path.join(ORACLE_DIR, "te_oracle.cpp")]
-    deps = srcs + [os.path.join(ORACLE_DIR, "te_oracle.h")]
-    if not force and not _newer(LIB_ORACLE, deps):
-        return LIB_ORACLE
-    _run(["g++", "-O3", "-march=x86-64-v3", "-std=c++14", "-fPIC", "-shared", "-fopenmp", "-Wall",
-          srcs[0], "-o", LIB_ORACLE])
-    return LIB_ORACLE
-
-
-def build_ref(force=False):
-    """Compile the PETSc-free slice of the reference from where it lies (oracle/Makefile.ref)."""
-    if not os.path.isdir(os.path.join(REF_ROOT, "src", "Thunderegg")):
-        return None
-    mk = os.path.join(ORACLE_DIR, "Makefile.ref")
-    if not os.path.exists(mk):
-        return None
-    _run(["make", "-s", "-C", ORACLE_DIR, "-f", "Makefile.ref", "THUNDEREGG_REF=" + REF_ROOT]
-         + (["-B"] if force else []))
-    return LIB_REF
-
-
 def build_all(force=False):
-    out = {"hip": build_hip(force), "oracle": build_oracle(force)}
-    try:
-        out["ref"] = build_ref(force)
-    except subprocess.CalledProcessError as e:  # reference slice is optional test tooling
-        print("warning: oracle/_ref build failed:", e, file=sys.stderr)
-        out["ref"] = None
-    return out
+    return {"hip": build_hip(force)}
 
 
 if __name__ == "__main__":

@@ -15,7 +15,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Make sure the native libraries exist (hipcc cross-compiles without a GPU)."""
+    from oracle import build as obuild
     from pressurepoissonsolver_amd import build
     build.build_hip()
-    build.build_oracle()
+    obuild.build_oracle()
+    obuild.build_ref()
     yield
