@@ -4,10 +4,12 @@
 #include "capi_common.hpp"
 #include "kernels3d.hpp"
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
+#include <tuple>
 #include <vector>
 
 using namespace te;
@@ -30,11 +32,11 @@ namespace
 {
 enum KClass : int {
 	KC_APPLY, KC_RESID, KC_JACOBI, KC_RBGS, KC_CFGHOST, KC_RESTRICT, KC_PROLONG, KC_PATCH_RHS,
-	KC_DST, KC_VECOP, KC_REDUCE, KC_COUNT
+	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_COUNT
 };
 const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_jacobi", "stencil_rbgs",
                                     "cf_ghost", "restrict", "prolong_add", "patch_rhs", "dst_axis",
-                                    "vecop", "reduce"};
+                                    "vecop", "reduce", "pack", "exchange"};
 
 template <typename T> struct DevBuf {
 	T     *p = nullptr;
@@ -59,6 +61,13 @@ template <typename T> struct DevBuf {
 	}
 };
 
+// one exchange = for every peer: send [send_off, +send_cnt) and receive [recv_off, +recv_cnt) doubles
+struct ExPlan {
+	std::vector<int32_t> peers;
+	std::vector<int64_t> send_off, send_cnt, recv_off, recv_cnt;
+	bool empty() const { return peers.empty(); }
+};
+
 struct LevelHost {
 	int    dim = 3, n = 0, P = 0;
 	size_t nc = 0, nf = 0;
@@ -69,9 +78,20 @@ struct LevelHost {
 	// coarse/fine faces
 	int             ncf = 0;
 	DevBuf<int32_t> cf_desc, cf_slots;
+	// remote same-level faces (multi-rank): ghost slots [0, nremote) are filled by the exchange
+	ExPlan          fx;          // per-peer counts; recv lands directly in `ghost`
+	int             nremote = 0; // faces received == faces sent
+	DevBuf<int32_t> send_faces;  // [nremote][2] (patch, side) in send order
+	DevBuf<double>  sendbuf;     // [nremote * nf]
 	// transfer to level+1
 	int             Pc = 0;
 	DevBuf<int32_t> parent, orth, child, copy;
+	// children / parents that live on another rank: blocks of nc/8 (or nc, copy-through) doubles
+	ExPlan          tx_up, tx_down; // child side (sends in restrict), parent side (sends in prolong)
+	int             n_up = 0, n_down = 0;
+	DevBuf<int32_t> up_desc, down_desc; // [n][2] (patch, orthant)
+	DevBuf<int64_t> up_off, down_off;   // block offsets inside upbuf / downbuf
+	DevBuf<double>  upbuf, downbuf;
 	// patch solve
 	DevBuf<int32_t> plan, zero_mode;
 	DevBuf<double>  mats, lam;
@@ -197,10 +217,49 @@ void transformMatrix(int type, int n, double *m)
 	}
 }
 
+// per-peer ranges of a list of (peer, count) items that is already sorted by peer
+void rangesByPeer(const std::vector<std::pair<int, int64_t>> &items, std::vector<int32_t> &peers,
+                  std::vector<int64_t> &off, std::vector<int64_t> &cnt)
+{
+	int64_t pos = 0;
+	for (auto &it : items) {
+		if (peers.empty() || peers.back() != it.first) {
+			peers.push_back(it.first);
+			off.push_back(pos);
+			cnt.push_back(0);
+		}
+		cnt.back() += it.second;
+		pos += it.second;
+	}
+}
+// merge the send-side and receive-side peer lists of one exchange into one ExPlan
+ExPlan mergePlan(const std::vector<std::pair<int, int64_t>> &sends, const std::vector<std::pair<int, int64_t>> &recvs)
+{
+	std::vector<int32_t> sp, rp;
+	std::vector<int64_t> so, sc, ro, rc;
+	rangesByPeer(sends, sp, so, sc);
+	rangesByPeer(recvs, rp, ro, rc);
+	std::map<int, std::array<int64_t, 4>> m;
+	for (size_t i = 0; i < sp.size(); i++) m[sp[i]] = {so[i], sc[i], 0, 0};
+	for (size_t i = 0; i < rp.size(); i++) {
+		auto &e = m[rp[i]];
+		e[2]    = ro[i];
+		e[3]    = rc[i];
+	}
+	ExPlan pl;
+	for (auto &kv : m) {
+		pl.peers.push_back(kv.first);
+		pl.send_off.push_back(kv.second[0]);
+		pl.send_cnt.push_back(kv.second[1]);
+		pl.recv_off.push_back(kv.second[2]);
+		pl.recv_cnt.push_back(kv.second[3]);
+	}
+	return pl;
+}
+
 int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 {
 	const Level &lv = H.levels[li];
-	if (H.nranks != 1) return te::fail(TE_EUNSUPPORTED, "te_gmg_create: multi-rank levels not built yet");
 	if (lv.dim != 3) return te::fail(TE_EUNSUPPORTED, "te_gmg_create: only dim == 3 has device kernels");
 	const int n = lv.n;
 	if (n != 4 && n != 8 && n != 16 && n != 32)
@@ -211,13 +270,59 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	L->P   = lv.P;
 	L->nc  = (size_t) n * n * n;
 	L->nf  = (size_t) n * n;
-	const int P = lv.P, NS = 6;
+	const int P = lv.P, NS = 6, me = H.rank;
+
+	// ---- remote same-level faces: canonical order = (peer, receiving patch (global), receiving side),
+	// which both ends can compute from the global tables
+	struct RFace {
+		int peer, key_patch, key_side, p, s;
+		bool operator<(const RFace &o) const
+		{
+			return std::tie(peer, key_patch, key_side) < std::tie(o.peer, o.key_patch, o.key_side);
+		}
+	};
+	std::vector<RFace> recvs, sends;
+	for (int p = 0; p < P; p++) {
+		const int gp = lv.l2g[p];
+		for (int s = 0; s < NS; s++) {
+			const size_t gf = (size_t) gp * NS + s;
+			if (lv.g_nbr_kind[gf] == NBR_NONE) continue;
+			for (int q = 0; q < 4; q++) {
+				const int nb = lv.g_nbr[gf * 4 + q];
+				if (nb < 0 || lv.g_rank[nb] == me) continue;
+				if (lv.g_nbr_kind[gf] != NBR_NORMAL)
+					return te::fail(TE_EUNSUPPORTED,
+					                "te_gmg_create: coarse/fine faces across ranks are not supported yet");
+				recvs.push_back({lv.g_rank[nb], gp, s, p, s});
+				sends.push_back({lv.g_rank[nb], nb, s ^ 1, p, s});
+			}
+		}
+	}
+	std::sort(recvs.begin(), recvs.end());
+	std::sort(sends.begin(), sends.end());
+	const int                 nremote = (int) recvs.size();
+	std::map<std::pair<int, int>, int> remote_slot; // (p, s) -> ghost slot
+	for (int i = 0; i < nremote; i++) remote_slot[{recvs[i].p, recvs[i].s}] = i;
+	{
+		std::vector<std::pair<int, int64_t>> si, ri;
+		std::vector<int32_t>                 sf;
+		for (auto &f : sends) {
+			si.emplace_back(f.peer, (int64_t) L->nf);
+			sf.push_back(f.p);
+			sf.push_back(f.s);
+		}
+		for (auto &f : recvs) ri.emplace_back(f.peer, (int64_t) L->nf);
+		L->fx      = mergePlan(si, ri);
+		L->nremote = nremote;
+		int rc0;
+		if ((rc0 = L->send_faces.upload(sf)) || (rc0 = L->sendbuf.alloc((size_t) std::max(nremote, 1) * L->nf))) return rc0;
+	}
 
 	std::vector<int32_t> fk(P * NS), fs(P * NS, -1), cfd, cfs, plan(P, 0);
 	std::vector<double>  kadj(P * NS, 0.0), rh2(P * 3);
 	std::map<int, int>   plan_of_key;
 	std::vector<int>     keys;
-	int                  nslots = 0;
+	int                  nslots = nremote;
 	for (int p = 0; p < P; p++) {
 		const int gp  = lv.l2g[p];
 		int       key = 0;
@@ -233,8 +338,14 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 				kadj[p * NS + s] = H.neumann ? -1.0 : 1.0;
 				if (H.neumann) key |= 1 << s;
 			} else if (kind == NBR_NORMAL) {
-				fk[p * NS + s] = FACE_LOCAL;
-				fs[p * NS + s] = lv.g_local[lv.g_nbr[gf * 4]];
+				const int nb = lv.g_nbr[gf * 4];
+				if (lv.g_rank[nb] == me) {
+					fk[p * NS + s] = FACE_LOCAL;
+					fs[p * NS + s] = lv.g_local[nb];
+				} else { // the neighbour's face cells arrive in a ghost slot; diagonal unchanged
+					fk[p * NS + s] = FACE_GHOST;
+					fs[p * NS + s] = remote_slot.at({p, s});
+				}
 			} else {
 				fk[p * NS + s]   = FACE_GHOST;
 				fs[p * NS + s]   = nslots;
@@ -309,31 +420,85 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 			return rc;
 	}
 
-	// transfers
+	// transfers to level li+1. A child (or a copy-through patch) whose parent lives on another rank
+	// ships its restricted block there; the parent's rank ships octant blocks back for prolongation.
+	// Canonical block order on both ends: (peer, parent patch (global), orthant).
 	if (li + 1 < (int) H.levels.size()) {
 		const Level         &cv = H.levels[li + 1];
 		std::vector<int32_t> parent(P), orth(P), child((size_t) cv.P * 8, -1), copy(cv.P, 0);
+		struct Blk {
+			int     peer, gpar, o, patch;
+			int64_t size;
+			bool    operator<(const Blk &b) const { return std::tie(peer, gpar, o) < std::tie(b.peer, b.gpar, b.o); }
+		};
+		std::vector<Blk> up, down;
 		for (int p = 0; p < P; p++) {
-			const int gp = lv.l2g[p];
-			const int pc = cv.g_local[lv.g_parent[gp]];
-			parent[p]    = pc;
+			const int gp = lv.l2g[p], gpar = lv.g_parent[gp];
 			orth[p]      = lv.g_orth_on_parent[gp];
-			if (orth[p] < 0) {
-				copy[pc]                = 1;
-				child[(size_t) pc * 8] = p;
+			if (cv.g_rank[gpar] == me) {
+				const int pc = cv.g_local[gpar];
+				parent[p]    = pc;
+				if (orth[p] < 0) {
+					copy[pc]                = 1;
+					child[(size_t) pc * 8] = p;
+				} else {
+					child[(size_t) pc * 8 + orth[p]] = p;
+				}
 			} else {
-				child[(size_t) pc * 8 + orth[p]] = p;
+				up.push_back({cv.g_rank[gpar], gpar, orth[p] < 0 ? 0 : orth[p], p,
+				              (int64_t) (orth[p] < 0 ? L->nc : L->nc / 8)});
 			}
 		}
+		for (int gf = 0; gf < lv.P_global; gf++) {
+			const int gpar = lv.g_parent[gf];
+			if (cv.g_rank[gpar] != me || lv.g_rank[gf] == me) continue;
+			const int o = lv.g_orth_on_parent[gf];
+			down.push_back({lv.g_rank[gf], gpar, o < 0 ? 0 : o, cv.g_local[gpar], (int64_t) (o < 0 ? L->nc : L->nc / 8)});
+			if (o < 0) copy[cv.g_local[gpar]] = 1;
+		}
+		std::sort(up.begin(), up.end());
+		std::sort(down.begin(), down.end());
+		std::vector<int32_t>                 upd, downd;
+		std::vector<int64_t>                 upo, downo;
+		std::vector<std::pair<int, int64_t>> ups, downs;
+		int64_t                              pos = 0;
+		for (size_t i = 0; i < up.size(); i++) {
+			upd.push_back(up[i].patch);
+			upd.push_back(orth[up[i].patch]);
+			upo.push_back(pos);
+			ups.emplace_back(up[i].peer, up[i].size);
+			parent[up[i].patch] = -((int) i + 2); // prolong reads block i of upbuf
+			pos += up[i].size;
+		}
+		const int64_t up_total = pos;
+		pos                    = 0;
+		for (size_t i = 0; i < down.size(); i++) {
+			const int pc = down[i].patch;
+			const bool cp = down[i].size == (int64_t) L->nc;
+			downd.push_back(pc);
+			downd.push_back(cp ? -1 : down[i].o);
+			downo.push_back(pos);
+			downs.emplace_back(down[i].peer, down[i].size);
+			child[(size_t) pc * 8 + (cp ? 0 : down[i].o)] = -((int) i + 2); // restrict reads block i of downbuf
+			pos += down[i].size;
+		}
+		const int64_t down_total = pos;
 		for (int pc = 0; pc < cv.P; pc++) {
 			if (copy[pc]) continue;
 			for (int o = 0; o < 8; o++)
-				if (child[(size_t) pc * 8 + o] < 0)
+				if (child[(size_t) pc * 8 + o] == -1)
 					return te::fail(TE_EINVAL, "te_gmg_create: coarse patch with a missing child");
 		}
-		L->Pc = cv.P;
+		L->Pc      = cv.P;
+		L->n_up    = (int) up.size();
+		L->n_down  = (int) down.size();
+		L->tx_up   = mergePlan(ups, downs);   // restrict: send child blocks, receive into downbuf
+		L->tx_down = mergePlan(downs, ups);   // prolong: send octants, receive into upbuf
 		if ((rc = L->parent.upload(parent)) || (rc = L->orth.upload(orth)) || (rc = L->child.upload(child))
-		    || (rc = L->copy.upload(copy)))
+		    || (rc = L->copy.upload(copy)) || (rc = L->up_desc.upload(upd)) || (rc = L->down_desc.upload(downd))
+		    || (rc = L->up_off.upload(upo)) || (rc = L->down_off.upload(downo))
+		    || (rc = L->upbuf.alloc((size_t) std::max<int64_t>(up_total, 1)))
+		    || (rc = L->downbuf.alloc((size_t) std::max<int64_t>(down_total, 1))))
 			return rc;
 	}
 	g->levels.push_back(std::move(L));
@@ -365,8 +530,30 @@ int newVec(te_gmg *g, int level, te_vec **out)
 inline bool sameShape(const te_vec *a, const te_vec *b) { return a && b && a->g == b->g && a->level == b->level; }
 
 // ------------------------------------------------------------------------------ launches
-template <int N> int launchCfGhost(te_gmg *g, LevelHost &L, const double *u)
+int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double *recv)
 {
+	if (pl.empty()) return TE_OK;
+	if (!g->exchange)
+		return te::fail(TE_ESTATE, "this level has off-rank neighbours: call te_gmg_set_exchange first");
+	Timed t(g, KC_EXCHANGE, 0);
+	int   rc = g->exchange(g->exchange_user, tag, send, recv, (int) pl.peers.size(), pl.peers.data(), pl.send_off.data(),
+	                       pl.send_cnt.data(), pl.recv_off.data(), pl.recv_cnt.data(), (void *) g->stream);
+	if (rc) return te::fail(TE_ESTATE, "exchange callback failed with status " + std::to_string(rc));
+	return TE_OK;
+}
+// make every ghost plane of `u` current: remote same-level faces (pack -> exchange -> ghost slots
+// [0, nremote)), then the coarse/fine planes. Replaces SchurHelper.h:145-150 updateInterfaceDist.
+template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u)
+{
+	if (L.nremote > 0) {
+		{
+			Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
+			hipLaunchKernelGGL(k_pack_faces3d<N>, dim3(L.nremote), dim3(N * N < 256 ? N * N : 256), 0, g->stream,
+			                   L.send_faces.p, u, L.sendbuf.p);
+		}
+		int rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p);
+		if (rc) return rc;
+	}
 	if (L.ncf == 0) return TE_OK;
 	Timed t(g, KC_CFGHOST, (size_t) L.ncf * L.nf);
 	hipLaunchKernelGGL(k_cf_ghost3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
@@ -376,7 +563,7 @@ template <int N> int launchCfGhost(te_gmg *g, LevelHost &L, const double *u)
 template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out,
                                               double omega)
 {
-	int rc = launchCfGhost<N>(g, L, u);
+	int rc = prepareGhosts<N>(g, L, u);
 	if (rc) return rc;
 	Timed     t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : KC_JACOBI), (size_t) L.P * L.nc);
 	const int tpb = Tile2<N>::TPB;
@@ -415,7 +602,7 @@ template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, 
 }
 template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out)
 {
-	int rc = launchCfGhost<N>(g, L, u);
+	int rc = prepareGhosts<N>(g, L, u);
 	if (rc) return rc;
 	Timed t(g, KC_RBGS, (size_t) L.P * L.nc);
 	hipLaunchKernelGGL(k_rbgs3d<N>, dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f, out);
@@ -434,7 +621,7 @@ int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double
 }
 template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1)
 {
-	int rc = launchCfGhost<N>(g, L, u);
+	int rc = prepareGhosts<N>(g, L, u);
 	if (rc) return rc;
 	const size_t total = (size_t) L.P * L.nc;
 	{
@@ -472,17 +659,33 @@ int patchSolve(te_gmg *g, LevelHost &L, const double *f, double *u)
 }
 template <int N> int restrictN(te_gmg *g, LevelHost &L, const double *fine, double *coarse)
 {
+	if (L.n_up > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_up * L.nc / 8);
+		hipLaunchKernelGGL(k_restrict_pack3d<N>, dim3(L.n_up), dim3(256), 0, g->stream, L.up_desc.p, L.up_off.p, fine,
+		                   L.upbuf.p);
+	}
+	int rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p);
+	if (rc) return rc;
+	if (L.Pc == 0) return TE_OK;
 	Timed t(g, KC_RESTRICT, (size_t) L.P * L.nc);
 	hipLaunchKernelGGL(k_restrict3d<N>, dim3(gridFor((size_t) L.Pc * L.nc, 256)), dim3(256), 0, g->stream, L.Pc,
-	                   L.child.p, L.copy.p, fine, coarse);
+	                   L.child.p, L.copy.p, fine, L.downbuf.p, L.down_off.p, coarse);
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
 template <int N> int prolongN(te_gmg *g, LevelHost &L, const double *coarse, double *fine)
 {
+	if (L.n_down > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 8);
+		hipLaunchKernelGGL(k_prolong_pack3d<N>, dim3(L.n_down), dim3(256), 0, g->stream, L.down_desc.p, L.down_off.p,
+		                   coarse, L.downbuf.p);
+	}
+	int rc = doExchange(g, 3, L.tx_down, L.downbuf.p, L.upbuf.p);
+	if (rc) return rc;
+	if (L.P == 0) return TE_OK;
 	Timed t(g, KC_PROLONG, (size_t) L.P * L.nc);
 	hipLaunchKernelGGL(k_prolong3d<N>, dim3(gridFor((size_t) L.P * L.nc / 2, 256)), dim3(256), 0, g->stream, L.P,
-	                   L.parent.p, L.orth.p, coarse, fine);
+	                   L.parent.p, L.orth.p, coarse, L.upbuf.p, L.up_off.p, fine);
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
@@ -546,7 +749,6 @@ int smoothOnce(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, d
 int doRestrict(te_gmg *g, int fine_level, const double *fine, double *coarse)
 {
 	LevelHost &L = *g->levels[fine_level];
-	if (L.Pc == 0) return TE_OK;
 	switch (L.n) {
 		case 4: return restrictN<4>(g, L, fine, coarse);
 		case 8: return restrictN<8>(g, L, fine, coarse);
@@ -557,7 +759,6 @@ int doRestrict(te_gmg *g, int fine_level, const double *fine, double *coarse)
 int doProlong(te_gmg *g, int fine_level, const double *coarse, double *fine)
 {
 	LevelHost &L = *g->levels[fine_level];
-	if (L.P == 0) return TE_OK;
 	switch (L.n) {
 		case 4: return prolongN<4>(g, L, coarse, fine);
 		case 8: return prolongN<8>(g, L, coarse, fine);

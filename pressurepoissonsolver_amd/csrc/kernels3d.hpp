@@ -497,14 +497,49 @@ __global__ void k_cf_ghost3d(const int32_t *__restrict__ desc, const int32_t *__
 	}
 }
 
-// AvgRstr.h:78-113, gathered per coarse cell (no atomics, no zero-fill pass): the eight fine
-// cells are summed in the order the reference's scatter loop visits them (x, then y, then z),
-// each divided by 2^D first, so the result is bit-identical.
-// child[pc*8 + o] = fine patch holding orthant o, or child[pc*8] = source, copy[pc] = 1.
+// Multi-rank: copy the face layers other ranks need into one contiguous send buffer.
+// faces[i] = (patch, side); one workgroup per face; layout (a, b) = remaining axes in order.
+template <int N>
+__global__ void k_pack_faces3d(const int32_t *__restrict__ faces, const double *__restrict__ u,
+                               double *__restrict__ sendbuf)
+{
+	constexpr int NN = N * N, NNN = N * N * N;
+	const int     p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
+	const int     ax = s >> 1;
+	const int     sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
+	const double *up = u + (size_t) p * NNN + ((s & 1) ? (N - 1) * sn : 0);
+	double       *o  = sendbuf + (size_t) blockIdx.x * NN;
+	for (int i = threadIdx.x; i < NN; i += blockDim.x) o[i] = up[(i % N) * sa + (i / N) * sb];
+}
+
+// restricted value of coarse cell (hx,hy,hz) of the octant a fine patch covers: the eight fine
+// cells summed in the order the reference's scatter loop visits them (AvgRstr.h:95-102: x, then
+// y, then z), each divided by 2^D first -> bit-identical to the reference.
+template <int N> __device__ __forceinline__ double restrictCell(const double *fp, int hx, int hy, int hz)
+{
+	constexpr int NN  = N * N;
+	double        acc = 0.0;
+#pragma unroll
+	for (int dz = 0; dz < 2; dz++)
+#pragma unroll
+		for (int dy = 0; dy < 2; dy++) {
+			const double2 v = *reinterpret_cast<const double2 *>(fp + 2 * hx + N * (2 * hy + dy) + NN * (2 * hz + dz));
+			acc += v.x / 8;
+			acc += v.y / 8;
+		}
+	return acc;
+}
+
+// AvgRstr.h:78-113, gathered per coarse cell (no atomics, no zero-fill pass).
+// child[pc*8 + o] = fine patch holding orthant o (or child[pc*8] = source when copy[pc]);
+// an entry <= -2 means the child lives on another rank and its already-restricted block
+// number -(entry+2) sits in `remote` at remote_off[block].
 template <int N>
 __global__ __launch_bounds__(256) void k_restrict3d(int Pc, const int32_t *__restrict__ child,
                                                     const int32_t *__restrict__ copy,
                                                     const double *__restrict__ fine,
+                                                    const double *__restrict__ remote,
+                                                    const int64_t *__restrict__ remote_off,
                                                     double *__restrict__ coarse)
 {
 	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
@@ -514,53 +549,93 @@ __global__ __launch_bounds__(256) void k_restrict3d(int Pc, const int32_t *__res
 		const int pc = (int) (idx / NNN), c = (int) (idx % NNN);
 		const int x = c % N, y = (c / N) % N, z = c / NN;
 		if (copy[pc]) {
-			coarse[idx] = 0.0 + fine[(size_t) child[(size_t) pc * 8] * NNN + c];
+			const int src = child[(size_t) pc * 8];
+			coarse[idx]   = 0.0 + (src >= 0 ? fine[(size_t) src * NNN + c] : remote[remote_off[-(src + 2)] + c]);
 			continue;
 		}
-		const int     ox = x >= H, oy = y >= H, oz = z >= H;
-		const double *fp = fine + (size_t) child[(size_t) pc * 8 + ox + 2 * oy + 4 * oz] * NNN;
-		const int     fx = 2 * (x - ox * H), fy = 2 * (y - oy * H), fz = 2 * (z - oz * H);
-		double        acc = 0.0;
-#pragma unroll
-		for (int dz = 0; dz < 2; dz++)
-#pragma unroll
-			for (int dy = 0; dy < 2; dy++) {
-				const double2 v = *reinterpret_cast<const double2 *>(fp + fx + N * (fy + dy) + NN * (fz + dz));
-				acc += v.x / 8;
-				acc += v.y / 8;
-			}
-		coarse[idx] = acc;
+		const int ox = x >= H, oy = y >= H, oz = z >= H;
+		const int hx = x - ox * H, hy = y - oy * H, hz = z - oz * H;
+		const int src = child[(size_t) pc * 8 + ox + 2 * oy + 4 * oz];
+		if (src >= 0)
+			coarse[idx] = restrictCell<N>(fine + (size_t) src * NNN, hx, hy, hz);
+		else
+			coarse[idx] = remote[remote_off[-(src + 2)] + hx + H * hy + H * H * hz];
+	}
+}
+// child side of a cross-rank restriction: desc[i] = (fine patch, orthant or -1), block i at off[i]
+template <int N>
+__global__ __launch_bounds__(256) void k_restrict_pack3d(const int32_t *__restrict__ desc,
+                                                         const int64_t *__restrict__ off,
+                                                         const double *__restrict__ fine, double *__restrict__ buf)
+{
+	constexpr int NNN = N * N * N, H = N / 2;
+	const int     p = desc[2 * blockIdx.x], o = desc[2 * blockIdx.x + 1];
+	const double *fp = fine + (size_t) p * NNN;
+	double       *b  = buf + off[blockIdx.x];
+	if (o < 0) {
+		for (int i = threadIdx.x; i < NNN; i += blockDim.x) b[i] = fp[i];
+	} else {
+		for (int i = threadIdx.x; i < H * H * H; i += blockDim.x)
+			b[i] = restrictCell<N>(fp, i % H, (i / H) % H, i / (H * H));
 	}
 }
 
-// DrctIntp.h:80-113: fine += coarse[parent][(c + orthant offset)/2]
+// DrctIntp.h:80-113: fine += coarse[parent][(c + orthant offset)/2].
+// parent[pf] <= -2: the parent lives on another rank; its octant (or whole patch, orthant -1)
+// was received as block -(parent+2) of `remote`.
 template <int N>
 __global__ __launch_bounds__(256) void k_prolong3d(int Pf, const int32_t *__restrict__ parent,
                                                    const int32_t *__restrict__ orth,
                                                    const double *__restrict__ coarse,
+                                                   const double *__restrict__ remote,
+                                                   const int64_t *__restrict__ remote_off,
                                                    double *__restrict__ fine)
 {
-	constexpr int NN = N * N, NNN = N * N * N;
+	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
 	const size_t  total = (size_t) Pf * (NNN / 2);
 	for (size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x; idx < total;
 	     idx += (size_t) gridDim.x * blockDim.x) {
-		const int     pf = (int) (idx / (NNN / 2)), c = (int) (idx % (NNN / 2)) * 2;
-		const int     x = c % N, y = (c / N) % N, z = c / NN;
-		const int     o  = orth[pf];
-		const double *cp = coarse + (size_t) parent[pf] * NNN;
-		double2      *fp = reinterpret_cast<double2 *>(fine + (size_t) pf * NNN + c);
-		double2       v  = *fp;
+		const int pf = (int) (idx / (NNN / 2)), c = (int) (idx % (NNN / 2)) * 2;
+		const int x = c % N, y = (c / N) % N, z = c / NN;
+		const int o  = orth[pf];
+		const int pa = parent[pf];
+		double2  *fp = reinterpret_cast<double2 *>(fine + (size_t) pf * NNN + c);
+		double2   v  = *fp;
 		if (o >= 0) {
-			const int cx = (x + ((o & 1) ? N : 0)) / 2, cy = (y + ((o & 2) ? N : 0)) / 2,
-			          cz = (z + ((o & 4) ? N : 0)) / 2;
-			const double cv = cp[cx + N * cy + NN * cz];
+			double cv;
+			if (pa >= 0) {
+				const int cx = (x + ((o & 1) ? N : 0)) / 2, cy = (y + ((o & 2) ? N : 0)) / 2,
+				          cz = (z + ((o & 4) ? N : 0)) / 2;
+				cv = coarse[(size_t) pa * NNN + cx + N * cy + NN * cz];
+			} else {
+				cv = remote[remote_off[-(pa + 2)] + x / 2 + H * (y / 2) + H * H * (z / 2)];
+			}
 			v.x += cv;
 			v.y += cv;
 		} else {
+			const double *cp = (pa >= 0) ? coarse + (size_t) pa * NNN : remote + remote_off[-(pa + 2)];
 			v.x += cp[c];
 			v.y += cp[c + 1];
 		}
 		*fp = v;
+	}
+}
+// parent side of a cross-rank prolongation: desc[i] = (coarse patch, orthant or -1)
+template <int N>
+__global__ __launch_bounds__(256) void k_prolong_pack3d(const int32_t *__restrict__ desc,
+                                                        const int64_t *__restrict__ off,
+                                                        const double *__restrict__ coarse, double *__restrict__ buf)
+{
+	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
+	const int     pc = desc[2 * blockIdx.x], o = desc[2 * blockIdx.x + 1];
+	const double *cp = coarse + (size_t) pc * NNN;
+	double       *b  = buf + off[blockIdx.x];
+	if (o < 0) {
+		for (int i = threadIdx.x; i < NNN; i += blockDim.x) b[i] = cp[i];
+	} else {
+		const int bx = (o & 1) ? H : 0, by = (o & 2) ? H : 0, bz = (o & 4) ? H : 0;
+		for (int i = threadIdx.x; i < H * H * H; i += blockDim.x)
+			b[i] = cp[bx + i % H + N * (by + (i / H) % H) + NN * (bz + i / (H * H))];
 	}
 }
 

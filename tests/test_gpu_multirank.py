@@ -1,0 +1,121 @@
+"""-m gpu: the native multi-rank path (remote ghost faces, cross-rank restriction / prolongation)
+with 2 / 4 / 8 VIRTUAL ranks sharing the one GPU of the test box (dist.LocalFabric: one thread per
+rank, device-to-device copies). Every per-cell operation is independent of the partition, so the
+sharded result must equal the single-rank result BIT FOR BIT; BiCGStab differs only through the
+order of the dot-product sums (tolerance 1e-9 on the solution, same iteration count +-1).
+The torch.distributed binding of the same callback is covered by tests/test_dist_gloo.py (CPU)
+and rehearsed with real processes in test_two_processes_gloo below."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pressurepoissonsolver_amd import capi, dist as tedist, problems, solver
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def shard_run(mesh, n, nranks, fn):
+    """fn(rank, H, g) -> dict of local arrays on level 0; returns them assembled in global order"""
+    fab = tedist.LocalFabric(nranks)
+    hs = [capi.Hierarchy(mesh, n, rank=r, nranks=nranks) for r in range(nranks)]
+    gs = [capi.GMG(h) for h in hs]
+    for r, g in enumerate(gs):
+        fab.attach(g, r)
+    outs = fab.run(lambda r: fn(r, hs[r], gs[r], fab))
+    P = hs[0].sizes(0)[1]
+    nc = n ** 3
+    merged = {}
+    for k in outs[0]:
+        if isinstance(outs[0][k], np.ndarray):
+            full = np.zeros(P * nc)
+            for r in range(nranks):
+                idx = hs[r].l2g(0)
+                full.reshape(P, nc)[idx] = outs[r][k].reshape(len(idx), nc)
+            merged[k] = full
+        else:
+            merged[k] = [o[k] for o in outs]
+    return merged
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+@pytest.mark.parametrize("divides,n", [(2, 8), (3, 4)])
+def test_sharded_ops_equal_single_rank(nranks, divides, n):
+    mesh = util.mesh("uniform", divides)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    size = H1.cells(0)
+    u = util.rand_vec(size, 1)
+    f = util.rand_vec(size, 2)
+    nc = n ** 3
+
+    def single(op):
+        du, df, dr = g1.new_vector(0, u), g1.new_vector(0, f), g1.new_vector(0)
+        op(g1, du, df, dr)
+        return dr.download()
+
+    ops = {
+        "apply": lambda g, du, df, dr: g.apply(du, dr),
+        "resid": lambda g, du, df, dr: g.residual(du, df, dr),
+        "rbgs": lambda g, du, df, dr: (g.smooth(df, du, smoother=capi.SMOOTH_RBGS), dr.copy(du)),
+        "jacobi": lambda g, du, df, dr: (g.smooth(df, du, smoother=capi.SMOOTH_JACOBI, omega=0.8), dr.copy(du)),
+        "patch": lambda g, du, df, dr: (g.smooth(df, du, smoother=capi.SMOOTH_PATCH_SOLVE), dr.copy(du)),
+        "vcycle_rbgs": lambda g, du, df, dr: g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, dr),
+        "vcycle_patch": lambda g, du, df, dr: g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, dr),
+        "wcycle_jacobi": lambda g, du, df, dr: g.cycle(g.default_opts(smoother=capi.SMOOTH_JACOBI, cycle_type=1,
+                                                                      omega=0.8), df, dr),
+    }
+    want = {k: single(op) for k, op in ops.items()}
+
+    def per_rank(r, H, g, fab):
+        idx = H.l2g(0)
+        lu = u.reshape(-1, nc)[idx].ravel()
+        lf = f.reshape(-1, nc)[idx].ravel()
+        out = {}
+        for k, op in ops.items():
+            du, df, dr = g.new_vector(0, lu), g.new_vector(0, lf), g.new_vector(0)
+            op(g, du, df, dr)
+            out[k] = dr.download()
+        return out
+
+    got = shard_run(mesh, n, nranks, per_rank)
+    for k in ops:
+        assert np.array_equal(got[k], want[k]), (k, np.abs(got[k] - want[k]).max())
+
+
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_sharded_bicgstab(nranks):
+    n = 8
+    mesh = util.mesh("uniform", 2)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    f, exact = problems.init_dirichlet(H1.tables(0), n)
+    x1 = g1.new_vector(0)
+    its1, rr1 = g1.bicgstab(x1, g1.new_vector(0, f), g1.default_opts(smoother=capi.SMOOTH_RBGS))
+    want = x1.download()
+    nc = n ** 3
+
+    def per_rank(r, H, g, fab):
+        idx = H.l2g(0)
+        b = g.new_vector(0, f.reshape(-1, nc)[idx].ravel())
+        x = g.new_vector(0)
+        its, rr = solver.bicgstab(g, x, b, g.default_opts(smoother=capi.SMOOTH_RBGS), allreduce=fab.allreduce(r))
+        return {"x": x.download(), "its": its, "rr": rr}
+
+    got = shard_run(mesh, n, nranks, per_rank)
+    assert all(abs(i - its1) <= 1 for i in got["its"]) and max(got["rr"]) <= 1e-12
+    assert np.linalg.norm(got["x"] - want) <= 1e-9 * np.linalg.norm(want)
+
+
+def test_two_processes_gloo():
+    """Real processes + torch.distributed (gloo staging through host) on the single GPU."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29611", os.path.join(root, "tests", "mr_worker.py"), "--backend", "gloo"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "MR_WORKER_OK" in r.stdout
