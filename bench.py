@@ -38,7 +38,8 @@ ALG_BYTES = {
     "vecop": 8.0,
     "patch_rhs": 24.0,
     "dst_axis": 16.0,
-    "resid_restrict": 17.0,
+    "resid_restrict": 17.0,      # read u, f; write coarse f (8/8): residual never stored
+    "stencil_rbgs_zero": 16.0,   # first sweep from a zero guess: read f, write u
 }
 
 

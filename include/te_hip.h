@@ -78,7 +78,9 @@ typedef struct {
 	int32_t smoother;   /* TE_SMOOTH_* */
 	double  omega;      /* Jacobi weight */
 	int32_t exact_coarse; /* pointwise smoothers: exact patch solve on a 1-patch coarsest level */
-	int32_t fuse;         /* 1: use fused residual+restrict / zero-guess kernels inside te_vcycle */
+	int32_t fuse;         /* 1 (default): inside te_vcycle use the fused residual+restrict kernel and the
+	                         zero-guess first sweep (bit-identical results, fewer HBM passes); 0: one kernel
+	                         per reference call (apply, scaleThenAdd, restrict, set, ...) */
 } te_cycle_opts;
 
 #define TE_SMOOTH_PATCH_SOLVE 0 /* reference: FFTBlockJacobiSmoother.h:55-58 (block Jacobi, exact patch solves) */

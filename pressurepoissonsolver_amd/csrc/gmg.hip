@@ -32,11 +32,11 @@ namespace
 {
 enum KClass : int {
 	KC_APPLY, KC_RESID, KC_JACOBI, KC_RBGS, KC_CFGHOST, KC_RESTRICT, KC_PROLONG, KC_PATCH_RHS,
-	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_COUNT
+	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_RBGS_ZERO, KC_RESID_RESTRICT, KC_COUNT
 };
 const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_jacobi", "stencil_rbgs",
                                     "cf_ghost", "restrict", "prolong_add", "patch_rhs", "dst_axis",
-                                    "vecop", "reduce", "pack", "exchange"};
+                                    "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict"};
 
 template <typename T> struct DevBuf {
 	T     *p = nullptr;
@@ -69,7 +69,7 @@ struct ExPlan {
 };
 
 struct LevelHost {
-	int    dim = 3, n = 0, P = 0;
+	int    dim = 3, n = 0, P = 0, P_global = 0;
 	size_t nc = 0, nf = 0;
 	// stencil tables
 	DevBuf<int32_t> face_kind, face_src;
@@ -268,6 +268,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	L->dim = lv.dim;
 	L->n   = n;
 	L->P   = lv.P;
+	L->P_global = lv.P_global;
 	L->nc  = (size_t) n * n * n;
 	L->nf  = (size_t) n * n;
 	const int P = lv.P, NS = 6, me = H.rank;
@@ -561,11 +562,12 @@ template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u)
 	return TE_OK;
 }
 template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out,
-                                              double omega)
+                                              double omega, RestrictDst rd = RestrictDst())
 {
 	int rc = prepareGhosts<N>(g, L, u);
 	if (rc) return rc;
-	Timed     t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : KC_JACOBI), (size_t) L.P * L.nc);
+	Timed     t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : (MODE == MODE_JACOBI ? KC_JACOBI : KC_RESID_RESTRICT)),
+	            (size_t) L.P * L.nc);
 	const int tpb = Tile2<N>::TPB;
 	// enough workgroups to fill 256 CUs a few times over: split patches into z-slabs when few
 	int zs = 1;
@@ -575,48 +577,85 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 	auto grid = [&](int z) { return dim3(8 * ((L.P * z + 7) / 8)); };
 	LevelDev D = L.dev();
 	switch (zs) {
-		case 1: hipLaunchKernelGGL((k_stencil3d<N, MODE, 1>), grid(1), dim3(tpb), 0, g->stream, D, u, f, out, omega); break;
+		case 1: hipLaunchKernelGGL((k_stencil3d<N, MODE, 1>), grid(1), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd); break;
 		case 2:
 			if constexpr (N >= 8)
-				hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega);
+				hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
 			break;
 		default:
 			if constexpr (N >= 16)
-				hipLaunchKernelGGL((k_stencil3d<N, MODE, 4>), grid(4), dim3(tpb), 0, g->stream, D, u, f, out, omega);
+				hipLaunchKernelGGL((k_stencil3d<N, MODE, 4>), grid(4), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
 			else if constexpr (N >= 8)
-				hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega);
+				hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
 			break;
 	}
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
-template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega)
+template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega,
+                                      RestrictDst rd = RestrictDst())
 {
 	if (L.P == 0) return TE_OK;
 	switch (L.n) {
-		case 4: return launchStencilN<4, MODE>(g, L, u, f, out, omega);
-		case 8: return launchStencilN<8, MODE>(g, L, u, f, out, omega);
-		case 16: return launchStencilN<16, MODE>(g, L, u, f, out, omega);
-		default: return launchStencilN<32, MODE>(g, L, u, f, out, omega);
+		case 4: return launchStencilN<4, MODE>(g, L, u, f, out, omega, rd);
+		case 8: return launchStencilN<8, MODE>(g, L, u, f, out, omega, rd);
+		case 16: return launchStencilN<16, MODE>(g, L, u, f, out, omega, rd);
+		default: return launchStencilN<32, MODE>(g, L, u, f, out, omega, rd);
 	}
 }
-template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out)
+template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess)
 {
-	int rc = prepareGhosts<N>(g, L, u);
-	if (rc) return rc;
-	Timed t(g, KC_RBGS, (size_t) L.P * L.nc);
-	hipLaunchKernelGGL(k_rbgs3d<N>, dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f, out);
+	if (!zero_guess) { // a zero iterate has zero ghosts everywhere: nothing to exchange or build
+		int rc = prepareGhosts<N>(g, L, u);
+		if (rc) return rc;
+	}
+	Timed t(g, zero_guess ? KC_RBGS_ZERO : KC_RBGS, (size_t) L.P * L.nc);
+	if (zero_guess)
+		hipLaunchKernelGGL((k_rbgs3d<N, true>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f, out);
+	else
+		hipLaunchKernelGGL((k_rbgs3d<N, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f, out);
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
-int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out)
+int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false)
 {
 	if (L.P == 0) return TE_OK;
 	switch (L.n) {
-		case 4: return launchRbgsN<4>(g, L, u, f, out);
-		case 8: return launchRbgsN<8>(g, L, u, f, out);
-		case 16: return launchRbgsN<16>(g, L, u, f, out);
-		default: return launchRbgsN<32>(g, L, u, f, out);
+		case 4: return launchRbgsN<4>(g, L, u, f, out, zero_guess);
+		case 8: return launchRbgsN<8>(g, L, u, f, out, zero_guess);
+		case 16: return launchRbgsN<16>(g, L, u, f, out, zero_guess);
+		default: return launchRbgsN<32>(g, L, u, f, out, zero_guess);
+	}
+}
+// Cycle.h:59-65 in one pass: coarse f = AvgRstr(f - A u), r never stored. Children whose parent is
+// on another rank write their block into upbuf; received blocks are placed by k_restrict_unpack3d.
+template <int N> int residRestrictN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse)
+{
+	RestrictDst rd;
+	rd.parent     = L.parent.p;
+	rd.orth       = L.orth.p;
+	rd.coarse     = coarse;
+	rd.remote     = L.upbuf.p;
+	rd.remote_off = L.up_off.p;
+	int rc        = TE_OK;
+	if (L.P > 0) rc = launchStencilN<N, MODE_RESID_RESTRICT>(g, L, u, f, L.r->d, 0.0, rd);
+	if (rc) return rc;
+	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
+	if (L.n_down > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 8);
+		hipLaunchKernelGGL(k_restrict_unpack3d<N>, dim3(L.n_down), dim3(256), 0, g->stream, L.down_desc.p, L.down_off.p,
+		                   L.downbuf.p, coarse);
+	}
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+int residRestrict(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse)
+{
+	switch (L.n) {
+		case 4: return residRestrictN<4>(g, L, u, f, coarse);
+		case 8: return residRestrictN<8>(g, L, u, f, coarse);
+		case 16: return residRestrictN<16>(g, L, u, f, coarse);
+		default: return residRestrictN<32>(g, L, u, f, coarse);
 	}
 }
 template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1)
@@ -727,7 +766,7 @@ template <int OP> int reduce(const te_vec *a, const te_vec *b, double *out)
 
 void swapData(te_vec *a, te_vec *b) { std::swap(a->d, b->d); }
 
-int smoothOnce(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega)
+int smoothOnce(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega, bool zero_guess = false)
 {
 	LevelHost &L = *g->levels[level];
 	int        rc;
@@ -739,7 +778,7 @@ int smoothOnce(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, d
 			swapData(u, L.t.get());
 			return TE_OK;
 		case TE_SMOOTH_RBGS:
-			rc = launchRbgs(g, L, u->d, f->d, L.t->d);
+			rc = launchRbgs(g, L, u->d, f->d, L.t->d, zero_guess);
 			if (rc) return rc;
 			swapData(u, L.t.get());
 			return TE_OK;
@@ -767,30 +806,53 @@ int doProlong(te_gmg *g, int fine_level, const double *coarse, double *fine)
 	}
 }
 
-// GMG/VCycle.h:44-62, GMG/WCycle.h:45-68, GMG/Cycle.h:56-90
-int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u)
+// GMG/VCycle.h:44-62, GMG/WCycle.h:45-68, GMG/Cycle.h:56-90.
+// `u_zero`: u is logically zero on entry but has NOT been written yet (fused mode): the first RB-GS
+// sweep then runs its zero-guess variant and the 8 B/site zero-fill never happens; any other first
+// consumer materialises the zeros first. Results are bit-identical to the unfused sequence.
+int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, bool u_zero)
 {
 	const int  nl       = (int) g->levels.size();
 	const bool coarsest = (l == nl - 1);
 	LevelHost &L        = *g->levels[l];
 	int        rc;
-	auto       smooth = [&](int sweeps, bool at_coarsest) -> int {
-        int sm = o->smoother;
-        if (at_coarsest && o->exact_coarse && L.P == 1) sm = TE_SMOOTH_PATCH_SOLVE;
-        for (int i = 0; i < sweeps; i++) {
-            int r = smoothOnce(g, l, f, u, sm, o->omega);
-            if (r) return r;
-        }
-        return TE_OK;
+	auto       materialise = [&]() -> int {
+        if (!u_zero) return TE_OK;
+        u_zero = false;
+        return vecop<VOP_SET>(u, nullptr, nullptr, 0.0, 0.0, 0.0);
 	};
-	if (coarsest) return smooth(o->coarse_sweeps, true);
+	auto smooth = [&](int sweeps, bool at_coarsest) -> int {
+		int sm = o->smoother;
+		if (at_coarsest && o->exact_coarse && L.P_global == 1) sm = TE_SMOOTH_PATCH_SOLVE;
+		for (int i = 0; i < sweeps; i++) {
+			int r;
+			if (u_zero && sm == TE_SMOOTH_RBGS) {
+				u_zero = false;
+				r      = smoothOnce(g, l, f, u, sm, o->omega, true);
+			} else {
+				if ((r = materialise())) return r;
+				r = smoothOnce(g, l, f, u, sm, o->omega);
+			}
+			if (r) return r;
+		}
+		return TE_OK;
+	};
+	if (coarsest) {
+		if ((rc = smooth(o->coarse_sweeps, true))) return rc;
+		return materialise();
+	}
 	LevelHost &C       = *g->levels[l + 1];
 	auto       descend = [&]() -> int {
-        int r = launchStencil<MODE_RESID>(g, L, u->d, f->d, L.r->d, 0.0); // prepCoarser: r = f - A u
+        int r = materialise();
         if (r) return r;
-        if ((r = doRestrict(g, l, L.r->d, C.f->d))) return r;
-        if ((r = vecop<VOP_SET>(C.u.get(), nullptr, nullptr, 0.0, 0.0, 0.0))) return r;
-        if ((r = visit(g, o, l + 1, C.f.get(), C.u.get()))) return r;
+        if (o->fuse) {
+            if ((r = residRestrict(g, L, u->d, f->d, C.f->d))) return r;
+        } else {
+            if ((r = launchStencil<MODE_RESID>(g, L, u->d, f->d, L.r->d, 0.0))) return r; // prepCoarser: r = f - A u
+            if ((r = doRestrict(g, l, L.r->d, C.f->d))) return r;
+            if ((r = vecop<VOP_SET>(C.u.get(), nullptr, nullptr, 0.0, 0.0, 0.0))) return r;
+        }
+        if ((r = visit(g, o, l + 1, C.f.get(), C.u.get(), o->fuse != 0))) return r;
         return doProlong(g, l, C.u->d, u->d); // prepFiner
 	};
 	if ((rc = smooth(o->pre_sweeps, false))) return rc;
@@ -812,7 +874,7 @@ void te_cycle_opts_default(te_cycle_opts *o)
 	o->smoother     = TE_SMOOTH_PATCH_SOLVE;
 	o->omega        = 6.0 / 7.0;
 	o->exact_coarse = 1;
-	o->fuse         = 0;
+	o->fuse         = 1;
 }
 
 int te_gmg_create(const te_hier *h, int device, te_gmg **out)
@@ -991,8 +1053,8 @@ int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u)
 	int rc;
 	if (!o) return te::fail(TE_EINVAL, "te_vcycle: null options");
 	if ((rc = checkLevelVec(g, 0, f, "te_vcycle")) || (rc = checkLevelVec(g, 0, u, "te_vcycle"))) return rc;
-	if ((rc = te_vec_set(u, 0.0))) return rc; // Cycle.h:118
-	return visit(g, o, 0, f, u);
+	if (!o->fuse && (rc = te_vec_set(u, 0.0))) return rc; // Cycle.h:118
+	return visit(g, o, 0, f, u, o->fuse != 0);
 }
 
 // BiCGStab.h:45-106, statement for statement, on device vectors

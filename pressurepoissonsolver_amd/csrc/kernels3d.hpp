@@ -19,7 +19,16 @@
 namespace te
 {
 enum FaceKind : int32_t { FACE_DIRICHLET = 0, FACE_NEUMANN = 1, FACE_LOCAL = 2, FACE_GHOST = 3 };
-enum StencilMode : int { MODE_APPLY = 0, MODE_RESID = 1, MODE_JACOBI = 2 };
+enum StencilMode : int { MODE_APPLY = 0, MODE_RESID = 1, MODE_JACOBI = 2, MODE_RESID_RESTRICT = 3 };
+
+// where the fused residual+restriction kernel puts the coarse right-hand side of a patch:
+// parent[p] >= 0: octant orth[p] of that coarse patch; parent[p] <= -2: block -(parent+2) of `remote`
+// (the parent lives on another rank); orth[p] < 0: the patch does not coarsen, r is copied through.
+struct RestrictDst {
+	const int32_t *parent, *orth;
+	double        *coarse, *remote;
+	const int64_t *remote_off;
+};
 
 struct LevelDev {
 	int32_t        P;         // local patches
@@ -149,6 +158,9 @@ __device__ __forceinline__ HaloSrc haloSrc(int tid, const int32_t *fk, const int
 // MODE_APPLY : out = A u                     (SchurHelper.h:360-376 + StarPatchOp.h:28-184)
 // MODE_RESID : out = f - A u                 (+ Cycle.h:60-61)
 // MODE_JACOBI: out = u + omega (f - A u)/diag(A)
+// MODE_RESID_RESTRICT: coarse f = AvgRstr(f - A u) without ever storing r (Cycle.h:59-65 fused); the
+//   eight fine residuals of a coarse cell are added in AvgRstr's own order (x, y, z), so the result
+//   is bit-identical to MODE_RESID followed by k_restrict3d.
 // grid: 8*ceil(P*ZS/8) blocks of Tile2<N>::TPB threads; ZS z-slabs per patch.
 // The steady-state loop is branch-free: every load of an iteration is issued unconditionally
 // from a (pointer, sign) pair chosen with scalar selects, so the compiler can keep the whole
@@ -156,7 +168,8 @@ __device__ __forceinline__ HaloSrc haloSrc(int tid, const int32_t *fk, const int
 template <int N, int MODE, int ZS>
 __global__ __launch_bounds__(Tile2<N>::TPB) void k_stencil3d(LevelDev L, const double *__restrict__ u,
                                                              const double *__restrict__ f,
-                                                             double *__restrict__ out, double omega)
+                                                             double *__restrict__ out, double omega,
+                                                             RestrictDst rd)
 {
 	using T               = Tile2<N>;
 	constexpr int  TPB    = T::TPB;
@@ -186,6 +199,28 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_stencil3d(LevelDev L, const d
 	const double2 *up2 = reinterpret_cast<const double2 *>(up);
 	const double2 *fp2 = reinterpret_cast<const double2 *>((MODE != MODE_APPLY ? f : u) + (size_t) pid * NNN);
 	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
+
+	// fused restriction target
+	double *rdst = nullptr; // base of the coarse octant (or remote block)
+	int     rsy = 0, rsz = 0, rorth = -1;
+	double  racc[CPT];
+	if (MODE == MODE_RESID_RESTRICT) {
+		const int pa = rd.parent[pid];
+		rorth        = rd.orth[pid];
+		if (rorth < 0) { // copy-through: r lands unchanged in the coarse patch / remote block
+			op2 = reinterpret_cast<double2 *>(pa >= 0 ? rd.coarse + (size_t) pa * NNN : rd.remote + rd.remote_off[-(pa + 2)]);
+		} else if (pa >= 0) {
+			rdst = rd.coarse + (size_t) pa * NNN + ((rorth & 1) ? H : 0) + N * ((rorth & 2) ? H : 0) + NN * ((rorth & 4) ? H : 0);
+			rsy  = N;
+			rsz  = NN;
+		} else {
+			rdst = rd.remote + rd.remote_off[-(pa + 2)];
+			rsy  = H;
+			rsz  = H * H;
+		}
+#pragma unroll
+		for (int k = 0; k < CPT; k++) racc[k] = 0.0;
+	}
 
 	if (MODE == MODE_JACOBI) {
 		if (tid < 27) {
@@ -268,7 +303,7 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_stencil3d(LevelDev L, const d
 			double2 r;
 			if (MODE == MODE_APPLY) {
 				r = lap;
-			} else if (MODE == MODE_RESID) {
+			} else if (MODE == MODE_RESID || MODE == MODE_RESID_RESTRICT) {
 				r.x = fc[k].x - lap.x;
 				r.y = fc[k].y - lap.y;
 			} else {
@@ -279,7 +314,20 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_stencil3d(LevelDev L, const d
 				r.x = c.x + omega * (fc[k].x - lap.x) * idiag[b + (x == 0 ? 0 : 1)];
 				r.y = c.y + omega * (fc[k].y - lap.y) * idiag[b + (x == N - 2 ? 2 : 1)];
 			}
-			if (act[k]) op2[z * NP + q[k]] = r;
+			if (MODE == MODE_RESID_RESTRICT && rorth >= 0) {
+				// row y+1 of the same plane sits H lanes up in this wave (H pairs per row)
+				const double ox = __shfl_down(r.x, H, 64), oy = __shfl_down(r.y, H, 64);
+				double       a  = (z & 1) ? racc[k] : 0.0;
+				a += r.x / 8;
+				a += r.y / 8;
+				a += ox / 8;
+				a += oy / 8;
+				racc[k]      = a;
+				const int y = q[k] / H, X = q[k] % H;
+				if ((z & 1) && !(y & 1) && act[k]) rdst[X + rsy * (y >> 1) + rsz * (z >> 1)] = a;
+			} else {
+				if (act[k]) op2[z * NP + q[k]] = r;
+			}
 		}
 #pragma unroll
 		for (int k = 0; k < CPT; k++) {
@@ -295,7 +343,7 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_stencil3d(LevelDev L, const d
 __device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a : b; }
 
 // relax the cells of colour `colour` of plane z; `cen` holds the plane's pairs (LDS copy in tl)
-template <int N>
+template <int N, bool ZERO_NBRS = false>
 __device__ __forceinline__ void rbgsRelax(double *tl, const double *idiag, int z, int colour,
                                           const int (&yy)[Tile2<N>::CPT], const int (&xx)[Tile2<N>::CPT],
                                           const bool (&act)[Tile2<N>::CPT], double rhx, double rhy, double rhz,
@@ -312,11 +360,12 @@ __device__ __forceinline__ void rbgsRelax(double *tl, const double *idiag, int z
 		double      *t0    = tl + (y + 1) * LW + xc + 2;
 		// sel() takes values, so no conditional lvalue (= dynamically indexed stack slot) is formed
 		const double2 cv = cen[k], bl = below[k], ab = above[k], rr = rhs[k];
-		const double  side = sel(first, t0[-1], t0[1]); // the x-neighbour outside the pair
+		const double  side = ZERO_NBRS ? 0.0 : sel(first, t0[-1], t0[1]); // the x-neighbour outside the pair
 		const double  mate = sel(first, cv.y, cv.x);
 		const double  zb = sel(first, bl.x, bl.y), za = sel(first, ab.x, ab.y);
 		const double  rh = sel(first, rr.x, rr.y);
-		const double  o  = (side + mate) * rhx + (t0[-LW] + t0[LW]) * rhy + (zb + za) * rhz;
+		// ZERO_NBRS: every neighbour is known to be 0 (first red half-sweep from a zero guess)
+		const double  o  = ZERO_NBRS ? 0.0 : (side + mate) * rhx + (t0[-LW] + t0[LW]) * rhy + (zb + za) * rhz;
 		const int     cx = (xc == 0) ? 0 : (xc == N - 1 ? 2 : 1);
 		const int     cy = (y == 0) ? 0 : (y == N - 1 ? 2 : 1);
 		const double  v  = (o - rh) * idiag[cx + 3 * cy + 9 * cz];
@@ -332,7 +381,10 @@ __device__ __forceinline__ void rbgsRelax(double *tl, const double *idiag, int z
 // In a pair (x even, x+1) exactly one cell has each colour, so every lane relaxes one cell per
 // phase and nothing diverges. Physical faces are folded into the diagonal (k = 3 Dirichlet,
 // 1 Neumann), so their ghost contributes 0 to the off-diagonal sum.
-template <int N>
+// ZERO: the sweep starts from u == 0 (first pre-smoothing sweep of a cycle, Cycle.h:118 /
+// :63): u is never read (neither the patch nor any ghost), results are bit-identical to the
+// general kernel fed with zeros.
+template <int N, bool ZERO>
 __global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const double *__restrict__ u,
                                                           const double *__restrict__ f,
                                                           double *__restrict__ out)
@@ -377,9 +429,15 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		idiag[tid] = 1.0 / (kf[0] * rhx + kf[1] * rhy + kf[2] * rhz);
 	}
 
-	const HaloSrc  hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, 0.0, 0.0);
-	const PlaneSrc bot = zPlaneSrc<N>(fk[4], fs[4], false, u, up, L.ghost, 0.0, 0.0);
-	const PlaneSrc top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, 0.0, 0.0);
+	HaloSrc  hs;
+	PlaneSrc bot, top;
+	if (!ZERO) {
+		hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, 0.0, 0.0);
+		bot = zPlaneSrc<N>(fk[4], fs[4], false, u, up, L.ghost, 0.0, 0.0);
+		top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, 0.0, 0.0);
+	} else { // halo ring stays zero for the whole sweep
+		for (int i = tid; i < 3 * T::LSZ; i += TPB) (&tile[0][0])[i] = 0.0;
+	}
 
 	int  q[CPT], lds[CPT], yy[CPT], xx[CPT];
 	bool act[CPT];
@@ -397,31 +455,39 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	double2 umm[CPT], um[CPT], uc[CPT], un[CPT], un2[CPT], fm[CPT], fc[CPT], fn[CPT];
 #pragma unroll
 	for (int k = 0; k < CPT; k++) {
-		uc[k]     = up2[q[k]];
-		double2 a = bot.p[q[k]];
-		um[k]     = double2{bot.s * a.x, bot.s * a.y};
-		un[k]     = up2[NP + q[k]];
-		fc[k]     = fp2[q[k]];
-		umm[k]    = double2{0.0, 0.0};
-		fm[k]     = double2{0.0, 0.0};
+		if (!ZERO) {
+			uc[k]     = up2[q[k]];
+			double2 a = bot.p[q[k]];
+			um[k]     = double2{bot.s * a.x, bot.s * a.y};
+			un[k]     = up2[NP + q[k]];
+		} else {
+			uc[k] = um[k] = un[k] = un2[k] = double2{0.0, 0.0};
+		}
+		fc[k]  = fp2[q[k]];
+		umm[k] = double2{0.0, 0.0};
+		fm[k]  = double2{0.0, 0.0};
 	}
-	double hv = hs.s * hs.p[0];
-	__syncthreads(); // idiag
+	double hv = ZERO ? 0.0 : hs.s * hs.p[0];
+	__syncthreads(); // idiag (and the zeroed tiles)
 
 #pragma unroll 1
 	for (int z = 0; z <= N; z++) {
 		// issue the next iteration's loads (clamped / redirected on the last iterations)
-		const double2 *pn = (z + 2 < N) ? up2 + (z + 2) * NP : top.p;
-		const double   sn = (z + 2 < N) ? 1.0 : top.s;
-		const int      zc = (z + 1 < N) ? z + 1 : N - 1;
+		const int zc = (z + 1 < N) ? z + 1 : N - 1;
+		double    hvn = 0.0;
+		if (!ZERO) {
+			const double2 *pn = (z + 2 < N) ? up2 + (z + 2) * NP : top.p;
+			const double   sn = (z + 2 < N) ? 1.0 : top.s;
 #pragma unroll
-		for (int k = 0; k < CPT; k++) {
-			double2 a = pn[q[k]];
-			un2[k]    = double2{sn * a.x, sn * a.y};
-			fn[k]     = fp2[zc * NP + q[k]];
+			for (int k = 0; k < CPT; k++) {
+				double2 a = pn[q[k]];
+				un2[k]    = double2{sn * a.x, sn * a.y};
+			}
+			hvn = hs.s * hs.p[zc * hs.stride];
 		}
-		const double hvn = hs.s * hs.p[zc * hs.stride];
-		if (z < N) {
+#pragma unroll
+		for (int k = 0; k < CPT; k++) fn[k] = fp2[zc * NP + q[k]];
+		if (!ZERO && z < N) {
 			double *tl = tile[z % 3];
 #pragma unroll
 			for (int k = 0; k < CPT; k++)
@@ -430,7 +496,8 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		}
 		// one barrier per plane: buffer z%3 was last read two iterations ago (black of plane z-3)
 		ldsBarrier();
-		if (z < N) rbgsRelax<N>(tile[z % 3], idiag, z, 0, yy, xx, act, rhx, rhy, rhz, uc, um, un, fc); // red cells of plane z from old black values
+		// red cells of plane z from old black values (all zero when ZERO)
+		if (z < N) rbgsRelax<N, ZERO>(tile[z % 3], idiag, z, 0, yy, xx, act, rhx, rhy, rhz, uc, um, un, fc);
 		if (z > 0) {
 			// black cells of plane z-1: x/y neighbours = new red in LDS; z neighbours = umm (new red,
 			// or the frozen bottom ghost) and uc (new red, or the frozen top ghost when z == N)
@@ -577,6 +644,26 @@ __global__ __launch_bounds__(256) void k_restrict_pack3d(const int32_t *__restri
 	} else {
 		for (int i = threadIdx.x; i < H * H * H; i += blockDim.x)
 			b[i] = restrictCell<N>(fp, i % H, (i / H) % H, i / (H * H));
+	}
+}
+
+// parent side of a cross-rank restriction when the local children were written by the fused
+// residual+restrict kernel: place received block i (desc[i] = coarse patch, orthant or -1)
+template <int N>
+__global__ __launch_bounds__(256) void k_restrict_unpack3d(const int32_t *__restrict__ desc,
+                                                           const int64_t *__restrict__ off,
+                                                           const double *__restrict__ buf, double *__restrict__ coarse)
+{
+	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
+	const int     pc = desc[2 * blockIdx.x], o = desc[2 * blockIdx.x + 1];
+	double       *cp = coarse + (size_t) pc * NNN;
+	const double *b  = buf + off[blockIdx.x];
+	if (o < 0) {
+		for (int i = threadIdx.x; i < NNN; i += blockDim.x) cp[i] = b[i];
+	} else {
+		const int bx = (o & 1) ? H : 0, by = (o & 2) ? H : 0, bz = (o & 4) ? H : 0;
+		for (int i = threadIdx.x; i < H * H * H; i += blockDim.x)
+			cp[bx + i % H + N * (by + (i / H) % H) + NN * (bz + i / (H * H))] = b[i];
 	}
 }
 

@@ -64,6 +64,7 @@ def test_sharded_ops_equal_single_rank(nranks, divides, n):
         "jacobi": lambda g, du, df, dr: (g.smooth(df, du, smoother=capi.SMOOTH_JACOBI, omega=0.8), dr.copy(du)),
         "patch": lambda g, du, df, dr: (g.smooth(df, du, smoother=capi.SMOOTH_PATCH_SOLVE), dr.copy(du)),
         "vcycle_rbgs": lambda g, du, df, dr: g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, dr),
+        "vcycle_rbgs_unfused": lambda g, du, df, dr: g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS, fuse=0), df, dr),
         "vcycle_patch": lambda g, du, df, dr: g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, dr),
         "wcycle_jacobi": lambda g, du, df, dr: g.cycle(g.default_opts(smoother=capi.SMOOTH_JACOBI, cycle_type=1,
                                                                       omega=0.8), df, dr),

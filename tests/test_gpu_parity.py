@@ -120,11 +120,31 @@ def test_blas1(case):
 def test_cycle(case, smoother, cycle_type):
     g, levels = case["g"], case["levels"]
     f = util.rand_vec(levels[0].size, 70)
-    o = g.default_opts(smoother=smoother, cycle_type=cycle_type, omega=0.8)
     oo = orc.cycle_opts(smoother=smoother, cycle_type=cycle_type, omega=0.8)
-    df, du = g.new_vector(0, f), g.new_vector(0)
-    g.cycle(o, df, du)
-    assert rel(du.download(), orc.cycle(levels, oo, f)) <= 1e-10
+    want = orc.cycle(levels, oo, f)
+    got = {}
+    for fuse in (0, 1):
+        o = g.default_opts(smoother=smoother, cycle_type=cycle_type, omega=0.8, fuse=fuse)
+        df, du = g.new_vector(0, f), g.new_vector(0)
+        du.set(123.0)  # Cycle::apply must ignore the incoming u (Cycle.h:118)
+        g.cycle(o, df, du)
+        got[fuse] = du.download()
+        assert rel(got[fuse], want) <= 1e-10
+    # fused residual+restrict and the zero-guess sweep change the number of HBM passes, not one bit
+    assert np.array_equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("sweeps", [(0, 1, 1), (2, 0, 3), (1, 2, 0)])
+def test_cycle_sweep_counts(case, sweeps):
+    g, levels = case["g"], case["levels"]
+    f = util.rand_vec(levels[0].size, 71)
+    pre, post, coarse = sweeps
+    want = orc.cycle(levels, orc.cycle_opts(pre=pre, post=post, coarse=coarse, smoother=2), f)
+    for fuse in (0, 1):
+        o = g.default_opts(smoother=capi.SMOOTH_RBGS, pre_sweeps=pre, post_sweeps=post, coarse_sweeps=coarse, fuse=fuse)
+        df, du = g.new_vector(0, f), g.new_vector(0)
+        g.cycle(o, df, du)
+        assert rel(du.download(), want) <= 1e-10
 
 
 def test_bicgstab_trig(case):
