@@ -69,23 +69,31 @@ def cpu_baseline(sample, smoother_id):
     on `sample`^3 cells with all host cores; a few cycles, bounded to ~10-30 s."""
     from oracle import oracle as orc
     from pressurepoissonsolver_amd import capi, problems
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     div = int(round(np.log2(sample // 32)))
     m = capi.Mesh.uniform(3, div)
     H = capi.Hierarchy(m, 32)
     levels = orc.levels_from_hierarchy(H)
     f = problems.random_rhs(H.tables(0)["id"], 32 ** 3)
-    orc.set_threads(cores)
     o = orc.cycle_opts(smoother=0)
-    orc.cycle(levels, o, f)  # warm
-    t0, reps = time.time(), 0
-    while reps < 3 or (time.time() - t0 < 10.0 and reps < 50):
-        orc.cycle(levels, o, f)
-        reps += 1
-    dt = (time.time() - t0) / reps
-    return {"value": levels[0].size / dt, "unit": "lattice-site updates/s", "cores": cores, "kind": "port",
+    best = None
+    # 1 thread = what one reference MPI rank does (the reference is single-threaded per rank);
+    # then OpenMP over patches on up to 16 cores (the `mpirun -np cores` analogue). Report the faster.
+    for threads in sorted({1, min(ncpu, 16)}):
+        orc.set_threads(threads)
+        orc.cycle(levels, o, f)  # warm
+        t0, reps = time.time(), 0
+        while reps < 3 or (time.time() - t0 < 6.0 and reps < 50):
+            orc.cycle(levels, o, f)
+            reps += 1
+        dt = (time.time() - t0) / reps
+        if best is None or dt < best[0]:
+            best = (dt, threads, reps)
+    dt, threads, reps = best
+    return {"value": levels[0].size / dt, "unit": "lattice-site updates/s", "cores": threads, "kind": "port",
             "sample": f"{sample}^3 uniform, {levels[0].P} patches of 32^3, V(1,1) with the reference's "
-                      f"block-Jacobi patch-solve smoother, {reps} cycles, OpenMP over patches",
+                      f"block-Jacobi patch-solve smoother, {reps} cycles, {threads} OpenMP thread(s) "
+                      f"(host has {ncpu} logical CPUs; 1 and {min(ncpu, 16)} threads tried)",
             "ms_per_step": dt * 1e3}
 
 

@@ -267,7 +267,25 @@ std::vector<double> transformMatrix(DftType t, int n)
 void transformAxis(const Geo &G, const std::vector<double> &M, int ax, const double *in, double *out)
 {
 	const int n = G.n, st = G.stride[ax];
-	// transposed copy so the inner loop runs over contiguous outputs
+	if (st == 1) {
+		// lines are contiguous: accumulate over j with the transposed matrix so the inner loop
+		// runs over the n contiguous outputs of one line
+		std::vector<double> MT((size_t) n * n);
+		for (int i = 0; i < n; i++)
+			for (int j = 0; j < n; j++) MT[(size_t) j * n + i] = M[(size_t) i * n + j];
+		const int lines = G.nc / n;
+		for (int r = 0; r < lines; r++) {
+			double       *dst = out + (size_t) r * n;
+			const double *src = in + (size_t) r * n;
+			for (int i = 0; i < n; i++) dst[i] = 0;
+			for (int j = 0; j < n; j++) {
+				const double  w  = src[j];
+				const double *mt = &MT[(size_t) j * n];
+				for (int i = 0; i < n; i++) dst[i] += mt[i] * w;
+			}
+		}
+		return;
+	}
 	const int outer = G.nc / (n * st); // blocks above the axis
 	for (int o = 0; o < outer; o++) {
 		for (int i = 0; i < n; i++) {
@@ -324,7 +342,26 @@ SolvePlan makePlan(const orc_level *L, const Geo &G, int p)
 	}
 	return pl;
 }
-void solvePatch(const orc_level *L, const Geo &G, const Ifaces &I, int p, const double *gamma,
+// one plan per distinct (physical Neumann sides, spacing) — the reference's DomainK key
+// (FftwPatchSolver.h:33-47) — built once per call, shared read-only by the patch loop
+struct PlanCache {
+	std::map<std::pair<int, double>, SolvePlan> plans;
+	std::vector<const SolvePlan *>              of_patch;
+	PlanCache(const orc_level *L, const Geo &G)
+	{
+		of_patch.resize(L->P);
+		for (int p = 0; p < L->P; p++) {
+			int key = 0;
+			for (int s = 0; s < G.nsides; s++)
+				if (((L->neumann[p] >> s) & 1) && L->nbr_kind[(size_t) p * G.nsides + s] == 0) key |= 1 << s;
+			auto k  = std::make_pair(key, L->h[(size_t) p * G.dim]);
+			auto it = plans.find(k);
+			if (it == plans.end()) it = plans.emplace(k, makePlan(L, G, p)).first;
+			of_patch[p] = &it->second;
+		}
+	}
+};
+void solvePatch(const orc_level *L, const Geo &G, const Ifaces &I, const PlanCache &PC, int p, const double *gamma,
                 const double *f, double *u)
 {
 	const int           n = G.n;
@@ -338,7 +375,7 @@ void solvePatch(const orc_level *L, const Geo &G, const Ifaces &I, int p, const 
 			for (int aa = 0; aa < n; aa++)
 				a[G.faceCell(s, aa, bb, 0)] -= 2.0 / h2 * gamma[(size_t) I.own[fidx] * G.nf + aa + n * bb];
 	}
-	SolvePlan pl = makePlan(L, G, p);
+	const SolvePlan &pl = *PC.of_patch[p];
 	double   *src = a.data(), *dst = b.data();
 	for (int ax = 0; ax < G.dim; ax++) {
 		transformAxis(G, pl.fwd[ax], ax, src, dst);
@@ -435,10 +472,11 @@ void orc_add_iface_rhs(const orc_level *L, const double *gamma, double *f)
 
 void orc_patch_solve(const orc_level *L, const double *gamma, const double *f, double *u)
 {
-	Geo    G(L);
-	Ifaces I = buildIfaces(L);
+	Geo       G(L);
+	Ifaces    I = buildIfaces(L);
+	PlanCache PC(L, G);
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic)
-	for (int p = 0; p < L->P; p++) solvePatch(L, G, I, p, gamma, f, u);
+	for (int p = 0; p < L->P; p++) solvePatch(L, G, I, PC, p, gamma, f, u);
 }
 
 void orc_smooth(const orc_level *L, const double *f, double *u)
@@ -447,8 +485,9 @@ void orc_smooth(const orc_level *L, const double *f, double *u)
 	Ifaces              I = buildIfaces(L);
 	std::vector<double> gamma((size_t) I.count * G.nf, 0.0);
 	for (int p = 0; p < L->P; p++) interpPatch(L, G, I, p, u, gamma.data());
-#pragma omp parallel for num_threads(g_threads) schedule(dynamic)
-	for (int p = 0; p < L->P; p++) solvePatch(L, G, I, p, gamma.data(), f, u);
+	PlanCache PC(L, G);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+	for (int p = 0; p < L->P; p++) solvePatch(L, G, I, PC, p, gamma.data(), f, u);
 }
 
 void orc_restrict(const orc_level *fine, const orc_level *coarse, const double *fv, double *cv)

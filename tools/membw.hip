@@ -80,6 +80,49 @@ template <int W, int NT> __global__ __launch_bounds__(256) void triad_patch(int 
 	}
 }
 
+// chunked walk: each workgroup streams CH planes (CH*8 KiB per array) of a contiguous array, chunks in
+// address order; CH = 32 is the patch walk, CH = 1 is one plane per workgroup
+template <int CH> __global__ __launch_bounds__(256) void triad_chunk(size_t nchunks, double *a, const double *b, const double *c)
+{
+	const size_t base = (size_t) blockIdx.x * CH * 512; // double2 units
+	for (int z = 0; z < CH; z++) {
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			size_t  i = base + z * 512 + k * 256 + threadIdx.x;
+			double2 x = ((const double2 *) b)[i], y = ((const double2 *) c)[i];
+			((double2 *) a)[i] = double2{x.x + 0.5 * y.x, x.y + 0.5 * y.y};
+		}
+	}
+}
+// same, but all loads of a chunk's plane are issued one plane ahead of the stores (software pipeline)
+template <int CH> __global__ __launch_bounds__(256) void triad_chunk_pipe(size_t nchunks, double *a, const double *b, const double *c)
+{
+	const size_t base = (size_t) blockIdx.x * CH * 512;
+	double2      x[2], y[2], xn[2], yn[2];
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		size_t i = base + k * 256 + threadIdx.x;
+		x[k]     = ((const double2 *) b)[i];
+		y[k]     = ((const double2 *) c)[i];
+	}
+	for (int z = 0; z < CH; z++) {
+		const int zn = (z + 1 < CH) ? z + 1 : z;
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			size_t i = base + zn * 512 + k * 256 + threadIdx.x;
+			xn[k]    = ((const double2 *) b)[i];
+			yn[k]    = ((const double2 *) c)[i];
+		}
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			size_t i = base + z * 512 + k * 256 + threadIdx.x;
+			((double2 *) a)[i] = double2{x[k].x + 0.5 * y[k].x, x[k].y + 0.5 * y[k].y};
+			x[k] = xn[k];
+			y[k] = yn[k];
+		}
+	}
+}
+
 int main(int argc, char **argv)
 {
 	size_t n = (size_t) 512 * 512 * 512;
@@ -143,5 +186,11 @@ int main(int argc, char **argv)
 	timeit("triad_patch W=16 stagger=0 remap=0", n * 24.0, [&] { hipLaunchKernelGGL((triad_patch<16, 0>), dim3(pg), dim3(256), 0, 0, P, a, b, c, 0, 0); });
 	timeit("triad_patch W=8 stagger=5 remap=1", n * 24.0, [&] { hipLaunchKernelGGL((triad_patch<8, 0>), dim3(pg), dim3(256), 0, 0, P, a, b, c, 5, 1); });
 	timeit("triad_patch W=16 nt stagger=5 remap=1", n * 24.0, [&] { hipLaunchKernelGGL((triad_patch<16, 1>), dim3(pg), dim3(256), 0, 0, P, a, b, c, 5, 1); });
+#define CHUNK(CH)                                                                                                        \
+	snprintf(nm, sizeof nm, "triad_chunk CH=%d", CH);                                                                    \
+	timeit(nm, n * 24.0, [&] { hipLaunchKernelGGL(triad_chunk<CH>, dim3(n / (CH * 1024)), dim3(256), 0, 0, n / (CH * 1024), a, b, c); }); \
+	snprintf(nm, sizeof nm, "triad_chunk_pipe CH=%d", CH);                                                               \
+	timeit(nm, n * 24.0, [&] { hipLaunchKernelGGL(triad_chunk_pipe<CH>, dim3(n / (CH * 1024)), dim3(256), 0, 0, n / (CH * 1024), a, b, c); });
+	CHUNK(1) CHUNK(2) CHUNK(4) CHUNK(8) CHUNK(16) CHUNK(32)
 	return 0;
 }
