@@ -3,6 +3,7 @@
 // if HIP cannot give us a device, te_gmg_create fails with TE_EHIP.
 #include "capi_common.hpp"
 #include "kernels3d.hpp"
+#include "patchsolve32.hpp"
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -32,11 +33,11 @@ namespace
 {
 enum KClass : int {
 	KC_APPLY, KC_RESID, KC_JACOBI, KC_RBGS, KC_CFGHOST, KC_RESTRICT, KC_PROLONG, KC_PATCH_RHS,
-	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_RBGS_ZERO, KC_RESID_RESTRICT, KC_COUNT
+	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_RBGS_ZERO, KC_RESID_RESTRICT, KC_PS_MFMA, KC_COUNT
 };
 const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_jacobi", "stencil_rbgs",
                                     "cf_ghost", "restrict", "prolong_add", "patch_rhs", "dst_axis",
-                                    "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict"};
+                                    "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict", "patch_solve_mfma"};
 
 template <typename T> struct DevBuf {
 	T     *p = nullptr;
@@ -94,7 +95,7 @@ struct LevelHost {
 	DevBuf<double>  upbuf, downbuf;
 	// patch solve
 	DevBuf<int32_t> plan, zero_mode;
-	DevBuf<double>  mats, lam;
+	DevBuf<double>  mats, lam, corr; // corr: [P][6][n^2] interface terms of the patch right-hand sides
 	// scratch
 	std::unique_ptr<te_vec> u, f, r, t;
 
@@ -416,6 +417,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 				}
 			}
 		}
+		if ((rc = L->corr.alloc((size_t) std::max(P, 1) * 6 * L->nf))) return rc;
 		if ((rc = L->plan.upload(plan)) || (rc = L->mats.upload(mats)) || (rc = L->lam.upload(lam))
 		    || (rc = L->zero_mode.upload(zm)))
 			return rc;
@@ -658,11 +660,42 @@ int residRestrict(te_gmg *g, LevelHost &L, const double *u, const double *f, dou
 		default: return residRestrictN<32>(g, L, u, f, coarse);
 	}
 }
-template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1)
+template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1,
+                                 bool zero_guess)
 {
-	int rc = prepareGhosts<N>(g, L, u);
-	if (rc) return rc;
 	const size_t total = (size_t) L.P * L.nc;
+	int          rc;
+	if (N == 32 && !getenv("TE_PS_SLOW")) {
+		// matrix-core path (patchsolve32.hpp): interface terms on the face layers only, then x,y forward
+		// per plane; z forward + eigenvalue divide + z inverse; x,y inverse. A zero initial guess has no
+		// interface term (gamma = 0) and u is overwritten without being read.
+		const dim3 gp(L.P), b256(256);
+		if (!zero_guess) {
+			if ((rc = prepareGhosts<N>(g, L, u))) return rc;
+			Timed t(g, KC_PATCH_RHS, (size_t) L.P * 6 * L.nf);
+			hipLaunchKernelGGL(k_face_corr3d<N>, dim3(L.P * 6), b256, 0, g->stream, L.dev(), u, L.corr.p);
+		}
+		{
+			Timed t(g, KC_PS_MFMA, total);
+			hipLaunchKernelGGL(k_ps_xy<false>, gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, f,
+			                   zero_guess ? (const double *) nullptr : (const double *) L.corr.p, s1);
+		}
+		{
+			Timed t(g, KC_PS_MFMA, total);
+			hipLaunchKernelGGL(k_ps_z, gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p, L.zero_mode.p, L.rh2.p, s1, s0);
+		}
+		{
+			Timed t(g, KC_PS_MFMA, total);
+			hipLaunchKernelGGL(k_ps_xy<true>, gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, s0, (const double *) nullptr, u);
+		}
+		HIPCHK(hipGetLastError());
+		return TE_OK;
+	}
+	if (zero_guess) {
+		Timed t(g, KC_VECOP, total);
+		HIPCHK(hipMemsetAsync(u, 0, sizeof(double) * total, g->stream));
+	}
+	if ((rc = prepareGhosts<N>(g, L, u))) return rc;
 	{
 		Timed t(g, KC_PATCH_RHS, total);
 		hipLaunchKernelGGL(k_patch_rhs3d<N>, dim3(gridFor(total, 256)), dim3(256), 0, g->stream, L.dev(), u, f, s0);
@@ -685,15 +718,15 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
-int patchSolve(te_gmg *g, LevelHost &L, const double *f, double *u)
+int patchSolve(te_gmg *g, LevelHost &L, const double *f, double *u, bool zero_guess = false)
 {
 	if (L.P == 0) return TE_OK;
 	double *s0 = L.r->d, *s1 = L.t->d;
 	switch (L.n) {
-		case 4: return patchSolveN<4>(g, L, f, u, s0, s1);
-		case 8: return patchSolveN<8>(g, L, f, u, s0, s1);
-		case 16: return patchSolveN<16>(g, L, f, u, s0, s1);
-		default: return patchSolveN<32>(g, L, f, u, s0, s1);
+		case 4: return patchSolveN<4>(g, L, f, u, s0, s1, zero_guess);
+		case 8: return patchSolveN<8>(g, L, f, u, s0, s1, zero_guess);
+		case 16: return patchSolveN<16>(g, L, f, u, s0, s1, zero_guess);
+		default: return patchSolveN<32>(g, L, f, u, s0, s1, zero_guess);
 	}
 }
 template <int N> int restrictN(te_gmg *g, LevelHost &L, const double *fine, double *coarse)
@@ -771,7 +804,7 @@ int smoothOnce(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, d
 	LevelHost &L = *g->levels[level];
 	int        rc;
 	switch (smoother) {
-		case TE_SMOOTH_PATCH_SOLVE: return patchSolve(g, L, f->d, u->d);
+		case TE_SMOOTH_PATCH_SOLVE: return patchSolve(g, L, f->d, u->d, zero_guess);
 		case TE_SMOOTH_JACOBI:
 			rc = launchStencil<MODE_JACOBI>(g, L, u->d, f->d, L.t->d, omega);
 			if (rc) return rc;
@@ -826,7 +859,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		if (at_coarsest && o->exact_coarse && L.P_global == 1) sm = TE_SMOOTH_PATCH_SOLVE;
 		for (int i = 0; i < sweeps; i++) {
 			int r;
-			if (u_zero && sm == TE_SMOOTH_RBGS) {
+			if (u_zero && (sm == TE_SMOOTH_RBGS || sm == TE_SMOOTH_PATCH_SOLVE)) {
 				u_zero = false;
 				r      = smoothOnce(g, l, f, u, sm, o->omega, true);
 			} else {

@@ -1,0 +1,252 @@
+// Reference block-Jacobi smoother, fast path for 32^3 patches: the exact per-patch Dirichlet /
+// Neumann solve of FftwPatchSolver.h:173-206 (transforms = DftPatchSolver.h:237-289 matrices) as
+// three HBM passes of dense 32x32 transforms on the fp64 matrix cores.
+//
+// This is the one GEMM-shaped piece of the path (64 flop per site per axis, 12.6 MFLOP per patch),
+// so unlike the stencils it belongs on MFMA: v_mfma_f64_16x16x4_f64, D(16x16) += A(16x4) B(4x16),
+// lane l holds A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], D[row = (l>>4) + 4r][col = l&15], r = 0..3.
+// The transform matrices live in registers as A (or B) fragments for the whole kernel; data
+// fragments come straight from global memory / an LDS plane. A D tile is reused as the next
+// product's B operand without moving data by letting k-step (mb, r) stand for row 16mb + g + 4r
+// (the sum over k does not care about the order; the other operand is built in that order).
+//
+//   k_ps_xy<INV=false> : per z-plane, x then y forward transform            (8 B read + 8 B write / site)
+//   k_ps_z             : z forward, eigenvalue divide, z inverse             (8 + 8)
+//   k_ps_xy<INV=true>  : per z-plane, x then y inverse transform, (2/N)^3    (8 + 8)
+#pragma once
+#include "kernels3d.hpp"
+
+namespace te
+{
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ v4f64 mfma_f64(double a, double b, v4f64 c)
+{
+	return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// Interface term of the patch right-hand side, StarPatchOp::addInterfaceToRHS (StarPatchOp.h:185-203):
+// corr[p][s][a + N b] = (2/h^2) gamma = rh2 * (m + ghost) on faces that have a neighbour, 0 on
+// physical faces. One workgroup per patch face; only face layers are touched (6/N of the sites).
+template <int N>
+__global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *__restrict__ u, double *__restrict__ corr)
+{
+	constexpr int NN = N * N, NNN = N * N * N;
+	const int     p = blockIdx.x / 6, s = blockIdx.x % 6, ax = s >> 1;
+	const int     kind = L.face_kind[(size_t) p * 6 + s], src = L.face_src[(size_t) p * 6 + s];
+	const int     sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
+	const int     mine = (s & 1) ? (N - 1) * sn : 0, oth = (s & 1) ? 0 : (N - 1) * sn;
+	const double  rh = L.rh2[(size_t) p * 3 + ax];
+	double       *c  = corr + ((size_t) p * 6 + s) * NN;
+	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+		double v = 0.0;
+		if (kind >= FACE_LOCAL) {
+			const int    cell = (i % N) * sa + (i / N) * sb;
+			const double m    = u[(size_t) p * NNN + mine + cell];
+			const double gh   = (kind == FACE_LOCAL) ? u[(size_t) src * NNN + oth + cell] : L.ghost[(size_t) src * NN + i];
+			v                 = 2.0 * rh * (0.5 * m + 0.5 * gh);
+		}
+		c[i] = v;
+	}
+}
+
+// mats: [nplans][6][32*32] row-major (forward x,y,z then inverse x,y,z); y_i = sum_j M[i*32+j] x_j
+// corr (forward pass only, may be null = zero initial guess, no interface term): see k_face_corr3d.
+template <bool INV>
+__global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict__ plan,
+                                               const double *__restrict__ mats, const double *__restrict__ in,
+                                               const double *__restrict__ corr, double *__restrict__ out)
+{
+	constexpr int N = 32, NN = N * N;
+	const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, g = l >> 4;
+	const int pid  = blockIdx.x; // one workgroup per patch; wave w owns planes w, w+4, ..., w+28
+	if (pid >= P) return;
+	const int     pl = plan[pid];
+	const double *Mx = mats + ((size_t) pl * 6 + (INV ? 3 : 0)) * NN;
+	const double *My = mats + ((size_t) pl * 6 + (INV ? 4 : 1)) * NN;
+
+	// matrix fragments, loaded once per wave. Output column kx = 2j + nb (a lane's two columns are
+	// adjacent in memory).
+	double bx[2][8];    // B = Mx^T: B[k = x = 4ks + g][col kx] = Mx[kx][x]
+	double ay[2][2][4]; // A = My: A[i = ky = 16mo + j][k-step (mb, r) = y = 16mb + g + 4r]
+#pragma unroll
+	for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+		for (int ks = 0; ks < 8; ks++) bx[nb][ks] = Mx[(2 * j + nb) * N + 4 * ks + g];
+#pragma unroll
+	for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+		for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) ay[mo][mb][r] = My[(16 * mo + j) * N + 16 * mb + g + 4 * r];
+
+	constexpr double scale = INV ? 8.0 / (32.0 * 32.0 * 32.0) : 1.0; // (2/N)^3, DftPatchSolver.h:214
+	// The data plane is read straight from global memory in the A layout, A[i = y = 16mb + j][k = x =
+	// 4ks + g]: a load touches 16 rows x 32 B; the 8 k-steps together consume each row's 256 B, served
+	// from L1 after the first touch. No LDS, no barrier, the next plane is in flight during the MFMAs.
+	const int     aoff = j * N + g;
+	const double *cr   = (!INV && corr) ? corr + (size_t) pid * 6 * NN : nullptr;
+	// element (y = 16mb + j, x = 4ks + g) of plane z, minus the interface terms of the faces it lies on,
+	// subtracted in the reference's side order W/E, S/N, B/T
+	// The x- and y-face terms are loaded unconditionally and masked (no divergent branch around a load,
+	// so the plane prefetch stays in flight); only the two z-face planes take a wave-uniform branch.
+	const double mW = (g == 0) ? 1.0 : 0.0, mE = (g == 3) ? 1.0 : 0.0, mS = (j == 0) ? 1.0 : 0.0, mN = (j == 15) ? 1.0 : 0.0;
+	auto fetch = [&](double(&dst)[2][8], int z) {
+		const double *ip = in + ((size_t) pid * N + z) * NN + aoff;
+#pragma unroll
+		for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+			for (int ks = 0; ks < 8; ks++) {
+				double v = ip[16 * mb * N + 4 * ks];
+				if (!INV && cr) {
+					const int y = 16 * mb + j, x = 4 * ks + g;
+					if (ks == 0) v -= mW * cr[0 * NN + y + N * z];
+					if (ks == 7) v -= mE * cr[1 * NN + y + N * z];
+					if (mb == 0) v -= mS * cr[2 * NN + x + N * z];
+					if (mb == 1) v -= mN * cr[3 * NN + x + N * z];
+				}
+				dst[mb][ks] = v;
+			}
+		if (!INV && cr && (z == 0 || z == N - 1)) {
+			const double *cz = cr + (z == 0 ? 4 : 5) * NN;
+#pragma unroll
+			for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+				for (int ks = 0; ks < 8; ks++) dst[mb][ks] -= cz[(4 * ks + g) + N * (16 * mb + j)];
+		}
+	};
+	double nxt[2][8];
+	fetch(nxt, wave);
+#pragma unroll 1
+	for (int it = 0; it < 8; it++) {
+		const int z = wave + 4 * it;
+		double    a[2][8];
+#pragma unroll
+		for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+			for (int ks = 0; ks < 8; ks++) a[mb][ks] = nxt[mb][ks];
+		fetch(nxt, (it + 1 < 8) ? z + 4 : z);
+		// x transform: D1[row y = 16mb + g + 4r][col kx] = sum_x X[y][x] Mx[kx][x]
+		v4f64 d1[2][2];
+#pragma unroll
+		for (int mb = 0; mb < 2; mb++) {
+			d1[mb][0] = d1[mb][1] = v4f64{0, 0, 0, 0};
+#pragma unroll
+			for (int ks = 0; ks < 8; ks++) {
+				d1[mb][0] = mfma_f64(a[mb][ks], bx[0][ks], d1[mb][0]);
+				d1[mb][1] = mfma_f64(a[mb][ks], bx[1][ks], d1[mb][1]);
+			}
+		}
+		// y transform: D2[row ky = 16mo + g + 4r][col kx] = sum_y My[ky][y] D1[y][kx]
+		double *op = out + ((size_t) pid * N + z) * NN;
+#pragma unroll
+		for (int mo = 0; mo < 2; mo++) {
+			v4f64 e0 = v4f64{0, 0, 0, 0}, e1 = v4f64{0, 0, 0, 0};
+#pragma unroll
+			for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					e0 = mfma_f64(ay[mo][mb][r], d1[mb][0][r], e0);
+					e1 = mfma_f64(ay[mo][mb][r], d1[mb][1][r], e1);
+				}
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const int ky = 16 * mo + g + 4 * r;
+				reinterpret_cast<double2 *>(op + ky * N)[j] = double2{e0[r] * scale, e1[r] * scale};
+			}
+		}
+	}
+}
+
+// lam: [nplans][3][32] = 4 sin^2(.), eigenvalue = -(lam_x rh2x + lam_y rh2y + lam_z rh2z)
+// (FftwPatchSolver.h:143-168). One wave = one x-row (fixed y) of a patch, all z.
+__global__ __launch_bounds__(256) void k_ps_z(int P, const int32_t *__restrict__ plan, const double *__restrict__ mats,
+                                              const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
+                                              const double *__restrict__ rh2, const double *__restrict__ in,
+                                              double *__restrict__ out)
+{
+	constexpr int N = 32, NN = N * N, NNN = N * N * N;
+	const int     wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, g = l >> 4;
+	const int     pid  = blockIdx.x; // one workgroup per patch; wave w owns rows y = w, w+4, ...
+	if (pid >= P) return;
+	const int     pl = plan[pid];
+	const double *Mf = mats + ((size_t) pl * 6 + 2) * NN;
+	const double *Mi = mats + ((size_t) pl * 6 + 5) * NN;
+
+	double af[2][8];    // A[i = kz = 16mb + j][k = z = 4ks + g]
+	double ai[2][2][4]; // A[i = z = 16mo + j][k-step (mb, r) = kz = 16mb + g + 4r]
+#pragma unroll
+	for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+		for (int ks = 0; ks < 8; ks++) af[mb][ks] = Mf[(16 * mb + j) * N + 4 * ks + g];
+#pragma unroll
+	for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+		for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) ai[mo][mb][r] = Mi[(16 * mo + j) * N + 16 * mb + g + 4 * r];
+
+	const double *lm = lam + (size_t) pl * 3 * N;
+	const double *rh = rh2 + (size_t) pid * 3;
+	const double  lx0 = lm[2 * j] * rh[0], lx1 = lm[2 * j + 1] * rh[0];
+	double        ez[2][4];
+#pragma unroll
+	for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) ez[mb][r] = lm[2 * N + 16 * mb + g + 4 * r] * rh[2];
+	const bool zmp = zero_mode[pl] != 0;
+
+	double2 nxt[8]; // B[k = z = 4ks + g][cols x = 2j, 2j+1]
+	{
+		const double *ip = in + (size_t) pid * NNN + wave * N;
+#pragma unroll
+		for (int ks = 0; ks < 8; ks++) nxt[ks] = reinterpret_cast<const double2 *>(ip + (4 * ks + g) * NN)[j];
+	}
+#pragma unroll 1
+	for (int it = 0; it < 8; it++) {
+		const int y = wave + 4 * it;
+		double2   v[8];
+#pragma unroll
+		for (int ks = 0; ks < 8; ks++) v[ks] = nxt[ks];
+		{
+			const int     yn = (it + 1 < 8) ? y + 4 : y;
+			const double *ip = in + (size_t) pid * NNN + yn * N;
+#pragma unroll
+			for (int ks = 0; ks < 8; ks++) nxt[ks] = reinterpret_cast<const double2 *>(ip + (4 * ks + g) * NN)[j];
+		}
+		const double ly   = lm[N + y] * rh[1];
+		const double exy0 = lx0 + ly, exy1 = lx1 + ly;
+		const bool   zm   = zmp && y == 0 && j == 0;
+		v4f64        d0[2], d1[2]; // D[row kz = 16mb + g + 4r][col]: even / odd x
+#pragma unroll
+		for (int mb = 0; mb < 2; mb++) {
+			d0[mb] = d1[mb] = v4f64{0, 0, 0, 0};
+#pragma unroll
+			for (int ks = 0; ks < 8; ks++) {
+				d0[mb] = mfma_f64(af[mb][ks], v[ks].x, d0[mb]);
+				d1[mb] = mfma_f64(af[mb][ks], v[ks].y, d1[mb]);
+			}
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				d0[mb][r] /= -(exy0 + ez[mb][r]);
+				d1[mb][r] /= -(exy1 + ez[mb][r]);
+				if (zm && 16 * mb + g + 4 * r == 0) d0[mb][r] = 0.0; // FftwPatchSolver.h:197
+			}
+		}
+		double *op = out + (size_t) pid * NNN + y * N;
+#pragma unroll
+		for (int mo = 0; mo < 2; mo++) {
+			v4f64 e0 = v4f64{0, 0, 0, 0}, e1 = v4f64{0, 0, 0, 0};
+#pragma unroll
+			for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					e0 = mfma_f64(ai[mo][mb][r], d0[mb][r], e0);
+					e1 = mfma_f64(ai[mo][mb][r], d1[mb][r], e1);
+				}
+#pragma unroll
+			for (int r = 0; r < 4; r++) reinterpret_cast<double2 *>(op + (16 * mo + g + 4 * r) * NN)[j] = double2{e0[r], e1[r]};
+		}
+	}
+}
+} // namespace te
