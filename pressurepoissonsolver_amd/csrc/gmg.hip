@@ -3,6 +3,7 @@
 // if HIP cannot give us a device, te_gmg_create fails with TE_EHIP.
 #include "capi_common.hpp"
 #include "kernels3d.hpp"
+#include "kernels2d.hpp"
 #include "patchsolve32.hpp"
 #include <algorithm>
 #include <array>
@@ -99,6 +100,18 @@ struct LevelHost {
 	// scratch
 	std::unique_ptr<te_vec> u, f, r, t;
 
+	Level2D dev2() const
+	{
+		Level2D L;
+		L.P         = P;
+		L.n         = n;
+		L.face_kind = face_kind.p;
+		L.face_src  = face_src.p;
+		L.face_kadj = face_kadj.p;
+		L.rh2       = rh2.p;
+		L.ghost     = ghost.p;
+		return L;
+	}
 	LevelDev dev() const
 	{
 		LevelDev L;
@@ -261,18 +274,18 @@ ExPlan mergePlan(const std::vector<std::pair<int, int64_t>> &sends, const std::v
 int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 {
 	const Level &lv = H.levels[li];
-	if (lv.dim != 3) return te::fail(TE_EUNSUPPORTED, "te_gmg_create: only dim == 3 has device kernels");
-	const int n = lv.n;
-	if (n != 4 && n != 8 && n != 16 && n != 32)
-		return te::fail(TE_EUNSUPPORTED, "te_gmg_create: n must be 4, 8, 16 or 32");
+	const int n = lv.n, D = lv.dim;
+	if (D == 3 && n != 4 && n != 8 && n != 16 && n != 32)
+		return te::fail(TE_EUNSUPPORTED, "te_gmg_create: 3D patches must have n = 4, 8, 16 or 32 cells per axis");
+	if (D == 2 && (n < 4 || (n & 1))) return te::fail(TE_EUNSUPPORTED, "te_gmg_create: 2D patches need an even n >= 4");
 	auto L = std::make_unique<LevelHost>();
-	L->dim = lv.dim;
+	L->dim = D;
 	L->n   = n;
 	L->P   = lv.P;
 	L->P_global = lv.P_global;
-	L->nc  = (size_t) n * n * n;
-	L->nf  = (size_t) n * n;
-	const int P = lv.P, NS = 6, me = H.rank;
+	L->nc  = (D == 3) ? (size_t) n * n * n : (size_t) n * n;
+	L->nf  = (D == 3) ? (size_t) n * n : (size_t) n;
+	const int P = lv.P, NS = 2 * D, NCH = 1 << D, NQ = 1 << (D - 1), me = H.rank;
 
 	// ---- remote same-level faces: canonical order = (peer, receiving patch (global), receiving side),
 	// which both ends can compute from the global tables
@@ -328,8 +341,9 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	for (int p = 0; p < P; p++) {
 		const int gp  = lv.l2g[p];
 		int       key = 0;
-		for (int a = 0; a < 3; a++) {
-			double h       = lv.g_lengths[(size_t) gp * 3 + a] / n;
+		rh2[p * 3 + 2] = 0.0;
+		for (int a = 0; a < D; a++) {
+			double h       = lv.g_lengths[(size_t) gp * D + a] / n;
 			rh2[p * 3 + a] = 1.0 / (h * h);
 		}
 		for (int s = 0; s < NS; s++) {
@@ -351,13 +365,13 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 			} else {
 				fk[p * NS + s]   = FACE_GHOST;
 				fs[p * NS + s]   = nslots;
-				kadj[p * NS + s] = (kind == NBR_COARSE) ? -5.0 / 6.0 : 1.0 / 3.0;
+				kadj[p * NS + s] = (kind == NBR_COARSE) ? (D == 3 ? -5.0 / 6.0 : -2.0 / 3.0) : 1.0 / 3.0;
 				cfd.push_back(p);
 				cfd.push_back(s);
 				cfd.push_back(kind);
 				cfd.push_back(lv.g_nbr_orth[gf]);
 				for (int q = 0; q < 4; q++) {
-					int nb = lv.g_nbr[gf * 4 + q];
+					int nb = (q < NQ) ? lv.g_nbr[gf * 4 + q] : -1;
 					cfd.push_back(nb >= 0 ? lv.g_local[nb] : -1);
 				}
 				cfs.push_back(nslots);
@@ -384,12 +398,12 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	// patch-solve plans (FftwPatchSolver.h:93-172: transform kinds per axis, eigenvalues)
 	{
 		const int            np = (int) keys.size();
-		std::vector<double>  mats((size_t) np * 6 * n * n), lam((size_t) np * 3 * n);
+		std::vector<double>  mats((size_t) np * 2 * D * n * n), lam((size_t) np * D * n);
 		std::vector<int32_t> zm(np, 0);
 		for (int k = 0; k < np; k++) {
 			const int key = keys[k];
-			zm[k]         = (key == 63);
-			for (int a = 0; a < 3; a++) {
+			zm[k]         = (key == (1 << NS) - 1);
+			for (int a = 0; a < D; a++) {
 				bool lo = (key >> (2 * a)) & 1, hi = (key >> (2 * a + 1)) & 1;
 				int  tf, ti;
 				if (lo && hi) {
@@ -403,8 +417,8 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 					tf = 3;
 					ti = 4;
 				}
-				transformMatrix(tf, n, &mats[((size_t) k * 6 + a) * n * n]);
-				transformMatrix(ti, n, &mats[((size_t) k * 6 + 3 + a) * n * n]);
+				transformMatrix(tf, n, &mats[((size_t) k * 2 * D + a) * n * n]);
+				transformMatrix(ti, n, &mats[((size_t) k * 2 * D + D + a) * n * n]);
 				for (int i = 0; i < n; i++) {
 					double s;
 					if (lo && hi)
@@ -413,11 +427,11 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 						s = sin((i + 0.5) * M_PI / (2 * n));
 					else
 						s = sin((i + 1) * M_PI / (2 * n));
-					lam[((size_t) k * 3 + a) * n + i] = 4 * s * s;
+					lam[((size_t) k * D + a) * n + i] = 4 * s * s;
 				}
 			}
 		}
-		if ((rc = L->corr.alloc((size_t) std::max(P, 1) * 6 * L->nf))) return rc;
+		if ((rc = L->corr.alloc((size_t) std::max(P, 1) * NS * L->nf))) return rc;
 		if ((rc = L->plan.upload(plan)) || (rc = L->mats.upload(mats)) || (rc = L->lam.upload(lam))
 		    || (rc = L->zero_mode.upload(zm)))
 			return rc;
@@ -428,7 +442,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	// Canonical block order on both ends: (peer, parent patch (global), orthant).
 	if (li + 1 < (int) H.levels.size()) {
 		const Level         &cv = H.levels[li + 1];
-		std::vector<int32_t> parent(P), orth(P), child((size_t) cv.P * 8, -1), copy(cv.P, 0);
+		std::vector<int32_t> parent(P), orth(P), child((size_t) cv.P * NCH, -1), copy(cv.P, 0);
 		struct Blk {
 			int     peer, gpar, o, patch;
 			int64_t size;
@@ -442,21 +456,21 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 				const int pc = cv.g_local[gpar];
 				parent[p]    = pc;
 				if (orth[p] < 0) {
-					copy[pc]                = 1;
-					child[(size_t) pc * 8] = p;
+					copy[pc]                  = 1;
+					child[(size_t) pc * NCH] = p;
 				} else {
-					child[(size_t) pc * 8 + orth[p]] = p;
+					child[(size_t) pc * NCH + orth[p]] = p;
 				}
 			} else {
 				up.push_back({cv.g_rank[gpar], gpar, orth[p] < 0 ? 0 : orth[p], p,
-				              (int64_t) (orth[p] < 0 ? L->nc : L->nc / 8)});
+				              (int64_t) (orth[p] < 0 ? L->nc : L->nc / NCH)});
 			}
 		}
 		for (int gf = 0; gf < lv.P_global; gf++) {
 			const int gpar = lv.g_parent[gf];
 			if (cv.g_rank[gpar] != me || lv.g_rank[gf] == me) continue;
 			const int o = lv.g_orth_on_parent[gf];
-			down.push_back({lv.g_rank[gf], gpar, o < 0 ? 0 : o, cv.g_local[gpar], (int64_t) (o < 0 ? L->nc : L->nc / 8)});
+			down.push_back({lv.g_rank[gf], gpar, o < 0 ? 0 : o, cv.g_local[gpar], (int64_t) (o < 0 ? L->nc : L->nc / NCH)});
 			if (o < 0) copy[cv.g_local[gpar]] = 1;
 		}
 		std::sort(up.begin(), up.end());
@@ -482,14 +496,14 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 			downd.push_back(cp ? -1 : down[i].o);
 			downo.push_back(pos);
 			downs.emplace_back(down[i].peer, down[i].size);
-			child[(size_t) pc * 8 + (cp ? 0 : down[i].o)] = -((int) i + 2); // restrict reads block i of downbuf
+			child[(size_t) pc * NCH + (cp ? 0 : down[i].o)] = -((int) i + 2); // restrict reads block i of downbuf
 			pos += down[i].size;
 		}
 		const int64_t down_total = pos;
 		for (int pc = 0; pc < cv.P; pc++) {
 			if (copy[pc]) continue;
-			for (int o = 0; o < 8; o++)
-				if (child[(size_t) pc * 8 + o] == -1)
+			for (int o = 0; o < NCH; o++)
+				if (child[(size_t) pc * NCH + o] == -1)
 					return te::fail(TE_EINVAL, "te_gmg_create: coarse patch with a missing child");
 		}
 		L->Pc      = cv.P;
@@ -594,10 +608,109 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
+// ------------------------------------------------------------------------------ 2D launches
+int prepareGhosts2d(te_gmg *g, LevelHost &L, const double *u)
+{
+	if (L.nremote > 0) {
+		{
+			Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
+			hipLaunchKernelGGL(k_pack_faces2d, dim3(L.nremote), dim3(64), 0, g->stream, L.n, L.send_faces.p, u, L.sendbuf.p);
+		}
+		int rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p);
+		if (rc) return rc;
+	}
+	if (L.ncf == 0) return TE_OK;
+	Timed t(g, KC_CFGHOST, (size_t) L.ncf * L.nf);
+	hipLaunchKernelGGL(k_cf_ghost2d, dim3(L.ncf), dim3(64), 0, g->stream, L.n, L.cf_desc.p, L.cf_slots.p, u, L.ghost.p);
+	return TE_OK;
+}
+template <int MODE> int launchStencil2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega)
+{
+	int rc = prepareGhosts2d(g, L, u);
+	if (rc) return rc;
+	Timed t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : KC_JACOBI), (size_t) L.P * L.nc);
+	hipLaunchKernelGGL(k_stencil2d<MODE>, dim3(gridFor((size_t) L.P * L.nc / 2, 256, 65536)), dim3(256), 0, g->stream, L.dev2(),
+	                   u, f, out, omega);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out)
+{
+	int rc = prepareGhosts2d(g, L, u);
+	if (rc) return rc;
+	Timed      t(g, KC_RBGS, (size_t) L.P * L.nc);
+	const dim3 grid(gridFor((size_t) L.P * L.nc, 256, 65536));
+	hipLaunchKernelGGL(k_rbgs2d<0>, grid, dim3(256), 0, g->stream, L.dev2(), u, f, out);
+	hipLaunchKernelGGL(k_rbgs2d<1>, grid, dim3(256), 0, g->stream, L.dev2(), u, f, out);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1)
+{
+	int rc = prepareGhosts2d(g, L, u);
+	if (rc) return rc;
+	const size_t total = (size_t) L.P * L.nc;
+	const dim3   grid(gridFor(total, 256, 65536)), blk(256);
+	{
+		Timed t(g, KC_PATCH_RHS, total);
+		hipLaunchKernelGGL(k_patch_rhs2d, grid, blk, 0, g->stream, L.dev2(), u, f, s0);
+	}
+#define TE_DST2(STAGE, IN, OUT)                                                                                          \
+	{                                                                                                                    \
+		Timed t(g, KC_DST, total);                                                                                       \
+		hipLaunchKernelGGL(k_dst_axis2d<STAGE>, grid, blk, 0, g->stream, L.n, L.P, L.plan.p, L.mats.p, L.lam.p,          \
+		                   L.zero_mode.p, L.rh2.p, IN, OUT);                                                             \
+	}
+	TE_DST2(0, s0, s1)
+	TE_DST2(1, s1, s0)
+	TE_DST2(2, s0, s1)
+	TE_DST2(3, s1, u)
+#undef TE_DST2
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+int restrict2d(te_gmg *g, LevelHost &L, const double *fine, double *coarse)
+{
+	if (L.n_up > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_up * L.nc / 4);
+		hipLaunchKernelGGL(k_restrict_pack2d, dim3(L.n_up), dim3(256), 0, g->stream, L.n, L.up_desc.p, L.up_off.p, fine, L.upbuf.p);
+	}
+	int rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p);
+	if (rc) return rc;
+	if (L.Pc == 0) return TE_OK;
+	Timed t(g, KC_RESTRICT, (size_t) L.P * L.nc);
+	hipLaunchKernelGGL(k_restrict2d, dim3(gridFor((size_t) L.Pc * L.nc, 256, 65536)), dim3(256), 0, g->stream, L.n, L.Pc,
+	                   L.child.p, L.copy.p, fine, L.downbuf.p, L.down_off.p, coarse);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+int prolong2d(te_gmg *g, LevelHost &L, const double *coarse, double *fine)
+{
+	if (L.n_down > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 4);
+		hipLaunchKernelGGL(k_prolong_pack2d, dim3(L.n_down), dim3(256), 0, g->stream, L.n, L.down_desc.p, L.down_off.p, coarse,
+		                   L.downbuf.p);
+	}
+	int rc = doExchange(g, 3, L.tx_down, L.downbuf.p, L.upbuf.p);
+	if (rc) return rc;
+	if (L.P == 0) return TE_OK;
+	Timed t(g, KC_PROLONG, (size_t) L.P * L.nc);
+	hipLaunchKernelGGL(k_prolong2d, dim3(gridFor((size_t) L.P * L.nc, 256, 65536)), dim3(256), 0, g->stream, L.n, L.P, L.parent.p,
+	                   L.orth.p, coarse, L.upbuf.p, L.up_off.p, fine);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
 template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega,
                                       RestrictDst rd = RestrictDst())
 {
 	if (L.P == 0) return TE_OK;
+	if (L.dim == 2) {
+		if constexpr (MODE == MODE_RESID_RESTRICT)
+			return te::fail(TE_EUNSUPPORTED, "fused residual+restrict has no 2D kernel");
+		else
+			return launchStencil2d<MODE>(g, L, u, f, out, omega);
+	}
 	switch (L.n) {
 		case 4: return launchStencilN<4, MODE>(g, L, u, f, out, omega, rd);
 		case 8: return launchStencilN<8, MODE>(g, L, u, f, out, omega, rd);
@@ -622,6 +735,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false)
 {
 	if (L.P == 0) return TE_OK;
+	if (L.dim == 2) return launchRbgs2d(g, L, u, f, out);
 	switch (L.n) {
 		case 4: return launchRbgsN<4>(g, L, u, f, out, zero_guess);
 		case 8: return launchRbgsN<8>(g, L, u, f, out, zero_guess);
@@ -722,6 +836,7 @@ int patchSolve(te_gmg *g, LevelHost &L, const double *f, double *u, bool zero_gu
 {
 	if (L.P == 0) return TE_OK;
 	double *s0 = L.r->d, *s1 = L.t->d;
+	if (L.dim == 2) return patchSolve2d(g, L, f, u, s0, s1);
 	switch (L.n) {
 		case 4: return patchSolveN<4>(g, L, f, u, s0, s1, zero_guess);
 		case 8: return patchSolveN<8>(g, L, f, u, s0, s1, zero_guess);
@@ -821,6 +936,7 @@ int smoothOnce(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, d
 int doRestrict(te_gmg *g, int fine_level, const double *fine, double *coarse)
 {
 	LevelHost &L = *g->levels[fine_level];
+	if (L.dim == 2) return restrict2d(g, L, fine, coarse);
 	switch (L.n) {
 		case 4: return restrictN<4>(g, L, fine, coarse);
 		case 8: return restrictN<8>(g, L, fine, coarse);
@@ -831,6 +947,7 @@ int doRestrict(te_gmg *g, int fine_level, const double *fine, double *coarse)
 int doProlong(te_gmg *g, int fine_level, const double *coarse, double *fine)
 {
 	LevelHost &L = *g->levels[fine_level];
+	if (L.dim == 2) return prolong2d(g, L, coarse, fine);
 	switch (L.n) {
 		case 4: return prolongN<4>(g, L, coarse, fine);
 		case 8: return prolongN<8>(g, L, coarse, fine);
@@ -859,7 +976,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		if (at_coarsest && o->exact_coarse && L.P_global == 1) sm = TE_SMOOTH_PATCH_SOLVE;
 		for (int i = 0; i < sweeps; i++) {
 			int r;
-			if (u_zero && (sm == TE_SMOOTH_RBGS || sm == TE_SMOOTH_PATCH_SOLVE)) {
+			if (u_zero && L.dim == 3 && (sm == TE_SMOOTH_RBGS || sm == TE_SMOOTH_PATCH_SOLVE)) {
 				u_zero = false;
 				r      = smoothOnce(g, l, f, u, sm, o->omega, true);
 			} else {
@@ -878,7 +995,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	auto       descend = [&]() -> int {
         int r = materialise();
         if (r) return r;
-        if (o->fuse) {
+        if (o->fuse && L.dim == 3) {
             if ((r = residRestrict(g, L, u->d, f->d, C.f->d))) return r;
         } else {
             if ((r = launchStencil<MODE_RESID>(g, L, u->d, f->d, L.r->d, 0.0))) return r; // prepCoarser: r = f - A u

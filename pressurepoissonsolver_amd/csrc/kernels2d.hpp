@@ -1,0 +1,293 @@
+// HIP kernels for the 2D twin of the path (configs C1: one 256^2 patch, C5: 4096^2 in 64^2 patches):
+// 5-point cell-centred Laplacian (StarPatchOp<2> == FivePtPatchOperator.h:28-261), interface weights of
+// BilinearInterpolator.cpp:61-117, AvgRstr / DrctIntp in 2D. Layout v[p*n*n + x + n*y]; faces W,E,S,N;
+// a face cell is addressed by the coordinate along the other axis. n is a run-time value (any even n).
+//
+// 2D problems are small next to 512^3 (16.8 M sites at most), so these kernels are the simple form:
+// one thread per pair of x-adjacent cells, neighbours read straight from global memory (the 4 re-reads
+// of a cell are L1/L2 hits); no LDS tiling. Same ghost formulation as kernels3d.hpp.
+#pragma once
+#include "kernels3d.hpp"
+
+namespace te
+{
+struct Level2D {
+	int32_t        P, n;
+	const int32_t *face_kind; // [P*4]
+	const int32_t *face_src;  // [P*4]
+	const double  *face_kadj; // [P*4]
+	const double  *rh2;       // [P*3] (x, y, unused)
+	const double  *ghost;     // [nslots*n]
+};
+
+// ghost value outside side s of patch p at face coordinate t; `own` = the cell just inside.
+// fold = true: physical faces return 0 (their closure is folded into the diagonal by the caller).
+__device__ __forceinline__ double ghost2d(const Level2D &L, const double *u, int p, int s, int t, double own, bool fold)
+{
+	const int n = L.n, kind = L.face_kind[p * 4 + s], src = L.face_src[p * 4 + s];
+	if (kind == FACE_DIRICHLET) return fold ? 0.0 : -own;
+	if (kind == FACE_NEUMANN) return fold ? 0.0 : own;
+	if (kind == FACE_GHOST) return L.ghost[(size_t) src * n + t];
+	// neighbour's facing cell
+	int cell;
+	switch (s) {
+		case 0: cell = (n - 1) + n * t; break;
+		case 1: cell = n * t; break;
+		case 2: cell = t + n * (n - 1); break;
+		default: cell = t; break;
+	}
+	return u[(size_t) src * n * n + cell];
+}
+__device__ __forceinline__ double kfold2d(const Level2D &L, int p, int s)
+{
+	const int kind = L.face_kind[p * 4 + s];
+	return kind == FACE_DIRICHLET ? 1.0 : (kind == FACE_NEUMANN ? -1.0 : 0.0);
+}
+
+// MODE_APPLY / MODE_RESID / MODE_JACOBI as in k_stencil3d
+template <int MODE>
+__global__ __launch_bounds__(256) void k_stencil2d(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
+                                                   double *__restrict__ out, double omega)
+{
+	const int    n = L.n, h = n / 2;
+	const size_t total = (size_t) L.P * n * h;
+	for (size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t) gridDim.x * blockDim.x) {
+		const int     p = (int) (idx / ((size_t) n * h)), q = (int) (idx % ((size_t) n * h));
+		const int     y = q / h, x = 2 * (q % h);
+		const double *up = u + (size_t) p * n * n;
+		const double2 c  = *reinterpret_cast<const double2 *>(up + x + n * y);
+		const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
+		const double  xl = (x > 0) ? up[x - 1 + n * y] : ghost2d(L, u, p, 0, y, c.x, false);
+		const double  xr = (x + 2 < n) ? up[x + 2 + n * y] : ghost2d(L, u, p, 1, y, c.y, false);
+		double2       ym, yp;
+		if (y > 0)
+			ym = *reinterpret_cast<const double2 *>(up + x + n * (y - 1));
+		else
+			ym = double2{ghost2d(L, u, p, 2, x, c.x, false), ghost2d(L, u, p, 2, x + 1, c.y, false)};
+		if (y + 1 < n)
+			yp = *reinterpret_cast<const double2 *>(up + x + n * (y + 1));
+		else
+			yp = double2{ghost2d(L, u, p, 3, x, c.x, false), ghost2d(L, u, p, 3, x + 1, c.y, false)};
+		double2 lap;
+		lap.x = (xl - 2 * c.x + c.y) * rhx;
+		lap.y = (c.x - 2 * c.y + xr) * rhx;
+		lap.x += (ym.x - 2 * c.x + yp.x) * rhy;
+		lap.y += (ym.y - 2 * c.y + yp.y) * rhy;
+		double2 r;
+		if (MODE == MODE_APPLY) {
+			r = lap;
+		} else {
+			const double2 fv = *reinterpret_cast<const double2 *>(f + (size_t) p * n * n + x + n * y);
+			if (MODE == MODE_RESID) {
+				r.x = fv.x - lap.x;
+				r.y = fv.y - lap.y;
+			} else {
+				const double *ka = L.face_kadj + p * 4;
+				const double  ky = 2.0 + (y == 0 ? ka[2] : 0.0) + (y == n - 1 ? ka[3] : 0.0);
+				const double  k0 = 2.0 + (x == 0 ? ka[0] : 0.0), k1 = 2.0 + (x + 2 == n ? ka[1] : 0.0);
+				r.x = c.x + omega * (fv.x - lap.x) / -(k0 * rhx + ky * rhy);
+				r.y = c.y + omega * (fv.y - lap.y) / -(k1 * rhx + ky * rhy);
+			}
+		}
+		*reinterpret_cast<double2 *>(out + (size_t) p * n * n + x + n * y) = r;
+	}
+}
+
+// patch-local red-black GS, ghosts frozen at the old iterate u. PHASE 0: red cells ((x+y) even) are
+// relaxed from u, black cells copied; PHASE 1: black cells relaxed in `out` from the new red values
+// in `out` (neighbour patches / ghost slots still come from the OLD iterate u).
+template <int PHASE>
+__global__ __launch_bounds__(256) void k_rbgs2d(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
+                                                double *__restrict__ out)
+{
+	const int    n = L.n;
+	const size_t total = (size_t) L.P * n * n;
+	for (size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t) gridDim.x * blockDim.x) {
+		const int p = (int) (idx / ((size_t) n * n)), c = (int) (idx % ((size_t) n * n));
+		const int x = c % n, y = c / n;
+		if (((x + y) & 1) != PHASE) {
+			if (PHASE == 0) out[idx] = u[idx];
+			continue;
+		}
+		const double *in  = (PHASE == 0 ? u : out) + (size_t) p * n * n;
+		const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
+		const double  own = u[idx];
+		const double  xl = (x > 0) ? in[c - 1] : ghost2d(L, u, p, 0, y, own, true);
+		const double  xr = (x + 1 < n) ? in[c + 1] : ghost2d(L, u, p, 1, y, own, true);
+		const double  yl = (y > 0) ? in[c - n] : ghost2d(L, u, p, 2, x, own, true);
+		const double  yr = (y + 1 < n) ? in[c + n] : ghost2d(L, u, p, 3, x, own, true);
+		const double  kx = 2.0 + (x == 0 ? kfold2d(L, p, 0) : 0.0) + (x == n - 1 ? kfold2d(L, p, 1) : 0.0);
+		const double  ky = 2.0 + (y == 0 ? kfold2d(L, p, 2) : 0.0) + (y == n - 1 ? kfold2d(L, p, 3) : 0.0);
+		const double  o  = (xl + xr) * rhx + (yl + yr) * rhy;
+		out[idx]         = (o - f[idx]) / (kx * rhx + ky * rhy);
+	}
+}
+
+// ghost slots of coarse/fine faces: 2*gamma - m, weights of BilinearInterpolator.cpp:76-115.
+// desc[8] = {patch, side, kind (2 = my neighbour is coarser, 3 = finer), half of the coarse face, nbr0, nbr1, -, -}
+__global__ void k_cf_ghost2d(int n, const int32_t *__restrict__ desc, const int32_t *__restrict__ slots,
+                             const double *__restrict__ u, double *__restrict__ ghost)
+{
+	const int32_t *d = desc + (size_t) blockIdx.x * 8;
+	const int      p = d[0], s = d[1], kind = d[2], q = d[3];
+	const int      ax = s >> 1;
+	const int      sa = (ax == 0) ? n : 1, sn = (ax == 0) ? 1 : n;
+	const int      mine = (s & 1) ? (n - 1) * sn : 0, oth = (s & 1) ? 0 : (n - 1) * sn;
+	double        *g  = ghost + (size_t) slots[blockIdx.x] * n;
+	const double  *up = u + (size_t) p * n * n;
+	for (int a = threadIdx.x; a < n; a += blockDim.x) {
+		const double m = up[mine + a * sa];
+		double       gamma;
+		if (kind == 2) {
+			const double other = up[mine + (a ^ 1) * sa];
+			const double C     = u[(size_t) d[4] * n * n + oth + ((a + (q ? n : 0)) / 2) * sa];
+			gamma              = 5.0 / 6 * m - 1.0 / 6 * other + 2.0 / 6 * C;
+		} else {
+			const int     qa = (a >= n / 2);
+			const double *fn = u + (size_t) d[4 + qa] * n * n;
+			const int     fa = 2 * (a - qa * (n / 2));
+			gamma            = 1.0 / 3 * m + (1.0 / 3 * fn[oth + fa * sa] + 1.0 / 3 * fn[oth + (fa + 1) * sa]);
+		}
+		g[a] = 2 * gamma - m;
+	}
+}
+
+__global__ void k_pack_faces2d(int n, const int32_t *__restrict__ faces, const double *__restrict__ u,
+                               double *__restrict__ sendbuf)
+{
+	const int     p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
+	const int     ax = s >> 1, sa = (ax == 0) ? n : 1, sn = (ax == 0) ? 1 : n;
+	const double *up = u + (size_t) p * n * n + ((s & 1) ? (n - 1) * sn : 0);
+	double       *o  = sendbuf + (size_t) blockIdx.x * n;
+	for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = up[i * sa];
+}
+
+__device__ __forceinline__ double restrictCell2d(const double *fp, int n, int hx, int hy)
+{
+	double acc = 0.0; // AvgRstr.h:95-102 order: x then y, each /(1<<D)
+	acc += fp[2 * hx + n * (2 * hy)] / 4;
+	acc += fp[2 * hx + 1 + n * (2 * hy)] / 4;
+	acc += fp[2 * hx + n * (2 * hy + 1)] / 4;
+	acc += fp[2 * hx + 1 + n * (2 * hy + 1)] / 4;
+	return acc;
+}
+__global__ __launch_bounds__(256) void k_restrict2d(int n, int Pc, const int32_t *__restrict__ child,
+                                                    const int32_t *__restrict__ copy, const double *__restrict__ fine,
+                                                    const double *__restrict__ remote, const int64_t *__restrict__ remote_off,
+                                                    double *__restrict__ coarse)
+{
+	const int    nn = n * n, h = n / 2;
+	const size_t total = (size_t) Pc * nn;
+	for (size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t) gridDim.x * blockDim.x) {
+		const int pc = (int) (idx / nn), c = (int) (idx % nn), x = c % n, y = c / n;
+		if (copy[pc]) {
+			const int src = child[(size_t) pc * 4];
+			coarse[idx]   = 0.0 + (src >= 0 ? fine[(size_t) src * nn + c] : remote[remote_off[-(src + 2)] + c]);
+			continue;
+		}
+		const int ox = x >= h, oy = y >= h, hx = x - ox * h, hy = y - oy * h;
+		const int src = child[(size_t) pc * 4 + ox + 2 * oy];
+		coarse[idx]   = (src >= 0) ? restrictCell2d(fine + (size_t) src * nn, n, hx, hy) : remote[remote_off[-(src + 2)] + hx + h * hy];
+	}
+}
+__global__ __launch_bounds__(256) void k_restrict_pack2d(int n, const int32_t *__restrict__ desc, const int64_t *__restrict__ off,
+                                                         const double *__restrict__ fine, double *__restrict__ buf)
+{
+	const int     nn = n * n, h = n / 2;
+	const int     p = desc[2 * blockIdx.x], o = desc[2 * blockIdx.x + 1];
+	const double *fp = fine + (size_t) p * nn;
+	double       *b  = buf + off[blockIdx.x];
+	if (o < 0)
+		for (int i = threadIdx.x; i < nn; i += blockDim.x) b[i] = fp[i];
+	else
+		for (int i = threadIdx.x; i < h * h; i += blockDim.x) b[i] = restrictCell2d(fp, n, i % h, i / h);
+}
+__global__ __launch_bounds__(256) void k_prolong2d(int n, int Pf, const int32_t *__restrict__ parent,
+                                                   const int32_t *__restrict__ orth, const double *__restrict__ coarse,
+                                                   const double *__restrict__ remote, const int64_t *__restrict__ remote_off,
+                                                   double *__restrict__ fine)
+{
+	const int    nn = n * n, h = n / 2;
+	const size_t total = (size_t) Pf * nn;
+	for (size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t) gridDim.x * blockDim.x) {
+		const int pf = (int) (idx / nn), c = (int) (idx % nn), x = c % n, y = c / n;
+		const int o = orth[pf], pa = parent[pf];
+		double    cv;
+		if (o >= 0) {
+			if (pa >= 0)
+				cv = coarse[(size_t) pa * nn + (x + ((o & 1) ? n : 0)) / 2 + n * ((y + ((o & 2) ? n : 0)) / 2)];
+			else
+				cv = remote[remote_off[-(pa + 2)] + x / 2 + h * (y / 2)];
+		} else {
+			cv = (pa >= 0) ? coarse[(size_t) pa * nn + c] : remote[remote_off[-(pa + 2)] + c];
+		}
+		fine[idx] += cv;
+	}
+}
+__global__ __launch_bounds__(256) void k_prolong_pack2d(int n, const int32_t *__restrict__ desc, const int64_t *__restrict__ off,
+                                                        const double *__restrict__ coarse, double *__restrict__ buf)
+{
+	const int     nn = n * n, h = n / 2;
+	const int     pc = desc[2 * blockIdx.x], o = desc[2 * blockIdx.x + 1];
+	const double *cp = coarse + (size_t) pc * nn;
+	double       *b  = buf + off[blockIdx.x];
+	if (o < 0) {
+		for (int i = threadIdx.x; i < nn; i += blockDim.x) b[i] = cp[i];
+	} else {
+		const int bx = (o & 1) ? h : 0, by = (o & 2) ? h : 0;
+		for (int i = threadIdx.x; i < h * h; i += blockDim.x) b[i] = cp[bx + i % h + n * (by + i / h)];
+	}
+}
+
+// ---- reference block-Jacobi patch solve in 2D (FftwPatchSolver<2>): rhs, then 4 dense transform passes
+__global__ __launch_bounds__(256) void k_patch_rhs2d(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
+                                                     double *__restrict__ rhs)
+{
+	const int    n = L.n, nn = n * n;
+	const size_t total = (size_t) L.P * nn;
+	for (size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t) gridDim.x * blockDim.x) {
+		const int p = (int) (idx / nn), c = (int) (idx % nn), x = c % n, y = c / n;
+		double    v = f[idx];
+		const double m = u[idx];
+		const int    xy[2] = {x, y};
+#pragma unroll
+		for (int ax = 0; ax < 2; ax++)
+#pragma unroll
+			for (int side = 0; side < 2; side++) {
+				if (xy[ax] != (side ? n - 1 : 0)) continue;
+				const int s = 2 * ax + side;
+				if (L.face_kind[p * 4 + s] < FACE_LOCAL) continue;
+				const double gh = ghost2d(L, u, p, s, xy[1 - ax], m, false);
+				v -= 2.0 * L.rh2[p * 3 + ax] * (0.5 * m + 0.5 * gh);
+			}
+		rhs[idx] = v;
+	}
+}
+// STAGE 0,1 forward x,y; 2,3 inverse x,y. mats: [nplans][4][n*n] row-major; lam: [nplans][2][n]
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_dst_axis2d(int n, int P, const int32_t *__restrict__ plan,
+                                                    const double *__restrict__ mats, const double *__restrict__ lam,
+                                                    const int32_t *__restrict__ zero_mode, const double *__restrict__ rh2,
+                                                    const double *__restrict__ in, double *__restrict__ out)
+{
+	constexpr int AX = STAGE % 2;
+	const int     nn = n * n, st = AX ? n : 1;
+	const size_t  total = (size_t) P * nn;
+	for (size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t) gridDim.x * blockDim.x) {
+		const int     p = (int) (idx / nn), c = (int) (idx % nn);
+		const int     pl = plan[p];
+		const double *M  = mats + ((size_t) pl * 4 + STAGE) * nn;
+		const int     i = (c / st) % n, base = c - i * st;
+		const double *ip = in + (size_t) p * nn + base;
+		double        acc = 0.0;
+		for (int j = 0; j < n; j++) acc += M[(size_t) i * n + j] * ip[(size_t) j * st];
+		if (STAGE == 1) {
+			const double *lm = lam + (size_t) pl * 2 * n;
+			acc /= -(lm[c % n] * rh2[p * 3] + lm[n + c / n] * rh2[p * 3 + 1]);
+			if (zero_mode[pl] && c == 0) acc = 0.0;
+		}
+		if (STAGE == 3) acc *= 4.0 / ((double) n * n);
+		out[idx] = acc;
+	}
+}
+} // namespace te

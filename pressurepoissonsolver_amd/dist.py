@@ -110,17 +110,22 @@ def attach(gmg, dist):
 
 
 class LocalFabric:
-    """n virtual ranks in one process. Each rank runs in its own thread (`run`); the exchange
-    copies device-to-device between the ranks' buffers once everybody has arrived."""
+    """n virtual ranks in one process. Each rank runs in its own thread (`run`). An exchange is a set of
+    point-to-point rendezvous: the sender posts (pointer, count, tag) to the (src, dst) mailbox, the
+    receiver copies device-to-device and acknowledges; ranks whose plan is empty do not take part
+    (exactly the semantics of the torch.distributed binding)."""
 
     def __init__(self, nranks):
+        import queue
         self.n = nranks
         self.barrier = threading.Barrier(nranks)
-        self.posted = [None] * nranks
+        self.mail = {(s, d): queue.Queue() for s in range(nranks) for d in range(nranks)}
+        self.acks = {(s, d): queue.Queue() for s in range(nranks) for d in range(nranks)}
         self.hip = C.CDLL("libamdhip64.so")
         self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.hip.hipMemcpy.restype = C.c_int
         self.errors = []
+        self.timeout = 120.0
 
     def attach(self, gmg, rank):
         fab = self
@@ -129,21 +134,23 @@ class LocalFabric:
             try:
                 pl = _plan_arrays(npeers, peers, soff, scnt, roff, rcnt)
                 capi.check(capi.lib().te_gmg_sync(gmg.h))  # my packed data is complete
-                fab.posted[rank] = (int(send_ptr or 0), tag, dict(zip(pl[0], zip(pl[1], pl[2]))))
-                fab.barrier.wait()
+                for r, so, sc in zip(pl[0], pl[1], pl[2]):
+                    if sc > 0:
+                        fab.mail[(rank, r)].put((int(send_ptr) + 8 * so, sc, tag))
                 for r, ro, rc in zip(pl[0], pl[3], pl[4]):
                     if rc == 0:
                         continue
-                    sp, stag, smap = fab.posted[r]
-                    so, sc = smap[rank]
+                    sp, sc, stag = fab.mail[(r, rank)].get(timeout=fab.timeout)
                     assert stag == tag and sc == rc, f"plan mismatch {rank}<-{r}: tag {stag}/{tag} cnt {sc}/{rc}"
-                    err = fab.hip.hipMemcpy(int(recv_ptr) + 8 * ro, sp + 8 * so, 8 * rc, 3)  # DeviceToDevice
+                    err = fab.hip.hipMemcpy(int(recv_ptr) + 8 * ro, sp, 8 * rc, 3)  # DeviceToDevice
                     assert err == 0, f"hipMemcpy failed: {err}"
-                fab.barrier.wait()  # nobody may repack before everyone has copied
+                    fab.acks[(r, rank)].put(tag)
+                for r, sc in zip(pl[0], pl[2]):  # nobody may repack before its receivers have copied
+                    if sc > 0:
+                        fab.acks[(rank, r)].get(timeout=fab.timeout)
                 return 0
             except Exception as e:
                 fab.errors.append(e)
-                fab.barrier.abort()
                 return 1
 
         gmg._cb = capi.EXCHANGE_FN(cb)

@@ -32,7 +32,46 @@ def gauss_rhs(x, y, z):
                        + 144 * e(c(12 * pi * z)) * c(12 * pi * z) - 144 * e(c(12 * pi * z)) * s(12 * pi * z) ** 2)
 
 
+def trig2d_exact(x, y):
+    """apps/2d/steady.cpp:316"""
+    return np.sin(np.pi * y) * np.cos(2 * np.pi * x)
+
+
+def trig2d_rhs(x, y):
+    """apps/2d/steady.cpp:314-315"""
+    return -5 * np.pi ** 2 * trig2d_exact(x, y)
+
+
 PROBLEMS = {"trig": (trig_rhs, trig_exact), "gauss": (gauss_rhs, gauss_exact)}
+PROBLEMS_2D = {"trig": (trig2d_rhs, trig2d_exact)}
+
+
+def init_dirichlet_2d(tables, n, problem="trig", patches=None):
+    """(f, exact) flat vectors for 2D levels, Init::initDirichlet2d (Init.cpp:304-361)."""
+    ffun, efun = PROBLEMS_2D[problem] if isinstance(problem, str) else problem
+    if patches is None:
+        patches = np.arange(len(tables["id"]))
+    starts, lengths = tables["starts"], tables["lengths"]
+    idx = np.arange(n) + 0.5
+    f = np.empty((len(patches), n, n))
+    ex = np.empty_like(f)
+    for k, p in enumerate(patches):
+        h = lengths[p] / n
+        Y, X = np.meshgrid(starts[p, 1] + h[1] * idx, starts[p, 0] + h[0] * idx, indexing="ij")
+        f[k], ex[k] = ffun(X, Y), efun(X, Y)
+        for s in range(4):
+            if tables["nbr_kind"][p, s] != 0:
+                continue
+            ax, up = s // 2, s & 1
+            sl = [slice(None)] * 2
+            sl[1 - ax] = -1 if up else 0
+            xb, yb = X[tuple(sl)].copy(), Y[tuple(sl)].copy()
+            if ax == 0:
+                xb += (0.5 if up else -0.5) * h[0]
+            else:
+                yb += (0.5 if up else -0.5) * h[1]
+            f[k][tuple(sl)] -= 2 * efun(xb, yb) / h[ax] ** 2
+    return f.ravel(), ex.ravel()
 
 
 def cell_centres(tables, n, patches=None):

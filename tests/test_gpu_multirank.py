@@ -18,7 +18,7 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def shard_run(mesh, n, nranks, fn):
+def shard_run(mesh, n, nranks, fn, dim=3):
     """fn(rank, H, g) -> dict of local arrays on level 0; returns them assembled in global order"""
     fab = tedist.LocalFabric(nranks)
     hs = [capi.Hierarchy(mesh, n, rank=r, nranks=nranks) for r in range(nranks)]
@@ -27,7 +27,7 @@ def shard_run(mesh, n, nranks, fn):
         fab.attach(g, r)
     outs = fab.run(lambda r: fn(r, hs[r], gs[r], fab))
     P = hs[0].sizes(0)[1]
-    nc = n ** 3
+    nc = n ** dim
     merged = {}
     for k in outs[0]:
         if isinstance(outs[0][k], np.ndarray):
@@ -42,15 +42,15 @@ def shard_run(mesh, n, nranks, fn):
 
 
 @pytest.mark.parametrize("nranks", [2, 4, 8])
-@pytest.mark.parametrize("divides,n", [(2, 8), (3, 4)])
-def test_sharded_ops_equal_single_rank(nranks, divides, n):
-    mesh = util.mesh("uniform", divides)
+@pytest.mark.parametrize("divides,n,dim", [(2, 8, 3), (3, 4, 3), (3, 8, 2)])
+def test_sharded_ops_equal_single_rank(nranks, divides, n, dim):
+    mesh = util.mesh("uniform", divides, dim)
     H1 = capi.Hierarchy(mesh, n)
     g1 = capi.GMG(H1)
     size = H1.cells(0)
     u = util.rand_vec(size, 1)
     f = util.rand_vec(size, 2)
-    nc = n ** 3
+    nc = n ** dim
 
     def single(op):
         du, df, dr = g1.new_vector(0, u), g1.new_vector(0, f), g1.new_vector(0)
@@ -82,7 +82,7 @@ def test_sharded_ops_equal_single_rank(nranks, divides, n):
             out[k] = dr.download()
         return out
 
-    got = shard_run(mesh, n, nranks, per_rank)
+    got = shard_run(mesh, n, nranks, per_rank, dim)
     for k in ops:
         assert np.array_equal(got[k], want[k]), (k, np.abs(got[k] - want[k]).max())
 

@@ -21,15 +21,19 @@ pytestmark = pytest.mark.gpu
 # kernels are instantiated for, Dirichlet and Neumann physical boundaries (StarPatchOp.h:49-65)
 CASES = [("2uni.bin", 8, 0, False), ("2refine.bin", 8, 0, False), ("3uni.bin", 4, 0, False), ("2uni.bin", 16, 1, False),
          ("2refine.bin", 16, 1, False), ("uniform", 32, 1, False), ("1uni.bin", 8, 0, False),
-         ("2uni.bin", 8, 0, True), ("2refine.bin", 8, 0, True), ("1uni.bin", 16, 0, True)]
+         ("2uni.bin", 8, 0, True), ("2refine.bin", 8, 0, True), ("1uni.bin", 16, 0, True),
+         # 2D twins (configs C1: one 256^2 patch; C5-style: 64^2 patches; refined quadtree; Neumann)
+         ("2d2uni.bin", 8, 0, False), ("2d2ref.bin", 8, 0, False), ("2d2ref.bin", 16, 1, False), ("2d2ref.bin", 8, 0, True),
+         ("uniform2d", 256, 0, False), ("uniform2d", 64, 2, False)]
 
 
 @pytest.fixture(scope="module", params=CASES, ids=lambda c: f"{c[0]}-n{c[1]}-d{c[2]}{'-neumann' if c[3] else ''}")
 def case(request):
     name, n, div, neu = request.param
-    m, H, levels = util.setup(name, n, div, neumann=neu)
+    dim = 2 if name.startswith(("2d", "uniform2d")) else 3
+    m, H, levels = util.setup("uniform" if name == "uniform2d" else name, n, div, neumann=neu, dim=dim)
     g = capi.GMG(H)
-    return dict(H=H, levels=levels, g=g, n=n, neumann=neu)
+    return dict(H=H, levels=levels, g=g, n=n, neumann=neu, dim=dim)
 
 
 def rel(a, b):
@@ -154,7 +158,8 @@ def test_bicgstab_trig(case):
     if case["neumann"]:
         pytest.skip("pure-Neumann solves need the drivers' null-space handling (apps/3d/steady.cpp:330-334)")
     g, levels, H = case["g"], case["levels"], case["H"]
-    f, exact = problems.init_dirichlet(H.tables(0), case["n"])
+    init = problems.init_dirichlet if case["dim"] == 3 else problems.init_dirichlet_2d
+    f, exact = init(H.tables(0), case["n"])
     for sm in (capi.SMOOTH_PATCH_SOLVE, capi.SMOOTH_RBGS):
         o = g.default_opts(smoother=sm)
         x_ref, its_ref, rr_ref = orc.bicgstab(levels, orc.cycle_opts(smoother=sm), f)
