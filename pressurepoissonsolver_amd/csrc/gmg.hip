@@ -289,35 +289,39 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 
 	// ---- remote same-level faces: canonical order = (peer, receiving patch (global), receiving side),
 	// which both ends can compute from the global tables
+	// A receiving (patch, side, q) gets ONE ghost slot holding the sender's facing layer: the ghost values
+	// themselves on a same-level face, raw neighbour cells for k_cf_ghost on a coarse/fine face (q = which
+	// of the finer neighbours; the coarse side of a coarse/fine face receives one slot per fine neighbour).
 	struct RFace {
-		int peer, key_patch, key_side, p, s;
+		int peer, key_patch, key_side, key_q, p, s;
 		bool operator<(const RFace &o) const
 		{
-			return std::tie(peer, key_patch, key_side) < std::tie(o.peer, o.key_patch, o.key_side);
+			return std::tie(peer, key_patch, key_side, key_q) < std::tie(o.peer, o.key_patch, o.key_side, o.key_q);
 		}
 	};
 	std::vector<RFace> recvs, sends;
 	for (int p = 0; p < P; p++) {
 		const int gp = lv.l2g[p];
 		for (int s = 0; s < NS; s++) {
-			const size_t gf = (size_t) gp * NS + s;
-			if (lv.g_nbr_kind[gf] == NBR_NONE) continue;
-			for (int q = 0; q < 4; q++) {
+			const size_t gf   = (size_t) gp * NS + s;
+			const int    kind = lv.g_nbr_kind[gf];
+			if (kind == NBR_NONE) continue;
+			for (int q = 0; q < NQ; q++) {
 				const int nb = lv.g_nbr[gf * 4 + q];
 				if (nb < 0 || lv.g_rank[nb] == me) continue;
-				if (lv.g_nbr_kind[gf] != NBR_NORMAL)
-					return te::fail(TE_EUNSUPPORTED,
-					                "te_gmg_create: coarse/fine faces across ranks are not supported yet");
-				recvs.push_back({lv.g_rank[nb], gp, s, p, s});
-				sends.push_back({lv.g_rank[nb], nb, s ^ 1, p, s});
+				recvs.push_back({lv.g_rank[nb], gp, s, q, p, s});
+				// what the neighbour files my layer under: its own (patch, side) and, when it is the coarse
+				// side, my position among its fine neighbours = my quadrant on its face
+				const int their_q = (kind == NBR_COARSE) ? lv.g_nbr_orth[gf] : 0;
+				sends.push_back({lv.g_rank[nb], nb, s ^ 1, their_q, p, s});
 			}
 		}
 	}
 	std::sort(recvs.begin(), recvs.end());
 	std::sort(sends.begin(), sends.end());
-	const int                 nremote = (int) recvs.size();
-	std::map<std::pair<int, int>, int> remote_slot; // (p, s) -> ghost slot
-	for (int i = 0; i < nremote; i++) remote_slot[{recvs[i].p, recvs[i].s}] = i;
+	const int                           nremote = (int) recvs.size();
+	std::map<std::tuple<int, int, int>, int> remote_slot; // (p, s, q) -> ghost slot
+	for (int i = 0; i < nremote; i++) remote_slot[std::make_tuple(recvs[i].p, recvs[i].s, recvs[i].key_q)] = i;
 	{
 		std::vector<std::pair<int, int64_t>> si, ri;
 		std::vector<int32_t>                 sf;
@@ -360,7 +364,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 					fs[p * NS + s] = lv.g_local[nb];
 				} else { // the neighbour's face cells arrive in a ghost slot; diagonal unchanged
 					fk[p * NS + s] = FACE_GHOST;
-					fs[p * NS + s] = remote_slot.at({p, s});
+					fs[p * NS + s] = remote_slot.at(std::make_tuple(p, s, 0));
 				}
 			} else {
 				fk[p * NS + s]   = FACE_GHOST;
@@ -370,9 +374,12 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 				cfd.push_back(s);
 				cfd.push_back(kind);
 				cfd.push_back(lv.g_nbr_orth[gf]);
-				for (int q = 0; q < 4; q++) {
+				for (int q = 0; q < 4; q++) { // local patch index, or -(slot+2) of the raw layer received for it
 					int nb = (q < NQ) ? lv.g_nbr[gf * 4 + q] : -1;
-					cfd.push_back(nb >= 0 ? lv.g_local[nb] : -1);
+					if (nb >= 0 && lv.g_rank[nb] != me)
+						cfd.push_back(-(remote_slot.at(std::make_tuple(p, s, q)) + 2));
+					else
+						cfd.push_back(nb >= 0 ? lv.g_local[nb] : -1);
 				}
 				cfs.push_back(nslots);
 				nslots++;

@@ -140,13 +140,15 @@ __global__ void k_cf_ghost2d(int n, const int32_t *__restrict__ desc, const int3
 		double       gamma;
 		if (kind == 2) {
 			const double other = up[mine + (a ^ 1) * sa];
-			const double C     = u[(size_t) d[4] * n * n + oth + ((a + (q ? n : 0)) / 2) * sa];
+			const int    ca    = (a + (q ? n : 0)) / 2;
+			const double C     = d[4] >= 0 ? u[(size_t) d[4] * n * n + oth + ca * sa] : ghost[(size_t) (-(d[4] + 2)) * n + ca];
 			gamma              = 5.0 / 6 * m - 1.0 / 6 * other + 2.0 / 6 * C;
 		} else {
-			const int     qa = (a >= n / 2);
-			const double *fn = u + (size_t) d[4 + qa] * n * n;
-			const int     fa = 2 * (a - qa * (n / 2));
-			gamma            = 1.0 / 3 * m + (1.0 / 3 * fn[oth + fa * sa] + 1.0 / 3 * fn[oth + (fa + 1) * sa]);
+			const int    qa = (a >= n / 2), nbq = d[4 + qa];
+			const int    fa = 2 * (a - qa * (n / 2));
+			const double f0 = nbq >= 0 ? u[(size_t) nbq * n * n + oth + fa * sa] : ghost[(size_t) (-(nbq + 2)) * n + fa];
+			const double f1 = nbq >= 0 ? u[(size_t) nbq * n * n + oth + (fa + 1) * sa] : ghost[(size_t) (-(nbq + 2)) * n + fa + 1];
+			gamma           = 1.0 / 3 * m + (1.0 / 3 * f0 + 1.0 / 3 * f1);
 		}
 		g[a] = 2 * gamma - m;
 	}

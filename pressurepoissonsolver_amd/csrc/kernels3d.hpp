@@ -549,15 +549,19 @@ __global__ void k_cf_ghost3d(const int32_t *__restrict__ desc, const int32_t *__
 				for (int aa = 0; aa < 2; aa++)
 					if (a0 + aa != a || b0 + bb != b) sum += up[mine + (a0 + aa) * sa + (b0 + bb) * sb];
 			const int ca = (a + ((q & 1) ? N : 0)) / 2, cb = (b + ((q & 2) ? N : 0)) / 2;
-			double    C  = u[(size_t) d[4] * NNN + oth + ca * sa + cb * sb];
+			// d[4] >= 0: the coarse neighbour is local; else its facing layer was received in a ghost slot
+			double    C  = d[4] >= 0 ? u[(size_t) d[4] * NNN + oth + ca * sa + cb * sb]
+			                         : ghost[(size_t) (-(d[4] + 2)) * NN + ca + N * cb];
 			gamma        = (11 * m - sum) / 12.0 + 4.0 * C / 12.0;
 		} else {
-			const int     qa = (a >= N / 2), qb = (b >= N / 2);
-			const double *fn = u + (size_t) d[4 + qa + 2 * qb] * NNN;
-			const int     fa = 2 * (a - qa * (N / 2)), fb = 2 * (b - qb * (N / 2));
-			double        sum = 0;
+			const int qa = (a >= N / 2), qb = (b >= N / 2);
+			const int nbq = d[4 + qa + 2 * qb];
+			const int fa = 2 * (a - qa * (N / 2)), fb = 2 * (b - qb * (N / 2));
+			double    sum = 0;
 			for (int bb = 0; bb < 2; bb++)
-				for (int aa = 0; aa < 2; aa++) sum += 1.0 / 6.0 * fn[oth + (fa + aa) * sa + (fb + bb) * sb];
+				for (int aa = 0; aa < 2; aa++)
+					sum += 1.0 / 6.0 * (nbq >= 0 ? u[(size_t) nbq * NNN + oth + (fa + aa) * sa + (fb + bb) * sb]
+					                             : ghost[(size_t) (-(nbq + 2)) * NN + (fa + aa) + N * (fb + bb)]);
 			gamma = 2.0 / 6.0 * m + sum;
 		}
 		g[i] = 2 * gamma - m;

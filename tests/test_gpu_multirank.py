@@ -41,10 +41,12 @@ def shard_run(mesh, n, nranks, fn, dim=3):
     return merged
 
 
-@pytest.mark.parametrize("nranks", [2, 4, 8])
-@pytest.mark.parametrize("divides,n,dim", [(2, 8, 3), (3, 4, 3), (3, 8, 2)])
-def test_sharded_ops_equal_single_rank(nranks, divides, n, dim):
-    mesh = util.mesh("uniform", divides, dim)
+@pytest.mark.parametrize("nranks", [2, 3, 4, 8])
+@pytest.mark.parametrize("name,divides,n,dim", [("uniform", 2, 8, 3), ("uniform", 3, 4, 3), ("uniform", 3, 8, 2),
+                                                # refined trees: coarse/fine faces cut by rank boundaries (config C4)
+                                                ("2refine.bin", 1, 8, 3), ("2d2ref.bin", 2, 8, 2)])
+def test_sharded_ops_equal_single_rank(nranks, name, divides, n, dim):
+    mesh = util.mesh(name, divides, dim)
     H1 = capi.Hierarchy(mesh, n)
     g1 = capi.GMG(H1)
     size = H1.cells(0)
