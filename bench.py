@@ -40,6 +40,7 @@ ALG_BYTES = {
     "dst_axis": 16.0,
     "resid_restrict": 17.0,      # read u, f; write coarse f (8/8): residual never stored
     "stencil_rbgs_zero": 16.0,   # first sweep from a zero guess: read f, write u
+    "stencil_rbgs_prolong": 25.0,  # post-sweep on u + P(coarse): read u, f, coarse (8/8); write u
 }
 
 

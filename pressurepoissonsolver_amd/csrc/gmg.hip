@@ -34,11 +34,11 @@ namespace
 {
 enum KClass : int {
 	KC_APPLY, KC_RESID, KC_JACOBI, KC_RBGS, KC_CFGHOST, KC_RESTRICT, KC_PROLONG, KC_PATCH_RHS,
-	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_RBGS_ZERO, KC_RESID_RESTRICT, KC_PS_MFMA, KC_COUNT
+	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_RBGS_ZERO, KC_RESID_RESTRICT, KC_PS_MFMA, KC_RBGS_PROLONG, KC_COUNT
 };
 const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_jacobi", "stencil_rbgs",
                                     "cf_ghost", "restrict", "prolong_add", "patch_rhs", "dst_axis",
-                                    "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict", "patch_solve_mfma"};
+                                    "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict", "patch_solve_mfma", "stencil_rbgs_prolong"};
 
 template <typename T> struct DevBuf {
 	T     *p = nullptr;
@@ -72,6 +72,7 @@ struct ExPlan {
 
 struct LevelHost {
 	int    dim = 3, n = 0, P = 0, P_global = 0;
+	bool   prolong_fusable = false; // every patch is an octant child of a LOCAL parent and no ghost slot exists
 	size_t nc = 0, nf = 0;
 	// stencil tables
 	DevBuf<int32_t> face_kind, face_src;
@@ -514,6 +515,8 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 					return te::fail(TE_EINVAL, "te_gmg_create: coarse patch with a missing child");
 		}
 		L->Pc      = cv.P;
+		L->prolong_fusable = (D == 3 && L->nslots == 0 && up.empty() && down.empty()
+		                      && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
 		L->n_up    = (int) up.size();
 		L->n_down  = (int) down.size();
 		L->tx_up   = mergePlan(ups, downs);   // restrict: send child blocks, receive into downbuf
@@ -725,29 +728,44 @@ template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, 
 		default: return launchStencilN<32, MODE>(g, L, u, f, out, omega, rd);
 	}
 }
-template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess)
+template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess,
+                                 const double *prolong_from)
 {
+	if (prolong_from) { // u + P(coarse) is formed on the fly: only for levels without ghost slots (checked by the caller)
+		ProlongSrc ps;
+		ps.parent = L.parent.p;
+		ps.orth   = L.orth.p;
+		ps.coarse = prolong_from;
+		Timed t(g, KC_RBGS_PROLONG, (size_t) L.P * L.nc);
+		hipLaunchKernelGGL((k_rbgs3d<N, false, true>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f,
+		                   out, ps);
+		HIPCHK(hipGetLastError());
+		return TE_OK;
+	}
 	if (!zero_guess) { // a zero iterate has zero ghosts everywhere: nothing to exchange or build
 		int rc = prepareGhosts<N>(g, L, u);
 		if (rc) return rc;
 	}
 	Timed t(g, zero_guess ? KC_RBGS_ZERO : KC_RBGS, (size_t) L.P * L.nc);
 	if (zero_guess)
-		hipLaunchKernelGGL((k_rbgs3d<N, true>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f, out);
+		hipLaunchKernelGGL((k_rbgs3d<N, true, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f, out,
+		                   ProlongSrc());
 	else
-		hipLaunchKernelGGL((k_rbgs3d<N, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f, out);
+		hipLaunchKernelGGL((k_rbgs3d<N, false, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f, out,
+		                   ProlongSrc());
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
-int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false)
+int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false,
+               const double *prolong_from = nullptr)
 {
 	if (L.P == 0) return TE_OK;
 	if (L.dim == 2) return launchRbgs2d(g, L, u, f, out);
 	switch (L.n) {
-		case 4: return launchRbgsN<4>(g, L, u, f, out, zero_guess);
-		case 8: return launchRbgsN<8>(g, L, u, f, out, zero_guess);
-		case 16: return launchRbgsN<16>(g, L, u, f, out, zero_guess);
-		default: return launchRbgsN<32>(g, L, u, f, out, zero_guess);
+		case 4: return launchRbgsN<4>(g, L, u, f, out, zero_guess, prolong_from);
+		case 8: return launchRbgsN<8>(g, L, u, f, out, zero_guess, prolong_from);
+		case 16: return launchRbgsN<16>(g, L, u, f, out, zero_guess, prolong_from);
+		default: return launchRbgsN<32>(g, L, u, f, out, zero_guess, prolong_from);
 	}
 }
 // Cycle.h:59-65 in one pass: coarse f = AvgRstr(f - A u), r never stored. Children whose parent is
@@ -978,11 +996,20 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         u_zero = false;
         return vecop<VOP_SET>(u, nullptr, nullptr, 0.0, 0.0, 0.0);
 	};
+	const double *pending_prolong = nullptr; // coarse correction still to be added to u
+	int           next_sweeps     = 0;       // sweeps that follow the descend() in progress
 	auto smooth = [&](int sweeps, bool at_coarsest) -> int {
 		int sm = o->smoother;
 		if (at_coarsest && o->exact_coarse && L.P_global == 1) sm = TE_SMOOTH_PATCH_SOLVE;
 		for (int i = 0; i < sweeps; i++) {
 			int r;
+			if (pending_prolong) {
+				const double *c = pending_prolong;
+				pending_prolong = nullptr;
+				if ((r = launchRbgs(g, L, u->d, f->d, L.t->d, false, c))) return r;
+				swapData(u, L.t.get());
+				continue;
+			}
 			if (u_zero && L.dim == 3 && (sm == TE_SMOOTH_RBGS || sm == TE_SMOOTH_PATCH_SOLVE)) {
 				u_zero = false;
 				r      = smoothOnce(g, l, f, u, sm, o->omega, true);
@@ -1010,12 +1037,20 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
             if ((r = vecop<VOP_SET>(C.u.get(), nullptr, nullptr, 0.0, 0.0, 0.0))) return r;
         }
         if ((r = visit(g, o, l + 1, C.f.get(), C.u.get(), o->fuse != 0))) return r;
-        return doProlong(g, l, C.u->d, u->d); // prepFiner
+        // prepFiner (Cycle.h:74-80). When the very next step is an RB-GS sweep on a level without ghost
+        // slots, that sweep reads u + P(coarse u) on the fly instead (same bits, one HBM pass less).
+        if (o->fuse && L.prolong_fusable && o->smoother == TE_SMOOTH_RBGS && next_sweeps > 0) {
+            pending_prolong = C.u->d;
+            return TE_OK;
+        }
+        return doProlong(g, l, C.u->d, u->d);
 	};
 	if ((rc = smooth(o->pre_sweeps, false))) return rc;
+	next_sweeps = (o->cycle_type == 1) ? o->mid_sweeps : o->post_sweeps;
 	if ((rc = descend())) return rc;
 	if (o->cycle_type == 1) {
 		if ((rc = smooth(o->mid_sweeps, false))) return rc;
+		next_sweeps = o->post_sweeps;
 		if ((rc = descend())) return rc;
 	}
 	return smooth(o->post_sweeps, false);

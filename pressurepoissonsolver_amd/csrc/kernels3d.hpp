@@ -342,6 +342,22 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_stencil3d(LevelDev L, const d
 
 __device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a : b; }
 
+// Fused prolongation (DrctIntp.h:99-106) for the first post-smoothing sweep: every value of u the
+// sweep reads is taken as u + coarse[parent][(c + orthant offset)/2], so the corrected iterate is
+// never written out and read back. Only used on levels where every patch is an octant child of a local
+// parent and no ghost slot exists (uniform refinement on one rank); the host falls back otherwise.
+struct ProlongSrc {
+	const int32_t *parent, *orth;
+	const double  *coarse;
+};
+// base of the coarse octant that fine patch p maps onto: coarse cell of fine (x,y,z) = base[x/2 + N (y/2) + N^2 (z/2)]
+template <int N> __device__ __forceinline__ const double *coarseOctant(const ProlongSrc &ps, int p)
+{
+	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
+	const int     o = ps.orth[p];
+	return ps.coarse + (size_t) ps.parent[p] * NNN + ((o & 1) ? H : 0) + N * ((o & 2) ? H : 0) + NN * ((o & 4) ? H : 0);
+}
+
 // relax the cells of colour `colour` of plane z; `cen` holds the plane's pairs (LDS copy in tl)
 template <int N, bool ZERO_NBRS = false>
 __device__ __forceinline__ void rbgsRelax(double *tl, const double *idiag, int z, int colour,
@@ -384,10 +400,11 @@ __device__ __forceinline__ void rbgsRelax(double *tl, const double *idiag, int z
 // ZERO: the sweep starts from u == 0 (first pre-smoothing sweep of a cycle, Cycle.h:118 /
 // :63): u is never read (neither the patch nor any ghost), results are bit-identical to the
 // general kernel fed with zeros.
-template <int N, bool ZERO>
+// PROLONG: the sweep runs on u + P(coarse) (see ProlongSrc).
+template <int N, bool ZERO, bool PROLONG>
 __global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const double *__restrict__ u,
                                                           const double *__restrict__ f,
-                                                          double *__restrict__ out)
+                                                          double *__restrict__ out, ProlongSrc ps)
 {
 	using T             = Tile2<N>;
 	constexpr int  TPB  = T::TPB;
@@ -438,6 +455,32 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	} else { // halo ring stays zero for the whole sweep
 		for (int i = tid; i < 3 * T::LSZ; i += TPB) (&tile[0][0])[i] = 0.0;
 	}
+	// coarse-correction sources matching hs / bot / top / the own planes (PROLONG only)
+	const double *cown = nullptr, *chalo = nullptr, *cbot = nullptr, *ctop = nullptr;
+	double        shalo = 0.0, sbot = 0.0, stop = 0.0;
+	if (PROLONG) {
+		cown  = coarseOctant<N>(ps, pid);
+		chalo = cbot = ctop = cown; // harmless valid address where no correction applies (scale 0)
+		if (tid < 4 * N) {
+			const int side = tid / N, t = tid % N;
+			if (fk[side] == FACE_LOCAL) {
+				const double *cn = coarseOctant<N>(ps, fs[side]);
+				// the neighbour's facing cell: west (N-1,t) east (0,t) south (t,N-1) north (t,0)
+				const int cx = (side == 0) ? H - 1 : (side == 1 ? 0 : t / 2);
+				const int cy = (side == 2) ? H - 1 : (side == 3 ? 0 : t / 2);
+				chalo = cn + cx + N * cy;
+				shalo = 1.0;
+			}
+		}
+		if (fk[4] == FACE_LOCAL) {
+			cbot = coarseOctant<N>(ps, fs[4]) + NN * (H - 1);
+			sbot = 1.0;
+		}
+		if (fk[5] == FACE_LOCAL) {
+			ctop = coarseOctant<N>(ps, fs[5]);
+			stop = 1.0;
+		}
+	}
 
 	int  q[CPT], lds[CPT], yy[CPT], xx[CPT];
 	bool act[CPT];
@@ -450,6 +493,9 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		xx[k]  = 2 * (q[k] % H);
 		lds[k] = (yy[k] + 1) * LW + xx[k] + 2;
 	}
+	int cq[CPT]; // in-plane coarse offset of pair k: x/2 + N (y/2)
+#pragma unroll
+	for (int k = 0; k < CPT; k++) cq[k] = (q[k] % H) + N * (yy[k] / 2);
 
 	// planes: umm = z-2, um = z-1, uc = z, un = z+1, un2 = z+2 (values are updated in place)
 	double2 umm[CPT], um[CPT], uc[CPT], un[CPT], un2[CPT], fm[CPT], fc[CPT], fn[CPT];
@@ -460,6 +506,11 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 			double2 a = bot.p[q[k]];
 			um[k]     = double2{bot.s * a.x, bot.s * a.y};
 			un[k]     = up2[NP + q[k]];
+			if (PROLONG) {
+				const double c0 = cown[cq[k]], cb = sbot * cbot[cq[k]]; // planes 0 and 1 share coarse plane 0
+				uc[k].x += c0, uc[k].y += c0, un[k].x += c0, un[k].y += c0;
+				um[k].x += bot.s * cb, um[k].y += bot.s * cb;
+			}
 		} else {
 			uc[k] = um[k] = un[k] = un2[k] = double2{0.0, 0.0};
 		}
@@ -467,7 +518,7 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		umm[k] = double2{0.0, 0.0};
 		fm[k]  = double2{0.0, 0.0};
 	}
-	double hv = ZERO ? 0.0 : hs.s * hs.p[0];
+	double hv = ZERO ? 0.0 : hs.s * (hs.p[0] + (PROLONG ? shalo * chalo[0] : 0.0));
 	__syncthreads(); // idiag (and the zeroed tiles)
 
 #pragma unroll 1
@@ -481,9 +532,15 @@ __global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 #pragma unroll
 			for (int k = 0; k < CPT; k++) {
 				double2 a = pn[q[k]];
-				un2[k]    = double2{sn * a.x, sn * a.y};
+				if (PROLONG) { // plane z+2 of the patch, or the top neighbour's plane 0
+					const double *cp = (z + 2 < N) ? cown + NN * ((z + 2) >> 1) : ctop;
+					const double  cs = (z + 2 < N) ? 1.0 : stop;
+					const double  c  = cs * cp[cq[k]];
+					a.x += c, a.y += c;
+				}
+				un2[k] = double2{sn * a.x, sn * a.y};
 			}
-			hvn = hs.s * hs.p[zc * hs.stride];
+			hvn = hs.s * (hs.p[zc * hs.stride] + (PROLONG ? shalo * chalo[NN * (zc >> 1)] : 0.0));
 		}
 #pragma unroll
 		for (int k = 0; k < CPT; k++) fn[k] = fp2[zc * NP + q[k]];

@@ -124,6 +124,7 @@ class LocalFabric:
         self.hip = C.CDLL("libamdhip64.so")
         self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.hip.hipMemcpy.restype = C.c_int
+        self.hip.hipDeviceSynchronize.restype = C.c_int
         self.errors = []
         self.timeout = 120.0
 
@@ -137,6 +138,7 @@ class LocalFabric:
                 for r, so, sc in zip(pl[0], pl[1], pl[2]):
                     if sc > 0:
                         fab.mail[(rank, r)].put((int(send_ptr) + 8 * so, sc, tag))
+                got = []
                 for r, ro, rc in zip(pl[0], pl[3], pl[4]):
                     if rc == 0:
                         continue
@@ -144,6 +146,11 @@ class LocalFabric:
                     assert stag == tag and sc == rc, f"plan mismatch {rank}<-{r}: tag {stag}/{tag} cnt {sc}/{rc}"
                     err = fab.hip.hipMemcpy(int(recv_ptr) + 8 * ro, sp, 8 * rc, 3)  # DeviceToDevice
                     assert err == 0, f"hipMemcpy failed: {err}"
+                    got.append(r)
+                # a device-to-device hipMemcpy is only ORDERED on the null stream, not complete on return;
+                # the solver streams are non-blocking, so finish the copies before anyone proceeds
+                assert fab.hip.hipDeviceSynchronize() == 0
+                for r in got:
                     fab.acks[(r, rank)].put(tag)
                 for r, sc in zip(pl[0], pl[2]):  # nobody may repack before its receivers have copied
                     if sc > 0:
