@@ -3,6 +3,7 @@
 // if HIP cannot give us a device, te_gmg_create fails with TE_EHIP.
 #include "capi_common.hpp"
 #include "kernels3d.hpp"
+#include "march3d.hpp"
 #include "kernels2d.hpp"
 #include "patchsolve32.hpp"
 #include <algorithm>
@@ -594,7 +595,7 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 	if (rc) return rc;
 	Timed     t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : (MODE == MODE_JACOBI ? KC_JACOBI : KC_RESID_RESTRICT)),
 	            (size_t) L.P * L.nc);
-	const int tpb = Tile2<N>::TPB;
+	const int tpb = Tile3<N>::TPB;
 	// enough workgroups to fill 256 CUs a few times over: split patches into z-slabs when few
 	int zs = 1;
 	if (N >= 8) {
@@ -737,7 +738,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 		ps.orth   = L.orth.p;
 		ps.coarse = prolong_from;
 		Timed t(g, KC_RBGS_PROLONG, (size_t) L.P * L.nc);
-		hipLaunchKernelGGL((k_rbgs3d<N, false, true>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f,
+		hipLaunchKernelGGL((k_rbgs3d<N, false, true>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, L.dev(), u, f,
 		                   out, ps);
 		HIPCHK(hipGetLastError());
 		return TE_OK;
@@ -748,10 +749,10 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 	}
 	Timed t(g, zero_guess ? KC_RBGS_ZERO : KC_RBGS, (size_t) L.P * L.nc);
 	if (zero_guess)
-		hipLaunchKernelGGL((k_rbgs3d<N, true, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f, out,
+		hipLaunchKernelGGL((k_rbgs3d<N, true, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, L.dev(), u, f, out,
 		                   ProlongSrc());
 	else
-		hipLaunchKernelGGL((k_rbgs3d<N, false, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile2<N>::TPB), 0, g->stream, L.dev(), u, f, out,
+		hipLaunchKernelGGL((k_rbgs3d<N, false, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, L.dev(), u, f, out,
 		                   ProlongSrc());
 	HIPCHK(hipGetLastError());
 	return TE_OK;

@@ -10,8 +10,8 @@
 // with 2*gamma - m from TriLinInterp.cpp:85-170's weights.
 //
 // Bandwidth-bound stencils: no MFMA. One workgroup marches one patch (or a z-slab of it)
-// plane by plane; z-neighbours live in registers, x/y-neighbours in a double-buffered LDS
-// plane with a one-cell halo; HBM sees each interior cell once per operand.
+// plane by plane (march3d.hpp); z-neighbours live in registers, x/y-neighbours in a double-buffered
+// LDS plane with a one-cell halo; HBM sees each interior cell once per operand.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,14 +37,6 @@ struct LevelDev {
 	const double  *face_kadj; // [P*6] change of the diagonal's per-axis factor 2 at that face
 	const double  *rh2;       // [P*3] 1/h^2
 	const double  *ghost;     // [nslots*N*N]
-};
-
-template <int N> struct Tile {
-	static constexpr int TPB = (N * N < 256) ? N * N : 256;
-	static constexpr int CPT = (N * N) / TPB;
-	static constexpr int LW  = N + 2; // LDS row length incl. halo
-	static constexpr int LSZ = LW * LW;
-	static_assert((N * N) % TPB == 0, "plane must tile the workgroup");
 };
 
 // Blocks b, b+8, b+16, ... share an XCD (observed round-robin dispatch); give every XCD one
@@ -153,427 +145,6 @@ __device__ __forceinline__ HaloSrc haloSrc(int tid, const int32_t *fk, const int
 		if (kind == FACE_NEUMANN) h.s = neu_sign;
 	}
 	return h;
-}
-
-// MODE_APPLY : out = A u                     (SchurHelper.h:360-376 + StarPatchOp.h:28-184)
-// MODE_RESID : out = f - A u                 (+ Cycle.h:60-61)
-// MODE_JACOBI: out = u + omega (f - A u)/diag(A)
-// MODE_RESID_RESTRICT: coarse f = AvgRstr(f - A u) without ever storing r (Cycle.h:59-65 fused); the
-//   eight fine residuals of a coarse cell are added in AvgRstr's own order (x, y, z), so the result
-//   is bit-identical to MODE_RESID followed by k_restrict3d.
-// grid: 8*ceil(P*ZS/8) blocks of Tile2<N>::TPB threads; ZS z-slabs per patch.
-// The steady-state loop is branch-free: every load of an iteration is issued unconditionally
-// from a (pointer, sign) pair chosen with scalar selects, so the compiler can keep the whole
-// next plane in flight behind the LDS barrier.
-template <int N, int MODE, int ZS>
-__global__ __launch_bounds__(Tile2<N>::TPB) void k_stencil3d(LevelDev L, const double *__restrict__ u,
-                                                             const double *__restrict__ f,
-                                                             double *__restrict__ out, double omega,
-                                                             RestrictDst rd)
-{
-	using T               = Tile2<N>;
-	constexpr int  TPB    = T::TPB;
-	constexpr int  CPT    = T::CPT;
-	constexpr int  LW     = T::LW;
-	constexpr int  NP     = T::NP;
-	constexpr int  NN     = N * N;
-	constexpr int  NNN    = N * N * N;
-	constexpr int  H      = N / 2;
-	constexpr int  ZL     = N / ZS; // planes per slab
-	constexpr bool FULL   = T::FULL;
-	const int      nblocks = L.P * ZS;
-	const int      work    = xcdRemap(blockIdx.x, nblocks);
-	if (work >= nblocks) return;
-	const int pid = work / ZS;
-	const int z0  = (work % ZS) * ZL;
-	const int tid = threadIdx.x;
-
-	__shared__ __attribute__((aligned(16))) double tile[2][T::LSZ];
-	__shared__ double idiag[27];
-
-	const int32_t *fk  = L.face_kind + (size_t) pid * 6;
-	const int32_t *fs  = L.face_src + (size_t) pid * 6;
-	const double   rhx = L.rh2[(size_t) pid * 3], rhy = L.rh2[(size_t) pid * 3 + 1],
-	             rhz = L.rh2[(size_t) pid * 3 + 2];
-	const double  *up  = u + (size_t) pid * NNN;
-	const double2 *up2 = reinterpret_cast<const double2 *>(up);
-	const double2 *fp2 = reinterpret_cast<const double2 *>((MODE != MODE_APPLY ? f : u) + (size_t) pid * NNN);
-	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
-
-	// fused restriction target
-	double *rdst = nullptr; // base of the coarse octant (or remote block)
-	int     rsy = 0, rsz = 0, rorth = -1;
-	double  racc[CPT];
-	if (MODE == MODE_RESID_RESTRICT) {
-		const int pa = rd.parent[pid];
-		rorth        = rd.orth[pid];
-		if (rorth < 0) { // copy-through: r lands unchanged in the coarse patch / remote block
-			op2 = reinterpret_cast<double2 *>(pa >= 0 ? rd.coarse + (size_t) pa * NNN : rd.remote + rd.remote_off[-(pa + 2)]);
-		} else if (pa >= 0) {
-			rdst = rd.coarse + (size_t) pa * NNN + ((rorth & 1) ? H : 0) + N * ((rorth & 2) ? H : 0) + NN * ((rorth & 4) ? H : 0);
-			rsy  = N;
-			rsz  = NN;
-		} else {
-			rdst = rd.remote + rd.remote_off[-(pa + 2)];
-			rsy  = H;
-			rsz  = H * H;
-		}
-#pragma unroll
-		for (int k = 0; k < CPT; k++) racc[k] = 0.0;
-	}
-
-	if (MODE == MODE_JACOBI) {
-		if (tid < 27) {
-			const double *ka = L.face_kadj + (size_t) pid * 6;
-			int           cx = tid % 3, cy = (tid / 3) % 3, cz = tid / 9;
-			double        kx = 2.0 + (cx == 0 ? ka[0] : 0.0) + (cx == 2 ? ka[1] : 0.0);
-			double        ky = 2.0 + (cy == 0 ? ka[2] : 0.0) + (cy == 2 ? ka[3] : 0.0);
-			double        kz = 2.0 + (cz == 0 ? ka[4] : 0.0) + (cz == 2 ? ka[5] : 0.0);
-			idiag[tid]       = -1.0 / (kx * rhx + ky * rhy + kz * rhz);
-		}
-	}
-
-	const HaloSrc  hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, -1.0, 1.0);
-	const PlaneSrc bot = zPlaneSrc<N>(fk[4], fs[4], false, u, up, L.ghost, -1.0, 1.0);
-	const PlaneSrc top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, -1.0, 1.0);
-
-	int  q[CPT], lds[CPT];
-	bool act[CPT];
-#pragma unroll
-	for (int k = 0; k < CPT; k++) {
-		q[k]   = tid + k * TPB;
-		act[k] = FULL || q[k] < NP;
-		if (!act[k]) q[k] = 0;
-		const int y = q[k] / H, x = 2 * (q[k] % H);
-		lds[k]      = (y + 1) * LW + x + 2;
-	}
-
-	// ---- register pipeline over z ------------------------------------------------------------
-	double2        um[CPT], uc[CPT], un[CPT], un2[CPT], fc[CPT], fn[CPT];
-	const double2 *pm  = (z0 > 0) ? up2 + (z0 - 1) * NP : bot.p;
-	const double   sm  = (z0 > 0) ? 1.0 : bot.s;
-	const double2 *pn1 = (z0 + 1 < N) ? up2 + (z0 + 1) * NP : top.p;
-	const double   sn1 = (z0 + 1 < N) ? 1.0 : top.s;
-#pragma unroll
-	for (int k = 0; k < CPT; k++) {
-		uc[k]      = up2[z0 * NP + q[k]];
-		double2 a  = pm[q[k]], b = pn1[q[k]];
-		um[k]      = double2{sm * a.x, sm * a.y};
-		un[k]      = double2{sn1 * b.x, sn1 * b.y};
-		if (MODE != MODE_APPLY) fc[k] = fp2[z0 * NP + q[k]];
-	}
-	double hv = hs.s * hs.p[z0 * hs.stride];
-
-#pragma unroll 1
-	for (int zz = 0; zz < ZL; zz++) {
-		const int z = z0 + zz;
-		// issue everything the NEXT iteration needs: plane z+2 (or the top ghost), rhs plane z+1,
-		// halo of plane z+1 (indices clamped on the last iterations: harmless re-reads)
-		const double2 *pn  = (z + 2 < N) ? up2 + (z + 2) * NP : top.p;
-		const double   sn  = (z + 2 < N) ? 1.0 : top.s;
-		const int      zc  = (z + 1 < N) ? z + 1 : N - 1;
-#pragma unroll
-		for (int k = 0; k < CPT; k++) {
-			double2 a = pn[q[k]];
-			un2[k]    = double2{sn * a.x, sn * a.y};
-			if (MODE != MODE_APPLY) fn[k] = fp2[zc * NP + q[k]];
-		}
-		const double hvn = hs.s * hs.p[zc * hs.stride];
-
-		double *tl = tile[zz & 1];
-#pragma unroll
-		for (int k = 0; k < CPT; k++)
-			if (act[k]) *reinterpret_cast<double2 *>(tl + lds[k]) = uc[k];
-		if (hs.lds >= 0) tl[hs.lds] = hv;
-		ldsBarrier();
-#pragma unroll
-		for (int k = 0; k < CPT; k++) {
-			const double *t0 = tl + lds[k];
-			const double2 c  = uc[k];
-			const double2 ym = *reinterpret_cast<const double2 *>(t0 - LW);
-			const double2 yp = *reinterpret_cast<const double2 *>(t0 + LW);
-			const double  xl = t0[-1], xr = t0[2];
-			double2       lap;
-			lap.x = (xl - 2 * c.x + c.y) * rhx;
-			lap.y = (c.x - 2 * c.y + xr) * rhx;
-			lap.x += (ym.x - 2 * c.x + yp.x) * rhy;
-			lap.y += (ym.y - 2 * c.y + yp.y) * rhy;
-			lap.x += (um[k].x - 2 * c.x + un[k].x) * rhz;
-			lap.y += (um[k].y - 2 * c.y + un[k].y) * rhz;
-			double2 r;
-			if (MODE == MODE_APPLY) {
-				r = lap;
-			} else if (MODE == MODE_RESID || MODE == MODE_RESID_RESTRICT) {
-				r.x = fc[k].x - lap.x;
-				r.y = fc[k].y - lap.y;
-			} else {
-				const int y = q[k] / H, x = 2 * (q[k] % H);
-				const int cy = (y == 0) ? 0 : (y == N - 1 ? 2 : 1);
-				const int cz = (z == 0) ? 0 : (z == N - 1 ? 2 : 1);
-				const int b  = 3 * cy + 9 * cz;
-				r.x = c.x + omega * (fc[k].x - lap.x) * idiag[b + (x == 0 ? 0 : 1)];
-				r.y = c.y + omega * (fc[k].y - lap.y) * idiag[b + (x == N - 2 ? 2 : 1)];
-			}
-			if (MODE == MODE_RESID_RESTRICT && rorth >= 0) {
-				// row y+1 of the same plane sits H lanes up in this wave (H pairs per row)
-				const double ox = __shfl_down(r.x, H, 64), oy = __shfl_down(r.y, H, 64);
-				double       a  = (z & 1) ? racc[k] : 0.0;
-				a += r.x / 8;
-				a += r.y / 8;
-				a += ox / 8;
-				a += oy / 8;
-				racc[k]      = a;
-				const int y = q[k] / H, X = q[k] % H;
-				if ((z & 1) && !(y & 1) && act[k]) rdst[X + rsy * (y >> 1) + rsz * (z >> 1)] = a;
-			} else {
-				if (act[k]) op2[z * NP + q[k]] = r;
-			}
-		}
-#pragma unroll
-		for (int k = 0; k < CPT; k++) {
-			um[k] = uc[k];
-			uc[k] = un[k];
-			un[k] = un2[k];
-			if (MODE != MODE_APPLY) fc[k] = fn[k];
-		}
-		hv = hvn;
-	}
-}
-
-__device__ __forceinline__ double sel(bool c, double a, double b) { return c ? a : b; }
-
-// Fused prolongation (DrctIntp.h:99-106) for the first post-smoothing sweep: every value of u the
-// sweep reads is taken as u + coarse[parent][(c + orthant offset)/2], so the corrected iterate is
-// never written out and read back. Only used on levels where every patch is an octant child of a local
-// parent and no ghost slot exists (uniform refinement on one rank); the host falls back otherwise.
-struct ProlongSrc {
-	const int32_t *parent, *orth;
-	const double  *coarse;
-};
-// base of the coarse octant that fine patch p maps onto: coarse cell of fine (x,y,z) = base[x/2 + N (y/2) + N^2 (z/2)]
-template <int N> __device__ __forceinline__ const double *coarseOctant(const ProlongSrc &ps, int p)
-{
-	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
-	const int     o = ps.orth[p];
-	return ps.coarse + (size_t) ps.parent[p] * NNN + ((o & 1) ? H : 0) + N * ((o & 2) ? H : 0) + NN * ((o & 4) ? H : 0);
-}
-
-// relax the cells of colour `colour` of plane z; `cen` holds the plane's pairs (LDS copy in tl)
-template <int N, bool ZERO_NBRS = false>
-__device__ __forceinline__ void rbgsRelax(double *tl, const double *idiag, int z, int colour,
-                                          const int (&yy)[Tile2<N>::CPT], const int (&xx)[Tile2<N>::CPT],
-                                          const bool (&act)[Tile2<N>::CPT], double rhx, double rhy, double rhz,
-                                          double2 (&cen)[Tile2<N>::CPT], const double2 (&below)[Tile2<N>::CPT],
-                                          const double2 (&above)[Tile2<N>::CPT], const double2 (&rhs)[Tile2<N>::CPT])
-{
-	constexpr int CPT = Tile2<N>::CPT, LW = Tile2<N>::LW;
-	const int     cz  = (z == 0) ? 0 : (z == N - 1 ? 2 : 1);
-#pragma unroll
-	for (int k = 0; k < CPT; k++) {
-		const int    y = yy[k], x = xx[k];
-		const bool   first = ((y + z + colour) & 1) == 0; // the even-x cell of the pair has this colour
-		const int    xc    = first ? x : x + 1;
-		double      *t0    = tl + (y + 1) * LW + xc + 2;
-		// sel() takes values, so no conditional lvalue (= dynamically indexed stack slot) is formed
-		const double2 cv = cen[k], bl = below[k], ab = above[k], rr = rhs[k];
-		const double  side = ZERO_NBRS ? 0.0 : sel(first, t0[-1], t0[1]); // the x-neighbour outside the pair
-		const double  mate = sel(first, cv.y, cv.x);
-		const double  zb = sel(first, bl.x, bl.y), za = sel(first, ab.x, ab.y);
-		const double  rh = sel(first, rr.x, rr.y);
-		// ZERO_NBRS: every neighbour is known to be 0 (first red half-sweep from a zero guess)
-		const double  o  = ZERO_NBRS ? 0.0 : (side + mate) * rhx + (t0[-LW] + t0[LW]) * rhy + (zb + za) * rhz;
-		const int     cx = (xc == 0) ? 0 : (xc == N - 1 ? 2 : 1);
-		const int     cy = (y == 0) ? 0 : (y == N - 1 ? 2 : 1);
-		const double  v  = (o - rh) * idiag[cx + 3 * cy + 9 * cz];
-		cen[k]           = double2{sel(first, v, cv.x), sel(first, cv.y, v)};
-		if (act[k]) *t0 = v;
-	}
-}
-
-// Patch-local red-black Gauss-Seidel sweep with neighbour ghosts frozen at the old iterate
-// (hybrid GS: Gauss-Seidel inside the patch, Jacobi across patch faces), out-of-place:
-// out = S(u, f). Red = (x+y+z) even. Plane z gets its red update from old black values;
-// plane z-1 then gets its black update from new red values, so output lags one plane.
-// In a pair (x even, x+1) exactly one cell has each colour, so every lane relaxes one cell per
-// phase and nothing diverges. Physical faces are folded into the diagonal (k = 3 Dirichlet,
-// 1 Neumann), so their ghost contributes 0 to the off-diagonal sum.
-// ZERO: the sweep starts from u == 0 (first pre-smoothing sweep of a cycle, Cycle.h:118 /
-// :63): u is never read (neither the patch nor any ghost), results are bit-identical to the
-// general kernel fed with zeros.
-// PROLONG: the sweep runs on u + P(coarse) (see ProlongSrc).
-template <int N, bool ZERO, bool PROLONG>
-__global__ __launch_bounds__(Tile2<N>::TPB) void k_rbgs3d(LevelDev L, const double *__restrict__ u,
-                                                          const double *__restrict__ f,
-                                                          double *__restrict__ out, ProlongSrc ps)
-{
-	using T             = Tile2<N>;
-	constexpr int  TPB  = T::TPB;
-	constexpr int  CPT  = T::CPT;
-	constexpr int  LW   = T::LW;
-	constexpr int  NP   = T::NP;
-	constexpr int  NN   = N * N;
-	constexpr int  NNN  = N * N * N;
-	constexpr int  H    = N / 2;
-	constexpr bool FULL = T::FULL;
-	const int      pid  = xcdRemap(blockIdx.x, L.P);
-	if (pid >= L.P) return;
-	const int tid = threadIdx.x;
-
-	__shared__ __attribute__((aligned(16))) double tile[3][T::LSZ]; // planes z-1, z, z+1 rotate
-	__shared__ double idiag[27]; // 1/diag per (x,y,z) position class
-
-	const int32_t *fk  = L.face_kind + (size_t) pid * 6;
-	const int32_t *fs  = L.face_src + (size_t) pid * 6;
-	const double   rhx = L.rh2[(size_t) pid * 3], rhy = L.rh2[(size_t) pid * 3 + 1],
-	             rhz = L.rh2[(size_t) pid * 3 + 2];
-	const double  *up  = u + (size_t) pid * NNN;
-	const double2 *up2 = reinterpret_cast<const double2 *>(up);
-	const double2 *fp2 = reinterpret_cast<const double2 *>(f + (size_t) pid * NNN);
-	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
-
-	if (tid < 27) {
-		double kf[3];
-		int    cls[3] = {tid % 3, (tid / 3) % 3, tid / 9};
-#pragma unroll
-		for (int ax = 0; ax < 3; ax++) {
-			kf[ax] = 2.0;
-			if (cls[ax] != 1) {
-				int kind = fk[2 * ax + (cls[ax] == 2)];
-				if (kind == FACE_DIRICHLET) kf[ax] = 3.0;
-				if (kind == FACE_NEUMANN) kf[ax] = 1.0;
-			}
-		}
-		idiag[tid] = 1.0 / (kf[0] * rhx + kf[1] * rhy + kf[2] * rhz);
-	}
-
-	HaloSrc  hs;
-	PlaneSrc bot, top;
-	if (!ZERO) {
-		hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, 0.0, 0.0);
-		bot = zPlaneSrc<N>(fk[4], fs[4], false, u, up, L.ghost, 0.0, 0.0);
-		top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, 0.0, 0.0);
-	} else { // halo ring stays zero for the whole sweep
-		for (int i = tid; i < 3 * T::LSZ; i += TPB) (&tile[0][0])[i] = 0.0;
-	}
-	// coarse-correction sources matching hs / bot / top / the own planes (PROLONG only)
-	const double *cown = nullptr, *chalo = nullptr, *cbot = nullptr, *ctop = nullptr;
-	double        shalo = 0.0, sbot = 0.0, stop = 0.0;
-	if (PROLONG) {
-		cown  = coarseOctant<N>(ps, pid);
-		chalo = cbot = ctop = cown; // harmless valid address where no correction applies (scale 0)
-		if (tid < 4 * N) {
-			const int side = tid / N, t = tid % N;
-			if (fk[side] == FACE_LOCAL) {
-				const double *cn = coarseOctant<N>(ps, fs[side]);
-				// the neighbour's facing cell: west (N-1,t) east (0,t) south (t,N-1) north (t,0)
-				const int cx = (side == 0) ? H - 1 : (side == 1 ? 0 : t / 2);
-				const int cy = (side == 2) ? H - 1 : (side == 3 ? 0 : t / 2);
-				chalo = cn + cx + N * cy;
-				shalo = 1.0;
-			}
-		}
-		if (fk[4] == FACE_LOCAL) {
-			cbot = coarseOctant<N>(ps, fs[4]) + NN * (H - 1);
-			sbot = 1.0;
-		}
-		if (fk[5] == FACE_LOCAL) {
-			ctop = coarseOctant<N>(ps, fs[5]);
-			stop = 1.0;
-		}
-	}
-
-	int  q[CPT], lds[CPT], yy[CPT], xx[CPT];
-	bool act[CPT];
-#pragma unroll
-	for (int k = 0; k < CPT; k++) {
-		q[k]   = tid + k * TPB;
-		act[k] = FULL || q[k] < NP;
-		if (!act[k]) q[k] = 0;
-		yy[k]  = q[k] / H;
-		xx[k]  = 2 * (q[k] % H);
-		lds[k] = (yy[k] + 1) * LW + xx[k] + 2;
-	}
-	int cq[CPT]; // in-plane coarse offset of pair k: x/2 + N (y/2)
-#pragma unroll
-	for (int k = 0; k < CPT; k++) cq[k] = (q[k] % H) + N * (yy[k] / 2);
-
-	// planes: umm = z-2, um = z-1, uc = z, un = z+1, un2 = z+2 (values are updated in place)
-	double2 umm[CPT], um[CPT], uc[CPT], un[CPT], un2[CPT], fm[CPT], fc[CPT], fn[CPT];
-#pragma unroll
-	for (int k = 0; k < CPT; k++) {
-		if (!ZERO) {
-			uc[k]     = up2[q[k]];
-			double2 a = bot.p[q[k]];
-			um[k]     = double2{bot.s * a.x, bot.s * a.y};
-			un[k]     = up2[NP + q[k]];
-			if (PROLONG) {
-				const double c0 = cown[cq[k]], cb = sbot * cbot[cq[k]]; // planes 0 and 1 share coarse plane 0
-				uc[k].x += c0, uc[k].y += c0, un[k].x += c0, un[k].y += c0;
-				um[k].x += bot.s * cb, um[k].y += bot.s * cb;
-			}
-		} else {
-			uc[k] = um[k] = un[k] = un2[k] = double2{0.0, 0.0};
-		}
-		fc[k]  = fp2[q[k]];
-		umm[k] = double2{0.0, 0.0};
-		fm[k]  = double2{0.0, 0.0};
-	}
-	double hv = ZERO ? 0.0 : hs.s * (hs.p[0] + (PROLONG ? shalo * chalo[0] : 0.0));
-	__syncthreads(); // idiag (and the zeroed tiles)
-
-#pragma unroll 1
-	for (int z = 0; z <= N; z++) {
-		// issue the next iteration's loads (clamped / redirected on the last iterations)
-		const int zc = (z + 1 < N) ? z + 1 : N - 1;
-		double    hvn = 0.0;
-		if (!ZERO) {
-			const double2 *pn = (z + 2 < N) ? up2 + (z + 2) * NP : top.p;
-			const double   sn = (z + 2 < N) ? 1.0 : top.s;
-#pragma unroll
-			for (int k = 0; k < CPT; k++) {
-				double2 a = pn[q[k]];
-				if (PROLONG) { // plane z+2 of the patch, or the top neighbour's plane 0
-					const double *cp = (z + 2 < N) ? cown + NN * ((z + 2) >> 1) : ctop;
-					const double  cs = (z + 2 < N) ? 1.0 : stop;
-					const double  c  = cs * cp[cq[k]];
-					a.x += c, a.y += c;
-				}
-				un2[k] = double2{sn * a.x, sn * a.y};
-			}
-			hvn = hs.s * (hs.p[zc * hs.stride] + (PROLONG ? shalo * chalo[NN * (zc >> 1)] : 0.0));
-		}
-#pragma unroll
-		for (int k = 0; k < CPT; k++) fn[k] = fp2[zc * NP + q[k]];
-		if (!ZERO && z < N) {
-			double *tl = tile[z % 3];
-#pragma unroll
-			for (int k = 0; k < CPT; k++)
-				if (act[k]) *reinterpret_cast<double2 *>(tl + lds[k]) = uc[k];
-			if (hs.lds >= 0) tl[hs.lds] = hv;
-		}
-		// one barrier per plane: buffer z%3 was last read two iterations ago (black of plane z-3)
-		ldsBarrier();
-		// red cells of plane z from old black values (all zero when ZERO)
-		if (z < N) rbgsRelax<N, ZERO>(tile[z % 3], idiag, z, 0, yy, xx, act, rhx, rhy, rhz, uc, um, un, fc);
-		if (z > 0) {
-			// black cells of plane z-1: x/y neighbours = new red in LDS; z neighbours = umm (new red,
-			// or the frozen bottom ghost) and uc (new red, or the frozen top ghost when z == N)
-			rbgsRelax<N>(tile[(z - 1) % 3], idiag, z - 1, 1, yy, xx, act, rhx, rhy, rhz, um, umm, uc, fm);
-#pragma unroll
-			for (int k = 0; k < CPT; k++)
-				if (act[k]) op2[(z - 1) * NP + q[k]] = um[k];
-		}
-#pragma unroll
-		for (int k = 0; k < CPT; k++) {
-			umm[k] = um[k];
-			um[k]  = uc[k];
-			uc[k]  = un[k];
-			un[k]  = un2[k];
-			fm[k]  = fc[k];
-			fc[k]  = fn[k];
-		}
-		hv = hvn;
-	}
 }
 
 // Ghost planes for coarse/fine faces: ghost = 2*gamma - m with gamma assembled from the

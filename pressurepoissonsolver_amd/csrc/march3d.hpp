@@ -1,0 +1,444 @@
+// The plane-marching stencil kernels of the 3D path (operator apply, residual, weighted Jacobi, fused
+// residual+restriction, and the patch-local red-black Gauss-Seidel sweep with its zero-guess and
+// fused-prolongation variants). See kernels3d.hpp for layout, ghost formulation and helpers.
+//
+// Thread map (Tile3): thread (X, Yp) owns the x-pair X (cells 2X, 2X+1) of the TWO adjacent rows
+// y = 2Yp and 2Yp+1 of every plane. Consequences that keep the instruction count low (these kernels
+// are co-limited by VALU/LDS issue, not only by HBM):
+//   * the y-neighbour inside the row pair is a register of the same thread; only the outer one is an
+//     LDS read (1 ds_read_b128 per pair for the stencil modes, 1 ds_read_b64 per relaxed cell);
+//   * row parity is the compile-time index k, so with the z loop unrolled by two the colour of every
+//     cell is static: the red-black sweep has no selects and no run-time LDS addressing;
+//   * the 2x2x2 children of a coarse cell sit in one thread (two planes apart in time), so the fused
+//     restriction needs no cross-lane traffic.
+#pragma once
+#include "kernels3d.hpp"
+#include <type_traits>
+
+namespace te
+{
+template <int N> struct Tile3 {
+	static constexpr int H   = N / 2;
+	static constexpr int NT  = H * H;               // threads that own cells
+	static constexpr int TPB = NT < 64 ? 64 : NT;   // 256 for N = 32
+	static constexpr int NP  = N * N / 2;           // pairs per plane
+	static constexpr int LW  = Tile2<N>::LW;
+	static constexpr int LSZ = Tile2<N>::LSZ;
+	static_assert(4 * N <= TPB, "one halo entry per thread");
+};
+
+// MODE_APPLY : out = A u                     (SchurHelper.h:360-376 + StarPatchOp.h:28-184)
+// MODE_RESID : out = f - A u                 (+ Cycle.h:60-61)
+// MODE_JACOBI: out = u + omega (f - A u)/diag(A)
+// MODE_RESID_RESTRICT: coarse f = AvgRstr(f - A u) without ever storing r (Cycle.h:59-65 fused); the
+//   eight fine residuals of a coarse cell are added in AvgRstr's own order (x, y, z), so the result
+//   is bit-identical to MODE_RESID followed by k_restrict3d.
+// grid: 8*ceil(P*ZS/8) blocks of Tile3<N>::TPB threads; ZS z-slabs per patch.
+// The steady-state loop is branch-free: every load of an iteration is issued unconditionally from a
+// (pointer, sign) pair chosen with scalar selects, so the whole next plane stays in flight behind the
+// LDS barrier.
+template <int N, int MODE, int ZS>
+__global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const double *__restrict__ u,
+                                                             const double *__restrict__ f,
+                                                             double *__restrict__ out, double omega, RestrictDst rd)
+{
+	using T            = Tile3<N>;
+	constexpr int TPB  = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
+	constexpr int NN   = N * N, NNN = N * N * N;
+	constexpr int ZL   = N / ZS; // planes per slab
+	const int nblocks  = L.P * ZS;
+	const int work     = xcdRemap(blockIdx.x, nblocks);
+	if (work >= nblocks) return;
+	const int pid = work / ZS;
+	const int z0  = (work % ZS) * ZL;
+	const int tid = threadIdx.x;
+
+	__shared__ __attribute__((aligned(16))) double tile[2][T::LSZ];
+	__shared__ double idiag[27];
+
+	const int32_t *fk  = L.face_kind + (size_t) pid * 6;
+	const int32_t *fs  = L.face_src + (size_t) pid * 6;
+	const double   rhx = L.rh2[(size_t) pid * 3], rhy = L.rh2[(size_t) pid * 3 + 1], rhz = L.rh2[(size_t) pid * 3 + 2];
+	const double  *up  = u + (size_t) pid * NNN;
+	const double2 *up2 = reinterpret_cast<const double2 *>(up);
+	const double2 *fp2 = reinterpret_cast<const double2 *>((MODE != MODE_APPLY ? f : u) + (size_t) pid * NNN);
+	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
+
+	const bool act = (T::NT == TPB) || tid < T::NT;
+	const int  X = act ? tid % H : 0, Yp = act ? tid / H : 0;
+	int        q[2], lds[2];
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		q[k]   = (2 * Yp + k) * H + X;
+		lds[k] = (2 * Yp + k + 1) * LW + 2 * X + 2;
+	}
+
+	// fused restriction target
+	double *rdst = nullptr; // this thread's coarse cell of plane pair 0 (octant of the parent, or a remote block)
+	int     rsz = 0, rorth = -1;
+	double  racc = 0.0;
+	if (MODE == MODE_RESID_RESTRICT) {
+		const int pa = rd.parent[pid];
+		rorth        = rd.orth[pid];
+		if (rorth < 0) { // copy-through: r lands unchanged in the coarse patch / remote block
+			op2 = reinterpret_cast<double2 *>(pa >= 0 ? rd.coarse + (size_t) pa * NNN : rd.remote + rd.remote_off[-(pa + 2)]);
+		} else if (pa >= 0) {
+			rdst = rd.coarse + (size_t) pa * NNN + ((rorth & 1) ? H : 0) + N * ((rorth & 2) ? H : 0) + NN * ((rorth & 4) ? H : 0) + X + N * Yp;
+			rsz  = NN;
+		} else {
+			rdst = rd.remote + rd.remote_off[-(pa + 2)] + X + H * Yp;
+			rsz  = H * H;
+		}
+	}
+
+	int dix[2][2] = {{0, 0}, {0, 0}}; // cx + 3 cy of (row k, cell)
+	if (MODE == MODE_JACOBI) {
+		if (tid < 27) {
+			const double *ka = L.face_kadj + (size_t) pid * 6;
+			int           cx = tid % 3, cy = (tid / 3) % 3, cz = tid / 9;
+			double        kx = 2.0 + (cx == 0 ? ka[0] : 0.0) + (cx == 2 ? ka[1] : 0.0);
+			double        ky = 2.0 + (cy == 0 ? ka[2] : 0.0) + (cy == 2 ? ka[3] : 0.0);
+			double        kz = 2.0 + (cz == 0 ? ka[4] : 0.0) + (cz == 2 ? ka[5] : 0.0);
+			idiag[tid]       = -1.0 / (kx * rhx + ky * rhy + kz * rhz);
+		}
+		const int cy0 = (Yp == 0) ? 0 : 1, cy1 = (Yp == H - 1) ? 2 : 1;
+		const int cx0 = (X == 0) ? 0 : 1, cx1 = (X == H - 1) ? 2 : 1;
+		dix[0][0] = cx0 + 3 * cy0, dix[0][1] = cx1 + 3 * cy0, dix[1][0] = cx0 + 3 * cy1, dix[1][1] = cx1 + 3 * cy1;
+	}
+
+	const HaloSrc  hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, -1.0, 1.0);
+	const PlaneSrc bot = zPlaneSrc<N>(fk[4], fs[4], false, u, up, L.ghost, -1.0, 1.0);
+	const PlaneSrc top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, -1.0, 1.0);
+
+	// ---- register pipeline over z ------------------------------------------------------------
+	double2        um[2], uc[2], un[2], un2[2], fc[2], fn[2];
+	const double2 *pm  = (z0 > 0) ? up2 + (z0 - 1) * NP : bot.p;
+	const double   sm  = (z0 > 0) ? 1.0 : bot.s;
+	const double2 *pn1 = (z0 + 1 < N) ? up2 + (z0 + 1) * NP : top.p;
+	const double   sn1 = (z0 + 1 < N) ? 1.0 : top.s;
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		uc[k]     = up2[z0 * NP + q[k]];
+		double2 a = pm[q[k]], b = pn1[q[k]];
+		um[k]     = double2{sm * a.x, sm * a.y};
+		un[k]     = double2{sn1 * b.x, sn1 * b.y};
+		if (MODE != MODE_APPLY) fc[k] = fp2[z0 * NP + q[k]];
+	}
+	double hv = hs.s * hs.p[z0 * hs.stride];
+
+#pragma unroll 1
+	for (int zz = 0; zz < ZL; zz++) {
+		const int z = z0 + zz;
+		// issue everything the NEXT iteration needs: plane z+2 (or the top ghost), rhs plane z+1,
+		// halo of plane z+1 (indices clamped on the last iterations: harmless re-reads)
+		const double2 *pn = (z + 2 < N) ? up2 + (z + 2) * NP : top.p;
+		const double   sn = (z + 2 < N) ? 1.0 : top.s;
+		const int      zc = (z + 1 < N) ? z + 1 : N - 1;
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			double2 a = pn[q[k]];
+			un2[k]    = double2{sn * a.x, sn * a.y};
+			if (MODE != MODE_APPLY) fn[k] = fp2[zc * NP + q[k]];
+		}
+		const double hvn = hs.s * hs.p[zc * hs.stride];
+
+		double *tl = tile[zz & 1];
+		if (act) {
+			*reinterpret_cast<double2 *>(tl + lds[0]) = uc[0];
+			*reinterpret_cast<double2 *>(tl + lds[1]) = uc[1];
+		}
+		if (hs.lds >= 0) tl[hs.lds] = hv;
+		ldsBarrier();
+
+		// outer y-neighbours from LDS, inner ones are the other row's registers
+		const double2 ylo = *reinterpret_cast<const double2 *>(tl + lds[0] - LW);
+		const double2 yhi = *reinterpret_cast<const double2 *>(tl + lds[1] + LW);
+		double2       r[2];
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			const double *t0 = tl + lds[k];
+			const double2 c  = uc[k];
+			const double2 ym = (k == 0) ? ylo : uc[0];
+			const double2 yp = (k == 0) ? uc[1] : yhi;
+			const double  xl = t0[-1], xr = t0[2];
+			double2       lap;
+			lap.x = (xl - 2 * c.x + c.y) * rhx;
+			lap.y = (c.x - 2 * c.y + xr) * rhx;
+			lap.x += (ym.x - 2 * c.x + yp.x) * rhy;
+			lap.y += (ym.y - 2 * c.y + yp.y) * rhy;
+			lap.x += (um[k].x - 2 * c.x + un[k].x) * rhz;
+			lap.y += (um[k].y - 2 * c.y + un[k].y) * rhz;
+			if (MODE == MODE_APPLY) {
+				r[k] = lap;
+			} else if (MODE == MODE_RESID || MODE == MODE_RESID_RESTRICT) {
+				r[k].x = fc[k].x - lap.x;
+				r[k].y = fc[k].y - lap.y;
+			} else {
+				const int cz = (z == 0) ? 0 : (z == N - 1 ? 18 : 9);
+				r[k].x       = c.x + omega * (fc[k].x - lap.x) * idiag[dix[k][0] + cz];
+				r[k].y       = c.y + omega * (fc[k].y - lap.y) * idiag[dix[k][1] + cz];
+			}
+		}
+		if (MODE == MODE_RESID_RESTRICT && rorth >= 0) {
+			double a = (z & 1) ? racc : 0.0; // AvgRstr.h:95-102 order: x, then y, then z; each /2^D first
+			a += r[0].x / 8;
+			a += r[0].y / 8;
+			a += r[1].x / 8;
+			a += r[1].y / 8;
+			racc = a;
+			if ((z & 1) && act) rdst[rsz * (z >> 1)] = a;
+		} else if (act) {
+			op2[z * NP + q[0]] = r[0];
+			op2[z * NP + q[1]] = r[1];
+		}
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			um[k] = uc[k];
+			uc[k] = un[k];
+			un[k] = un2[k];
+			if (MODE != MODE_APPLY) fc[k] = fn[k];
+		}
+		hv = hvn;
+	}
+}
+
+// Fused prolongation (DrctIntp.h:99-106) for the first post-smoothing sweep: every value of u the
+// sweep reads is taken as u + coarse[parent][(c + orthant offset)/2], so the corrected iterate is
+// never written out and read back. Only used on levels where every patch is an octant child of a local
+// parent and no ghost slot exists (uniform refinement on one rank); the host falls back otherwise.
+struct ProlongSrc {
+	const int32_t *parent, *orth;
+	const double  *coarse;
+};
+// base of the coarse octant that fine patch p maps onto: coarse cell of fine (x,y,z) = base[x/2 + N (y/2) + N^2 (z/2)]
+template <int N> __device__ __forceinline__ const double *coarseOctant(const ProlongSrc &ps, int p)
+{
+	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
+	const int     o = ps.orth[p];
+	return ps.coarse + (size_t) ps.parent[p] * NNN + ((o & 1) ? H : 0) + N * ((o & 2) ? H : 0) + NN * ((o & 4) ? H : 0);
+}
+
+// Relax cell CB (0: even x, 1: odd x) of row k of the plane held in `cen` (LDS copy in tl):
+// v = (sum of off-diagonal neighbours / h^2 - f) / diag. Everything about the cell's position is static.
+template <int N, int K, int CB, bool ZERO_NBRS>
+__device__ __forceinline__ void relaxCell(double *tl, const double *idiag, int cz9, const int (&lds)[2], const int (&dix)[2][2],
+                                          bool act, double rhx, double rhy, double rhz, double2 (&cen)[2],
+                                          const double2 (&below)[2], const double2 (&above)[2], const double2 (&rhs)[2])
+{
+	constexpr int LW = Tile3<N>::LW;
+	const double  rh = CB ? rhs[K].y : rhs[K].x;
+	double        o  = 0.0;
+	if (!ZERO_NBRS) { // ZERO_NBRS: every neighbour is known to be 0 (first red half-sweep from a zero guess)
+		const double side  = CB ? tl[lds[K] + 2] : tl[lds[K] - 1]; // the x-neighbour outside the pair
+		const double mate  = CB ? cen[K].x : cen[K].y;
+		const double inner = CB ? cen[1 - K].y : cen[1 - K].x;                            // other row of the pair: a register
+		const double outer = (K == 0) ? tl[lds[0] - LW + CB] : tl[lds[1] + LW + CB];        // row y-1 / y+2: LDS
+		const double ym = (K == 0) ? outer : inner, yp = (K == 0) ? inner : outer;
+		const double zb = CB ? below[K].y : below[K].x, za = CB ? above[K].y : above[K].x;
+		o               = (side + mate) * rhx + (ym + yp) * rhy + (zb + za) * rhz;
+	}
+	const double v = (o - rh) * idiag[dix[K][CB] + cz9];
+	if (CB)
+		cen[K].y = v;
+	else
+		cen[K].x = v;
+	if (act) tl[lds[K] + CB] = v;
+}
+
+// Patch-local red-black Gauss-Seidel sweep with neighbour ghosts frozen at the old iterate
+// (hybrid GS: Gauss-Seidel inside the patch, Jacobi across patch faces), out-of-place:
+// out = S(u, f). Red = (x+y+z) even. Plane z gets its red update from old black values;
+// plane z-1 then gets its black update from new red values, so output lags one plane and the sweep
+// costs one pass over u and f. Physical faces are folded into the diagonal (k = 3 Dirichlet,
+// 1 Neumann), so their ghost contributes 0 to the off-diagonal sum.
+// ZERO: the sweep starts from u == 0 (first pre-smoothing sweep of a cycle, Cycle.h:118 / :63): u is
+// never read (neither the patch nor any ghost); bit-identical to the general kernel fed with zeros.
+// PROLONG: the sweep runs on u + P(coarse) (see ProlongSrc).
+template <int N, bool ZERO, bool PROLONG>
+__global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const double *__restrict__ u,
+                                                          const double *__restrict__ f,
+                                                          double *__restrict__ out, ProlongSrc ps)
+{
+	using T           = Tile3<N>;
+	constexpr int TPB = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
+	constexpr int NN  = N * N, NNN = N * N * N;
+	const int     pid = xcdRemap(blockIdx.x, L.P);
+	if (pid >= L.P) return;
+	const int tid = threadIdx.x;
+
+	__shared__ __attribute__((aligned(16))) double tile[3][T::LSZ]; // planes z-1, z, z+1 rotate
+	__shared__ double idiag[27]; // 1/diag per (x,y,z) position class
+
+	const int32_t *fk  = L.face_kind + (size_t) pid * 6;
+	const int32_t *fs  = L.face_src + (size_t) pid * 6;
+	const double   rhx = L.rh2[(size_t) pid * 3], rhy = L.rh2[(size_t) pid * 3 + 1], rhz = L.rh2[(size_t) pid * 3 + 2];
+	const double  *up  = u + (size_t) pid * NNN;
+	const double2 *up2 = reinterpret_cast<const double2 *>(up);
+	const double2 *fp2 = reinterpret_cast<const double2 *>(f + (size_t) pid * NNN);
+	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
+
+	if (tid < 27) {
+		double kf[3];
+		int    cls[3] = {tid % 3, (tid / 3) % 3, tid / 9};
+#pragma unroll
+		for (int ax = 0; ax < 3; ax++) {
+			kf[ax] = 2.0;
+			if (cls[ax] != 1) {
+				int kind = fk[2 * ax + (cls[ax] == 2)];
+				if (kind == FACE_DIRICHLET) kf[ax] = 3.0;
+				if (kind == FACE_NEUMANN) kf[ax] = 1.0;
+			}
+		}
+		idiag[tid] = 1.0 / (kf[0] * rhx + kf[1] * rhy + kf[2] * rhz);
+	}
+
+	HaloSrc  hs;
+	PlaneSrc bot, top;
+	if (!ZERO) {
+		hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, 0.0, 0.0);
+		bot = zPlaneSrc<N>(fk[4], fs[4], false, u, up, L.ghost, 0.0, 0.0);
+		top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, 0.0, 0.0);
+	} else { // halo ring stays zero for the whole sweep
+		for (int i = tid; i < 3 * T::LSZ; i += TPB) (&tile[0][0])[i] = 0.0;
+	}
+
+	const bool act = (T::NT == TPB) || tid < T::NT;
+	const int  X = act ? tid % H : 0, Yp = act ? tid / H : 0;
+	int        q[2], lds[2], dix[2][2];
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		q[k]   = (2 * Yp + k) * H + X;
+		lds[k] = (2 * Yp + k + 1) * LW + 2 * X + 2;
+	}
+	{
+		const int cy0 = (Yp == 0) ? 0 : 1, cy1 = (Yp == H - 1) ? 2 : 1;
+		const int cx0 = (X == 0) ? 0 : 1, cx1 = (X == H - 1) ? 2 : 1;
+		dix[0][0] = cx0 + 3 * cy0, dix[0][1] = cx1 + 3 * cy0, dix[1][0] = cx0 + 3 * cy1, dix[1][1] = cx1 + 3 * cy1;
+	}
+
+	// coarse-correction sources matching the own planes / hs / bot / top (PROLONG only)
+	const double *cown = nullptr, *chalo = nullptr, *cbot = nullptr, *ctop = nullptr;
+	double        shalo = 0.0, sbot = 0.0, stop = 0.0;
+	const int     cq = X + N * Yp; // in-plane coarse offset of this thread's cells (both rows share it)
+	if (PROLONG) {
+		cown  = coarseOctant<N>(ps, pid);
+		chalo = cbot = ctop = cown; // harmless valid address where no correction applies (scale 0)
+		if (tid < 4 * N) {
+			const int side = tid / N, t = tid % N;
+			if (fk[side] == FACE_LOCAL) {
+				const double *cn = coarseOctant<N>(ps, fs[side]);
+				// the neighbour's facing cell: west (N-1,t) east (0,t) south (t,N-1) north (t,0)
+				const int cx = (side == 0) ? H - 1 : (side == 1 ? 0 : t / 2);
+				const int cy = (side == 2) ? H - 1 : (side == 3 ? 0 : t / 2);
+				chalo = cn + cx + N * cy;
+				shalo = 1.0;
+			}
+		}
+		if (fk[4] == FACE_LOCAL) {
+			cbot = coarseOctant<N>(ps, fs[4]) + NN * (H - 1);
+			sbot = 1.0;
+		}
+		if (fk[5] == FACE_LOCAL) {
+			ctop = coarseOctant<N>(ps, fs[5]);
+			stop = 1.0;
+		}
+	}
+
+	// planes: umm = z-2, um = z-1, uc = z, un = z+1, un2 = z+2 (values are updated in place)
+	double2 umm[2], um[2], uc[2], un[2], un2[2], fm[2], fc[2], fn[2];
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		if (!ZERO) {
+			uc[k]     = up2[q[k]];
+			double2 a = bot.p[q[k]];
+			um[k]     = double2{bot.s * a.x, bot.s * a.y};
+			un[k]     = up2[NP + q[k]];
+			if (PROLONG) {
+				const double c0 = cown[cq], cb = sbot * cbot[cq]; // planes 0 and 1 share coarse plane 0
+				uc[k].x += c0, uc[k].y += c0, un[k].x += c0, un[k].y += c0;
+				um[k].x += bot.s * cb, um[k].y += bot.s * cb;
+			}
+		} else {
+			uc[k] = um[k] = un[k] = un2[k] = double2{0.0, 0.0};
+		}
+		fc[k]  = fp2[q[k]];
+		umm[k] = double2{0.0, 0.0};
+		fm[k]  = double2{0.0, 0.0};
+	}
+	double hv = ZERO ? 0.0 : hs.s * (hs.p[0] + (PROLONG ? shalo * chalo[0] : 0.0));
+	__syncthreads(); // idiag (and the zeroed tiles)
+
+	int bz = 0; // z % 3
+	// one plane step; ZPAR = z & 1 is a compile-time constant so that every cell's colour is static
+	auto step = [&](auto zpar, int z) {
+		constexpr int ZPAR = decltype(zpar)::value;
+		// issue the next iteration's loads (clamped / redirected on the last iterations)
+		const int zc  = (z + 1 < N) ? z + 1 : N - 1;
+		double    hvn = 0.0;
+		if (!ZERO) {
+			const double2 *pn = (z + 2 < N) ? up2 + (z + 2) * NP : top.p;
+			const double   sn = (z + 2 < N) ? 1.0 : top.s;
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				double2 a = pn[q[k]];
+				if (PROLONG) { // plane z+2 of the patch, or the top neighbour's plane 0
+					const double *cp = (z + 2 < N) ? cown + NN * ((z + 2) >> 1) : ctop;
+					const double  cs = (z + 2 < N) ? 1.0 : stop;
+					const double  c  = cs * cp[cq];
+					a.x += c, a.y += c;
+				}
+				un2[k] = double2{sn * a.x, sn * a.y};
+			}
+			hvn = hs.s * (hs.p[zc * hs.stride] + (PROLONG ? shalo * chalo[NN * (zc >> 1)] : 0.0));
+		}
+#pragma unroll
+		for (int k = 0; k < 2; k++) fn[k] = fp2[zc * NP + q[k]];
+		double *tz = tile[bz];                    // plane z
+		double *tm = tile[bz == 0 ? 2 : bz - 1];  // plane z-1
+		if (!ZERO && z < N) {
+			if (act) {
+				*reinterpret_cast<double2 *>(tz + lds[0]) = uc[0];
+				*reinterpret_cast<double2 *>(tz + lds[1]) = uc[1];
+			}
+			if (hs.lds >= 0) tz[hs.lds] = hv;
+		}
+		// one barrier per plane: buffer z%3 was last read two iterations ago (black of plane z-3)
+		ldsBarrier();
+		if (z < N) {
+			// red cells of plane z from old black values: cell parity = (0 + k + z) & 1
+			const int cz9 = (z == 0) ? 0 : (z == N - 1 ? 18 : 9);
+			relaxCell<N, 0, (0 + ZPAR) & 1, ZERO>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, uc, um, un, fc);
+			relaxCell<N, 1, (1 + ZPAR) & 1, ZERO>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, uc, um, un, fc);
+		}
+		if (z > 0) {
+			// black cells of plane z-1: x/y neighbours = new red (LDS / registers); z neighbours = umm (new
+			// red, or the frozen bottom ghost) and uc (new red, or the frozen top ghost when z == N).
+			// plane z-1 has parity 1-ZPAR; black: (x + y + z - 1) odd -> cell parity = (1 + k + (1-ZPAR)) & 1
+			const int cz9 = (z - 1 == 0) ? 0 : (z - 1 == N - 1 ? 18 : 9);
+			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
+			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
+			if (act) {
+				op2[(z - 1) * NP + q[0]] = um[0];
+				op2[(z - 1) * NP + q[1]] = um[1];
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			umm[k] = um[k];
+			um[k]  = uc[k];
+			uc[k]  = un[k];
+			un[k]  = un2[k];
+			fm[k]  = fc[k];
+			fc[k]  = fn[k];
+		}
+		hv = hvn;
+		bz = (bz == 2) ? 0 : bz + 1;
+	};
+#pragma unroll 1
+	for (int z = 0; z < N; z += 2) {
+		step(std::integral_constant<int, 0>{}, z);
+		step(std::integral_constant<int, 1>{}, z + 1);
+	}
+	step(std::integral_constant<int, 0>{}, N); // black update and store of the last plane
+}
+} // namespace te
