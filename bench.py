@@ -136,8 +136,25 @@ def main():
     mesh = capi.Mesh.uniform(3, div)
     H = capi.Hierarchy(mesh, n, rank=rank, nranks=world)
     g = capi.GMG(H, device=local_rank)
+    exchange_backend = "none"
     if world > 1:
-        tedist.attach(g, dist)
+        # RCCL point-to-point issued by the native library itself (no Python per exchange); the
+        # torch.distributed callback is the fallback (and the only choice for the gloo rehearsal)
+        exchange_backend = "torch.distributed"
+        want = os.environ.get("TE_EXCHANGE", "rccl" if backend == "nccl" else "torch")
+        ok = 0
+        if want == "rccl":
+            try:
+                tedist.attach_rccl(g, dist, rank, world)
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks must use the same back-end
+        if int(flag.item()) == 1:
+            exchange_backend = "rccl (native ncclSend/ncclRecv groups)"
+        else:
+            tedist.attach(g, dist)
     sm = {"rbgs": capi.SMOOTH_RBGS, "jacobi": capi.SMOOTH_JACOBI, "patch_solve": capi.SMOOTH_PATCH_SOLVE}[a.smoother]
     opts = g.default_opts(smoother=sm)
 
@@ -208,7 +225,8 @@ def main():
             "config": {"workload": f"apps/3d/steady-equivalent: {a.size}^3 uniform, {cells_global[0] // n ** 3} "
                                    f"patches of 32^3, {H.num_levels} levels, V(1,1), smoother={a.smoother}, "
                                    "Dirichlet, f ~ U(-1,1) splitmix64(0x5EED + patch id)",
-                       "parallelism": f"patch-sharded x{world} (Morton ranges)", "levels": H.num_levels,
+                       "parallelism": f"patch-sharded x{world} (Morton ranges)", "exchange": exchange_backend,
+                       "levels": H.num_levels,
                        "smoother": a.smoother, "residual_reduction_per_cycle": reduction},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

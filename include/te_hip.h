@@ -156,6 +156,15 @@ typedef int (*te_exchange_fn)(void *user, int tag, const double *send, double *r
                               const int64_t *send_cnt, const int64_t *recv_off,
                               const int64_t *recv_cnt, void *stream);
 int te_gmg_set_exchange(te_gmg *g, te_exchange_fn fn, void *user);
+/* Alternative to the callback: let the library issue the exchanges itself as RCCL point-to-point
+ * groups (ncclGroupStart; ncclRecv/ncclSend per peer; ncclGroupEnd) on its solver stream — the
+ * direct replacement of the MPI path under the PETSc VecScatter (SchurHelper.h:123-150). `libpath`
+ * names the librccl.so to dlopen (the one the host process already uses); `id128` is the 128-byte
+ * ncclUniqueId produced by te_rccl_unique_id on rank 0 and broadcast by the host. */
+int te_rccl_unique_id(const char *libpath, char *id128);
+int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank, int nranks);
+/* moves n doubles through the active exchange back-end with this rank as its own peer (diagnostic) */
+int te_gmg_exchange_selftest(te_gmg *g, int n);
 
 /* kernel timing hooks for bench.py: HIP-event time of the last te_vcycle's dominant kernel */
 int te_gmg_profile(te_gmg *g, int enable);

@@ -99,6 +99,9 @@ SYMBOLS = {
     "te_vcycle": (_I, [_P, C.POINTER(CycleOpts), _P, _P]),
     "te_bicgstab": (_I, [_P, C.POINTER(CycleOpts), _P, _P, _I, _D, C.POINTER(_I), _PD]),
     "te_gmg_set_exchange": (_I, [_P, EXCHANGE_FN, _P]),
+    "te_rccl_unique_id": (_I, [C.c_char_p, C.c_char_p]),
+    "te_gmg_use_rccl": (_I, [_P, C.c_char_p, C.c_char_p, _I, _I]),
+    "te_gmg_exchange_selftest": (_I, [_P, _I]),
     "te_gmg_profile": (_I, [_P, _I]),
     "te_gmg_profile_rows": (_I, [_P, _I, _P, _P, _P, _P]),
     "te_gmg_profile_reset": (_I, [_P]),
@@ -115,6 +118,14 @@ def lib():
             raise TeLibraryMissing(
                 f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no fallback implementation.")
+        # One HIP runtime per process: PyTorch's ROCm wheel bundles its own libamdhip64.so.7 (same soname as
+        # /opt/rocm's). If torch is loaded first the dynamic loader hands that copy to libte_hip.so as well;
+        # the other order leaves two runtimes that cannot see each other's allocations (torch.distributed /
+        # RCCL would then reject our device pointers). A pure C++ host simply gets /opt/rocm's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)

@@ -10,6 +10,7 @@
 #include <array>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
 #include <map>
 #include <memory>
 #include <tuple>
@@ -143,6 +144,16 @@ struct te_gmg {
 	int                                     red_blocks  = 1024;
 	te_exchange_fn                          exchange    = nullptr;
 	void                                   *exchange_user = nullptr;
+	// optional: RCCL point-to-point called straight from this library (no host callback per exchange)
+	struct Rccl {
+		void *lib = nullptr, *comm = nullptr;
+		int (*GroupStart)()                                                          = nullptr;
+		int (*GroupEnd)()                                                            = nullptr;
+		int (*Send)(const void *, size_t, int, int, void *, hipStream_t)             = nullptr;
+		int (*Recv)(void *, size_t, int, int, void *, hipStream_t)                   = nullptr;
+		int (*CommDestroy)(void *)                                                   = nullptr;
+		const char *(*GetErrorString)(int)                                           = nullptr;
+	} rccl;
 	// profiling
 	bool                   profiling = false;
 	std::vector<EventPair> ev_pool;
@@ -561,8 +572,24 @@ inline bool sameShape(const te_vec *a, const te_vec *b) { return a && b && a->g 
 int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double *recv)
 {
 	if (pl.empty()) return TE_OK;
+	if (g->rccl.comm) {
+		// one RCCL group per exchange, enqueued on the solver stream behind the pack kernel: every
+		// send/recv of the exchange progresses together over the direct xGMI links, no host round trip
+		Timed t(g, KC_EXCHANGE, 0);
+		constexpr int ncclFloat64 = 8; // rccl.h:467
+		int           rc         = g->rccl.GroupStart();
+		for (size_t i = 0; i < pl.peers.size() && rc == 0; i++) {
+			if (pl.recv_cnt[i] > 0)
+				rc = g->rccl.Recv(recv + pl.recv_off[i], (size_t) pl.recv_cnt[i], ncclFloat64, pl.peers[i], g->rccl.comm, g->stream);
+			if (rc == 0 && pl.send_cnt[i] > 0)
+				rc = g->rccl.Send(send + pl.send_off[i], (size_t) pl.send_cnt[i], ncclFloat64, pl.peers[i], g->rccl.comm, g->stream);
+		}
+		int rc2 = g->rccl.GroupEnd();
+		if (rc || rc2) return te::fail(TE_ESTATE, std::string("RCCL exchange failed: ") + g->rccl.GetErrorString(rc ? rc : rc2));
+		return TE_OK;
+	}
 	if (!g->exchange)
-		return te::fail(TE_ESTATE, "this level has off-rank neighbours: call te_gmg_set_exchange first");
+		return te::fail(TE_ESTATE, "this level has off-rank neighbours: call te_gmg_set_exchange or te_gmg_use_rccl first");
 	Timed t(g, KC_EXCHANGE, 0);
 	int   rc = g->exchange(g->exchange_user, tag, send, recv, (int) pl.peers.size(), pl.peers.data(), pl.send_off.data(),
 	                       pl.send_cnt.data(), pl.recv_off.data(), pl.recv_cnt.data(), (void *) g->stream);
@@ -1121,6 +1148,7 @@ void te_gmg_destroy(te_gmg *g)
 		(void) hipEventDestroy(e.a);
 		(void) hipEventDestroy(e.b);
 	}
+	if (g->rccl.comm && g->rccl.CommDestroy) (void) g->rccl.CommDestroy(g->rccl.comm);
 	if (g->result_host) (void) hipHostFree(g->result_host);
 	(void) hipStreamDestroy(g->stream);
 	delete g;
@@ -1136,8 +1164,75 @@ void *te_gmg_stream(te_gmg *g) { return g ? (void *) g->stream : nullptr; }
 int   te_gmg_set_exchange(te_gmg *g, te_exchange_fn fn, void *user)
 {
 	if (!g) return te::fail(TE_EINVAL, "te_gmg_set_exchange: null");
+	if (fn && g->rccl.comm) { // an explicit callback replaces the native RCCL back-end
+		(void) g->rccl.CommDestroy(g->rccl.comm);
+		g->rccl.comm = nullptr;
+	}
 	g->exchange      = fn;
 	g->exchange_user = user;
+	return TE_OK;
+}
+
+static void *rcclSym(void *lib, const char *name) { return dlsym(lib, name); }
+int te_rccl_unique_id(const char *libpath, char *id128)
+{
+	if (!libpath || !id128) return te::fail(TE_EINVAL, "te_rccl_unique_id: null argument");
+	void *lib = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
+	if (!lib) return te::fail(TE_EIO, std::string("te_rccl_unique_id: dlopen failed: ") + dlerror());
+	auto get = (int (*)(void *)) rcclSym(lib, "ncclGetUniqueId");
+	if (!get) return te::fail(TE_EIO, "te_rccl_unique_id: ncclGetUniqueId not found");
+	int rc = get(id128);
+	if (rc) return te::fail(TE_ESTATE, "ncclGetUniqueId failed");
+	return TE_OK;
+}
+int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank, int nranks)
+{
+	if (!g || !libpath || !id128) return te::fail(TE_EINVAL, "te_gmg_use_rccl: null argument");
+	HIPCHK(hipSetDevice(g->device));
+	void *lib = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
+	if (!lib) return te::fail(TE_EIO, std::string("te_gmg_use_rccl: dlopen failed: ") + dlerror());
+	struct Id {
+		char b[128];
+	} id;
+	memcpy(id.b, id128, 128);
+	auto init = (int (*)(void **, int, Id, int)) rcclSym(lib, "ncclCommInitRank");
+	te_gmg::Rccl r;
+	r.lib            = lib;
+	r.GroupStart     = (int (*)()) rcclSym(lib, "ncclGroupStart");
+	r.GroupEnd       = (int (*)()) rcclSym(lib, "ncclGroupEnd");
+	r.Send           = (int (*)(const void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclSend");
+	r.Recv           = (int (*)(void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclRecv");
+	r.CommDestroy    = (int (*)(void *)) rcclSym(lib, "ncclCommDestroy");
+	r.GetErrorString = (const char *(*) (int) ) rcclSym(lib, "ncclGetErrorString");
+	if (!init || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.CommDestroy || !r.GetErrorString)
+		return te::fail(TE_EIO, "te_gmg_use_rccl: RCCL symbols missing in " + std::string(libpath));
+	int rc = init(&r.comm, nranks, id, rank);
+	if (rc) return te::fail(TE_ESTATE, std::string("ncclCommInitRank failed: ") + r.GetErrorString(rc));
+	g->rccl = r;
+	return TE_OK;
+}
+// moves n doubles from a scratch send buffer to a scratch receive buffer of level 0 through the same
+// code path as a real exchange, with this rank as its own peer; returns TE_OK iff the data arrived intact
+int te_gmg_exchange_selftest(te_gmg *g, int n)
+{
+	if (!g || n < 1) return te::fail(TE_EINVAL, "te_gmg_exchange_selftest: bad argument");
+	LevelHost &L = *g->levels[0];
+	if ((size_t) 2 * n > L.r->n) return te::fail(TE_EINVAL, "te_gmg_exchange_selftest: n too large");
+	std::vector<double> h(n), back(n);
+	for (int i = 0; i < n; i++) h[i] = 1.0 + i * 0.5;
+	double *send = L.r->d, *recv = L.r->d + n;
+	HIPCHK(hipMemcpyAsync(send, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, g->stream));
+	HIPCHK(hipMemsetAsync(recv, 0, sizeof(double) * n, g->stream));
+	ExPlan pl;
+	int    me = 0;
+	pl.peers  = {me};
+	pl.send_off = {0}, pl.send_cnt = {n}, pl.recv_off = {0}, pl.recv_cnt = {n};
+	int rc = doExchange(g, 9, pl, send, recv);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(back.data(), recv, sizeof(double) * n, hipMemcpyDeviceToHost, g->stream));
+	HIPCHK(hipStreamSynchronize(g->stream));
+	for (int i = 0; i < n; i++)
+		if (back[i] != h[i]) return te::fail(TE_ESTATE, "te_gmg_exchange_selftest: data mismatch");
 	return TE_OK;
 }
 

@@ -109,6 +109,31 @@ def attach(gmg, dist):
     capi.check(capi.lib().te_gmg_set_exchange(gmg.h, gmg._cb, None))
 
 
+def rccl_library():
+    """The librccl.so the process already uses (torch's), so that only one RCCL runtime is loaded."""
+    import glob
+    import os
+    import torch
+    hits = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))
+    return hits[0] if hits else "/opt/rocm/lib/librccl.so"
+
+
+def attach_rccl(gmg, dist, rank, world):
+    """Give the native library its own RCCL communicator (ncclCommInitRank with an id made on rank 0 and
+    broadcast through torch.distributed); exchanges then never enter Python. Raises TeError on failure."""
+    import torch
+    lib = rccl_library().encode()
+    ident = C.create_string_buffer(128)
+    if rank == 0:
+        capi.check(capi.lib().te_rccl_unique_id(lib, ident))
+    if dist is not None and world > 1:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor(list(ident.raw), dtype=torch.uint8, device=dev)
+        dist.broadcast(t, src=0)
+        ident = C.create_string_buffer(bytes(t.cpu().tolist()), 128)
+    capi.check(capi.lib().te_gmg_use_rccl(gmg.h, lib, ident, rank, world))
+
+
 class LocalFabric:
     """n virtual ranks in one process. Each rank runs in its own thread (`run`). An exchange is a set of
     point-to-point rendezvous: the sender posts (pointer, count, tag) to the (src, dst) mailbox, the

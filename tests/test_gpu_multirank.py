@@ -122,3 +122,14 @@ def test_two_processes_gloo():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "MR_WORKER_OK" in r.stdout
+
+
+def test_native_rccl_backend_selftest():
+    """The library's own RCCL back-end (dlopen of the process's librccl.so, ncclCommInitRank, one
+    ncclGroup of ncclRecv + ncclSend on the solver stream) moving data with this rank as its own peer:
+    everything except a second GPU."""
+    import ctypes as C
+    H = capi.Hierarchy(util.mesh("uniform", 1), 8)
+    g = capi.GMG(H)
+    tedist.attach_rccl(g, None, 0, 1)
+    capi.check(capi.lib().te_gmg_exchange_selftest(g.h, 1000))
