@@ -16,15 +16,18 @@ import json
 import os
 import sys
 
-CLASS = [("k_rbgs3d", "stencil_rbgs"), ("k_stencil3d<32, 0", "stencil_apply"), ("k_stencil3d<32, 1", "stencil_resid"),
-         ("k_stencil3d<32, 2", "stencil_jacobi"), ("k_resid_restrict3d", "resid_restrict"),
-         ("k_restrict3d", "restrict"), ("k_prolong3d", "prolong_add"), ("k_vecop", "vecop"),
-         ("k_dst_axis3d", "dst_axis"), ("k_patch_rhs3d", "patch_rhs"), ("k_rbgs_zero3d", "stencil_rbgs_zero")]
+import re
+
+CLASS = [(r"k_rbgs3d<\d+, true", "stencil_rbgs_zero"), (r"k_rbgs3d<\d+, false, true", "stencil_rbgs_prolong"),
+         (r"k_rbgs3d<", "stencil_rbgs"), (r"k_stencil3d<\d+, 0,", "stencil_apply"), (r"k_stencil3d<\d+, 1,", "stencil_resid"),
+         (r"k_stencil3d<\d+, 2,", "stencil_jacobi"), (r"k_stencil3d<\d+, 3,", "resid_restrict"),
+         (r"k_restrict3d", "restrict"), (r"k_prolong3d", "prolong_add"), (r"k_vecop", "vecop"),
+         (r"k_dst_axis3d", "dst_axis"), (r"k_patch_rhs3d|k_face_corr3d", "patch_rhs"), (r"k_ps_", "patch_solve_mfma")]
 
 
 def klass(name):
     for pat, c in CLASS:
-        if pat in name:
+        if re.search(pat, name):
             return c
     return None
 
