@@ -42,7 +42,7 @@ struct Geo {
 	{
 		int ax  = s / 2;
 		int pos = (s & 1) ? (n - 1 - off) : off;
-		int fa[2], k = 0;
+		int fa[2] = {0, 0}, k = 0;
 		for (int i = 0; i < dim; i++)
 			if (i != ax) fa[k++] = i;
 		int idx = pos * stride[ax] + a * stride[fa[0]];
