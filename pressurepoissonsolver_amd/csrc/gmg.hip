@@ -937,7 +937,9 @@ template <int OP> int vecop(te_vec *v, const te_vec *a, const te_vec *b, double 
 	if (v->n == 0) return TE_OK;
 	te_gmg *g = v->g;
 	Timed   t(g, KC_VECOP, v->n);
-	hipLaunchKernelGGL(k_vecop<OP>, dim3(gridFor(v->n / 2, 256, 2048)), dim3(256), 0, g->stream, v->n / 2,
+	// one 16-B element per thread: on this chip a flat grid in address order streams 25-40 % faster than a
+	// capped grid-stride loop (tools/membw.hip: fill 6.9 vs 4.9 TB/s, triad 6.0-6.5 vs 4.9 TB/s)
+	hipLaunchKernelGGL(k_vecop<OP>, dim3(gridFor(v->n / 2, 256, 1 << 30)), dim3(256), 0, g->stream, v->n / 2,
 	                   reinterpret_cast<double2 *>(v->d), a ? reinterpret_cast<const double2 *>(a->d) : nullptr,
 	                   b ? reinterpret_cast<const double2 *>(b->d) : nullptr, alpha, beta, gamma);
 	HIPCHK(hipGetLastError());
@@ -1116,7 +1118,7 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 	int rc;
 	for (int li = 0; li < (int) h->h.levels.size(); li++)
 		if ((rc = buildLevel(g.get(), h->h, li))) return rc;
-	if ((rc = g->partial.alloc(g->red_blocks)) || (rc = g->result.alloc(8))) return rc;
+	if ((rc = g->partial.alloc(2 * g->red_blocks)) || (rc = g->result.alloc(8))) return rc;
 	HIPCHK(hipHostMalloc((void **) &g->result_host, 8 * sizeof(double), hipHostMallocDefault));
 	for (int li = 0; li < (int) g->levels.size(); li++) {
 		LevelHost &L = *g->levels[li];
@@ -1369,8 +1371,20 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 	TE_TRY(te_vec_copy(rhat, resid));
 	TE_TRY(te_vec_copy(p, resid));
 	TE_TRY(te_vec_dot(rhat, resid, &rho));
-	int num_its = 0;
-	rsq         = r0sq;
+	int          num_its = 0;
+	const size_t n2      = x->n / 2;
+	const int    fat     = gridFor(n2, 256, 1 << 30), rb = gridFor(n2, 256, g->red_blocks / 2);
+	auto         two     = [&](double *a, double *b2) -> int { // fixed-order sum of the per-block pairs -> host
+        hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(256), 0, g->stream, rb, g->partial.p, g->result.p);
+        HIPCHK(hipMemcpyAsync(g->result_host, g->result.p, 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+        HIPCHK(hipStreamSynchronize(g->stream));
+        *a  = g->result_host[0];
+        *b2 = g->result_host[1];
+        return TE_OK;
+	};
+	rsq = r0sq;
+	// Loop body = BiCGStab.h:71-104 statement for statement; the vector statements between two operator
+	// applications are fused into one kernel each (same expressions per element, 160 instead of 232 B/site).
 	while (sqrt(rsq) / r0_norm > tol && num_its < max_it) {
 		if (o) {
 			TE_TRY(te_vcycle(g, o, p, mp));
@@ -1380,31 +1394,46 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 		}
 		TE_TRY(te_vec_dot(rhat, ap, &tmp));
 		const double alpha = rho / tmp;
-		TE_TRY(te_vec_copy(s, resid));
-		TE_TRY(te_vec_add_scaled(s, -alpha, ap));
+		if (n2 > 0) {
+			Timed t(g, KC_VECOP, x->n);
+			hipLaunchKernelGGL(k_bicg_s, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) s->d, (const double2 *) resid->d,
+			                   (const double2 *) ap->d, -alpha);
+		}
 		if (o) {
 			TE_TRY(te_vcycle(g, o, s, ms));
 			TE_TRY(te_apply(g, 0, ms, as));
 		} else {
 			TE_TRY(te_apply(g, 0, s, as));
 		}
-		TE_TRY(te_vec_dot(as, s, &tmp));
-		TE_TRY(te_vec_dot(as, as, &tmp2));
-		const double omega = tmp / tmp2;
-		if (o) {
-			TE_TRY(te_vec_add_scaled2(x, alpha, mp, omega, ms));
-		} else {
-			TE_TRY(te_vec_add_scaled2(x, alpha, p, omega, s));
+		tmp = tmp2 = 0.0;
+		if (n2 > 0) {
+			{
+				Timed t(g, KC_REDUCE, x->n);
+				hipLaunchKernelGGL(k_bicg_omega, dim3(rb), dim3(256), 0, g->stream, n2, (const double2 *) as->d,
+				                   (const double2 *) s->d, g->partial.p);
+			}
+			TE_TRY(two(&tmp, &tmp2));
 		}
-		TE_TRY(te_vec_add_scaled2(resid, -alpha, ap, -omega, as));
-		double rho_new;
-		TE_TRY(te_vec_dot(resid, rhat, &rho_new));
+		const double   omega = tmp / tmp2;
+		const te_vec *dp = o ? mp : p, *ds = o ? ms : s;
+		double         rho_new = 0.0;
+		if (n2 > 0) {
+			{
+				Timed t(g, KC_VECOP, x->n);
+				hipLaunchKernelGGL(k_bicg_update, dim3(rb), dim3(256), 0, g->stream, n2, (double2 *) x->d, (double2 *) resid->d,
+				                   (const double2 *) dp->d, (const double2 *) ds->d, (const double2 *) ap->d,
+				                   (const double2 *) as->d, (const double2 *) rhat->d, alpha, omega, g->partial.p);
+			}
+			TE_TRY(two(&rho_new, &rsq));
+		}
 		const double beta = rho_new * alpha / (rho * omega);
-		TE_TRY(te_vec_add_scaled(p, -omega, ap));
-		TE_TRY(te_vec_scale_then_add(p, beta, resid));
+		if (n2 > 0) {
+			Timed t(g, KC_VECOP, x->n);
+			hipLaunchKernelGGL(k_bicg_p, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) p->d, (const double2 *) ap->d,
+			                   (const double2 *) resid->d, -omega, beta);
+		}
 		num_its++;
 		rho = rho_new;
-		TE_TRY(te_vec_two_norm_sq(resid, &rsq));
 	}
 #undef TE_TRY
 	if (iterations) *iterations = num_its;

@@ -548,4 +548,110 @@ __global__ __launch_bounds__(256) void k_reduce_final(int nparts, const double *
 	acc = blockReduce<OP>(acc);
 	if (threadIdx.x == 0) result[0] = acc;
 }
+
+// ---- fused BLAS-1 of one BiCGStab iteration (BiCGStab.h:71-104): same expressions, fewer HBM passes ----
+// two sums per block, combined by k_reduce_final2 in fixed order
+__device__ __forceinline__ void blockReduce2(double &a, double &b)
+{
+	__shared__ double w0[16], w1[16];
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) {
+		a += __shfl_down(a, off, 64);
+		b += __shfl_down(b, off, 64);
+	}
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	if (lane == 0) {
+		w0[w] = a;
+		w1[w] = b;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		a = w0[0];
+		b = w1[0];
+		for (int i = 1; i < (int) (blockDim.x >> 6); i++) {
+			a += w0[i];
+			b += w1[i];
+		}
+	}
+}
+__global__ __launch_bounds__(256) void k_reduce_final2(int nparts, const double *__restrict__ partial, double *__restrict__ result)
+{
+	double a = 0.0, b = 0.0;
+	for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
+		a += partial[2 * i];
+		b += partial[2 * i + 1];
+	}
+	blockReduce2(a, b);
+	if (threadIdx.x == 0) {
+		result[0] = a;
+		result[1] = b;
+	}
+}
+// s = resid; s += ap * (-alpha)          (BiCGStab.h:79-80)
+__global__ __launch_bounds__(256) void k_bicg_s(size_t n2, double2 *__restrict__ s, const double2 *__restrict__ resid,
+                                                const double2 *__restrict__ ap, double malpha)
+{
+	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if (i >= n2) return;
+	const double2 r = resid[i], a = ap[i];
+	s[i]            = double2{r.x + a.x * malpha, r.y + a.y * malpha};
+}
+// (as . s, as . as)                      (BiCGStab.h:87)
+__global__ __launch_bounds__(256) void k_bicg_omega(size_t n2, const double2 *__restrict__ as, const double2 *__restrict__ s,
+                                                    double *__restrict__ partial)
+{
+	double d0 = 0.0, d1 = 0.0;
+	for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t) gridDim.x * 256) {
+		const double2 a = as[i], b = s[i];
+		d0 += a.x * b.x;
+		d0 += a.y * b.y;
+		d1 += a.x * a.x;
+		d1 += a.y * a.y;
+	}
+	blockReduce2(d0, d1);
+	if (threadIdx.x == 0) {
+		partial[2 * blockIdx.x]     = d0;
+		partial[2 * blockIdx.x + 1] = d1;
+	}
+}
+// x += mp*alpha + ms*omega; resid += ap*(-alpha) + as*(-omega); (resid . rhat, resid . resid)   (BiCGStab.h:90-97,71)
+__global__ __launch_bounds__(256) void k_bicg_update(size_t n2, double2 *__restrict__ x, double2 *__restrict__ resid,
+                                                     const double2 *__restrict__ mp, const double2 *__restrict__ ms,
+                                                     const double2 *__restrict__ ap, const double2 *__restrict__ as,
+                                                     const double2 *__restrict__ rhat, double alpha, double omega,
+                                                     double *__restrict__ partial)
+{
+	double d0 = 0.0, d1 = 0.0;
+	for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n2; i += (size_t) gridDim.x * 256) {
+		double2       xv = x[i], rv = resid[i];
+		const double2 p = mp[i], q = ms[i], a = ap[i], b = as[i], h = rhat[i];
+		xv.x += p.x * alpha + q.x * omega;
+		xv.y += p.y * alpha + q.y * omega;
+		rv.x += a.x * -alpha + b.x * -omega;
+		rv.y += a.y * -alpha + b.y * -omega;
+		x[i]     = xv;
+		resid[i] = rv;
+		d0 += rv.x * h.x;
+		d0 += rv.y * h.y;
+		d1 += rv.x * rv.x;
+		d1 += rv.y * rv.y;
+	}
+	blockReduce2(d0, d1);
+	if (threadIdx.x == 0) {
+		partial[2 * blockIdx.x]     = d0;
+		partial[2 * blockIdx.x + 1] = d1;
+	}
+}
+// p += ap*(-omega); p = beta*p + resid      (BiCGStab.h:99-100)
+__global__ __launch_bounds__(256) void k_bicg_p(size_t n2, double2 *__restrict__ p, const double2 *__restrict__ ap,
+                                                const double2 *__restrict__ resid, double momega, double beta)
+{
+	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if (i >= n2) return;
+	double2       pv = p[i];
+	const double2 a = ap[i], r = resid[i];
+	pv.x += a.x * momega;
+	pv.y += a.y * momega;
+	p[i] = double2{beta * pv.x + r.x, beta * pv.y + r.y};
+}
 } // namespace te

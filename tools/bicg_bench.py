@@ -1,0 +1,23 @@
+import sys, time
+sys.path.insert(0, '/root/repo')
+import numpy as np, torch
+from pressurepoissonsolver_amd import capi, problems
+n=32
+mesh = capi.Mesh.uniform(3, 4)
+H = capi.Hierarchy(mesh, n)
+g = capi.GMG(H)
+t = H.tables(0)
+f, exact = problems.init_dirichlet(t, n)
+for sm in (capi.SMOOTH_RBGS, capi.SMOOTH_PATCH_SOLVE):
+    b = g.new_vector(0, f); x = g.new_vector(0)
+    o = g.default_opts(smoother=sm)
+    g.sync(); t0=time.time()
+    its, rr = g.bicgstab(x, b, o, tol=1e-12)
+    g.sync(); dt=time.time()-t0
+    err = np.linalg.norm(x.download()-exact)/np.linalg.norm(exact)
+    print('smoother',sm,'its',its,'rr %.2e'%rr,'time %.1f ms'%(dt*1e3),'per it %.2f ms'%(dt*1e3/max(its,1)),'err %.3e'%err)
+g.profile(True); g.profile_reset()
+b = g.new_vector(0, f); x = g.new_vector(0)
+its, rr = g.bicgstab(x, b, g.default_opts(smoother=capi.SMOOTH_RBGS), tol=1e-12)
+rows = g.profile_rows()
+for k,v in sorted(rows.items(), key=lambda kv:-kv[1]['ms']): print(k, v['calls'], round(v['ms'],2))
