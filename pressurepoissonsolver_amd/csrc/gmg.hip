@@ -124,6 +124,20 @@ struct LevelHost {
 		L.face_kadj = face_kadj.p;
 		L.rh2       = rh2.p;
 		L.ghost     = ghost.p;
+		L.order     = nullptr;
+		L.first     = 0;
+		L.count     = P;
+		return L;
+	}
+	// interior patches (no ghost-slot face) first, then boundary patches
+	DevBuf<int32_t> order;
+	int             n_int = 0, n_bnd = 0;
+	LevelDev        devPart(bool boundary) const
+	{
+		LevelDev L = dev();
+		L.order    = order.p;
+		L.first    = boundary ? n_int : 0;
+		L.count    = boundary ? n_bnd : n_int;
 		return L;
 	}
 };
@@ -137,6 +151,10 @@ struct EventPair {
 struct te_gmg {
 	int                                     device = 0;
 	hipStream_t                             stream = nullptr;
+	// ghost exchanges run on their own stream so that interior patches compute underneath them
+	hipStream_t comm_stream = nullptr;
+	hipEvent_t  ev_pack = nullptr, ev_recv = nullptr;
+	bool        overlap = true;
 	int                                     dim = 3, n = 0;
 	std::vector<std::unique_ptr<LevelHost>> levels;
 	DevBuf<double>                          partial, result;
@@ -410,6 +428,18 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	L->nslots = nslots;
 	L->ncf    = (int) cfs.size();
 	int rc;
+	{
+		std::vector<int32_t> ord, bnd;
+		for (int p = 0; p < P; p++) {
+			bool b = false;
+			for (int s = 0; s < NS; s++) b |= (fk[p * NS + s] == FACE_GHOST);
+			(b ? bnd : ord).push_back(p);
+		}
+		L->n_int = (int) ord.size();
+		L->n_bnd = (int) bnd.size();
+		ord.insert(ord.end(), bnd.begin(), bnd.end());
+		if ((rc = L->order.upload(ord))) return rc;
+	}
 	if ((rc = L->face_kind.upload(fk)) || (rc = L->face_src.upload(fs)) || (rc = L->face_kadj.upload(kadj))
 	    || (rc = L->rh2.upload(rh2)) || (rc = L->cf_desc.upload(cfd)) || (rc = L->cf_slots.upload(cfs))
 	    || (rc = L->ghost.alloc((size_t) std::max(nslots, 1) * L->nf)))
@@ -569,20 +599,22 @@ int newVec(te_gmg *g, int level, te_vec **out)
 inline bool sameShape(const te_vec *a, const te_vec *b) { return a && b && a->g == b->g && a->level == b->level; }
 
 // ------------------------------------------------------------------------------ launches
-int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double *recv)
+int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double *recv, hipStream_t stream = nullptr)
 {
+	if (!stream) stream = g->stream;
+	const bool timed = (stream == g->stream);
 	if (pl.empty()) return TE_OK;
 	if (g->rccl.comm) {
 		// one RCCL group per exchange, enqueued on the solver stream behind the pack kernel: every
 		// send/recv of the exchange progresses together over the direct xGMI links, no host round trip
-		Timed t(g, KC_EXCHANGE, 0);
+		std::unique_ptr<Timed> t(timed ? new Timed(g, KC_EXCHANGE, 0) : nullptr);
 		constexpr int ncclFloat64 = 8; // rccl.h:467
 		int           rc         = g->rccl.GroupStart();
 		for (size_t i = 0; i < pl.peers.size() && rc == 0; i++) {
 			if (pl.recv_cnt[i] > 0)
-				rc = g->rccl.Recv(recv + pl.recv_off[i], (size_t) pl.recv_cnt[i], ncclFloat64, pl.peers[i], g->rccl.comm, g->stream);
+				rc = g->rccl.Recv(recv + pl.recv_off[i], (size_t) pl.recv_cnt[i], ncclFloat64, pl.peers[i], g->rccl.comm, stream);
 			if (rc == 0 && pl.send_cnt[i] > 0)
-				rc = g->rccl.Send(send + pl.send_off[i], (size_t) pl.send_cnt[i], ncclFloat64, pl.peers[i], g->rccl.comm, g->stream);
+				rc = g->rccl.Send(send + pl.send_off[i], (size_t) pl.send_cnt[i], ncclFloat64, pl.peers[i], g->rccl.comm, stream);
 		}
 		int rc2 = g->rccl.GroupEnd();
 		if (rc || rc2) return te::fail(TE_ESTATE, std::string("RCCL exchange failed: ") + g->rccl.GetErrorString(rc ? rc : rc2));
@@ -590,9 +622,9 @@ int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double 
 	}
 	if (!g->exchange)
 		return te::fail(TE_ESTATE, "this level has off-rank neighbours: call te_gmg_set_exchange or te_gmg_use_rccl first");
-	Timed t(g, KC_EXCHANGE, 0);
+	std::unique_ptr<Timed> t(timed ? new Timed(g, KC_EXCHANGE, 0) : nullptr);
 	int   rc = g->exchange(g->exchange_user, tag, send, recv, (int) pl.peers.size(), pl.peers.data(), pl.send_off.data(),
-	                       pl.send_cnt.data(), pl.recv_off.data(), pl.recv_cnt.data(), (void *) g->stream);
+	                       pl.send_cnt.data(), pl.recv_off.data(), pl.recv_cnt.data(), (void *) stream);
 	if (rc) return te::fail(TE_ESTATE, "exchange callback failed with status " + std::to_string(rc));
 	return TE_OK;
 }
@@ -615,34 +647,68 @@ template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u)
 	                   L.cf_slots.p, u, L.ghost.p);
 	return TE_OK;
 }
+// Run `launch(subset)` over all patches of the level with current ghosts. With off-rank neighbours the
+// exchange goes to the communication stream and the interior patches (no ghost-slot face) are computed
+// underneath it; the boundary patches follow once the receive has landed. (north star: "ghost-cell
+// exchange ... overlapped with interior smoothing")
+template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *u, F launch)
+{
+	if (L.nremote == 0 || !g->overlap || L.n_int == 0) {
+		int rc = prepareGhosts<N>(g, L, u);
+		if (rc) return rc;
+		launch(L.dev());
+		return TE_OK;
+	}
+	{
+		Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
+		hipLaunchKernelGGL(k_pack_faces3d<N>, dim3(L.nremote), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.send_faces.p, u,
+		                   L.sendbuf.p);
+	}
+	HIPCHK(hipEventRecord(g->ev_pack, g->stream));
+	HIPCHK(hipStreamWaitEvent(g->comm_stream, g->ev_pack, 0));
+	int rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p, g->comm_stream);
+	if (rc) return rc;
+	HIPCHK(hipEventRecord(g->ev_recv, g->comm_stream));
+	launch(L.devPart(false)); // interior, concurrent with the exchange
+	HIPCHK(hipStreamWaitEvent(g->stream, g->ev_recv, 0));
+	if (L.ncf > 0) {
+		Timed t(g, KC_CFGHOST, (size_t) L.ncf * L.nf);
+		hipLaunchKernelGGL(k_cf_ghost3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p, L.cf_slots.p,
+		                   u, L.ghost.p);
+	}
+	launch(L.devPart(true)); // boundary
+	return TE_OK;
+}
 template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out,
                                               double omega, RestrictDst rd = RestrictDst())
 {
-	int rc = prepareGhosts<N>(g, L, u);
-	if (rc) return rc;
-	Timed     t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : (MODE == MODE_JACOBI ? KC_JACOBI : KC_RESID_RESTRICT)),
-	            (size_t) L.P * L.nc);
 	const int tpb = Tile3<N>::TPB;
 	// enough workgroups to fill 256 CUs a few times over: split patches into z-slabs when few
 	int zs = 1;
 	if (N >= 8) {
 		while (zs < 4 && (getenv("TE_ZS_FORCE") || (size_t) L.P * zs < 2048) && N / (zs * 2) >= 4) zs *= 2;
 	}
-	auto grid = [&](int z) { return dim3(8 * ((L.P * z + 7) / 8)); };
-	LevelDev D = L.dev();
-	switch (zs) {
-		case 1: hipLaunchKernelGGL((k_stencil3d<N, MODE, 1>), grid(1), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd); break;
-		case 2:
-			if constexpr (N >= 8)
-				hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
-			break;
-		default:
-			if constexpr (N >= 16)
-				hipLaunchKernelGGL((k_stencil3d<N, MODE, 4>), grid(4), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
-			else if constexpr (N >= 8)
-				hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
-			break;
-	}
+	auto launch = [&](LevelDev D) {
+		if (D.count == 0) return;
+		Timed t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : (MODE == MODE_JACOBI ? KC_JACOBI : KC_RESID_RESTRICT)),
+		        (size_t) D.count * L.nc);
+		auto grid = [&](int z) { return dim3(8 * ((D.count * z + 7) / 8)); };
+		switch (zs) {
+			case 1: hipLaunchKernelGGL((k_stencil3d<N, MODE, 1>), grid(1), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd); break;
+			case 2:
+				if constexpr (N >= 8)
+					hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
+				break;
+			default:
+				if constexpr (N >= 16)
+					hipLaunchKernelGGL((k_stencil3d<N, MODE, 4>), grid(4), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
+				else if constexpr (N >= 8)
+					hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
+				break;
+		}
+	};
+	int rc = withGhosts<N>(g, L, u, launch);
+	if (rc) return rc;
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
@@ -770,17 +836,21 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 		HIPCHK(hipGetLastError());
 		return TE_OK;
 	}
-	if (!zero_guess) { // a zero iterate has zero ghosts everywhere: nothing to exchange or build
-		int rc = prepareGhosts<N>(g, L, u);
-		if (rc) return rc;
-	}
-	Timed t(g, zero_guess ? KC_RBGS_ZERO : KC_RBGS, (size_t) L.P * L.nc);
-	if (zero_guess)
+	if (zero_guess) { // a zero iterate has zero ghosts everywhere: nothing to exchange or build
+		Timed t(g, KC_RBGS_ZERO, (size_t) L.P * L.nc);
 		hipLaunchKernelGGL((k_rbgs3d<N, true, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, L.dev(), u, f, out,
 		                   ProlongSrc());
-	else
-		hipLaunchKernelGGL((k_rbgs3d<N, false, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, L.dev(), u, f, out,
+		HIPCHK(hipGetLastError());
+		return TE_OK;
+	}
+	auto launch = [&](LevelDev D) {
+		if (D.count == 0) return;
+		Timed t(g, KC_RBGS, (size_t) D.count * L.nc);
+		hipLaunchKernelGGL((k_rbgs3d<N, false, false>), dim3(8 * ((D.count + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, u, f, out,
 		                   ProlongSrc());
+	};
+	int rc = withGhosts<N>(g, L, u, launch);
+	if (rc) return rc;
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
@@ -1115,6 +1185,10 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 	memset(g->cells, 0, sizeof(g->cells));
 	memset(g->total_ms, 0, sizeof(g->total_ms));
 	HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking));
+	HIPCHK(hipEventCreateWithFlags(&g->ev_pack, hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&g->ev_recv, hipEventDisableTiming));
+	g->overlap = getenv("TE_NO_OVERLAP") == nullptr;
 	int rc;
 	for (int li = 0; li < (int) h->h.levels.size(); li++)
 		if ((rc = buildLevel(g.get(), h->h, li))) return rc;
@@ -1142,6 +1216,7 @@ void te_gmg_destroy(te_gmg *g)
 {
 	if (!g) return;
 	(void) hipStreamSynchronize(g->stream);
+	if (g->comm_stream) (void) hipStreamSynchronize(g->comm_stream);
 	for (auto &L : g->levels) {
 		for (te_vec *v : {L->u.get(), L->f.get(), L->r.get(), L->t.get()})
 			if (v && v->d) (void) hipFree(v->d);
@@ -1152,6 +1227,9 @@ void te_gmg_destroy(te_gmg *g)
 	}
 	if (g->rccl.comm && g->rccl.CommDestroy) (void) g->rccl.CommDestroy(g->rccl.comm);
 	if (g->result_host) (void) hipHostFree(g->result_host);
+	if (g->ev_pack) (void) hipEventDestroy(g->ev_pack);
+	if (g->ev_recv) (void) hipEventDestroy(g->ev_recv);
+	if (g->comm_stream) (void) hipStreamDestroy(g->comm_stream);
 	(void) hipStreamDestroy(g->stream);
 	delete g;
 }

@@ -37,6 +37,10 @@ struct LevelDev {
 	const double  *face_kadj; // [P*6] change of the diagonal's per-axis factor 2 at that face
 	const double  *rh2;       // [P*3] 1/h^2
 	const double  *ghost;     // [nslots*N*N]
+	// a launch covers patches order[first .. first+count) (order == nullptr: patches first .. first+count):
+	// interior patches can run while the ghost exchange of the boundary patches is still in flight
+	const int32_t *order;
+	int32_t        first, count;
 };
 
 // Blocks b, b+8, b+16, ... share an XCD (observed round-robin dispatch); give every XCD one

@@ -46,10 +46,10 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 	constexpr int TPB  = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
 	constexpr int NN   = N * N, NNN = N * N * N;
 	constexpr int ZL   = N / ZS; // planes per slab
-	const int nblocks  = L.P * ZS;
+	const int nblocks  = L.count * ZS;
 	const int work     = xcdRemap(blockIdx.x, nblocks);
 	if (work >= nblocks) return;
-	const int pid = work / ZS;
+	const int pid = L.order ? L.order[L.first + work / ZS] : L.first + work / ZS;
 	const int z0  = (work % ZS) * ZL;
 	const int tid = threadIdx.x;
 
@@ -262,8 +262,9 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	using T           = Tile3<N>;
 	constexpr int TPB = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
 	constexpr int NN  = N * N, NNN = N * N * N;
-	const int     pid = xcdRemap(blockIdx.x, L.P);
-	if (pid >= L.P) return;
+	const int     slot = xcdRemap(blockIdx.x, L.count);
+	if (slot >= L.count) return;
+	const int pid = L.order ? L.order[L.first + slot] : L.first + slot;
 	const int tid = threadIdx.x;
 
 	__shared__ __attribute__((aligned(16))) double tile[3][T::LSZ]; // planes z-1, z, z+1 rotate

@@ -150,6 +150,8 @@ class LocalFabric:
         self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         self.hip.hipMemcpy.restype = C.c_int
         self.hip.hipDeviceSynchronize.restype = C.c_int
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipStreamSynchronize.restype = C.c_int
         self.errors = []
         self.timeout = 120.0
 
@@ -159,7 +161,8 @@ class LocalFabric:
         def cb(user, tag, send_ptr, recv_ptr, npeers, peers, soff, scnt, roff, rcnt, stream):
             try:
                 pl = _plan_arrays(npeers, peers, soff, scnt, roff, rcnt)
-                capi.check(capi.lib().te_gmg_sync(gmg.h))  # my packed data is complete
+                capi.check(capi.lib().te_gmg_sync(gmg.h))  # my packed data is complete (solver stream) ...
+                assert fab.hip.hipStreamSynchronize(C.c_void_p(stream)) == 0  # ... and whatever `stream` still holds
                 for r, so, sc in zip(pl[0], pl[1], pl[2]):
                     if sc > 0:
                         fab.mail[(rank, r)].put((int(send_ptr) + 8 * so, sc, tag))
