@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=512, help="cells per axis of the uniform grid (multiple of 32)")
     ap.add_argument("--smoother", default="rbgs", choices=["rbgs", "jacobi", "patch_solve"])
+    ap.add_argument("--dim", type=int, default=3, choices=[2, 3], help="2: the 2D twin (config C5: --dim 2 --size 4096 --patch 64)")
+    ap.add_argument("--patch", type=int, default=32, help="cells per axis per patch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=128, help="cells per axis of the CPU baseline sample")
     return ap.parse_args()
@@ -130,10 +132,10 @@ def main():
     from pressurepoissonsolver_amd import capi, problems
     from pressurepoissonsolver_amd import dist as tedist
 
-    n = 32
-    assert a.size % n == 0 and (a.size // n) & (a.size // n - 1) == 0, "--size must be 32 * 2^k"
+    n = a.patch
+    assert a.size % n == 0 and (a.size // n) & (a.size // n - 1) == 0, "--size must be patch * 2^k"
     div = int(round(np.log2(a.size // n)))
-    mesh = capi.Mesh.uniform(3, div)
+    mesh = capi.Mesh.uniform(a.dim, div)
     H = capi.Hierarchy(mesh, n, rank=rank, nranks=world)
     g = capi.GMG(H, device=local_rank)
     exchange_backend = "none"
@@ -160,9 +162,9 @@ def main():
 
     t = H.tables(0)
     ids = t["id"][H.l2g(0)]
-    f = g.new_vector(0, problems.random_rhs(ids, n ** 3))
+    f = g.new_vector(0, problems.random_rhs(ids, n ** a.dim))
     u = g.new_vector(0)
-    cells_global = [H.sizes(l)[1] * n ** 3 for l in range(H.num_levels)]
+    cells_global = [H.sizes(l)[1] * n ** a.dim for l in range(H.num_levels)]
 
     def barrier():
         g.sync()
@@ -217,13 +219,13 @@ def main():
                 traffic = None
         b_alg = vcycle_alg_bytes_per_finest_cell(cells_global)
         out = {
-            "metric": "V-cycle lattice-site updates/sec, 512^3 3D Poisson" if a.size == 512 else
-                      f"V-cycle lattice-site updates/sec, {a.size}^3 3D Poisson",
+            "metric": "V-cycle lattice-site updates/sec, 512^3 3D Poisson" if (a.size == 512 and a.dim == 3) else
+                      f"V-cycle lattice-site updates/sec, {a.size}^{a.dim} {a.dim}D Poisson",
             "value": value, "unit": "lattice-site updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"apps/3d/steady-equivalent: {a.size}^3 uniform, {cells_global[0] // n ** 3} "
-                                   f"patches of 32^3, {H.num_levels} levels, V(1,1), smoother={a.smoother}, "
+            "config": {"workload": f"apps/{a.dim}d/steady-equivalent: {a.size}^{a.dim} uniform, {cells_global[0] // n ** a.dim} "
+                                   f"patches of {n}^{a.dim}, {H.num_levels} levels, V(1,1), smoother={a.smoother}, "
                                    "Dirichlet, f ~ U(-1,1) splitmix64(0x5EED + patch id)",
                        "parallelism": f"patch-sharded x{world} (Morton ranges)", "exchange": exchange_backend,
                        "levels": H.num_levels,
