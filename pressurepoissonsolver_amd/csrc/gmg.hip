@@ -127,8 +127,15 @@ struct LevelHost {
 		L.order     = nullptr;
 		L.first     = 0;
 		L.count     = P;
+		L.xf        = nullptr;
+		L.xf_out    = nullptr;
 		return L;
 	}
+	// compact x-face columns of the level's current iterate inside te_vcycle (ping-pong with the sweeps'
+	// out-of-place output); xf_valid_for = the data pointer they describe, or null
+	DevBuf<double> xfbuf[2];
+	int            xf_cur       = 0;
+	const double  *xf_valid_for = nullptr;
 	// interior patches (no ghost-slot face) first, then boundary patches
 	DevBuf<int32_t> order;
 	int             n_int = 0, n_bnd = 0;
@@ -155,6 +162,7 @@ struct te_gmg {
 	hipStream_t comm_stream = nullptr;
 	hipEvent_t  ev_pack = nullptr, ev_recv = nullptr;
 	bool        overlap = true;
+	bool        in_cycle = false; // te_vcycle in progress: the levels' xf_valid_for bookkeeping is trustworthy
 	int                                     dim = 3, n = 0;
 	std::vector<std::unique_ptr<LevelHost>> levels;
 	DevBuf<double>                          partial, result;
@@ -440,6 +448,8 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		ord.insert(ord.end(), bnd.begin(), bnd.end());
 		if ((rc = L->order.upload(ord))) return rc;
 	}
+	if (D == 3 && ((rc = L->xfbuf[0].alloc((size_t) std::max(P, 1) * 2 * L->nf)) || (rc = L->xfbuf[1].alloc((size_t) std::max(P, 1) * 2 * L->nf))))
+		return rc;
 	if ((rc = L->face_kind.upload(fk)) || (rc = L->face_src.upload(fs)) || (rc = L->face_kadj.upload(kadj))
 	    || (rc = L->rh2.upload(rh2)) || (rc = L->cf_desc.upload(cfd)) || (rc = L->cf_slots.upload(cfs))
 	    || (rc = L->ghost.alloc((size_t) std::max(nslots, 1) * L->nf)))
@@ -651,8 +661,14 @@ template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u)
 // exchange goes to the communication stream and the interior patches (no ghost-slot face) are computed
 // underneath it; the boundary patches follow once the receive has landed. (north star: "ghost-cell
 // exchange ... overlapped with interior smoothing")
-template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *u, F launch)
+template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *u, F launch_, const double *xf_in = nullptr,
+                                         double *xf_out = nullptr)
 {
+	auto launch = [&](LevelDev D) {
+		D.xf     = xf_in;
+		D.xf_out = xf_out;
+		launch_(D);
+	};
 	if (L.nremote == 0 || !g->overlap || L.n_int == 0) {
 		int rc = prepareGhosts<N>(g, L, u);
 		if (rc) return rc;
@@ -680,7 +696,7 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 	return TE_OK;
 }
 template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out,
-                                              double omega, RestrictDst rd = RestrictDst())
+                                              double omega, RestrictDst rd = RestrictDst(), const double *xf_in = nullptr)
 {
 	const int tpb = Tile3<N>::TPB;
 	// enough workgroups to fill 256 CUs a few times over: split patches into z-slabs when few
@@ -707,7 +723,7 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 				break;
 		}
 	};
-	int rc = withGhosts<N>(g, L, u, launch);
+	int rc = withGhosts<N>(g, L, u, launch, xf_in);
 	if (rc) return rc;
 	HIPCHK(hipGetLastError());
 	return TE_OK;
@@ -806,7 +822,7 @@ int prolong2d(te_gmg *g, LevelHost &L, const double *coarse, double *fine)
 }
 
 template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega,
-                                      RestrictDst rd = RestrictDst())
+                                      RestrictDst rd = RestrictDst(), const double *xf_in = nullptr)
 {
 	if (L.P == 0) return TE_OK;
 	if (L.dim == 2) {
@@ -816,29 +832,33 @@ template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, 
 			return launchStencil2d<MODE>(g, L, u, f, out, omega);
 	}
 	switch (L.n) {
-		case 4: return launchStencilN<4, MODE>(g, L, u, f, out, omega, rd);
-		case 8: return launchStencilN<8, MODE>(g, L, u, f, out, omega, rd);
-		case 16: return launchStencilN<16, MODE>(g, L, u, f, out, omega, rd);
-		default: return launchStencilN<32, MODE>(g, L, u, f, out, omega, rd);
+		case 4: return launchStencilN<4, MODE>(g, L, u, f, out, omega, rd, xf_in);
+		case 8: return launchStencilN<8, MODE>(g, L, u, f, out, omega, rd, xf_in);
+		case 16: return launchStencilN<16, MODE>(g, L, u, f, out, omega, rd, xf_in);
+		default: return launchStencilN<32, MODE>(g, L, u, f, out, omega, rd, xf_in);
 	}
 }
 template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess,
-                                 const double *prolong_from)
+                                 const double *prolong_from, const double *xf_in, double *xf_out)
 {
 	if (prolong_from) { // u + P(coarse) is formed on the fly: only for levels without ghost slots (checked by the caller)
 		ProlongSrc ps;
 		ps.parent = L.parent.p;
 		ps.orth   = L.orth.p;
 		ps.coarse = prolong_from;
-		Timed t(g, KC_RBGS_PROLONG, (size_t) L.P * L.nc);
-		hipLaunchKernelGGL((k_rbgs3d<N, false, true>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, L.dev(), u, f,
-		                   out, ps);
+		Timed    t(g, KC_RBGS_PROLONG, (size_t) L.P * L.nc);
+		LevelDev D = L.dev();
+		D.xf       = xf_in;
+		D.xf_out   = xf_out;
+		hipLaunchKernelGGL((k_rbgs3d<N, false, true>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, u, f, out, ps);
 		HIPCHK(hipGetLastError());
 		return TE_OK;
 	}
 	if (zero_guess) { // a zero iterate has zero ghosts everywhere: nothing to exchange or build
-		Timed t(g, KC_RBGS_ZERO, (size_t) L.P * L.nc);
-		hipLaunchKernelGGL((k_rbgs3d<N, true, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, L.dev(), u, f, out,
+		Timed    t(g, KC_RBGS_ZERO, (size_t) L.P * L.nc);
+		LevelDev D = L.dev();
+		D.xf_out   = xf_out;
+		hipLaunchKernelGGL((k_rbgs3d<N, true, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, u, f, out,
 		                   ProlongSrc());
 		HIPCHK(hipGetLastError());
 		return TE_OK;
@@ -849,26 +869,26 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 		hipLaunchKernelGGL((k_rbgs3d<N, false, false>), dim3(8 * ((D.count + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, u, f, out,
 		                   ProlongSrc());
 	};
-	int rc = withGhosts<N>(g, L, u, launch);
+	int rc = withGhosts<N>(g, L, u, launch, xf_in, xf_out);
 	if (rc) return rc;
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
 int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false,
-               const double *prolong_from = nullptr)
+               const double *prolong_from = nullptr, const double *xf_in = nullptr, double *xf_out = nullptr)
 {
 	if (L.P == 0) return TE_OK;
 	if (L.dim == 2) return launchRbgs2d(g, L, u, f, out);
 	switch (L.n) {
-		case 4: return launchRbgsN<4>(g, L, u, f, out, zero_guess, prolong_from);
-		case 8: return launchRbgsN<8>(g, L, u, f, out, zero_guess, prolong_from);
-		case 16: return launchRbgsN<16>(g, L, u, f, out, zero_guess, prolong_from);
-		default: return launchRbgsN<32>(g, L, u, f, out, zero_guess, prolong_from);
+		case 4: return launchRbgsN<4>(g, L, u, f, out, zero_guess, prolong_from, xf_in, xf_out);
+		case 8: return launchRbgsN<8>(g, L, u, f, out, zero_guess, prolong_from, xf_in, xf_out);
+		case 16: return launchRbgsN<16>(g, L, u, f, out, zero_guess, prolong_from, xf_in, xf_out);
+		default: return launchRbgsN<32>(g, L, u, f, out, zero_guess, prolong_from, xf_in, xf_out);
 	}
 }
 // Cycle.h:59-65 in one pass: coarse f = AvgRstr(f - A u), r never stored. Children whose parent is
 // on another rank write their block into upbuf; received blocks are placed by k_restrict_unpack3d.
-template <int N> int residRestrictN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse)
+template <int N> int residRestrictN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse, const double *xf_in)
 {
 	RestrictDst rd;
 	rd.parent     = L.parent.p;
@@ -877,7 +897,7 @@ template <int N> int residRestrictN(te_gmg *g, LevelHost &L, const double *u, co
 	rd.remote     = L.upbuf.p;
 	rd.remote_off = L.up_off.p;
 	int rc        = TE_OK;
-	if (L.P > 0) rc = launchStencilN<N, MODE_RESID_RESTRICT>(g, L, u, f, L.r->d, 0.0, rd);
+	if (L.P > 0) rc = launchStencilN<N, MODE_RESID_RESTRICT>(g, L, u, f, L.r->d, 0.0, rd, xf_in);
 	if (rc) return rc;
 	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
 	if (L.n_down > 0) {
@@ -888,13 +908,13 @@ template <int N> int residRestrictN(te_gmg *g, LevelHost &L, const double *u, co
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
-int residRestrict(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse)
+int residRestrict(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse, const double *xf_in = nullptr)
 {
 	switch (L.n) {
-		case 4: return residRestrictN<4>(g, L, u, f, coarse);
-		case 8: return residRestrictN<8>(g, L, u, f, coarse);
-		case 16: return residRestrictN<16>(g, L, u, f, coarse);
-		default: return residRestrictN<32>(g, L, u, f, coarse);
+		case 4: return residRestrictN<4>(g, L, u, f, coarse, xf_in);
+		case 8: return residRestrictN<8>(g, L, u, f, coarse, xf_in);
+		case 16: return residRestrictN<16>(g, L, u, f, coarse, xf_in);
+		default: return residRestrictN<32>(g, L, u, f, coarse, xf_in);
 	}
 }
 template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1,
@@ -1006,6 +1026,7 @@ template <int OP> int vecop(te_vec *v, const te_vec *a, const te_vec *b, double 
 		return te::fail(TE_EINVAL, "te_vec_*: vectors of different levels");
 	if (v->n == 0) return TE_OK;
 	te_gmg *g = v->g;
+	if (g->levels[v->level]->xf_valid_for == v->d) g->levels[v->level]->xf_valid_for = nullptr; // v changes in place
 	Timed   t(g, KC_VECOP, v->n);
 	// one 16-B element per thread: on this chip a flat grid in address order streams 25-40 % faster than a
 	// capped grid-stride loop (tools/membw.hip: fill 6.9 vs 4.9 TB/s, triad 6.0-6.5 vs 4.9 TB/s)
@@ -1039,20 +1060,34 @@ template <int OP> int reduce(const te_vec *a, const te_vec *b, double *out)
 
 void swapData(te_vec *a, te_vec *b) { std::swap(a->d, b->d); }
 
+// x-face columns of `d`, if the level still holds them (only RB-GS sweeps inside te_vcycle produce them)
+inline const double *xfFor(LevelHost &L, const double *d) { return (d && L.xf_valid_for == d) ? L.xfbuf[L.xf_cur].p : nullptr; }
+// the sweep wrote `out` together with its x-face columns into the other buffer: make them current
+inline void xfProduced(LevelHost &L, const double *out)
+{
+	L.xf_cur ^= 1;
+	L.xf_valid_for = out;
+}
 int smoothOnce(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega, bool zero_guess = false)
 {
 	LevelHost &L = *g->levels[level];
 	int        rc;
+	const bool xfok = (L.dim == 3 && g->in_cycle); // outside te_vcycle nobody keeps xf_valid_for honest
 	switch (smoother) {
-		case TE_SMOOTH_PATCH_SOLVE: return patchSolve(g, L, f->d, u->d, zero_guess);
+		case TE_SMOOTH_PATCH_SOLVE:
+			L.xf_valid_for = nullptr; // u is rewritten in place
+			return patchSolve(g, L, f->d, u->d, zero_guess);
 		case TE_SMOOTH_JACOBI:
+			L.xf_valid_for = nullptr;
 			rc = launchStencil<MODE_JACOBI>(g, L, u->d, f->d, L.t->d, omega);
 			if (rc) return rc;
 			swapData(u, L.t.get());
 			return TE_OK;
 		case TE_SMOOTH_RBGS:
-			rc = launchRbgs(g, L, u->d, f->d, L.t->d, zero_guess);
+			rc = launchRbgs(g, L, u->d, f->d, L.t->d, zero_guess, nullptr, xfok ? xfFor(L, u->d) : nullptr,
+			                xfok ? L.xfbuf[L.xf_cur ^ 1].p : nullptr);
 			if (rc) return rc;
+			if (xfok) xfProduced(L, L.t->d);
 			swapData(u, L.t.get());
 			return TE_OK;
 		default: return te::fail(TE_EINVAL, "te_smooth: unknown smoother");
@@ -1093,7 +1128,8 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	int        rc;
 	auto       materialise = [&]() -> int {
         if (!u_zero) return TE_OK;
-        u_zero = false;
+        u_zero         = false;
+        L.xf_valid_for = nullptr;
         return vecop<VOP_SET>(u, nullptr, nullptr, 0.0, 0.0, 0.0);
 	};
 	const double *pending_prolong = nullptr; // coarse correction still to be added to u
@@ -1106,7 +1142,8 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 			if (pending_prolong) {
 				const double *c = pending_prolong;
 				pending_prolong = nullptr;
-				if ((r = launchRbgs(g, L, u->d, f->d, L.t->d, false, c))) return r;
+				if ((r = launchRbgs(g, L, u->d, f->d, L.t->d, false, c, xfFor(L, u->d), L.xfbuf[L.xf_cur ^ 1].p))) return r;
+				xfProduced(L, L.t->d);
 				swapData(u, L.t.get());
 				continue;
 			}
@@ -1130,9 +1167,9 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         int r = materialise();
         if (r) return r;
         if (o->fuse && L.dim == 3) {
-            if ((r = residRestrict(g, L, u->d, f->d, C.f->d))) return r;
+            if ((r = residRestrict(g, L, u->d, f->d, C.f->d, xfFor(L, u->d)))) return r;
         } else {
-            if ((r = launchStencil<MODE_RESID>(g, L, u->d, f->d, L.r->d, 0.0))) return r; // prepCoarser: r = f - A u
+            if ((r = launchStencil<MODE_RESID>(g, L, u->d, f->d, L.r->d, 0.0, RestrictDst(), xfFor(L, u->d)))) return r; // prepCoarser: r = f - A u
             if ((r = doRestrict(g, l, L.r->d, C.f->d))) return r;
             if ((r = vecop<VOP_SET>(C.u.get(), nullptr, nullptr, 0.0, 0.0, 0.0))) return r;
         }
@@ -1143,6 +1180,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
             pending_prolong = C.u->d;
             return TE_OK;
         }
+        L.xf_valid_for = nullptr; // u changes in place
         return doProlong(g, l, C.u->d, u->d);
 	};
 	if ((rc = smooth(o->pre_sweeps, false))) return rc;
@@ -1422,7 +1460,12 @@ int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u)
 	if (!o) return te::fail(TE_EINVAL, "te_vcycle: null options");
 	if ((rc = checkLevelVec(g, 0, f, "te_vcycle")) || (rc = checkLevelVec(g, 0, u, "te_vcycle"))) return rc;
 	if (!o->fuse && (rc = te_vec_set(u, 0.0))) return rc; // Cycle.h:118
-	return visit(g, o, 0, f, u, o->fuse != 0);
+	for (auto &L : g->levels) L->xf_valid_for = nullptr;
+	g->in_cycle = getenv("TE_NO_XF") == nullptr;
+	rc          = visit(g, o, 0, f, u, o->fuse != 0);
+	g->in_cycle = false;
+	for (auto &L : g->levels) L->xf_valid_for = nullptr;
+	return rc;
 }
 
 // BiCGStab.h:45-106, statement for statement, on device vectors

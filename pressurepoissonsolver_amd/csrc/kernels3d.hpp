@@ -41,6 +41,11 @@ struct LevelDev {
 	// interior patches can run while the ghost exchange of the boundary patches is still in flight
 	const int32_t *order;
 	int32_t        first, count;
+	// compact copies of the patches' two x-face columns, [p][W|E][y + N z]: an x-halo gathered from the
+	// neighbour patch itself uses 8 B of every 128-B line; from here it is a contiguous 256-B run per plane.
+	// xf (may be null) belongs to the input iterate u; xf_out (may be null) is filled for the output.
+	const double *xf;
+	double       *xf_out;
 };
 
 // Blocks b, b+8, b+16, ... share an XCD (observed round-robin dispatch); give every XCD one
@@ -108,7 +113,8 @@ struct HaloSrc {
 };
 template <int N>
 __device__ __forceinline__ HaloSrc haloSrc(int tid, const int32_t *fk, const int32_t *fs, const double *u,
-                                           const double *up, const double *ghost, double dir_sign, double neu_sign)
+                                           const double *up, const double *ghost, double dir_sign, double neu_sign,
+                                           const double *xf = nullptr)
 {
 	constexpr int NN = N * N, NNN = N * N * N, LW = Tile2<N>::LW;
 	HaloSrc       h;
@@ -141,6 +147,10 @@ __device__ __forceinline__ HaloSrc haloSrc(int tid, const int32_t *fk, const int
 		h.s      = 1.0;
 		h.p      = up + own;
 		if (kind == FACE_LOCAL) h.p = u + (size_t) src * NNN + nbr;
+		if (kind == FACE_LOCAL && side < 2 && xf) { // the neighbour's opposite x-face column, contiguous in (y, z)
+			h.p      = xf + ((size_t) src * 2 + (side ^ 1)) * NN + t;
+			h.stride = N;
+		}
 		if (kind == FACE_GHOST) { // ghost plane cell (a,b) = (t, z)
 			h.p      = ghost + (size_t) src * NN + t;
 			h.stride = N;

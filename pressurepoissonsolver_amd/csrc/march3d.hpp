@@ -106,7 +106,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 		dix[0][0] = cx0 + 3 * cy0, dix[0][1] = cx1 + 3 * cy0, dix[1][0] = cx0 + 3 * cy1, dix[1][1] = cx1 + 3 * cy1;
 	}
 
-	const HaloSrc  hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, -1.0, 1.0);
+	const HaloSrc  hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, -1.0, 1.0, L.xf);
 	const PlaneSrc bot = zPlaneSrc<N>(fk[4], fs[4], false, u, up, L.ghost, -1.0, 1.0);
 	const PlaneSrc top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, -1.0, 1.0);
 
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	HaloSrc  hs;
 	PlaneSrc bot, top;
 	if (!ZERO) {
-		hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, 0.0, 0.0);
+		hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, 0.0, 0.0, L.xf);
 		bot = zPlaneSrc<N>(fk[4], fs[4], false, u, up, L.ghost, 0.0, 0.0);
 		top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, 0.0, 0.0);
 	} else { // halo ring stays zero for the whole sweep
@@ -421,6 +421,11 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 			if (act) {
 				op2[(z - 1) * NP + q[0]] = um[0];
 				op2[(z - 1) * NP + q[1]] = um[1];
+				if (L.xf_out) { // export this plane's x-face columns of the new iterate (rows 2Yp, 2Yp+1 are adjacent)
+					double *xo = L.xf_out + (size_t) pid * 2 * NN + N * (z - 1) + 2 * Yp;
+					if (X == 0) *reinterpret_cast<double2 *>(xo) = double2{um[0].x, um[1].x};
+					if (X == H - 1) *reinterpret_cast<double2 *>(xo + NN) = double2{um[0].y, um[1].y};
+				}
 			}
 		}
 #pragma unroll
