@@ -759,6 +759,12 @@ int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, doub
 	int rc = prepareGhosts2d(g, L, u);
 	if (rc) return rc;
 	Timed      t(g, KC_RBGS, (size_t) L.P * L.nc);
+	if (L.n <= 64 && !getenv("TE_2D_SIMPLE")) { // the patch and its halo ring fit in LDS: one pass
+		const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
+		hipLaunchKernelGGL(k_rbgs2d_lds, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out);
+		HIPCHK(hipGetLastError());
+		return TE_OK;
+	}
 	const dim3 grid(gridFor((size_t) L.P * L.nc, 256, 65536));
 	hipLaunchKernelGGL(k_rbgs2d<0>, grid, dim3(256), 0, g->stream, L.dev2(), u, f, out);
 	hipLaunchKernelGGL(k_rbgs2d<1>, grid, dim3(256), 0, g->stream, L.dev2(), u, f, out);
