@@ -924,7 +924,7 @@ int residRestrict(te_gmg *g, LevelHost &L, const double *u, const double *f, dou
 	}
 }
 template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1,
-                                 bool zero_guess)
+                                 bool zero_guess, const double *prolong_from)
 {
 	const size_t total = (size_t) L.P * L.nc;
 	int          rc;
@@ -934,9 +934,16 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 		// interface term (gamma = 0) and u is overwritten without being read.
 		const dim3 gp(L.P), b256(256);
 		if (!zero_guess) {
-			if ((rc = prepareGhosts<N>(g, L, u))) return rc;
+			ProlongSrc ps;
+			ps.parent = L.parent.p;
+			ps.orth   = L.orth.p;
+			ps.coarse = prolong_from;
+			if (!prolong_from && (rc = prepareGhosts<N>(g, L, u))) return rc; // prolong_from implies: no ghost slots
 			Timed t(g, KC_PATCH_RHS, (size_t) L.P * 6 * L.nf);
-			hipLaunchKernelGGL(k_face_corr3d<N>, dim3(L.P * 6), b256, 0, g->stream, L.dev(), u, L.corr.p);
+			if (prolong_from)
+				hipLaunchKernelGGL((k_face_corr3d<N, true>), dim3(L.P * 6), b256, 0, g->stream, L.dev(), u, L.corr.p, ps);
+			else
+				hipLaunchKernelGGL((k_face_corr3d<N, false>), dim3(L.P * 6), b256, 0, g->stream, L.dev(), u, L.corr.p, ps);
 		}
 		{
 			Timed t(g, KC_PS_MFMA, total);
@@ -981,16 +988,17 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
-int patchSolve(te_gmg *g, LevelHost &L, const double *f, double *u, bool zero_guess = false)
+int patchSolve(te_gmg *g, LevelHost &L, const double *f, double *u, bool zero_guess = false,
+               const double *prolong_from = nullptr)
 {
 	if (L.P == 0) return TE_OK;
 	double *s0 = L.r->d, *s1 = L.t->d;
 	if (L.dim == 2) return patchSolve2d(g, L, f, u, s0, s1);
 	switch (L.n) {
-		case 4: return patchSolveN<4>(g, L, f, u, s0, s1, zero_guess);
-		case 8: return patchSolveN<8>(g, L, f, u, s0, s1, zero_guess);
-		case 16: return patchSolveN<16>(g, L, f, u, s0, s1, zero_guess);
-		default: return patchSolveN<32>(g, L, f, u, s0, s1, zero_guess);
+		case 4: return patchSolveN<4>(g, L, f, u, s0, s1, zero_guess, prolong_from);
+		case 8: return patchSolveN<8>(g, L, f, u, s0, s1, zero_guess, prolong_from);
+		case 16: return patchSolveN<16>(g, L, f, u, s0, s1, zero_guess, prolong_from);
+		default: return patchSolveN<32>(g, L, f, u, s0, s1, zero_guess, prolong_from);
 	}
 }
 template <int N> int restrictN(te_gmg *g, LevelHost &L, const double *fine, double *coarse)
@@ -1148,6 +1156,11 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 			if (pending_prolong) {
 				const double *c = pending_prolong;
 				pending_prolong = nullptr;
+				if (sm == TE_SMOOTH_PATCH_SOLVE) { // reads u + P c on the face layers only, then overwrites u
+					L.xf_valid_for = nullptr;
+					if ((r = patchSolve(g, L, f->d, u->d, false, c))) return r;
+					continue;
+				}
 				if ((r = launchRbgs(g, L, u->d, f->d, L.t->d, false, c, xfFor(L, u->d), L.xfbuf[L.xf_cur ^ 1].p))) return r;
 				xfProduced(L, L.t->d);
 				swapData(u, L.t.get());
@@ -1182,7 +1195,8 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         if ((r = visit(g, o, l + 1, C.f.get(), C.u.get(), o->fuse != 0))) return r;
         // prepFiner (Cycle.h:74-80). When the very next step is an RB-GS sweep on a level without ghost
         // slots, that sweep reads u + P(coarse u) on the fly instead (same bits, one HBM pass less).
-        if (o->fuse && L.prolong_fusable && o->smoother == TE_SMOOTH_RBGS && next_sweeps > 0) {
+        if (o->fuse && L.prolong_fusable && next_sweeps > 0
+            && (o->smoother == TE_SMOOTH_RBGS || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.n == 32 && !getenv("TE_PS_SLOW")))) {
             pending_prolong = C.u->d;
             return TE_OK;
         }

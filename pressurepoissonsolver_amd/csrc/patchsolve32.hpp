@@ -14,7 +14,7 @@
 //   k_ps_z             : z forward, eigenvalue divide, z inverse             (8 + 8)
 //   k_ps_xy<INV=true>  : per z-plane, x then y inverse transform, (2/N)^3    (8 + 8)
 #pragma once
-#include "kernels3d.hpp"
+#include "march3d.hpp"
 
 namespace te
 {
@@ -28,8 +28,12 @@ __device__ __forceinline__ v4f64 mfma_f64(double a, double b, v4f64 c)
 // Interface term of the patch right-hand side, StarPatchOp::addInterfaceToRHS (StarPatchOp.h:185-203):
 // corr[p][s][a + N b] = (2/h^2) gamma = rh2 * (m + ghost) on faces that have a neighbour, 0 on
 // physical faces. One workgroup per patch face; only face layers are touched (6/N of the sites).
-template <int N>
-__global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *__restrict__ u, double *__restrict__ corr)
+// PROLONG: the iterate is u + P(coarse) (DrctIntp.h:99-106) without that sum ever being stored: a block-
+// Jacobi sweep overwrites u and reads the old iterate ONLY through these interface terms, so the
+// prolongation has to be evaluated on the face layers alone (levels without ghost slots, see ProlongSrc).
+template <int N, bool PROLONG>
+__global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *__restrict__ u, double *__restrict__ corr,
+                                                     ProlongSrc ps)
 {
 	constexpr int NN = N * N, NNN = N * N * N;
 	const int     p = blockIdx.x / 6, s = blockIdx.x % 6, ax = s >> 1;
@@ -38,13 +42,25 @@ __global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *_
 	const int     mine = (s & 1) ? (N - 1) * sn : 0, oth = (s & 1) ? 0 : (N - 1) * sn;
 	const double  rh = L.rh2[(size_t) p * 3 + ax];
 	double       *c  = corr + ((size_t) p * 6 + s) * NN;
+	const double *cm = nullptr, *cn = nullptr; // coarse octants of this patch / of the neighbour
+	if (PROLONG && kind == FACE_LOCAL) {
+		cm = coarseOctant<N>(ps, p);
+		cn = coarseOctant<N>(ps, src);
+	}
 	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
 		double v = 0.0;
 		if (kind >= FACE_LOCAL) {
-			const int    cell = (i % N) * sa + (i / N) * sb;
-			const double m    = u[(size_t) p * NNN + mine + cell];
-			const double gh   = (kind == FACE_LOCAL) ? u[(size_t) src * NNN + oth + cell] : L.ghost[(size_t) src * NN + i];
-			v                 = 2.0 * rh * (0.5 * m + 0.5 * gh);
+			const int a = i % N, b = i / N;
+			const int cell = a * sa + b * sb;
+			double    m    = u[(size_t) p * NNN + mine + cell];
+			double    gh   = (kind == FACE_LOCAL) ? u[(size_t) src * NNN + oth + cell] : L.ghost[(size_t) src * NN + i];
+			if (PROLONG && kind == FACE_LOCAL) {
+				// coarse cell of fine (x, y, z): x/2 + N (y/2) + N^2 (z/2); on the face layer the normal index is 0 or N-1
+				const int ccell = (a / 2) * sa + (b / 2) * sb;
+				m += cm[ccell + ((s & 1) ? (N / 2 - 1) * sn : 0)];
+				gh += cn[ccell + ((s & 1) ? 0 : (N / 2 - 1) * sn)];
+			}
+			v = 2.0 * rh * (0.5 * m + 0.5 * gh);
 		}
 		c[i] = v;
 	}
