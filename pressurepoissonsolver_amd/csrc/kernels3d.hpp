@@ -69,16 +69,11 @@ __device__ __forceinline__ int xcdRemap(int b, int nblocks)
 // plane; keeping those in flight across the barrier is what lets the plane pipeline stream.
 __device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Plane tiling used by the marching kernels: each thread owns CPT pairs of x-adjacent cells
-// (16 B per lane, the widest coalesced access), pair q of a plane = cells 2q, 2q+1.
+// LDS plane of the marching kernels (march3d.hpp): [pad, west halo, N cells, east halo, pad] per row so that
+// the interior is 16-B aligned for ds_read/write_b128, plus one halo row below and above.
 template <int N> struct Tile2 {
-	static constexpr int  NP   = N * N / 2;
-	static constexpr int  TPB  = NP < 64 ? 64 : (NP > 256 ? 256 : NP);
-	static constexpr int  CPT  = (NP + TPB - 1) / TPB;
-	static constexpr bool FULL = (NP % TPB == 0);
-	static constexpr int  LW   = N + 4; // [pad, west halo, N cells, east halo, pad]: interior 16-B aligned
-	static constexpr int  LSZ  = LW * (N + 2);
-	static_assert(4 * N <= TPB, "one halo entry per thread");
+	static constexpr int LW  = N + 4;
+	static constexpr int LSZ = LW * (N + 2);
 };
 
 // A plane just outside the patch in z, as "sign * memory": FACE_LOCAL -> the neighbour's facing
