@@ -932,7 +932,13 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 		// matrix-core path (patchsolve32.hpp): interface terms on the face layers only, then x,y forward
 		// per plane; z forward + eigenvalue divide + z inverse; x,y inverse. A zero initial guess has no
 		// interface term (gamma = 0) and u is overwritten without being read.
-		const dim3 gp(L.P), b256(256);
+		// few patches: the three-pass kernels, each patch spread over `seg` workgroups (one patch per CU would
+		// leave most of the chip idle and a single solve takes ~80 us); otherwise the single-pass kernel
+		// (TE_PS_MODE = 1pass | 3pass pins the choice; 3pass also pins one workgroup per patch: tests)
+		const char *mode     = getenv("TE_PS_MODE");
+		const bool  one_pass = mode ? !strcmp(mode, "1pass") : L.P >= 256;
+		const int   seg      = (one_pass || mode) ? 1 : (L.P >= 128 ? 2 : (L.P >= 64 ? 4 : 8));
+		const dim3 gp(L.P, seg), b256(256);
 		if (!zero_guess) {
 			ProlongSrc ps;
 			ps.parent = L.parent.p;
@@ -945,10 +951,34 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 			else
 				hipLaunchKernelGGL((k_face_corr3d<N, false>), dim3(L.P * 6), b256, 0, g->stream, L.dev(), u, L.corr.p, ps);
 		}
+		if (one_pass) { // the whole solve in one pass over HBM (k_ps_fused)
+			static bool lds_ok = false;
+			if (!lds_ok) {
+				HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_fused<false>),
+				                           hipFuncAttributeMaxDynamicSharedMemorySize, PSF_LDS_BYTES));
+				HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_fused<true>),
+				                           hipFuncAttributeMaxDynamicSharedMemorySize, PSF_LDS_BYTES));
+				lds_ok = true;
+			}
+			Timed      t(g, KC_PS_MFMA, total);
+			const dim3 gf(8 * ((L.P + 7) / 8)), b512(512);
+			if (zero_guess)
+				hipLaunchKernelGGL(k_ps_fused<false>, gf, b512, PSF_LDS_BYTES, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p,
+				                   L.zero_mode.p, L.rh2.p, f, (const double *) nullptr, u);
+			else
+				hipLaunchKernelGGL(k_ps_fused<true>, gf, b512, PSF_LDS_BYTES, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p,
+				                   L.zero_mode.p, L.rh2.p, f, (const double *) L.corr.p, u);
+			HIPCHK(hipGetLastError());
+			return TE_OK;
+		}
 		{
 			Timed t(g, KC_PS_MFMA, total);
-			hipLaunchKernelGGL(k_ps_xy<false>, gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, f,
-			                   zero_guess ? (const double *) nullptr : (const double *) L.corr.p, s1);
+			if (zero_guess)
+				hipLaunchKernelGGL((k_ps_xy<false, false>), gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, f,
+				                   (const double *) nullptr, s1);
+			else
+				hipLaunchKernelGGL((k_ps_xy<false, true>), gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, f,
+				                   (const double *) L.corr.p, s1);
 		}
 		{
 			Timed t(g, KC_PS_MFMA, total);

@@ -68,14 +68,16 @@ __global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *_
 
 // mats: [nplans][6][32*32] row-major (forward x,y,z then inverse x,y,z); y_i = sum_j M[i*32+j] x_j
 // corr (forward pass only, may be null = zero initial guess, no interface term): see k_face_corr3d.
-template <bool INV>
+template <bool INV, bool CORR = false>
 __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict__ plan,
                                                const double *__restrict__ mats, const double *__restrict__ in,
                                                const double *__restrict__ corr, double *__restrict__ out)
 {
 	constexpr int N = 32, NN = N * N;
 	const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, g = l >> 4;
-	const int pid  = blockIdx.x; // one workgroup per patch; wave w owns planes w, w+4, ..., w+28
+	// one workgroup per patch and segment: wave w owns planes w + 4 it, it in [it0, it0 + 8 / gridDim.y)
+	// (gridDim.y > 1 spreads the few patches of a coarse level over more CUs)
+	const int pid = blockIdx.x, its = 8 / gridDim.y, it0 = blockIdx.y * its;
 	if (pid >= P) return;
 	const int     pl = plan[pid];
 	const double *Mx = mats + ((size_t) pl * 6 + (INV ? 3 : 0)) * NN;
@@ -101,7 +103,8 @@ __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict_
 	// 4ks + g]: a load touches 16 rows x 32 B; the 8 k-steps together consume each row's 256 B, served
 	// from L1 after the first touch. No LDS, no barrier, the next plane is in flight during the MFMAs.
 	const int     aoff = j * N + g;
-	const double *cr   = (!INV && corr) ? corr + (size_t) pid * 6 * NN : nullptr;
+	const double *cr   = CORR ? corr + (size_t) pid * 6 * NN : nullptr;
+	static_assert(!(INV && CORR), "interface terms belong to the forward pass");
 	// element (y = 16mb + j, x = 4ks + g) of plane z, minus the interface terms of the faces it lies on,
 	// subtracted in the reference's side order W/E, S/N, B/T
 	// The x- and y-face terms are loaded unconditionally and masked (no divergent branch around a load,
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict_
 #pragma unroll
 			for (int ks = 0; ks < 8; ks++) {
 				double v = ip[16 * mb * N + 4 * ks];
-				if (!INV && cr) {
+				if (CORR) { // compile-time: a run-time test here puts every load in its own block with its own wait
 					const int y = 16 * mb + j, x = 4 * ks + g;
 					if (ks == 0) v -= mW * cr[0 * NN + y + N * z];
 					if (ks == 7) v -= mE * cr[1 * NN + y + N * z];
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict_
 				}
 				dst[mb][ks] = v;
 			}
-		if (!INV && cr && (z == 0 || z == N - 1)) {
+		if (CORR && (z == 0 || z == N - 1)) {
 			const double *cz = cr + (z == 0 ? 4 : 5) * NN;
 #pragma unroll
 			for (int mb = 0; mb < 2; mb++)
@@ -132,16 +135,16 @@ __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict_
 		}
 	};
 	double nxt[2][8];
-	fetch(nxt, wave);
+	fetch(nxt, wave + 4 * it0);
 #pragma unroll 1
-	for (int it = 0; it < 8; it++) {
+	for (int it = it0; it < it0 + its; it++) {
 		const int z = wave + 4 * it;
 		double    a[2][8];
 #pragma unroll
 		for (int mb = 0; mb < 2; mb++)
 #pragma unroll
 			for (int ks = 0; ks < 8; ks++) a[mb][ks] = nxt[mb][ks];
-		fetch(nxt, (it + 1 < 8) ? z + 4 : z);
+		fetch(nxt, (it + 1 < it0 + its) ? z + 4 : z);
 		// x transform: D1[row y = 16mb + g + 4r][col kx] = sum_x X[y][x] Mx[kx][x]
 		v4f64 d1[2][2];
 #pragma unroll
@@ -183,7 +186,8 @@ __global__ __launch_bounds__(256) void k_ps_z(int P, const int32_t *__restrict__
 {
 	constexpr int N = 32, NN = N * N, NNN = N * N * N;
 	const int     wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, g = l >> 4;
-	const int     pid  = blockIdx.x; // one workgroup per patch; wave w owns rows y = w, w+4, ...
+	const int     pid  = blockIdx.x; // one workgroup per patch and segment (see k_ps_xy); wave w owns rows y = w + 4 it
+	const int     its = 8 / gridDim.y, it0 = blockIdx.y * its;
 	if (pid >= P) return;
 	const int     pl = plan[pid];
 	const double *Mf = mats + ((size_t) pl * 6 + 2) * NN;
@@ -214,18 +218,18 @@ __global__ __launch_bounds__(256) void k_ps_z(int P, const int32_t *__restrict__
 
 	double2 nxt[8]; // B[k = z = 4ks + g][cols x = 2j, 2j+1]
 	{
-		const double *ip = in + (size_t) pid * NNN + wave * N;
+		const double *ip = in + (size_t) pid * NNN + (wave + 4 * it0) * N;
 #pragma unroll
 		for (int ks = 0; ks < 8; ks++) nxt[ks] = reinterpret_cast<const double2 *>(ip + (4 * ks + g) * NN)[j];
 	}
 #pragma unroll 1
-	for (int it = 0; it < 8; it++) {
+	for (int it = it0; it < it0 + its; it++) {
 		const int y = wave + 4 * it;
 		double2   v[8];
 #pragma unroll
 		for (int ks = 0; ks < 8; ks++) v[ks] = nxt[ks];
 		{
-			const int     yn = (it + 1 < 8) ? y + 4 : y;
+			const int     yn = (it + 1 < it0 + its) ? y + 4 : y;
 			const double *ip = in + (size_t) pid * NNN + yn * N;
 #pragma unroll
 			for (int ks = 0; ks < 8; ks++) nxt[ks] = reinterpret_cast<const double2 *>(ip + (4 * ks + g) * NN)[j];
@@ -262,6 +266,292 @@ __global__ __launch_bounds__(256) void k_ps_z(int P, const int32_t *__restrict__
 				}
 #pragma unroll
 			for (int r = 0; r < 4; r++) reinterpret_cast<double2 *>(op + (16 * mo + g + 4 * r) * NN)[j] = double2{e0[r], e1[r]};
+		}
+	}
+}
+
+// ---- single-pass patch solve -------------------------------------------------------------------
+// The three kernels above move every site through HBM three times (48 B/site). k_ps_fused keeps the
+// whole 32^3 patch on chip: one workgroup of 8 waves per patch, the patch lives in
+// registers (64 doubles per lane) and crosses between the "plane" distribution (x,y transforms: wave
+// w owns planes w, w+8, w+16, w+24) and the "column" distribution (z transform: wave w owns the
+// (z, kx) slabs of ky = 2w, 2w+1, 16+2w, 17+2w) through one 144 KiB LDS image, half a patch at a time:
+//   A   per plane: load f (minus interface terms), x,y forward            [as k_ps_xy<false>]
+//   X1  planes -> columns, ky halves (rows of the y-transform's two output tiles)
+//   Z   per slab: z forward, eigenvalue divide, zero mode, z inverse       [as k_ps_z]
+//   X2  columns -> planes, z halves; per plane x,y inverse, scale, store   [as k_ps_xy<true>]
+// 16 B/site of HBM traffic (read f, write u) + the face terms. The arithmetic (operands, MFMA order)
+// is that of the three-pass kernels, so the result is bit-identical to them.
+constexpr int PSF_S1        = 32 * 32;          // X1 image: [ky_local 16][z 32][kx 32], slab stride in doubles
+constexpr int PSF_P2        = 36;               // X2 image: [z_local 16][ky 32][kx 32 (+4)]: the A-layout reads of
+constexpr int PSF_S2        = 32 * PSF_P2;      //   phase C step 16 rows at once; pitch 36 spreads them over the banks
+constexpr int PSF_LDS_BYTES = 16 * PSF_S2 * 8; // 147456
+#ifdef PSF_TIMING // tools/psf_bench.hip: shader-clock stamps of workgroup 0 at the phase boundaries
+static __device__ long long psf_stamp[8][12];
+#define PSF_STAMP(k) do { if (blockIdx.x == 2048 && l == 0) psf_stamp[wave][k] = clock64(); } while (0)
+#else
+#define PSF_STAMP(k)
+#endif
+
+template <bool CORR>
+__global__ __launch_bounds__(512) void k_ps_fused(int P, const int32_t *__restrict__ plan, const double *__restrict__ mats,
+                                                  const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
+                                                  const double *__restrict__ rh2, const double *__restrict__ in,
+                                                  const double *__restrict__ corr, double *__restrict__ out)
+{
+	constexpr int N = 32, NN = N * N;
+	extern __shared__ __attribute__((aligned(16))) double xbuf[];
+	const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, g = l >> 4;
+	const int pid  = xcdRemap(blockIdx.x, P);
+	if (pid >= P) return;
+	const int     pl = plan[pid];
+	const double *M  = mats + (size_t) pl * 6 * NN;
+	PSF_STAMP(0);
+
+	// ---- A: x,y forward of this wave's four planes ---------------------------------------------
+	v4f64 hi[4][2]; // ky >= 16 half of the y-transform output, parked until the image is free again
+	{
+		const double *Mx = M, *My = M + NN;
+		double        bx[2][8], ay[2][2][4];
+#pragma unroll
+		for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+			for (int ks = 0; ks < 8; ks++) bx[nb][ks] = Mx[(2 * j + nb) * N + 4 * ks + g];
+#pragma unroll
+		for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+			for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) ay[mo][mb][r] = My[(16 * mo + j) * N + 16 * mb + g + 4 * r];
+
+		const int     aoff = j * N + g;
+		const double *cr   = CORR ? corr + (size_t) pid * 6 * NN : nullptr;
+		const double  mW = (g == 0) ? 1.0 : 0.0, mE = (g == 3) ? 1.0 : 0.0, mS = (j == 0) ? 1.0 : 0.0, mN = (j == 15) ? 1.0 : 0.0;
+		auto fetch = [&](double(&dst)[2][8], int z) { // see k_ps_xy
+			const double *ip = in + ((size_t) pid * N + z) * NN + aoff;
+#pragma unroll
+			for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+				for (int ks = 0; ks < 8; ks++) {
+					double v = ip[16 * mb * N + 4 * ks];
+					if (CORR) {
+						const int y = 16 * mb + j, x = 4 * ks + g;
+						if (ks == 0) v -= mW * cr[0 * NN + y + N * z];
+						if (ks == 7) v -= mE * cr[1 * NN + y + N * z];
+						if (mb == 0) v -= mS * cr[2 * NN + x + N * z];
+						if (mb == 1) v -= mN * cr[3 * NN + x + N * z];
+					}
+					dst[mb][ks] = v;
+				}
+			if (CORR && (z == 0 || z == N - 1)) {
+				const double *cz = cr + (z == 0 ? 4 : 5) * NN;
+#pragma unroll
+				for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+					for (int ks = 0; ks < 8; ks++) dst[mb][ks] -= cz[(4 * ks + g) + N * (16 * mb + j)];
+			}
+		};
+		double a[2][8];
+		fetch(a, wave);
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int z = wave + 8 * i;
+			v4f64     d1[2][2];
+#pragma unroll
+			for (int mb = 0; mb < 2; mb++) {
+				d1[mb][0] = d1[mb][1] = v4f64{0, 0, 0, 0};
+#pragma unroll
+				for (int ks = 0; ks < 8; ks++) {
+					d1[mb][0] = mfma_f64(a[mb][ks], bx[0][ks], d1[mb][0]);
+					d1[mb][1] = mfma_f64(a[mb][ks], bx[1][ks], d1[mb][1]);
+				}
+			}
+			if (i < 3) fetch(a, z + 8); // the next plane's loads fly behind the y transform
+#pragma unroll
+			for (int mo = 0; mo < 2; mo++) {
+				v4f64 e0 = v4f64{0, 0, 0, 0}, e1 = v4f64{0, 0, 0, 0};
+#pragma unroll
+				for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						e0 = mfma_f64(ay[mo][mb][r], d1[mb][0][r], e0);
+						e1 = mfma_f64(ay[mo][mb][r], d1[mb][1][r], e1);
+					}
+				if (mo == 0) {
+#pragma unroll
+					for (int r = 0; r < 4; r++)
+						*reinterpret_cast<double2 *>(xbuf + (g + 4 * r) * PSF_S1 + z * N + 2 * j) = double2{e0[r], e1[r]};
+				} else {
+					hi[i][0] = e0, hi[i][1] = e1;
+				}
+			}
+		}
+	}
+	PSF_STAMP(1);
+	ldsBarrier();
+	PSF_STAMP(2);
+
+	// ---- X1: this wave's four (z, kx) slabs; V[t] = slab of ky = 16 (t >> 1) + 2 wave + (t & 1) ----
+	double2 V[4][8]; // B[k = z = 4ks + g][cols kx = 2j, 2j + 1]
+#pragma unroll
+	for (int t = 0; t < 2; t++)
+#pragma unroll
+		for (int ks = 0; ks < 8; ks++)
+			V[t][ks] = *reinterpret_cast<const double2 *>(xbuf + (2 * wave + t) * PSF_S1 + (4 * ks + g) * N + 2 * j);
+	ldsBarrier();
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+#pragma unroll
+		for (int r = 0; r < 4; r++)
+			*reinterpret_cast<double2 *>(xbuf + (g + 4 * r) * PSF_S1 + (wave + 8 * i) * N + 2 * j) = double2{hi[i][0][r], hi[i][1][r]};
+	ldsBarrier();
+#pragma unroll
+	for (int t = 0; t < 2; t++)
+#pragma unroll
+		for (int ks = 0; ks < 8; ks++)
+			V[2 + t][ks] = *reinterpret_cast<const double2 *>(xbuf + (2 * wave + t) * PSF_S1 + (4 * ks + g) * N + 2 * j);
+
+	PSF_STAMP(3);
+	// ---- Z: forward, divide by the eigenvalue, inverse -------------------------------------------
+	v4f64 D[4][2][2]; // [slab][mb][even / odd kx]: rows kz = 16mb + g + 4r
+	{
+		const double *Mf = M + 2 * NN;
+		double        af[2][8];
+#pragma unroll
+		for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+			for (int ks = 0; ks < 8; ks++) af[mb][ks] = Mf[(16 * mb + j) * N + 4 * ks + g];
+		const double *lm = lam + (size_t) pl * 3 * N;
+		const double *rh = rh2 + (size_t) pid * 3;
+		const double  lx0 = lm[2 * j] * rh[0], lx1 = lm[2 * j + 1] * rh[0];
+		double        ez[2][4];
+#pragma unroll
+		for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) ez[mb][r] = lm[2 * N + 16 * mb + g + 4 * r] * rh[2];
+		const bool zmp = zero_mode[pl] != 0;
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const int    ky   = 16 * (t >> 1) + 2 * wave + (t & 1);
+			const double ly   = lm[N + ky] * rh[1];
+			const double exy0 = lx0 + ly, exy1 = lx1 + ly;
+			const bool   zm   = zmp && ky == 0 && j == 0;
+#pragma unroll
+			for (int mb = 0; mb < 2; mb++) {
+				v4f64 d0 = v4f64{0, 0, 0, 0}, d1 = v4f64{0, 0, 0, 0};
+#pragma unroll
+				for (int ks = 0; ks < 8; ks++) {
+					d0 = mfma_f64(af[mb][ks], V[t][ks].x, d0);
+					d1 = mfma_f64(af[mb][ks], V[t][ks].y, d1);
+				}
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+#ifdef PSF_NODIV
+					d0[r] *= -(exy0 + ez[mb][r]);
+					d1[r] *= -(exy1 + ez[mb][r]);
+#else
+					d0[r] /= -(exy0 + ez[mb][r]);
+					d1[r] /= -(exy1 + ez[mb][r]);
+#endif
+					if (zm && 16 * mb + g + 4 * r == 0) d0[r] = 0.0; // FftwPatchSolver.h:197
+				}
+				D[t][mb][0] = d0, D[t][mb][1] = d1;
+			}
+		}
+	}
+	PSF_STAMP(4);
+	v4f64 E[4][2][2]; // [slab][mo][even / odd kx]: rows z = 16mo + g + 4r
+	{
+		const double *Mi = M + 5 * NN;
+		double        ai[2][2][4];
+#pragma unroll
+		for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+			for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) ai[mo][mb][r] = Mi[(16 * mo + j) * N + 16 * mb + g + 4 * r];
+#pragma unroll
+		for (int t = 0; t < 4; t++)
+#pragma unroll
+			for (int mo = 0; mo < 2; mo++) {
+				v4f64 e0 = v4f64{0, 0, 0, 0}, e1 = v4f64{0, 0, 0, 0};
+#pragma unroll
+				for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						e0 = mfma_f64(ai[mo][mb][r], D[t][mb][0][r], e0);
+						e1 = mfma_f64(ai[mo][mb][r], D[t][mb][1][r], e1);
+					}
+				E[t][mo][0] = e0, E[t][mo][1] = e1;
+			}
+	}
+
+	PSF_STAMP(5);
+	// ---- X2 + C: back to planes, z halves; x,y inverse, scale, store ------------------------------
+	{
+		const double *Mx = M + 3 * NN, *My = M + 4 * NN;
+		double        bx[2][8], ay[2][2][4];
+#pragma unroll
+		for (int nb = 0; nb < 2; nb++)
+#pragma unroll
+			for (int ks = 0; ks < 8; ks++) bx[nb][ks] = Mx[(2 * j + nb) * N + 4 * ks + g];
+#pragma unroll
+		for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+			for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) ay[mo][mb][r] = My[(16 * mo + j) * N + 16 * mb + g + 4 * r];
+		constexpr double scale = 8.0 / (32.0 * 32.0 * 32.0); // (2/N)^3, DftPatchSolver.h:214
+#pragma unroll
+		for (int zh = 0; zh < 2; zh++) {
+			ldsBarrier(); // every wave is done reading the previous image
+			PSF_STAMP(6 + 3 * zh);
+#pragma unroll
+			for (int t = 0; t < 4; t++) {
+				const int ky = 16 * (t >> 1) + 2 * wave + (t & 1);
+#pragma unroll
+				for (int r = 0; r < 4; r++)
+					*reinterpret_cast<double2 *>(xbuf + (g + 4 * r) * PSF_S2 + ky * PSF_P2 + 2 * j) =
+					    double2{E[t][zh][0][r], E[t][zh][1][r]};
+			}
+			ldsBarrier();
+			PSF_STAMP(7 + 3 * zh);
+#pragma unroll
+			for (int ii = 0; ii < 2; ii++) {
+				const int     zl = wave + 8 * ii, z = 16 * zh + zl;
+				const double *ip = xbuf + zl * PSF_S2 + j * PSF_P2 + g; // A[i = ky = 16mb + j][k = kx = 4ks + g]
+				double        a[2][8];
+#pragma unroll
+				for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+					for (int ks = 0; ks < 8; ks++) a[mb][ks] = ip[16 * mb * PSF_P2 + 4 * ks];
+				v4f64 d1[2][2];
+#pragma unroll
+				for (int mb = 0; mb < 2; mb++) {
+					d1[mb][0] = d1[mb][1] = v4f64{0, 0, 0, 0};
+#pragma unroll
+					for (int ks = 0; ks < 8; ks++) {
+						d1[mb][0] = mfma_f64(a[mb][ks], bx[0][ks], d1[mb][0]);
+						d1[mb][1] = mfma_f64(a[mb][ks], bx[1][ks], d1[mb][1]);
+					}
+				}
+				double *op = out + ((size_t) pid * N + z) * NN;
+#pragma unroll
+				for (int mo = 0; mo < 2; mo++) {
+					v4f64 e0 = v4f64{0, 0, 0, 0}, e1 = v4f64{0, 0, 0, 0};
+#pragma unroll
+					for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+						for (int r = 0; r < 4; r++) {
+							e0 = mfma_f64(ay[mo][mb][r], d1[mb][0][r], e0);
+							e1 = mfma_f64(ay[mo][mb][r], d1[mb][1][r], e1);
+						}
+#pragma unroll
+					for (int r = 0; r < 4; r++)
+						reinterpret_cast<double2 *>(op + (16 * mo + g + 4 * r) * N)[j] = double2{e0[r] * scale, e1[r] * scale};
+				}
+			}
+			PSF_STAMP(8 + 3 * zh);
 		}
 	}
 }

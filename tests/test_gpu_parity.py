@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 CASES = [("2uni.bin", 8, 0, False), ("2refine.bin", 8, 0, False), ("3uni.bin", 4, 0, False), ("2uni.bin", 16, 1, False),
          ("2refine.bin", 16, 1, False), ("uniform", 32, 1, False), ("1uni.bin", 8, 0, False),
          ("2uni.bin", 8, 0, True), ("2refine.bin", 8, 0, True), ("1uni.bin", 16, 0, True),
+         ("uniform", 32, 1, True), ("2refine.bin", 32, 0, False),  # 32^3: the matrix-core patch solve, every transform type
          # 2D twins (configs C1: one 256^2 patch; C5-style: 64^2 patches; refined quadtree; Neumann)
          ("2d2uni.bin", 8, 0, False), ("2d2ref.bin", 8, 0, False), ("2d2ref.bin", 16, 1, False), ("2d2ref.bin", 8, 0, True),
          ("uniform2d", 256, 0, False), ("uniform2d", 64, 2, False)]
@@ -96,6 +97,31 @@ def test_block_jacobi_patch_solve(case):
         du, df = g.new_vector(l, u), g.new_vector(l, f)
         g.smooth(df, du, level=l, smoother=capi.SMOOTH_PATCH_SOLVE)
         assert rel(du.download(), orc.smooth(L, f, u)) <= 1e-11
+
+
+def test_patch_solve_single_pass_is_three_pass(case, monkeypatch):
+    """k_ps_fused (one HBM pass, patch resident in registers/LDS) runs the same MFMA sequence as the
+    three-pass kernels, and so do the three-pass kernels when a patch is split over several workgroups
+    (the automatic choice on levels with few patches): bit-identical, with and without interface terms
+    (zero-guess sweep inside a cycle)."""
+    if case["n"] != 32 or case["dim"] != 3:
+        pytest.skip("the matrix-core patch solve is the 32^3 path")
+    g, L = case["g"], case["levels"][0]
+    u = util.rand_vec(L.size, 41)
+    f = util.rand_vec(L.size, 51) / L.a["h"].min() ** 2
+    got = {}
+    for mode in ("1pass", "3pass", None):
+        if mode:
+            monkeypatch.setenv("TE_PS_MODE", mode)
+        else:
+            monkeypatch.delenv("TE_PS_MODE", raising=False)
+        du, df, dc = g.new_vector(0, u), g.new_vector(0, f), g.new_vector(0)
+        g.smooth(df, du, level=0, smoother=capi.SMOOTH_PATCH_SOLVE)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, dc)
+        got[mode] = (du.download(), dc.download())
+    for mode in ("3pass", None):
+        assert np.array_equal(got["1pass"][0], got[mode][0])
+        assert np.array_equal(got["1pass"][1], got[mode][1])
 
 
 def test_blas1(case):
