@@ -6,6 +6,7 @@
 #include "march3d.hpp"
 #include "kernels2d.hpp"
 #include "patchsolve32.hpp"
+#include "patchsolve32_sym.hpp"
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -100,6 +101,8 @@ struct LevelHost {
 	// patch solve
 	DevBuf<int32_t> plan, zero_mode;
 	DevBuf<double>  mats, lam, corr; // corr: [P][6][n^2] interface terms of the patch right-hand sides
+	DevBuf<double>  matsym;          // half matrices in MFMA fragment order (patchsolve32_sym.hpp), 32^3 patches
+	bool            sym_ok = false;  // every plan of the level has pure (DST-II/III or DCT-II/III) axes
 	// scratch
 	std::unique_ptr<te_vec> u, f, r, t;
 
@@ -490,6 +493,33 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 					lam[((size_t) k * D + a) * n + i] = 4 * s * s;
 				}
 			}
+		}
+		if (D == 3 && n == 32) { // k_ps_sym's tables: [plan][transform 6][parity 2][k-step 4][lane 64]
+			std::vector<double> fs((size_t) np * PSS_FRAG, 0.0);
+			bool                pure = true;
+			for (int k = 0; k < np; k++)
+				for (int a = 0; a < 3; a++) {
+					const bool lo = (keys[k] >> (2 * a)) & 1, hi = (keys[k] >> (2 * a + 1)) & 1;
+					if (lo != hi) {
+						pure = false;
+						continue;
+					}
+					const double *F = &mats[((size_t) k * 6 + a) * n * n], *G = &mats[((size_t) k * 6 + 3 + a) * n * n];
+					for (int p = 0; p < 2; p++)
+						for (int q = 0; q < 4; q++)
+							for (int ln = 0; ln < 64; ln++) {
+								const int j = ln & 15, g = ln >> 4;
+								// forward: y as B operand and z as A operand take k = n = 4q + g, x as A operand k = g + 4q
+								// (y comes first in the kernel: slot 0 = y, 1 = x, 2 = z)
+								// inverse: x as B operand (k = m = 4q + g), y and z as A operands with k = m = g + 4q
+								const int nf = (a == 0) ? g + 4 * q : 4 * q + g, mi = (a == 0) ? 4 * q + g : g + 4 * q;
+								const int sf = (a == 0) ? 1 : (a == 1 ? 0 : 2);
+								fs[(size_t) k * PSS_FRAG + ((sf * 2 + p) * 4 + q) * 64 + ln]      = F[(2 * j + p) * n + nf];
+								fs[(size_t) k * PSS_FRAG + (((3 + a) * 2 + p) * 4 + q) * 64 + ln] = G[j * n + 2 * mi + p];
+							}
+				}
+			L->sym_ok = pure;
+			if ((rc = L->matsym.upload(fs))) return rc;
 		}
 		if ((rc = L->corr.alloc((size_t) std::max(P, 1) * NS * L->nf))) return rc;
 		if ((rc = L->plan.upload(plan)) || (rc = L->mats.upload(mats)) || (rc = L->lam.upload(lam))
@@ -934,9 +964,9 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 		// interface term (gamma = 0) and u is overwritten without being read.
 		// few patches: the three-pass kernels, each patch spread over `seg` workgroups (one patch per CU would
 		// leave most of the chip idle and a single solve takes ~80 us); otherwise the single-pass kernel
-		// (TE_PS_MODE = 1pass | 3pass pins the choice; 3pass also pins one workgroup per patch: tests)
+		// (TE_PS_MODE = 1pass | 1pass-dense | 3pass pins the choice; 3pass also pins one workgroup per patch: tests)
 		const char *mode     = getenv("TE_PS_MODE");
-		const bool  one_pass = mode ? !strcmp(mode, "1pass") : L.P >= 256;
+		const bool  one_pass = mode ? !strncmp(mode, "1pass", 5) : L.P >= 256;
 		const int   seg      = (one_pass || mode) ? 1 : (L.P >= 128 ? 2 : (L.P >= 64 ? 4 : 8));
 		const dim3 gp(L.P, seg), b256(256);
 		if (!zero_guess) {
@@ -953,21 +983,42 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 		}
 		if (one_pass) { // the whole solve in one pass over HBM (k_ps_fused)
 			static bool lds_ok = false;
+			static int  ncu    = 0;
 			if (!lds_ok) {
+				int dev = 0;
+				HIPCHK(hipGetDevice(&dev));
+				HIPCHK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
 				HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_fused<false>),
 				                           hipFuncAttributeMaxDynamicSharedMemorySize, PSF_LDS_BYTES));
 				HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_fused<true>),
 				                           hipFuncAttributeMaxDynamicSharedMemorySize, PSF_LDS_BYTES));
+				HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_sym<false>),
+				                           hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS_BYTES));
+				HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_sym<true>),
+				                           hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS_BYTES));
 				lds_ok = true;
 			}
-			Timed      t(g, KC_PS_MFMA, total);
-			const dim3 gf(8 * ((L.P + 7) / 8)), b512(512);
-			if (zero_guess)
-				hipLaunchKernelGGL(k_ps_fused<false>, gf, b512, PSF_LDS_BYTES, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p,
-				                   L.zero_mode.p, L.rh2.p, f, (const double *) nullptr, u);
-			else
-				hipLaunchKernelGGL(k_ps_fused<true>, gf, b512, PSF_LDS_BYTES, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p,
-				                   L.zero_mode.p, L.rh2.p, f, (const double *) L.corr.p, u);
+			Timed         t(g, KC_PS_MFMA, total);
+			const dim3    b512(512);
+			const double *cp = zero_guess ? (const double *) nullptr : (const double *) L.corr.p;
+			if (L.sym_ok && !(mode && !strcmp(mode, "1pass-dense"))) {
+				// pure axes: half-size transforms; one resident workgroup per CU walks over the patches
+				const dim3 gs(std::min(L.P, ncu));
+				if (zero_guess)
+					hipLaunchKernelGGL(k_ps_sym<false>, gs, b512, PSS_LDS_BYTES, g->stream, L.P, L.plan.p, L.matsym.p, L.lam.p,
+					                   L.zero_mode.p, L.rh2.p, f, cp, u);
+				else
+					hipLaunchKernelGGL(k_ps_sym<true>, gs, b512, PSS_LDS_BYTES, g->stream, L.P, L.plan.p, L.matsym.p, L.lam.p,
+					                   L.zero_mode.p, L.rh2.p, f, cp, u);
+			} else {
+				const dim3 gf(8 * ((L.P + 7) / 8));
+				if (zero_guess)
+					hipLaunchKernelGGL(k_ps_fused<false>, gf, b512, PSF_LDS_BYTES, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p,
+					                   L.zero_mode.p, L.rh2.p, f, cp, u);
+				else
+					hipLaunchKernelGGL(k_ps_fused<true>, gf, b512, PSF_LDS_BYTES, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p,
+					                   L.zero_mode.p, L.rh2.p, f, cp, u);
+			}
 			HIPCHK(hipGetLastError());
 			return TE_OK;
 		}

@@ -1,0 +1,373 @@
+// Single-pass patch solve with half-size transforms, for patches whose three axes are "pure": DST-II/III
+// (interface or Dirichlet on both sides) or DCT-II/III (Neumann on both sides). Those 32x32 matrices are
+// (anti)symmetric under n -> 31-n, F[k][31-n] = (-1)^k F[k][n] (same for the inverse in its row index),
+// so a 32-point transform is a butterfly plus two 16x16 products:
+//     forward  y[2m+p] = sum_{n<16} F[2m+p][n] (x[n] + (-1)^p x[31-n])
+//     inverse  x[n], x[31-n] = P[n] +- Q[n],  P = sum_m G[n][2m] y[2m],  Q = sum_m G[n][2m+1] y[2m+1]
+// which halves the work on the fp64 matrix cores (MI355X: the same peak as the vector ALUs, 64 cycles per
+// v_mfma_f64_16x16x4, so the dense form is bound by them). The butterflies stay inside a lane because
+// every tile that feeds one is produced with its upper half in mirrored order (rows 31-r instead of 16+r),
+// which costs nothing: row order is set by load addresses or by the previous product's matrix fragment.
+// Frequencies come out split by parity (even block, odd block); only the eigenvalue lookup notices.
+//
+// Data flow (one 8-wave workgroup per CU walks over patches; lane = (j = l & 15, g = l >> 4)):
+//   A    wave w owns planes z = w, w+8, w+16, w+24. Per plane: load f in the y transform's A-operand layout
+//        (sixteen lanes read 128 contiguous bytes), subtract the interface terms, y forward (data as A
+//        operand: x moves to the rows), x forward (B operand). Result rows kx = 2r+parity, cols ky.
+//        Even kx go to the LDS image [kx/2][z][ky] (128 KiB = half a patch), odd kx wait in registers.
+//   Z    wave w owns the (z, ky) slabs kx/2 = 2w, 2w+1 of the image: z forward, eigenvalue divide, zero mode,
+//        z inverse, written back IN PLACE. The same image therefore serves both exchanges: planes write rows
+//        (slab, z, :), slabs read (slab, :, :), planes read their rows back.
+//   C1   per plane: P = the even-kx half of the x inverse (the parity split of the half transforms is the
+//        split of the image), kept in registers; then the odd-kx half goes through the image (Z again) and
+//   C2   per plane: Q = odd-kx half, x = P +- Q, y inverse, scale, store.
+// The matrix fragments (24 KiB per plan) sit in LDS, so the loop issues no loads but the planes themselves:
+// loads return in order, and a table load queued behind a plane from HBM would stall the transforms.
+// Only one patch fits a CU, so nothing but this workgroup can hide its own load latency: the first two
+// planes of the NEXT patch are requested during the second z stage (registers are free, no stores are
+// queued behind them), the other two while the first ones are processed. Interface terms of a plane's ring
+// (128 doubles) arrive with two coalesced loads per lane one plane ahead and are dealt out through a
+// per-wave LDS strip. Mixed Dirichlet/Neumann axes (type-IV transforms) have no such symmetry: those levels
+// use k_ps_fused.
+#pragma once
+#include "patchsolve32.hpp"
+
+namespace te
+{
+// fragment-ordered half matrices, per plan: [transform 6][parity 2][k-step 4][lane 64]
+//   0 y fwd  B[k = n = 4q+g][col j]  = Fy[2j+p][4q+g]        3 x inv  B[k = m = 4q+g][col j] = Gx[j][2(4q+g)+p]
+//   1 x fwd  A[i = j][k = n = g+4q]  = Fx[2j+p][g+4q]        4 y inv  A[i = j][k = m = g+4q] = Gy[j][2(g+4q)+p]
+//   2 z fwd  A[i = j][k = n = 4q+g]  = Fz[2j+p][4q+g]        5 z inv  A[i = j][k = m = g+4q] = Gz[j][2(g+4q)+p]
+constexpr int PSS_FRAG      = 6 * 2 * 4 * 64;
+constexpr int PSS_SLAB      = 32 * 32;                             // image: [kx/2 16][z 32][ky 32] doubles
+constexpr int PSS_RING      = 16 * PSS_SLAB;                       // per-wave ring strips: [wave 8][128]
+constexpr int PSS_TAB       = PSS_RING + 8 * 128;                  // the current plan's fragment table
+constexpr int PSS_LDS_BYTES = (PSS_TAB + PSS_FRAG) * 8;            // 163840: all of a CU's LDS
+#ifdef PSF_TIMING
+static __device__ long long pss_stamp[8][12];
+#define PSS_STAMP(k) do { if (blockIdx.x == 100 && l == 0 && pid == (int) (blockIdx.x + 8 * gridDim.x)) pss_stamp[wave][k] = clock64(); } while (0)
+#else
+#define PSS_STAMP(k)
+#endif
+
+// One plane as the A operand of the y transform, A[i <-> x][k <-> y]: lane (j, g) holds rows y = 4q+g ("l") and
+// 31-y ("h"), q = 0..3, of columns x = j ("l") and 31-j ("h"). Sixteen lanes read 128 contiguous bytes.
+struct PssPlane {
+	double ll[4], lh[4], hl[4], hh[4]; // [row half][column half][q]
+};
+
+template <bool CORR>
+__global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict__ plan, const double *__restrict__ frag,
+                                                const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
+                                                const double *__restrict__ rh2, const double *__restrict__ in,
+                                                const double *__restrict__ corr, double *__restrict__ out)
+{
+	constexpr int N = 32, NN = N * N;
+	extern __shared__ __attribute__((aligned(16))) double xbuf[];
+	// The walk over patches is a loop, and everything derived from the lane id is loop-invariant: left alone
+	// the compiler hoists dozens of LDS/global offsets out of the loop and then spills them (scratch
+	// reloads sit in the same in-order vmcnt queue as the prefetches and stall on them). So the wave id is
+	// made scalar and each phase re-derives its lane coordinates from an opaque copy of the lane id.
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
+	struct Lane {
+		int l, j, g;
+	};
+	auto lane = [&]() {
+		int v = l;
+		asm volatile("" : "+v"(v));
+		return Lane{v, v & 15, v >> 4};
+	};
+	// this wave's planes in phase A's order: a z-face plane (0 for wave 0, 31 for wave 7) comes last so that
+	// its whole-plane interface term can be requested a plane ahead like everything else
+	const int     zrot  = (wave == 0) ? 1 : 0;
+	const bool    zface = (wave == 0 || wave == 7);
+	auto          zof   = [&](int i) { return wave + 8 * ((i + zrot) & 3); };
+	double       *ring  = xbuf + PSS_RING + wave * 128;
+	const double *tab   = xbuf + PSS_TAB;
+	auto          frg   = [&](const Lane &q, int tr, int p, int k) { return tab[((tr * 2 + p) * 4 + k) * 64 + q.l]; };
+
+	auto loadPlane = [&](const Lane &q, PssPlane &d, const double *base) { // base: a plane stored [y][x]
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const double *rl = base + (4 * k + q.g) * N, *rh = base + (N - 1 - 4 * k - q.g) * N;
+			d.ll[k] = rl[q.j], d.lh[k] = rl[N - 1 - q.j];
+			d.hl[k] = rh[q.j], d.hh[k] = rh[N - 1 - q.j];
+		}
+	};
+	// ring terms of plane z: lane l < 32 holds W[l] and S[l], l >= 32 holds E[l-32] and N[l-32]
+	auto loadRing = [&](const Lane &q, double(&c)[2], const double *cr, int z) {
+		c[0] = cr[(q.l >> 5) * NN + N * z + (q.l & 31)];
+		c[1] = cr[(2 + (q.l >> 5)) * NN + N * z + (q.l & 31)];
+	};
+	// d -= ring terms, per element in the reference's side order W/E, then S/N (StarPatchOp.h:185-203)
+	auto applyRing = [&](const Lane &q, PssPlane &d, const double(&c)[2]) {
+		const int    l = q.l, j = q.j, g = q.g, y = l & 31;
+		const double m0 = (g == 0) ? 1.0 : 0.0, mj = (j == 0) ? 1.0 : 0.0;
+		// W/E strips: the eight values a lane needs (y = 4q+g, then 31-y) adjacent: [g][l q 0..3 | h q 0..3]
+		ring[(l >> 5) * 32 + (y < 16 ? (y & 3) * 8 + (y >> 2) : (3 - (y & 3)) * 8 + 4 + (7 - (y >> 2)))] = c[0];
+		ring[64 + l] = c[1];
+		double wv[8], ev[8];
+#pragma unroll
+		for (int k = 0; k < 8; k++) wv[k] = ring[g * 8 + k], ev[k] = ring[32 + g * 8 + k];
+		const double s0 = ring[64 + j], s1 = ring[64 + 31 - j], n0 = ring[96 + j], n1 = ring[96 + 31 - j];
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			d.ll[k] -= mj * wv[k], d.hl[k] -= mj * wv[4 + k]; // x = 0
+			d.lh[k] -= mj * ev[k], d.hh[k] -= mj * ev[4 + k]; // x = 31
+		}
+		d.ll[0] -= m0 * s0, d.lh[0] -= m0 * s1; // y = 0
+		d.hl[0] -= m0 * n0, d.hh[0] -= m0 * n1; // y = 31
+	};
+
+	// planes in flight: slot 0 = plane z_0 then z_2 (then the z-face term), slot 1 = z_1 then z_3
+	PssPlane s0, s1;
+	double   c[2] = {0.0, 0.0};
+	int      pid  = blockIdx.x, cur_plan = -1;
+	if (pid < P) {
+		const Lane q = lane();
+		loadPlane(q, s0, in + ((size_t) pid * N + zof(0)) * NN);
+		loadPlane(q, s1, in + ((size_t) pid * N + zof(1)) * NN);
+		if (CORR) loadRing(q, c, corr + (size_t) pid * 6 * NN, zof(0));
+	}
+	// A CU keeps about one L1's worth (32 KiB) of loads in flight, so a burst of plane requests takes several
+	// memory latencies and holds up every store queued behind it (the memory pipeline is in order): the next
+	// patch's first two planes are requested apart, at the start and at the end of the second z stage.
+	auto prefetch = [&](int which) {
+		const int np = pid + gridDim.x;
+		if (np >= P) return;
+		const Lane qn = lane();
+		if (which == 0) {
+			loadPlane(qn, s0, in + ((size_t) np * N + zof(0)) * NN);
+			if (CORR) loadRing(qn, c, corr + (size_t) np * 6 * NN, zof(0));
+		} else {
+			loadPlane(qn, s1, in + ((size_t) np * N + zof(1)) * NN);
+		}
+	};
+
+#pragma unroll 1
+	for (; pid < P; pid += gridDim.x) {
+		const int pl = plan[pid];
+		if (pl != cur_plan) { // (re)load the plan's fragment table; every wave is past the previous patch here
+			const double *src = frag + (size_t) pl * PSS_FRAG;
+			for (int i = threadIdx.x; i < PSS_FRAG; i += 512) xbuf[PSS_TAB + i] = src[i];
+			cur_plan = pl;
+			ldsBarrier();
+		}
+		const double *ip = in + (size_t) pid * N * NN;
+		const double *cr = CORR ? corr + (size_t) pid * 6 * NN : nullptr;
+		PSS_STAMP(0);
+
+		// ---- A: y,x forward of this wave's four planes ---------------------------------------------
+		v4f64 hi[4][2]; // odd-kx half of the transformed planes, parked until the image is free again
+		{
+			const Lane q = lane();
+			const int  j = q.j, g = q.g;
+			v4f64      t[2][2]; // [x half][ky parity]: rows x = r (half 0) / 31 - r (half 1), r = g + 4r'; cols ky = 2j + parity
+			auto       yfwd = [&](PssPlane &a) {
+                t[0][0] = t[0][1] = t[1][0] = t[1][1] = v4f64{0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const double b0 = frg(q, 0, 0, k), b1 = frg(q, 0, 1, k);
+                    t[0][0] = mfma_f64(a.ll[k] + a.hl[k], b0, t[0][0]);
+                    t[0][1] = mfma_f64(a.ll[k] - a.hl[k], b1, t[0][1]);
+                    t[1][0] = mfma_f64(a.lh[k] + a.hh[k], b0, t[1][0]);
+                    t[1][1] = mfma_f64(a.lh[k] - a.hh[k], b1, t[1][1]);
+                }
+			};
+			auto xfwd = [&](int z, v4f64(&h)[2]) {
+				v4f64       e[2][2]; // [kx parity][ky parity]: rows kx = 2 (g + 4r) + parity
+				const v4f64 sx0 = t[0][0] + t[1][0], dx0 = t[0][0] - t[1][0], sx1 = t[0][1] + t[1][1], dx1 = t[0][1] - t[1][1];
+				e[0][0] = e[0][1] = e[1][0] = e[1][1] = v4f64{0, 0, 0, 0};
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					const double a0 = frg(q, 1, 0, r), a1 = frg(q, 1, 1, r);
+					e[0][0] = mfma_f64(a0, sx0[r], e[0][0]);
+					e[0][1] = mfma_f64(a0, sx1[r], e[0][1]);
+					e[1][0] = mfma_f64(a1, dx0[r], e[1][0]);
+					e[1][1] = mfma_f64(a1, dx1[r], e[1][1]);
+				}
+				// even kx -> the image now, odd kx wait in h
+#pragma unroll
+				for (int r = 0; r < 4; r++)
+					*reinterpret_cast<double2 *>(xbuf + (g + 4 * r) * PSS_SLAB + z * N + 2 * j) = double2{e[0][0][r], e[0][1][r]};
+				h[0] = e[1][0], h[1] = e[1][1];
+			};
+			double cn[2];
+			// plane z_0 (slot 0), then request z_2 -> slot 0
+			if (CORR) {
+				loadRing(q, cn, cr, zof(1));
+				applyRing(q, s0, c);
+			}
+			yfwd(s0);
+			loadPlane(q, s0, ip + zof(2) * NN);
+			xfwd(zof(0), hi[0]);
+			// plane z_1 (slot 1), then request z_3 -> slot 1
+			if (CORR) {
+				loadRing(q, c, cr, zof(2));
+				applyRing(q, s1, cn);
+			}
+			yfwd(s1);
+			loadPlane(q, s1, ip + zof(3) * NN);
+			xfwd(zof(1), hi[1]);
+			// plane z_2 (slot 0), then the z-face term of z_3 -> slot 0
+			if (CORR) {
+				loadRing(q, cn, cr, zof(3));
+				applyRing(q, s0, c);
+			}
+			yfwd(s0);
+			if (CORR && zface) loadPlane(q, s0, cr + (wave == 0 ? 4 : 5) * NN);
+			xfwd(zof(2), hi[2]);
+			// plane z_3 (slot 1)
+			if (CORR) {
+				applyRing(q, s1, cn);
+				if (zface) {
+#pragma unroll
+					for (int k = 0; k < 4; k++)
+						s1.ll[k] -= s0.ll[k], s1.lh[k] -= s0.lh[k], s1.hl[k] -= s0.hl[k], s1.hh[k] -= s0.hh[k];
+				}
+			}
+			yfwd(s1);
+			xfwd(zof(3), hi[3]);
+		}
+		PSS_STAMP(1);
+
+		// ---- Z on one half of the image (kx = 2 slab + half), in place ----------------------------------
+		auto zstage = [&](int half, bool fetch_next) {
+			const Lane    q  = lane();
+			const int     j = q.j, g = q.g;
+			const double *lm = lam + (size_t) pl * 3 * N;
+			const double *rh = rh2 + (size_t) pid * 3;
+			const double  ly0 = lm[N + 2 * j] * rh[1], ly1 = lm[N + 2 * j + 1] * rh[1];
+			double        ez[2][4];
+#pragma unroll
+			for (int p = 0; p < 2; p++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) ez[p][r] = lm[2 * N + 2 * (g + 4 * r) + p] * rh[2];
+			const bool zmp = zero_mode[pl] != 0;
+			// the next patch's planes are requested behind this stage's own (cached) tables: loads return in order
+			asm volatile("" ::: "memory");
+			if (fetch_next) prefetch(0);
+#pragma unroll
+			for (int t = 0; t < 2; t++) {
+				const int    sl = 2 * wave + t, kx = 2 * sl + half;
+				double      *sp = xbuf + sl * PSS_SLAB + 2 * j;
+				const double lx = lm[kx] * rh[0];
+				const double exy0 = lx + ly0, exy1 = lx + ly1;
+				const bool   zm   = zmp && kx == 0 && j == 0;
+				v4f64        d[2][2]; // [kz parity][ky parity]: rows kz = 2 (g + 4r) + parity
+				d[0][0] = d[0][1] = d[1][0] = d[1][1] = v4f64{0, 0, 0, 0};
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					const double2 vl = *reinterpret_cast<const double2 *>(sp + (4 * k + g) * N);
+					const double2 vh = *reinterpret_cast<const double2 *>(sp + (N - 1 - 4 * k - g) * N);
+					const double  a0 = frg(q, 2, 0, k), a1 = frg(q, 2, 1, k);
+					d[0][0] = mfma_f64(a0, vl.x + vh.x, d[0][0]);
+					d[0][1] = mfma_f64(a0, vl.y + vh.y, d[0][1]);
+					d[1][0] = mfma_f64(a1, vl.x - vh.x, d[1][0]);
+					d[1][1] = mfma_f64(a1, vl.y - vh.y, d[1][1]);
+				}
+#pragma unroll
+				for (int p = 0; p < 2; p++)
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						d[p][0][r] /= -(exy0 + ez[p][r]);
+						d[p][1][r] /= -(exy1 + ez[p][r]);
+						if (zm && p == 0 && g + 4 * r == 0) d[p][0][r] = 0.0; // FftwPatchSolver.h:197
+					}
+				v4f64 pz[2], qz[2];
+				pz[0] = pz[1] = qz[0] = qz[1] = v4f64{0, 0, 0, 0};
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					const double a0 = frg(q, 5, 0, r), a1 = frg(q, 5, 1, r);
+					pz[0] = mfma_f64(a0, d[0][0][r], pz[0]);
+					pz[1] = mfma_f64(a0, d[0][1][r], pz[1]);
+					qz[0] = mfma_f64(a1, d[1][0][r], qz[0]);
+					qz[1] = mfma_f64(a1, d[1][1][r], qz[1]);
+				}
+				// rows z = g + 4r (P + Q) and 31 - z (P - Q); every read of this slab is complete (same wave, in order)
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					*reinterpret_cast<double2 *>(sp + (g + 4 * r) * N)         = double2{pz[0][r] + qz[0][r], pz[1][r] + qz[1][r]};
+					*reinterpret_cast<double2 *>(sp + (N - 1 - g - 4 * r) * N) = double2{pz[0][r] - qz[0][r], pz[1][r] - qz[1][r]};
+				}
+			}
+			if (fetch_next) prefetch(1);
+		};
+		// half of the x inverse of plane z from the image: A[i = j <-> ky = 2j (.x), 2j+1 (.y)][k = m = 4q+g <-> slab]
+		auto xhalf = [&](const Lane &q, int z, int half, v4f64(&acc)[2]) {
+			const double *rp = xbuf + q.g * PSS_SLAB + z * N + 2 * q.j;
+			acc[0] = acc[1] = v4f64{0, 0, 0, 0};
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const double2 v = *reinterpret_cast<const double2 *>(rp + 4 * k * PSS_SLAB);
+				const double  b = frg(q, 3, half, k);
+				acc[0] = mfma_f64(v.x, b, acc[0]);
+				acc[1] = mfma_f64(v.y, b, acc[1]);
+			}
+		};
+
+		ldsBarrier();
+		PSS_STAMP(2);
+		zstage(0, false);
+		PSS_STAMP(3);
+		ldsBarrier();
+		PSS_STAMP(4);
+		v4f64 Pe[4][2]; // even-kx half of the x inverse of planes z = wave + 8i: rows ky = 2 (g + 4r) + parity, cols x
+		{
+			const Lane q = lane();
+#pragma unroll
+			for (int i = 0; i < 4; i++) xhalf(q, wave + 8 * i, 0, Pe[i]);
+		}
+		PSS_STAMP(5);
+		ldsBarrier(); // every wave is done with the even half: the odd one takes its place
+		{
+			const Lane q = lane();
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+#pragma unroll
+				for (int r = 0; r < 4; r++)
+					*reinterpret_cast<double2 *>(xbuf + (q.g + 4 * r) * PSS_SLAB + zof(i) * N + 2 * q.j) = double2{hi[i][0][r], hi[i][1][r]};
+		}
+		ldsBarrier();
+		PSS_STAMP(6);
+		zstage(1, true);
+		PSS_STAMP(7);
+		ldsBarrier();
+		PSS_STAMP(8);
+
+		// ---- C2: odd half of the x inverse, y inverse, scale, store --------------------------------------
+		{
+			const Lane       q = lane();
+			const int        j = q.j, g = q.g;
+			constexpr double scale = 8.0 / (32.0 * 32.0 * 32.0); // (2/N)^3, DftPatchSolver.h:214
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const int z = wave + 8 * i;
+				v4f64     Qo[2];
+				xhalf(q, z, 1, Qo);
+				double *op = out + ((size_t) pid * N + z) * NN;
+#pragma unroll
+				for (int xc = 0; xc < 2; xc++) { // columns x = j (P + Q) and 31 - j (P - Q)
+					const v4f64 x0 = xc ? Pe[i][0] - Qo[0] : Pe[i][0] + Qo[0]; // rows ky = 2 (g + 4r)
+					const v4f64 x1 = xc ? Pe[i][1] - Qo[1] : Pe[i][1] + Qo[1]; // rows ky = 2 (g + 4r) + 1
+					v4f64       py = v4f64{0, 0, 0, 0}, qy = v4f64{0, 0, 0, 0};
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						py = mfma_f64(frg(q, 4, 0, r), x0[r], py);
+						qy = mfma_f64(frg(q, 4, 1, r), x1[r], qy);
+					}
+					const int   x  = xc ? N - 1 - j : j;
+					const v4f64 yl = (py + qy) * scale, yh = (py - qy) * scale;
+#pragma unroll
+					for (int r = 0; r < 4; r++) {
+						op[(g + 4 * r) * N + x]         = yl[r];
+						op[(N - 1 - g - 4 * r) * N + x] = yh[r];
+					}
+				}
+			}
+		}
+		PSS_STAMP(9);
+		ldsBarrier(); // the image is rewritten by the next patch's phase A
+	}
+}
+} // namespace te

@@ -99,18 +99,19 @@ def test_block_jacobi_patch_solve(case):
         assert rel(du.download(), orc.smooth(L, f, u)) <= 1e-11
 
 
-def test_patch_solve_single_pass_is_three_pass(case, monkeypatch):
-    """k_ps_fused (one HBM pass, patch resident in registers/LDS) runs the same MFMA sequence as the
-    three-pass kernels, and so do the three-pass kernels when a patch is split over several workgroups
-    (the automatic choice on levels with few patches): bit-identical, with and without interface terms
-    (zero-guess sweep inside a cycle)."""
+def test_patch_solve_variants_agree(case, monkeypatch):
+    """The 32^3 patch solve has four implementations of one algorithm: the three-pass MFMA kernels (one
+    workgroup per patch, or split over several on small levels), the single-pass kernel k_ps_fused
+    (patch resident in registers/LDS, same MFMA sequence -> bit-identical), and the single-pass kernel
+    with half-size transforms k_ps_sym (pure DST/DCT axes only; different summation -> a few ulp).
+    With and without interface terms (smooth from a random iterate; zero-guess sweep inside a cycle)."""
     if case["n"] != 32 or case["dim"] != 3:
         pytest.skip("the matrix-core patch solve is the 32^3 path")
     g, L = case["g"], case["levels"][0]
     u = util.rand_vec(L.size, 41)
     f = util.rand_vec(L.size, 51) / L.a["h"].min() ** 2
     got = {}
-    for mode in ("1pass", "3pass", None):
+    for mode in ("1pass", "1pass-dense", "3pass", None):
         if mode:
             monkeypatch.setenv("TE_PS_MODE", mode)
         else:
@@ -120,8 +121,12 @@ def test_patch_solve_single_pass_is_three_pass(case, monkeypatch):
         g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, dc)
         got[mode] = (du.download(), dc.download())
     for mode in ("3pass", None):
-        assert np.array_equal(got["1pass"][0], got[mode][0])
-        assert np.array_equal(got["1pass"][1], got[mode][1])
+        assert np.array_equal(got["1pass-dense"][0], got[mode][0])
+        assert np.array_equal(got["1pass-dense"][1], got[mode][1])
+    want = orc.smooth(L, f, u)
+    assert rel(got["1pass"][0], want) <= 1e-11
+    assert rel(got["1pass"][0], got["3pass"][0]) <= 1e-13
+    assert rel(got["1pass"][1], got["3pass"][1]) <= 1e-13
 
 
 def test_blas1(case):

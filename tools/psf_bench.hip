@@ -1,7 +1,7 @@
 // Tooling (not product): times k_ps_fused / the three-pass kernels on synthetic data and calibrates the
 // f64 MFMA issue rate. hipcc --offload-arch=gfx950 -O3 -std=c++17 -I pressurepoissonsolver_amd/csrc tools/psf_bench.hip
 #define PSF_TIMING
-#include "patchsolve32.hpp"
+#include "patchsolve32_sym.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -66,17 +66,37 @@ int main(int argc, char **argv)
 		printf("  -> %.1f ns per MFMA per SIMD (%.1f cycles at 2.4 GHz); %.1f TFLOP/s\n", ms * 1e6 / per_simd, ms * 1e6 / per_simd * 2.4,
 		       256.0 * 512 / 64 * iters * 4 * 2048 / (ms * 1e-3) / 1e12);
 	}
-	const dim3 gf(8 * ((P + 7) / 8));
+	const dim3 gf(8 * ((P + 7) / 8)), gs(P < 256 ? P : 256);
+	double *fr; CK(hipMalloc(&fr, PSS_FRAG * 8)); CK(hipMemcpy(fr, h.data(), PSS_FRAG * 8, hipMemcpyHostToDevice));
+	CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_sym<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS_BYTES));
+	CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_sym<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS_BYTES));
 	auto stamps = [&] {
 		long long st[8][12];
 		CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(psf_stamp), sizeof st));
+		const char *nm[12] = {"start", "A", "B1", "Z0", "B2", "C1", "B4", "Z1", "B5", "C2", "-", "-"};
+		for (int w = 0; w < 8; w += 7) {
+			printf("  wave %d:", w);
+			for (int k = 1; k < 10; k++) printf(" %s=%lld", nm[k], st[w][k] - st[0][0]);
+			printf("\n");
+		}
+	};
+	auto sstamps = [&] {
+		long long st[8][12];
+		CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(pss_stamp), sizeof st));
 		const char *nm[12] = {"start", "A", "B1", "X1", "Zfwd", "Zinv", "B4", "B5", "C0", "B6", "B7", "C1"};
-		for (int w = 0; w < 8; w++) {
+		for (int w = 0; w < 8; w += 7) {
 			printf("  wave %d:", w);
 			for (int k = 1; k < 12; k++) printf(" %s=%lld", nm[k], st[w][k] - st[0][0]);
 			printf("\n");
 		}
 	};
+	for (int skew = 0; skew <= 0; skew++) {
+		printf("skew %d\n", skew);
+		timeit("sym zero-guess", [&] { hipLaunchKernelGGL(k_ps_sym<false>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, (const double *) nullptr, out); });
+		sstamps();
+		timeit("sym with corr", [&] { hipLaunchKernelGGL(k_ps_sym<true>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, corr, out); });
+		sstamps();
+	}
 	timeit("fused zero-guess", [&] { hipLaunchKernelGGL(k_ps_fused<false>, gf, dim3(512), PSF_LDS_BYTES, 0, P, plan, mats, lam, zm, rh2, in, (const double *) nullptr, out); });
 	stamps();
 	timeit("fused with corr", [&] { hipLaunchKernelGGL(k_ps_fused<true>, gf, dim3(512), PSF_LDS_BYTES, 0, P, plan, mats, lam, zm, rh2, in, corr, out); });
