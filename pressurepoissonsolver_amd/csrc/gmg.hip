@@ -953,6 +953,14 @@ int residRestrict(te_gmg *g, LevelHost &L, const double *u, const double *f, dou
 		default: return residRestrictN<32>(g, L, u, f, coarse, xf_in);
 	}
 }
+// x-face columns of `d`, if the level still holds them (RB-GS sweeps and the single-pass patch solve produce them, inside te_vcycle)
+inline const double *xfFor(LevelHost &L, const double *d) { return (d && L.xf_valid_for == d) ? L.xfbuf[L.xf_cur].p : nullptr; }
+// the sweep wrote `out` together with its x-face columns into the other buffer: make them current
+inline void xfProduced(LevelHost &L, const double *out)
+{
+	L.xf_cur ^= 1;
+	L.xf_valid_for = out;
+}
 template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1,
                                  bool zero_guess, const double *prolong_from)
 {
@@ -969,17 +977,22 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 		const bool  one_pass = mode ? !strncmp(mode, "1pass", 5) : L.P >= 256;
 		const int   seg      = (one_pass || mode) ? 1 : (L.P >= 128 ? 2 : (L.P >= 64 ? 4 : 8));
 		const dim3 gp(L.P, seg), b256(256);
+		// x-face columns of the old iterate, if its producer exported them (te_vcycle only: see xfFor)
+		const double *xf_in = (g->in_cycle && !zero_guess) ? xfFor(L, u) : nullptr;
+		L.xf_valid_for      = nullptr; // u is rewritten in place
 		if (!zero_guess) {
 			ProlongSrc ps;
 			ps.parent = L.parent.p;
 			ps.orth   = L.orth.p;
 			ps.coarse = prolong_from;
 			if (!prolong_from && (rc = prepareGhosts<N>(g, L, u))) return rc; // prolong_from implies: no ghost slots
-			Timed t(g, KC_PATCH_RHS, (size_t) L.P * 6 * L.nf);
+			Timed    t(g, KC_PATCH_RHS, (size_t) L.P * 6 * L.nf);
+			LevelDev D = L.dev();
+			D.xf       = xf_in;
 			if (prolong_from)
-				hipLaunchKernelGGL((k_face_corr3d<N, true>), dim3(L.P * 6), b256, 0, g->stream, L.dev(), u, L.corr.p, ps);
+				hipLaunchKernelGGL((k_face_corr3d<N, true>), dim3(L.P * 6), b256, 0, g->stream, D, u, L.corr.p, ps);
 			else
-				hipLaunchKernelGGL((k_face_corr3d<N, false>), dim3(L.P * 6), b256, 0, g->stream, L.dev(), u, L.corr.p, ps);
+				hipLaunchKernelGGL((k_face_corr3d<N, false>), dim3(L.P * 6), b256, 0, g->stream, D, u, L.corr.p, ps);
 		}
 		if (one_pass) { // the whole solve in one pass over HBM (k_ps_fused)
 			static bool lds_ok = false;
@@ -1004,12 +1017,14 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 			if (L.sym_ok && !(mode && !strcmp(mode, "1pass-dense"))) {
 				// pure axes: half-size transforms; one resident workgroup per CU walks over the patches
 				const dim3 gs(std::min(L.P, ncu));
+				double    *xo = g->in_cycle ? L.xfbuf[L.xf_cur ^ 1].p : nullptr;
 				if (zero_guess)
 					hipLaunchKernelGGL(k_ps_sym<false>, gs, b512, PSS_LDS_BYTES, g->stream, L.P, L.plan.p, L.matsym.p, L.lam.p,
-					                   L.zero_mode.p, L.rh2.p, f, cp, u);
+					                   L.zero_mode.p, L.rh2.p, f, cp, u, xo);
 				else
 					hipLaunchKernelGGL(k_ps_sym<true>, gs, b512, PSS_LDS_BYTES, g->stream, L.P, L.plan.p, L.matsym.p, L.lam.p,
-					                   L.zero_mode.p, L.rh2.p, f, cp, u);
+					                   L.zero_mode.p, L.rh2.p, f, cp, u, xo);
+				if (xo) xfProduced(L, u);
 			} else {
 				const dim3 gf(8 * ((L.P + 7) / 8));
 				if (zero_guess)
@@ -1042,6 +1057,7 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 		HIPCHK(hipGetLastError());
 		return TE_OK;
 	}
+	L.xf_valid_for = nullptr; // u is rewritten in place
 	if (zero_guess) {
 		Timed t(g, KC_VECOP, total);
 		HIPCHK(hipMemsetAsync(u, 0, sizeof(double) * total, g->stream));
@@ -1155,23 +1171,13 @@ template <int OP> int reduce(const te_vec *a, const te_vec *b, double *out)
 
 void swapData(te_vec *a, te_vec *b) { std::swap(a->d, b->d); }
 
-// x-face columns of `d`, if the level still holds them (only RB-GS sweeps inside te_vcycle produce them)
-inline const double *xfFor(LevelHost &L, const double *d) { return (d && L.xf_valid_for == d) ? L.xfbuf[L.xf_cur].p : nullptr; }
-// the sweep wrote `out` together with its x-face columns into the other buffer: make them current
-inline void xfProduced(LevelHost &L, const double *out)
-{
-	L.xf_cur ^= 1;
-	L.xf_valid_for = out;
-}
 int smoothOnce(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega, bool zero_guess = false)
 {
 	LevelHost &L = *g->levels[level];
 	int        rc;
 	const bool xfok = (L.dim == 3 && g->in_cycle); // outside te_vcycle nobody keeps xf_valid_for honest
 	switch (smoother) {
-		case TE_SMOOTH_PATCH_SOLVE:
-			L.xf_valid_for = nullptr; // u is rewritten in place
-			return patchSolve(g, L, f->d, u->d, zero_guess);
+		case TE_SMOOTH_PATCH_SOLVE: return patchSolve(g, L, f->d, u->d, zero_guess); // keeps xf_valid_for itself
 		case TE_SMOOTH_JACOBI:
 			L.xf_valid_for = nullptr;
 			rc = launchStencil<MODE_JACOBI>(g, L, u->d, f->d, L.t->d, omega);
@@ -1238,7 +1244,6 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 				const double *c = pending_prolong;
 				pending_prolong = nullptr;
 				if (sm == TE_SMOOTH_PATCH_SOLVE) { // reads u + P c on the face layers only, then overwrites u
-					L.xf_valid_for = nullptr;
 					if ((r = patchSolve(g, L, f->d, u->d, false, c))) return r;
 					continue;
 				}

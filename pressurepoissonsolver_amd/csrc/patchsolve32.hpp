@@ -52,8 +52,14 @@ __global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *_
 		if (kind >= FACE_LOCAL) {
 			const int a = i % N, b = i / N;
 			const int cell = a * sa + b * sb;
-			double    m    = u[(size_t) p * NNN + mine + cell];
-			double    gh   = (kind == FACE_LOCAL) ? u[(size_t) src * NNN + oth + cell] : L.ghost[(size_t) src * NN + i];
+			double    m, gh;
+			if (ax == 0 && L.xf) { // x faces from the compact columns the producer of u exported (LevelDev.xf): no strided reads
+				m  = L.xf[((size_t) p * 2 + (s & 1)) * NN + i];
+				gh = (kind == FACE_LOCAL) ? L.xf[((size_t) src * 2 + ((s & 1) ^ 1)) * NN + i] : L.ghost[(size_t) src * NN + i];
+			} else {
+				m  = u[(size_t) p * NNN + mine + cell];
+				gh = (kind == FACE_LOCAL) ? u[(size_t) src * NNN + oth + cell] : L.ghost[(size_t) src * NN + i];
+			}
 			if (PROLONG && kind == FACE_LOCAL) {
 				// coarse cell of fine (x, y, z): x/2 + N (y/2) + N^2 (z/2); on the face layer the normal index is 0 or N-1
 				const int ccell = (a / 2) * sa + (b / 2) * sb;

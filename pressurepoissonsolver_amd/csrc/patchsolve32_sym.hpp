@@ -21,6 +21,8 @@
 //   C1   per plane: P = the even-kx half of the x inverse (the parity split of the half transforms is the
 //        split of the image), kept in registers; then the odd-kx half goes through the image (Z again) and
 //   C2   per plane: Q = odd-kx half, x = P +- Q, y inverse, scale, store.
+// xf_out (may be null) receives the x-face columns of the result, which the next interface-term and residual
+// kernels read instead of gathering them with stride 256 B.
 // The matrix fragments (24 KiB per plan) sit in LDS, so the loop issues no loads but the planes themselves:
 // loads return in order, and a table load queued behind a plane from HBM would stall the transforms.
 // Only one patch fits a CU, so nothing but this workgroup can hide its own load latency: the first two
@@ -60,7 +62,8 @@ template <bool CORR>
 __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict__ plan, const double *__restrict__ frag,
                                                 const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
                                                 const double *__restrict__ rh2, const double *__restrict__ in,
-                                                const double *__restrict__ corr, double *__restrict__ out)
+                                                const double *__restrict__ corr, double *__restrict__ out,
+                                                double *__restrict__ xf_out)
 {
 	constexpr int N = 32, NN = N * N;
 	extern __shared__ __attribute__((aligned(16))) double xbuf[];
@@ -362,6 +365,11 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 					for (int r = 0; r < 4; r++) {
 						op[(g + 4 * r) * N + x]         = yl[r];
 						op[(N - 1 - g - 4 * r) * N + x] = yh[r];
+					}
+					if (xf_out && j == 0) { // the two x-face columns of the new iterate, compact (LevelDev.xf layout: [side][z][y])
+						double *xo = xf_out + ((size_t) pid * 2 + xc) * NN + N * z;
+#pragma unroll
+						for (int r = 0; r < 4; r++) xo[g + 4 * r] = yl[r], xo[N - 1 - g - 4 * r] = yh[r];
 					}
 				}
 			}

@@ -92,9 +92,9 @@ int main(int argc, char **argv)
 	};
 	for (int skew = 0; skew <= 0; skew++) {
 		printf("skew %d\n", skew);
-		timeit("sym zero-guess", [&] { hipLaunchKernelGGL(k_ps_sym<false>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, (const double *) nullptr, out); });
+		timeit("sym zero-guess", [&] { hipLaunchKernelGGL(k_ps_sym<false>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, (const double *) nullptr, out, s0); });
 		sstamps();
-		timeit("sym with corr", [&] { hipLaunchKernelGGL(k_ps_sym<true>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, corr, out); });
+		timeit("sym with corr", [&] { hipLaunchKernelGGL(k_ps_sym<true>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, corr, out, s0); });
 		sstamps();
 	}
 	timeit("fused zero-guess", [&] { hipLaunchKernelGGL(k_ps_fused<false>, gf, dim3(512), PSF_LDS_BYTES, 0, P, plan, mats, lam, zm, rh2, in, (const double *) nullptr, out); });
