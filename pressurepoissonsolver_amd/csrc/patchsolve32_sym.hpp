@@ -229,8 +229,15 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 						s1.ll[k] -= s0.ll[k], s1.lh[k] -= s0.lh[k], s1.hl[k] -= s0.hl[k], s1.hh[k] -= s0.hh[k];
 				}
 			}
+			// eigenvalue tables of this patch, lam * 1/h^2 per axis ([x 32 | y 32 | z 32]), for the z stages: requested
+			// behind the last plane, parked in this wave's (now idle) ring strip, so that the z stages issue no loads
+			const double *lm = lam + (size_t) pl * 3 * N;
+			const double *rh = rh2 + (size_t) pid * 3;
+			const double  e0 = lm[q.l] * rh[q.l >> 5], e1 = lm[2 * N + (q.l & 31)] * rh[2];
 			yfwd(s1);
 			xfwd(zof(3), hi[3]);
+			ring[q.l] = e0;
+			if (q.l < 32) ring[2 * N + q.l] = e1;
 		}
 		PSS_STAMP(1);
 
@@ -238,24 +245,21 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 		auto zstage = [&](int half, bool fetch_next) {
 			const Lane    q  = lane();
 			const int     j = q.j, g = q.g;
-			const double *lm = lam + (size_t) pl * 3 * N;
-			const double *rh = rh2 + (size_t) pid * 3;
-			const double  ly0 = lm[N + 2 * j] * rh[1], ly1 = lm[N + 2 * j + 1] * rh[1];
-			double        ez[2][4];
+			const double2 ly = *reinterpret_cast<const double2 *>(ring + N + 2 * j); // ky = 2j, 2j + 1
+			double        ez[2][4];                                                    // kz = 2 (g + 4r) + parity
 #pragma unroll
-			for (int p = 0; p < 2; p++)
-#pragma unroll
-				for (int r = 0; r < 4; r++) ez[p][r] = lm[2 * N + 2 * (g + 4 * r) + p] * rh[2];
+			for (int r = 0; r < 4; r++) {
+				const double2 v = *reinterpret_cast<const double2 *>(ring + 2 * N + 2 * (g + 4 * r));
+				ez[0][r] = v.x, ez[1][r] = v.y;
+			}
 			const bool zmp = zero_mode[pl] != 0;
-			// the next patch's planes are requested behind this stage's own (cached) tables: loads return in order
-			asm volatile("" ::: "memory");
 			if (fetch_next) prefetch(0);
 #pragma unroll
 			for (int t = 0; t < 2; t++) {
 				const int    sl = 2 * wave + t, kx = 2 * sl + half;
 				double      *sp = xbuf + sl * PSS_SLAB + 2 * j;
-				const double lx = lm[kx] * rh[0];
-				const double exy0 = lx + ly0, exy1 = lx + ly1;
+				const double lx = ring[kx];
+				const double exy0 = lx + ly.x, exy1 = lx + ly.y;
 				const bool   zm   = zmp && kx == 0 && j == 0;
 				v4f64        d[2][2]; // [kz parity][ky parity]: rows kz = 2 (g + 4r) + parity
 				d[0][0] = d[0][1] = d[1][0] = d[1][1] = v4f64{0, 0, 0, 0};
