@@ -75,7 +75,7 @@ struct ExPlan {
 
 struct LevelHost {
 	int    dim = 3, n = 0, P = 0, P_global = 0;
-	bool   prolong_fusable = false; // every patch is an octant child of a LOCAL parent and no ghost slot exists
+	bool   prolong_fusable = false; // every patch is an octant child of a LOCAL parent and there is no coarse/fine face
 	size_t nc = 0, nf = 0;
 	// stencil tables
 	DevBuf<int32_t> face_kind, face_src;
@@ -597,7 +597,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 					return te::fail(TE_EINVAL, "te_gmg_create: coarse patch with a missing child");
 		}
 		L->Pc      = cv.P;
-		L->prolong_fusable = (D == 3 && L->nslots == 0 && up.empty() && down.empty()
+		L->prolong_fusable = (D == 3 && L->ncf == 0 && up.empty() && down.empty()
 		                      && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
 		L->n_up    = (int) up.size();
 		L->n_down  = (int) down.size();
@@ -670,14 +670,20 @@ int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double 
 }
 // make every ghost plane of `u` current: remote same-level faces (pack -> exchange -> ghost slots
 // [0, nremote)), then the coarse/fine planes. Replaces SchurHelper.h:145-150 updateInterfaceDist.
-template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u)
+// `ps`: the iterate is u + P(ps->coarse) (never stored): the faces are packed with the correction added.
+template <int N> void packFaces(te_gmg *g, LevelHost &L, const double *u, const ProlongSrc *ps)
+{
+	Timed      t(g, KC_PACK, (size_t) L.nremote * L.nf);
+	const dim3 grid(L.nremote), blk(N * N < 256 ? N * N : 256);
+	if (ps)
+		hipLaunchKernelGGL(k_pack_faces_prolong3d<N>, grid, blk, 0, g->stream, L.send_faces.p, u, *ps, L.sendbuf.p);
+	else
+		hipLaunchKernelGGL(k_pack_faces3d<N>, grid, blk, 0, g->stream, L.send_faces.p, u, L.sendbuf.p);
+}
+template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u, const ProlongSrc *ps = nullptr)
 {
 	if (L.nremote > 0) {
-		{
-			Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
-			hipLaunchKernelGGL(k_pack_faces3d<N>, dim3(L.nremote), dim3(N * N < 256 ? N * N : 256), 0, g->stream,
-			                   L.send_faces.p, u, L.sendbuf.p);
-		}
+		packFaces<N>(g, L, u, ps);
 		int rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p);
 		if (rc) return rc;
 	}
@@ -692,7 +698,7 @@ template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u)
 // underneath it; the boundary patches follow once the receive has landed. (north star: "ghost-cell
 // exchange ... overlapped with interior smoothing")
 template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *u, F launch_, const double *xf_in = nullptr,
-                                         double *xf_out = nullptr)
+                                         double *xf_out = nullptr, const ProlongSrc *ps = nullptr)
 {
 	auto launch = [&](LevelDev D) {
 		D.xf     = xf_in;
@@ -700,16 +706,12 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 		launch_(D);
 	};
 	if (L.nremote == 0 || !g->overlap || L.n_int == 0) {
-		int rc = prepareGhosts<N>(g, L, u);
+		int rc = prepareGhosts<N>(g, L, u, ps);
 		if (rc) return rc;
 		launch(L.dev());
 		return TE_OK;
 	}
-	{
-		Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
-		hipLaunchKernelGGL(k_pack_faces3d<N>, dim3(L.nremote), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.send_faces.p, u,
-		                   L.sendbuf.p);
-	}
+	packFaces<N>(g, L, u, ps);
 	HIPCHK(hipEventRecord(g->ev_pack, g->stream));
 	HIPCHK(hipStreamWaitEvent(g->comm_stream, g->ev_pack, 0));
 	int rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p, g->comm_stream);
@@ -882,11 +884,15 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 		ps.parent = L.parent.p;
 		ps.orth   = L.orth.p;
 		ps.coarse = prolong_from;
-		Timed    t(g, KC_RBGS_PROLONG, (size_t) L.P * L.nc);
-		LevelDev D = L.dev();
-		D.xf       = xf_in;
-		D.xf_out   = xf_out;
-		hipLaunchKernelGGL((k_rbgs3d<N, false, true>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, u, f, out, ps);
+		auto launch = [&](LevelDev D) {
+			if (D.count == 0) return;
+			Timed t(g, KC_RBGS_PROLONG, (size_t) D.count * L.nc);
+			hipLaunchKernelGGL((k_rbgs3d<N, false, true>), dim3(8 * ((D.count + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, u, f,
+			                   out, ps);
+		};
+		// neighbours on other ranks receive this rank's face layers of u + P(coarse) (exchange under the interior)
+		int rc = withGhosts<N>(g, L, u, launch, xf_in, xf_out, &ps);
+		if (rc) return rc;
 		HIPCHK(hipGetLastError());
 		return TE_OK;
 	}
@@ -985,7 +991,7 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 			ps.parent = L.parent.p;
 			ps.orth   = L.orth.p;
 			ps.coarse = prolong_from;
-			if (!prolong_from && (rc = prepareGhosts<N>(g, L, u))) return rc; // prolong_from implies: no ghost slots
+			if ((rc = prepareGhosts<N>(g, L, u, prolong_from ? &ps : nullptr))) return rc;
 			Timed    t(g, KC_PATCH_RHS, (size_t) L.P * 6 * L.nf);
 			LevelDev D = L.dev();
 			D.xf       = xf_in;

@@ -205,7 +205,9 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 // Fused prolongation (DrctIntp.h:99-106) for the first post-smoothing sweep: every value of u the
 // sweep reads is taken as u + coarse[parent][(c + orthant offset)/2], so the corrected iterate is
 // never written out and read back. Only used on levels where every patch is an octant child of a local
-// parent and no ghost slot exists (uniform refinement on one rank); the host falls back otherwise.
+// parent and no coarse/fine ghost slot exists (uniform refinement); the host falls back otherwise. Faces
+// whose neighbour lives on another rank arrive already corrected: the sender packs u + P(coarse)
+// (k_pack_faces_prolong3d), so ghost slots are read as they are.
 struct ProlongSrc {
 	const int32_t *parent, *orth;
 	const double  *coarse;
@@ -216,6 +218,25 @@ template <int N> __device__ __forceinline__ const double *coarseOctant(const Pro
 	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
 	const int     o = ps.orth[p];
 	return ps.coarse + (size_t) ps.parent[p] * NNN + ((o & 1) ? H : 0) + N * ((o & 2) ? H : 0) + NN * ((o & 4) ? H : 0);
+}
+
+// k_pack_faces3d for the iterate u + P(coarse u) that is never stored (see ProlongSrc): the face layers other
+// ranks need, with this rank's coarse correction added on the way out.
+template <int N>
+__global__ void k_pack_faces_prolong3d(const int32_t *__restrict__ faces, const double *__restrict__ u, ProlongSrc ps,
+                                       double *__restrict__ sendbuf)
+{
+	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
+	const int     p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
+	const int     ax = s >> 1;
+	const int     sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
+	const double *up = u + (size_t) p * NNN + ((s & 1) ? (N - 1) * sn : 0);
+	const double *cp = coarseOctant<N>(ps, p) + ((s & 1) ? (H - 1) * sn : 0);
+	double       *o  = sendbuf + (size_t) blockIdx.x * NN;
+	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+		const int a = i % N, b = i / N;
+		o[i] = up[a * sa + b * sb] + cp[(a / 2) * sa + (b / 2) * sb];
+	}
 }
 
 // Relax cell CB (0: even x, 1: odd x) of row k of the plane held in `cen` (LDS copy in tl):

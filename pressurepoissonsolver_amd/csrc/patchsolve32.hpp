@@ -30,7 +30,7 @@ __device__ __forceinline__ v4f64 mfma_f64(double a, double b, v4f64 c)
 // physical faces. One workgroup per patch face; only face layers are touched (6/N of the sites).
 // PROLONG: the iterate is u + P(coarse) (DrctIntp.h:99-106) without that sum ever being stored: a block-
 // Jacobi sweep overwrites u and reads the old iterate ONLY through these interface terms, so the
-// prolongation has to be evaluated on the face layers alone (levels without ghost slots, see ProlongSrc).
+// prolongation has to be evaluated on the face layers alone (levels without coarse/fine faces, see ProlongSrc).
 template <int N, bool PROLONG>
 __global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *__restrict__ u, double *__restrict__ corr,
                                                      ProlongSrc ps)
@@ -43,9 +43,9 @@ __global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *_
 	const double  rh = L.rh2[(size_t) p * 3 + ax];
 	double       *c  = corr + ((size_t) p * 6 + s) * NN;
 	const double *cm = nullptr, *cn = nullptr; // coarse octants of this patch / of the neighbour
-	if (PROLONG && kind == FACE_LOCAL) {
+	if (PROLONG && kind >= FACE_LOCAL) { // a ghost slot (neighbour on another rank) holds u + P e already: the sender adds it
 		cm = coarseOctant<N>(ps, p);
-		cn = coarseOctant<N>(ps, src);
+		if (kind == FACE_LOCAL) cn = coarseOctant<N>(ps, src);
 	}
 	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
 		double v = 0.0;
@@ -60,11 +60,11 @@ __global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *_
 				m  = u[(size_t) p * NNN + mine + cell];
 				gh = (kind == FACE_LOCAL) ? u[(size_t) src * NNN + oth + cell] : L.ghost[(size_t) src * NN + i];
 			}
-			if (PROLONG && kind == FACE_LOCAL) {
+			if (PROLONG) {
 				// coarse cell of fine (x, y, z): x/2 + N (y/2) + N^2 (z/2); on the face layer the normal index is 0 or N-1
 				const int ccell = (a / 2) * sa + (b / 2) * sb;
 				m += cm[ccell + ((s & 1) ? (N / 2 - 1) * sn : 0)];
-				gh += cn[ccell + ((s & 1) ? 0 : (N / 2 - 1) * sn)];
+				if (kind == FACE_LOCAL) gh += cn[ccell + ((s & 1) ? 0 : (N / 2 - 1) * sn)];
 			}
 			v = 2.0 * rh * (0.5 * m + 0.5 * gh);
 		}
