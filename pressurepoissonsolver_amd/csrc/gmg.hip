@@ -876,10 +876,30 @@ template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, 
 		default: return launchStencilN<32, MODE>(g, L, u, f, out, omega, rd, xf_in);
 	}
 }
+// z-slabs per patch for the RB-GS kernels: enough workgroups to occupy 256 CUs x 4 when the level has few patches
+template <int N> inline int rbgsSlabs(int count)
+{
+	int zs = 1;
+	while (zs < 4 && !getenv("TE_RBGS_NOSLAB") && (size_t) count * zs < 1024 && N / (zs * 2) >= 4) zs *= 2;
+	return zs;
+}
+template <int N, bool ZERO, bool PROLONG>
+void launchRbgsKernel(te_gmg *g, const LevelDev &D, const double *u, const double *f, double *out, const ProlongSrc &ps)
+{
+	const int  zs = rbgsSlabs<N>(D.count);
+	const dim3 grid(8 * ((D.count * zs + 7) / 8)), blk(Tile3<N>::TPB);
+	if (zs == 4) {
+		if constexpr (N >= 16) hipLaunchKernelGGL((k_rbgs3d<N, ZERO, PROLONG, 4>), grid, blk, 0, g->stream, D, u, f, out, ps);
+	} else if (zs == 2) {
+		if constexpr (N >= 8) hipLaunchKernelGGL((k_rbgs3d<N, ZERO, PROLONG, 2>), grid, blk, 0, g->stream, D, u, f, out, ps);
+	} else {
+		hipLaunchKernelGGL((k_rbgs3d<N, ZERO, PROLONG, 1>), grid, blk, 0, g->stream, D, u, f, out, ps);
+	}
+}
 template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess,
                                  const double *prolong_from, const double *xf_in, double *xf_out)
 {
-	if (prolong_from) { // u + P(coarse) is formed on the fly: only for levels without ghost slots (checked by the caller)
+	if (prolong_from) { // u + P(coarse) is formed on the fly: only for levels without coarse/fine faces (checked by the caller)
 		ProlongSrc ps;
 		ps.parent = L.parent.p;
 		ps.orth   = L.orth.p;
@@ -887,8 +907,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 		auto launch = [&](LevelDev D) {
 			if (D.count == 0) return;
 			Timed t(g, KC_RBGS_PROLONG, (size_t) D.count * L.nc);
-			hipLaunchKernelGGL((k_rbgs3d<N, false, true>), dim3(8 * ((D.count + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, u, f,
-			                   out, ps);
+			launchRbgsKernel<N, false, true>(g, D, u, f, out, ps);
 		};
 		// neighbours on other ranks receive this rank's face layers of u + P(coarse) (exchange under the interior)
 		int rc = withGhosts<N>(g, L, u, launch, xf_in, xf_out, &ps);
@@ -900,16 +919,14 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 		Timed    t(g, KC_RBGS_ZERO, (size_t) L.P * L.nc);
 		LevelDev D = L.dev();
 		D.xf_out   = xf_out;
-		hipLaunchKernelGGL((k_rbgs3d<N, true, false>), dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, u, f, out,
-		                   ProlongSrc());
+		launchRbgsKernel<N, true, false>(g, D, u, f, out, ProlongSrc());
 		HIPCHK(hipGetLastError());
 		return TE_OK;
 	}
 	auto launch = [&](LevelDev D) {
 		if (D.count == 0) return;
 		Timed t(g, KC_RBGS, (size_t) D.count * L.nc);
-		hipLaunchKernelGGL((k_rbgs3d<N, false, false>), dim3(8 * ((D.count + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, u, f, out,
-		                   ProlongSrc());
+		launchRbgsKernel<N, false, false>(g, D, u, f, out, ProlongSrc());
 	};
 	int rc = withGhosts<N>(g, L, u, launch, xf_in, xf_out);
 	if (rc) return rc;

@@ -246,6 +246,11 @@ __device__ __forceinline__ void relaxCell(double *tl, const double *idiag, int c
                                           bool act, double rhx, double rhy, double rhz, double2 (&cen)[2],
                                           const double2 (&below)[2], const double2 (&above)[2], const double2 (&rhs)[2])
 {
+	// No implicit contraction in here: a neighbour value that was itself just produced as (o - rh) * idiag would be
+	// fused into the sum below as one FMA whenever both updates land in the same basic block, which depends
+	// on the instantiation (ZS, PROLONG) -- the variants must stay bit-identical to each other. The two
+	// intended FMAs are explicit.
+#pragma clang fp contract(off)
 	constexpr int LW = Tile3<N>::LW;
 	const double  rh = CB ? rhs[K].y : rhs[K].x;
 	double        o  = 0.0;
@@ -256,7 +261,7 @@ __device__ __forceinline__ void relaxCell(double *tl, const double *idiag, int c
 		const double outer = (K == 0) ? tl[lds[0] - LW + CB] : tl[lds[1] + LW + CB];        // row y-1 / y+2: LDS
 		const double ym = (K == 0) ? outer : inner, yp = (K == 0) ? inner : outer;
 		const double zb = CB ? below[K].y : below[K].x, za = CB ? above[K].y : above[K].x;
-		o               = (side + mate) * rhx + (ym + yp) * rhy + (zb + za) * rhz;
+		o = __builtin_fma(zb + za, rhz, __builtin_fma(ym + yp, rhy, (side + mate) * rhx));
 	}
 	const double v = (o - rh) * idiag[dix[K][CB] + cz9];
 	if (CB)
@@ -275,7 +280,10 @@ __device__ __forceinline__ void relaxCell(double *tl, const double *idiag, int c
 // ZERO: the sweep starts from u == 0 (first pre-smoothing sweep of a cycle, Cycle.h:118 / :63): u is
 // never read (neither the patch nor any ghost); bit-identical to the general kernel fed with zeros.
 // PROLONG: the sweep runs on u + P(coarse) (see ProlongSrc).
-template <int N, bool ZERO, bool PROLONG>
+// ZS > 1 (levels with few patches): a patch is split into ZS z-slabs, one workgroup each. A slab [z0, z1) needs
+// the new red values of planes z0-1 and z1, which depend on old values only: they are recomputed (never
+// stored), so the result is bit-identical to the whole-patch sweep at 2/(N/ZS) extra arithmetic and reads.
+template <int N, bool ZERO, bool PROLONG, int ZS = 1>
 __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const double *__restrict__ u,
                                                           const double *__restrict__ f,
                                                           double *__restrict__ out, ProlongSrc ps)
@@ -283,8 +291,14 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	using T           = Tile3<N>;
 	constexpr int TPB = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
 	constexpr int NN  = N * N, NNN = N * N * N;
-	const int     slot = xcdRemap(blockIdx.x, L.count);
-	if (slot >= L.count) return;
+	constexpr int ZL  = N / ZS; // planes per slab (even)
+	static_assert(ZL % 2 == 0 && ZL >= 2, "slabs start on even planes");
+	const int     nwork = L.count * ZS;
+	const int     work  = xcdRemap(blockIdx.x, nwork);
+	if (work >= nwork) return;
+	const int slot = work / ZS;
+	const int z0 = (work % ZS) * ZL, z1 = z0 + ZL; // planes this workgroup stores
+	const int zs = (z0 > 0) ? z0 - 1 : 0;          // first plane it relaxes (red only when zs < z0)
 	const int pid = L.order ? L.order[L.first + slot] : L.first + slot;
 	const int tid = threadIdx.x;
 
@@ -366,28 +380,31 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		}
 	}
 
-	// planes: umm = z-2, um = z-1, uc = z, un = z+1, un2 = z+2 (values are updated in place)
+	// planes: umm = z-2, um = z-1, uc = z, un = z+1, un2 = z+2 (values are updated in place); start at z = zs
 	double2 umm[2], um[2], uc[2], un[2], un2[2], fm[2], fc[2], fn[2];
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		if (!ZERO) {
-			uc[k]     = up2[q[k]];
-			double2 a = bot.p[q[k]];
-			um[k]     = double2{bot.s * a.x, bot.s * a.y};
-			un[k]     = up2[NP + q[k]];
+			const double2 *pm = (zs > 0) ? up2 + (zs - 1) * NP : bot.p; // zs + 1 < N always (a slab has >= 2 planes)
+			const double   sm = (zs > 0) ? 1.0 : bot.s;
+			uc[k]     = up2[zs * NP + q[k]];
+			double2 a = pm[q[k]];
+			um[k]     = double2{sm * a.x, sm * a.y};
+			un[k]     = up2[(zs + 1) * NP + q[k]];
 			if (PROLONG) {
-				const double c0 = cown[cq], cb = sbot * cbot[cq]; // planes 0 and 1 share coarse plane 0
-				uc[k].x += c0, uc[k].y += c0, un[k].x += c0, un[k].y += c0;
-				um[k].x += bot.s * cb, um[k].y += bot.s * cb;
+				const double c0 = cown[NN * (zs >> 1) + cq], c1 = cown[NN * ((zs + 1) >> 1) + cq];
+				const double cb = (zs > 0) ? cown[NN * ((zs - 1) >> 1) + cq] : sbot * cbot[cq];
+				uc[k].x += c0, uc[k].y += c0, un[k].x += c1, un[k].y += c1;
+				um[k].x += sm * cb, um[k].y += sm * cb;
 			}
 		} else {
 			uc[k] = um[k] = un[k] = un2[k] = double2{0.0, 0.0};
 		}
-		fc[k]  = fp2[q[k]];
+		fc[k]  = fp2[zs * NP + q[k]];
 		umm[k] = double2{0.0, 0.0};
 		fm[k]  = double2{0.0, 0.0};
 	}
-	double hv = ZERO ? 0.0 : hs.s * (hs.p[0] + (PROLONG ? shalo * chalo[0] : 0.0));
+	double hv = ZERO ? 0.0 : hs.s * (hs.p[zs * hs.stride] + (PROLONG ? shalo * chalo[NN * (zs >> 1)] : 0.0));
 	__syncthreads(); // idiag (and the zeroed tiles)
 
 	int bz = 0; // z % 3
@@ -432,7 +449,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 			relaxCell<N, 0, (0 + ZPAR) & 1, ZERO>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, uc, um, un, fc);
 			relaxCell<N, 1, (1 + ZPAR) & 1, ZERO>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, uc, um, un, fc);
 		}
-		if (z > 0) {
+		if (z > z0) { // (the plane below a slab only lends its red values: no black update, nothing stored)
 			// black cells of plane z-1: x/y neighbours = new red (LDS / registers); z neighbours = umm (new
 			// red, or the frozen bottom ghost) and uc (new red, or the frozen top ghost when z == N).
 			// plane z-1 has parity 1-ZPAR; black: (x + y + z - 1) odd -> cell parity = (1 + k + (1-ZPAR)) & 1
@@ -461,11 +478,12 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		hv = hvn;
 		bz = (bz == 2) ? 0 : bz + 1;
 	};
+	if (ZS > 1 && z0 > 0) step(std::integral_constant<int, 1>{}, z0 - 1); // red values of the plane below the slab
 #pragma unroll 1
-	for (int z = 0; z < N; z += 2) {
+	for (int z = z0; z < z1; z += 2) {
 		step(std::integral_constant<int, 0>{}, z);
 		step(std::integral_constant<int, 1>{}, z + 1);
 	}
-	step(std::integral_constant<int, 0>{}, N); // black update and store of the last plane
+	step(std::integral_constant<int, 0>{}, z1); // black update and store of the last plane (and, inside a patch, the red values above it)
 }
 } // namespace te

@@ -99,6 +99,29 @@ def test_block_jacobi_patch_solve(case):
         assert rel(du.download(), orc.smooth(L, f, u)) <= 1e-11
 
 
+def test_rbgs_z_slabs_bit_identical(case, monkeypatch):
+    """Levels with few patches split each patch into z-slabs (one workgroup each, the red values of the two
+    adjacent planes recomputed): same bits as the whole-patch sweep, for the plain, zero-guess and
+    fused-prolongation variants (the latter two run inside a cycle)."""
+    if case["dim"] != 3 or case["n"] < 8:
+        pytest.skip("z-slabs exist for 3D patches of 8^3 and larger")
+    g, L = case["g"], case["levels"][0]
+    u = util.rand_vec(L.size, 42)
+    f = util.rand_vec(L.size, 52) / L.a["h"].min() ** 2
+    got = {}
+    for slabs in (True, False):
+        if slabs:
+            monkeypatch.delenv("TE_RBGS_NOSLAB", raising=False)
+        else:
+            monkeypatch.setenv("TE_RBGS_NOSLAB", "1")
+        du, df, dc = g.new_vector(0, u), g.new_vector(0, f), g.new_vector(0)
+        g.smooth(df, du, level=0, smoother=capi.SMOOTH_RBGS)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS, pre_sweeps=2, post_sweeps=2), df, dc)
+        got[slabs] = (du.download(), dc.download())
+    assert np.array_equal(got[True][0], got[False][0])
+    assert np.array_equal(got[True][1], got[False][1])
+
+
 def test_patch_solve_variants_agree(case, monkeypatch):
     """The 32^3 patch solve has four implementations of one algorithm: the three-pass MFMA kernels (one
     workgroup per patch, or split over several on small levels), the single-pass kernel k_ps_fused
