@@ -173,6 +173,10 @@ int te_gmg_profile(te_gmg *g, int enable);
 int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *calls, double *total_ms,
                         int64_t *cells);
 int te_gmg_profile_reset(te_gmg *g);
+/* time only the launches of kernel class `name` (a row name of te_gmg_profile_rows); NULL or "" = every class.
+ * A HIP event pair around a launch costs a few microseconds of stream time, which matters for a V-cycle of
+ * a dozen launches: bench.py times only the dominant class inside its timed region. */
+int te_gmg_profile_select(te_gmg *g, const char *name);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,7 @@ SYMBOLS = {
     "te_gmg_profile": (_I, [_P, _I]),
     "te_gmg_profile_rows": (_I, [_P, _I, _P, _P, _P, _P]),
     "te_gmg_profile_reset": (_I, [_P]),
+    "te_gmg_profile_select": (_I, [_P, C.c_char_p]),
 }
 
 _lib = None
@@ -366,6 +367,7 @@ class GMG:
 
     def profile(self, enable=True): check(lib().te_gmg_profile(self.h, int(enable)))
     def profile_reset(self): check(lib().te_gmg_profile_reset(self.h))
+    def profile_select(self, name=None): check(lib().te_gmg_profile_select(self.h, (name or "").encode()))
 
     def profile_rows(self):
         names = (C.c_char * 64 * 32)()

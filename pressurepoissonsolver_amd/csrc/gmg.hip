@@ -185,6 +185,7 @@ struct te_gmg {
 	} rccl;
 	// profiling
 	bool                   profiling = false;
+	int                    prof_only = -1; // >= 0: only this kernel class is timed
 	std::vector<EventPair> ev_pool;
 	size_t                 ev_used = 0;
 	int64_t                calls[KC_COUNT];
@@ -199,7 +200,7 @@ struct Timed {
 	int     idx = -1;
 	Timed(te_gmg *g_, int kc, size_t ncells = 0) : g(g_)
 	{
-		if (!g->profiling) return;
+		if (!g->profiling || (g->prof_only >= 0 && g->prof_only != kc)) return;
 		g->cells[kc] += (int64_t) ncells;
 		if (g->ev_used == g->ev_pool.size()) {
 			EventPair e;
@@ -1697,6 +1698,19 @@ int te_gmg_profile(te_gmg *g, int enable)
 	drainEvents(g);
 	g->profiling = enable != 0;
 	return TE_OK;
+}
+int te_gmg_profile_select(te_gmg *g, const char *name)
+{
+	if (!g) return te::fail(TE_EINVAL, "te_gmg_profile_select: null");
+	drainEvents(g);
+	g->prof_only = -1;
+	if (!name || !*name) return TE_OK;
+	for (int k = 0; k < KC_COUNT; k++)
+		if (!strcmp(name, kclassName[k])) {
+			g->prof_only = k;
+			return TE_OK;
+		}
+	return te::fail(TE_EINVAL, std::string("te_gmg_profile_select: unknown kernel class ") + name);
 }
 int te_gmg_profile_reset(te_gmg *g)
 {
