@@ -76,6 +76,10 @@ struct ExPlan {
 struct LevelHost {
 	int    dim = 3, n = 0, P = 0, P_global = 0;
 	bool   prolong_fusable = false; // every patch is an octant child of a LOCAL parent and there is no coarse/fine face
+	// 2D: lds2d = patches fit in LDS (the same on every rank: it decides whether the zero-guess sweep skips its
+	// ghost exchange, and all ranks must agree on that); fuse2d = additionally all parents are local (rank-local:
+	// residual+restrict in one pass; peers see the same exchanges either way)
+	bool   lds2d = false, fuse2d = false;
 	size_t nc = 0, nf = 0;
 	// stencil tables
 	DevBuf<int32_t> face_kind, face_src;
@@ -438,6 +442,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		}
 	}
 	L->nslots = nslots;
+	L->lds2d  = (D == 2 && n <= 64 && n % 2 == 0 && !getenv("TE_2D_SIMPLE"));
 	L->ncf    = (int) cfs.size();
 	int rc;
 	{
@@ -600,6 +605,10 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		L->Pc      = cv.P;
 		L->prolong_fusable = (D == 3 && L->ncf == 0 && up.empty() && down.empty()
 		                      && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
+		if (D == 2 && L->lds2d && up.empty() && down.empty()) {
+			L->fuse2d          = true;
+			L->prolong_fusable = (L->nslots == 0 && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
+		}
 		L->n_up    = (int) up.size();
 		L->n_down  = (int) down.size();
 		L->tx_up   = mergePlan(ups, downs);   // restrict: send child blocks, receive into downbuf
@@ -787,20 +796,43 @@ template <int MODE> int launchStencil2d(te_gmg *g, LevelHost &L, const double *u
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
-int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out)
+// zero_guess: levels with L.lds2d; prolong_from: levels with L.fuse2d && L.prolong_fusable (the caller checks)
+int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false,
+                 const double *prolong_from = nullptr)
 {
-	int rc = prepareGhosts2d(g, L, u);
-	if (rc) return rc;
-	Timed      t(g, KC_RBGS, (size_t) L.P * L.nc);
+	int rc;
+	if (!zero_guess && !prolong_from && (rc = prepareGhosts2d(g, L, u))) return rc; // (prolong_from: no ghost slots)
 	if (L.n <= 64 && !getenv("TE_2D_SIMPLE")) { // the patch and its halo ring fit in LDS: one pass
 		const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
-		hipLaunchKernelGGL(k_rbgs2d_lds, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out);
+		Prolong2D    ps{L.parent.p, L.orth.p, prolong_from};
+		Timed        t(g, zero_guess ? KC_RBGS_ZERO : (prolong_from ? KC_RBGS_PROLONG : KC_RBGS), (size_t) L.P * L.nc);
+		if (zero_guess)
+			hipLaunchKernelGGL((k_rbgs2d_lds<true, false>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);
+		else if (prolong_from)
+			hipLaunchKernelGGL((k_rbgs2d_lds<false, true>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);
+		else
+			hipLaunchKernelGGL((k_rbgs2d_lds<false, false>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);
 		HIPCHK(hipGetLastError());
 		return TE_OK;
 	}
+	if (zero_guess || prolong_from) return te::fail(TE_ESTATE, "launchRbgs2d: fused variants need patches that fit in LDS");
+	Timed      t(g, KC_RBGS, (size_t) L.P * L.nc);
 	const dim3 grid(gridFor((size_t) L.P * L.nc, 256, 65536));
 	hipLaunchKernelGGL(k_rbgs2d<0>, grid, dim3(256), 0, g->stream, L.dev2(), u, f, out);
 	hipLaunchKernelGGL(k_rbgs2d<1>, grid, dim3(256), 0, g->stream, L.dev2(), u, f, out);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+// coarse f = AvgRstr(f - A u) in one pass (levels with L.fuse2d)
+int residRestrict2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse)
+{
+	if (L.P == 0) return TE_OK; // a rank without patches on this level (fuse2d: it has no transfers either)
+	int rc = prepareGhosts2d(g, L, u);
+	if (rc) return rc;
+	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
+	Timed        t(g, KC_RESID_RESTRICT, (size_t) L.P * L.nc);
+	hipLaunchKernelGGL(k_resid_restrict2d_lds, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f,
+	                   Prolong2D{L.parent.p, L.orth.p, nullptr}, coarse);
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
@@ -938,7 +970,7 @@ int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double
                const double *prolong_from = nullptr, const double *xf_in = nullptr, double *xf_out = nullptr)
 {
 	if (L.P == 0) return TE_OK;
-	if (L.dim == 2) return launchRbgs2d(g, L, u, f, out);
+	if (L.dim == 2) return launchRbgs2d(g, L, u, f, out, zero_guess, prolong_from);
 	switch (L.n) {
 		case 4: return launchRbgsN<4>(g, L, u, f, out, zero_guess, prolong_from, xf_in, xf_out);
 		case 8: return launchRbgsN<8>(g, L, u, f, out, zero_guess, prolong_from, xf_in, xf_out);
@@ -970,6 +1002,7 @@ template <int N> int residRestrictN(te_gmg *g, LevelHost &L, const double *u, co
 }
 int residRestrict(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse, const double *xf_in = nullptr)
 {
+	if (L.dim == 2) return residRestrict2d(g, L, u, f, coarse);
 	switch (L.n) {
 		case 4: return residRestrictN<4>(g, L, u, f, coarse, xf_in);
 		case 8: return residRestrictN<8>(g, L, u, f, coarse, xf_in);
@@ -1276,7 +1309,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 				swapData(u, L.t.get());
 				continue;
 			}
-			if (u_zero && L.dim == 3 && (sm == TE_SMOOTH_RBGS || sm == TE_SMOOTH_PATCH_SOLVE)) {
+			if (u_zero && ((L.dim == 3 && (sm == TE_SMOOTH_RBGS || sm == TE_SMOOTH_PATCH_SOLVE)) || (L.lds2d && sm == TE_SMOOTH_RBGS))) {
 				u_zero = false;
 				r      = smoothOnce(g, l, f, u, sm, o->omega, true);
 			} else {
@@ -1295,7 +1328,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	auto       descend = [&]() -> int {
         int r = materialise();
         if (r) return r;
-        if (o->fuse && L.dim == 3) {
+        if (o->fuse && (L.dim == 3 || L.fuse2d)) {
             if ((r = residRestrict(g, L, u->d, f->d, C.f->d, xfFor(L, u->d)))) return r;
         } else {
             if ((r = launchStencil<MODE_RESID>(g, L, u->d, f->d, L.r->d, 0.0, RestrictDst(), xfFor(L, u->d)))) return r; // prepCoarser: r = f - A u
@@ -1306,7 +1339,8 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         // prepFiner (Cycle.h:74-80). When the very next step is an RB-GS sweep on a level without ghost
         // slots, that sweep reads u + P(coarse u) on the fly instead (same bits, one HBM pass less).
         if (o->fuse && L.prolong_fusable && next_sweeps > 0
-            && (o->smoother == TE_SMOOTH_RBGS || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.n == 32 && !getenv("TE_PS_SLOW")))) {
+            && (o->smoother == TE_SMOOTH_RBGS
+                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.dim == 3 && L.n == 32 && !getenv("TE_PS_SLOW")))) {
             pending_prolong = C.u->d;
             return TE_OK;
         }

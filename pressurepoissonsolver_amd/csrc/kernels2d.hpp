@@ -44,6 +44,21 @@ __device__ __forceinline__ double kfold2d(const Level2D &L, int p, int s)
 	return kind == FACE_DIRICHLET ? 1.0 : (kind == FACE_NEUMANN ? -1.0 : 0.0);
 }
 
+// (l - 2c + r)/hx^2 + (ym - 2c + yp)/hy^2 with one fixed rounding sequence: shared by the plain and the fused
+// residual kernels, which must agree bit for bit (implicit FMA contraction may differ between kernels)
+__device__ __forceinline__ double lap2d(double l, double c, double r, double ym, double yp, double rhx, double rhy)
+{
+#pragma clang fp contract(off)
+	return __builtin_fma(ym - 2 * c + yp, rhy, (l - 2 * c + r) * rhx);
+}
+
+// off-diagonal sum of the relaxation, (xl + xr)/hx^2 + (yl + yr)/hy^2, pinned the same way (plain and LDS sweeps)
+__device__ __forceinline__ double offdiag2d(double xl, double xr, double yl, double yr, double rhx, double rhy)
+{
+#pragma clang fp contract(off)
+	return __builtin_fma(yl + yr, rhy, (xl + xr) * rhx);
+}
+
 // MODE_APPLY / MODE_RESID / MODE_JACOBI as in k_stencil3d
 template <int MODE>
 __global__ __launch_bounds__(256) void k_stencil2d(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
@@ -69,10 +84,8 @@ __global__ __launch_bounds__(256) void k_stencil2d(Level2D L, const double *__re
 		else
 			yp = double2{ghost2d(L, u, p, 3, x, c.x, false), ghost2d(L, u, p, 3, x + 1, c.y, false)};
 		double2 lap;
-		lap.x = (xl - 2 * c.x + c.y) * rhx;
-		lap.y = (c.x - 2 * c.y + xr) * rhx;
-		lap.x += (ym.x - 2 * c.x + yp.x) * rhy;
-		lap.y += (ym.y - 2 * c.y + yp.y) * rhy;
+		lap.x = lap2d(xl, c.x, c.y, ym.x, yp.x, rhx, rhy);
+		lap.y = lap2d(c.x, c.y, xr, ym.y, yp.y, rhx, rhy);
 		double2 r;
 		if (MODE == MODE_APPLY) {
 			r = lap;
@@ -118,16 +131,31 @@ __global__ __launch_bounds__(256) void k_rbgs2d(Level2D L, const double *__restr
 		const double  yr = (y + 1 < n) ? in[c + n] : ghost2d(L, u, p, 3, x, own, true);
 		const double  kx = 2.0 + (x == 0 ? kfold2d(L, p, 0) : 0.0) + (x == n - 1 ? kfold2d(L, p, 1) : 0.0);
 		const double  ky = 2.0 + (y == 0 ? kfold2d(L, p, 2) : 0.0) + (y == n - 1 ? kfold2d(L, p, 3) : 0.0);
-		const double  o  = (xl + xr) * rhx + (yl + yr) * rhy;
+		const double  o  = offdiag2d(xl, xr, yl, yr, rhx, rhy);
 		out[idx]         = (o - f[idx]) / (kx * rhx + ky * rhy);
 	}
+}
+
+// Coarse correction of the post-smoothing sweep (DrctIntp.h:99-106) that is never stored: the sweep reads
+// u + coarse[parent][(c + quadrant offset)/2]. coarse == nullptr: none. (Levels without ghost slots only.)
+struct Prolong2D {
+	const int32_t *parent, *orth;
+	const double  *coarse;
+};
+__device__ __forceinline__ double coarseAt2d(const Prolong2D &ps, int n, int p, int x, int y)
+{
+	const int o = ps.orth[p];
+	return ps.coarse[(size_t) ps.parent[p] * n * n + (x + ((o & 1) ? n : 0)) / 2 + n * ((y + ((o & 2) ? n : 0)) / 2)];
 }
 
 // The same sweep in ONE pass for patches that fit in LDS (n <= 64: (n+2)^2 doubles = 34 KiB): one workgroup
 // per patch loads u and its frozen halo ring once, relaxes red then black in LDS, and stores the result:
 // 24 B per site instead of two passes over u, f and out. Bit-identical to k_rbgs2d<0> + k_rbgs2d<1>.
+// ZERO: the iterate is zero (first sweep of a cycle): u and its ghosts are never read (16 B per site).
+// PROLONG: the iterate is u + P(coarse) (see Prolong2D), formed while loading (26 B per site).
+template <bool ZERO, bool PROLONG>
 __global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
-                                                    double *__restrict__ out)
+                                                    double *__restrict__ out, Prolong2D ps)
 {
 	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // (n+2) x (n+2), then 9 inverse diagonals
 	const int     n = L.n, lw = n + 2, nn = n * n;
@@ -142,17 +170,29 @@ __global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__r
 		const double ky = 2.0 + (cy == 0 ? kfold2d(L, p, 2) : 0.0) + (cy == 2 ? kfold2d(L, p, 3) : 0.0);
 		idg[tid]        = kx * rhx + ky * rhy;
 	}
-	for (int i = tid; i < nn / 2; i += blockDim.x) { // interior, 16 B per lane
-		const int     y = (2 * i) / n, x = (2 * i) % n;
-		const double2 v = reinterpret_cast<const double2 *>(up)[i];
-		tile2d[(y + 1) * lw + x + 1] = v.x;
-		tile2d[(y + 1) * lw + x + 2] = v.y;
-	}
-	for (int i = tid; i < 4 * n; i += blockDim.x) { // halo ring: frozen ghosts (physical faces folded -> 0)
-		const int s = i / n, t = i % n;
-		const double g = ghost2d(L, u, p, s, t, 0.0, true);
-		const int idx = (s == 0) ? (t + 1) * lw : (s == 1) ? (t + 1) * lw + n + 1 : (s == 2) ? t + 1 : (n + 1) * lw + t + 1;
-		tile2d[idx]   = g;
+	if (ZERO) {
+		for (int i = tid; i < lw * lw; i += blockDim.x) tile2d[i] = 0.0;
+	} else {
+		for (int i = tid; i < nn / 2; i += blockDim.x) { // interior, 16 B per lane
+			const int y = (2 * i) / n, x = (2 * i) % n;
+			double2   v = reinterpret_cast<const double2 *>(up)[i];
+			if (PROLONG) {
+				const double c = coarseAt2d(ps, n, p, x, y); // x even: both cells of the pair share the coarse cell
+				v.x += c, v.y += c;
+			}
+			tile2d[(y + 1) * lw + x + 1] = v.x;
+			tile2d[(y + 1) * lw + x + 2] = v.y;
+		}
+		for (int i = tid; i < 4 * n; i += blockDim.x) { // halo ring: frozen ghosts (physical faces folded -> 0)
+			const int s = i / n, t = i % n;
+			double    g = ghost2d(L, u, p, s, t, 0.0, true);
+			if (PROLONG && L.face_kind[p * 4 + s] == FACE_LOCAL) { // the neighbour's facing cell carries its own correction
+				const int src = L.face_src[p * 4 + s];
+				g += coarseAt2d(ps, n, src, s == 0 ? n - 1 : (s == 1 ? 0 : t), s == 2 ? n - 1 : (s == 3 ? 0 : t));
+			}
+			const int idx = (s == 0) ? (t + 1) * lw : (s == 1) ? (t + 1) * lw + n + 1 : (s == 2) ? t + 1 : (n + 1) * lw + t + 1;
+			tile2d[idx]   = g;
+		}
 	}
 	__syncthreads();
 	for (int colour = 0; colour < 2; colour++) {
@@ -160,7 +200,7 @@ __global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__r
 			const int y = (2 * i) / n, x = (2 * i) % n + ((y + colour) & 1);
 			double   *t0 = tile2d + (y + 1) * lw + x + 1;
 			const int cx = (x == 0) ? 0 : (x == n - 1 ? 2 : 1), cy = (y == 0) ? 0 : (y == n - 1 ? 2 : 1);
-			const double o = (t0[-1] + t0[1]) * rhx + (t0[-lw] + t0[lw]) * rhy;
+			const double o = offdiag2d(t0[-1], t0[1], t0[-lw], t0[lw], rhx, rhy);
 			*t0            = (o - fp[x + n * y]) / idg[cx + 3 * cy];
 		}
 		__syncthreads();
@@ -168,6 +208,59 @@ __global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__r
 	for (int i = tid; i < nn / 2; i += blockDim.x) {
 		const int y = (2 * i) / n, x = (2 * i) % n;
 		reinterpret_cast<double2 *>(out + (size_t) p * nn)[i] = double2{tile2d[(y + 1) * lw + x + 1], tile2d[(y + 1) * lw + x + 2]};
+	}
+}
+
+// Fused residual + restriction for patches that fit in LDS (Cycle.h:59-65 in one pass): one workgroup per
+// fine patch loads u and its ghost ring, each thread forms the four residuals of a coarse cell and adds
+// them in AvgRstr's order (restrictCell2d): bit-identical to k_stencil2d<MODE_RESID> + k_restrict2d,
+// 18 B per site (read u, f; write 1/4) instead of 34. Parents are local (checked by the host).
+__global__ __launch_bounds__(256) void k_resid_restrict2d_lds(Level2D L, const double *__restrict__ u,
+                                                              const double *__restrict__ f, Prolong2D dst /* coarse = coarse f (written) */,
+                                                              double *__restrict__ coarse)
+{
+	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // (n+2) x (n+2)
+	const int     n = L.n, lw = n + 2, nn = n * n, h = n / 2;
+	const int     p = blockIdx.x, tid = threadIdx.x;
+	const double *up = u + (size_t) p * nn;
+	const double *fp = f + (size_t) p * nn;
+	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
+	for (int i = tid; i < nn / 2; i += blockDim.x) {
+		const int     y = (2 * i) / n, x = (2 * i) % n;
+		const double2 v = reinterpret_cast<const double2 *>(up)[i];
+		tile2d[(y + 1) * lw + x + 1] = v.x;
+		tile2d[(y + 1) * lw + x + 2] = v.y;
+	}
+	for (int i = tid; i < 4 * n; i += blockDim.x) { // ghost ring (physical faces: -own / +own)
+		const int    s = i / n, t = i % n;
+		const double own = up[s == 0 ? n * t : (s == 1 ? n - 1 + n * t : (s == 2 ? t : t + n * (n - 1)))];
+		const int    idx = (s == 0) ? (t + 1) * lw : (s == 1) ? (t + 1) * lw + n + 1 : (s == 2) ? t + 1 : (n + 1) * lw + t + 1;
+		tile2d[idx]      = ghost2d(L, u, p, s, t, own, false);
+	}
+	__syncthreads();
+	const int pa = dst.parent[p], o = dst.orth[p];
+	double   *cp = coarse + (size_t) pa * nn;
+	if (o < 0) { // copy-through: the residual lands unchanged in the coarse patch
+		for (int i = tid; i < nn; i += blockDim.x) {
+			const int     x = i % n, y = i / n;
+			const double *t0 = tile2d + (y + 1) * lw + x + 1;
+			cp[i]            = 0.0 + (fp[i] - lap2d(t0[-1], t0[0], t0[1], t0[-lw], t0[lw], rhx, rhy));
+		}
+		return;
+	}
+	cp += ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0);
+	for (int i = tid; i < h * h; i += blockDim.x) {
+		const int hx = i % h, hy = i / h;
+		double    acc = 0.0; // AvgRstr.h:95-102 order: x then y, each /(1 << D)
+#pragma unroll
+		for (int dy = 0; dy < 2; dy++) {
+			const int     y = 2 * hy + dy, x = 2 * hx;
+			const double *t0 = tile2d + (y + 1) * lw + x + 1;
+			const double2 fv = *reinterpret_cast<const double2 *>(fp + x + n * y);
+			acc += (fv.x - lap2d(t0[-1], t0[0], t0[1], t0[-lw], t0[lw], rhx, rhy)) / 4;
+			acc += (fv.y - lap2d(t0[0], t0[1], t0[2], t0[1 - lw], t0[1 + lw], rhx, rhy)) / 4;
+		}
+		cp[hx + n * hy] = acc;
 	}
 }
 
