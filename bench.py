@@ -42,6 +42,11 @@ ALG_BYTES = {
     "stencil_rbgs_zero": 16.0,   # first sweep from a zero guess: read f, write u
     "stencil_rbgs_prolong": 25.0,  # post-sweep on u + P(coarse): read u, f, coarse (8/8); write u
     "patch_solve_mfma": 16.0,    # single-pass exact patch solve: read f, write u (+ face terms, not counted)
+    # levels with few patches run other instantiations, timed as classes of their own (one class = one kernel
+    # symbol for the large levels); they only become "dominant" for small problems (--size 256):
+    "stencil_rbgs_slabs": 20.5,  # z-slab RB-GS: a V(1,1) launches as many zero-guess (16) as fused-prolong (25) sweeps
+    "stencil_slabs": 17.0,       # z-slab stencil kernel: residual+restrict is its only use in the fused cycle
+    "patch_solve_3pass": 16.0,   # three-pass patch solve: read 8 + write 8 per launch
 }
 
 

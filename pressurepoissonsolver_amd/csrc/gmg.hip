@@ -37,11 +37,15 @@ namespace
 {
 enum KClass : int {
 	KC_APPLY, KC_RESID, KC_JACOBI, KC_RBGS, KC_CFGHOST, KC_RESTRICT, KC_PROLONG, KC_PATCH_RHS,
-	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_RBGS_ZERO, KC_RESID_RESTRICT, KC_PS_MFMA, KC_RBGS_PROLONG, KC_COUNT
+	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_RBGS_ZERO, KC_RESID_RESTRICT, KC_PS_MFMA, KC_RBGS_PROLONG,
+	// launches on levels with few patches run other instantiations (z-slabs, split patches): classes of their own, so
+	// that a class above is one kernel symbol and its average duration is the one rocprofv3 --stats reports
+	KC_RBGS_SLABS, KC_STENCIL_SLABS, KC_PS_3PASS, KC_COUNT
 };
 const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_jacobi", "stencil_rbgs",
                                     "cf_ghost", "restrict", "prolong_add", "patch_rhs", "dst_axis",
-                                    "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict", "patch_solve_mfma", "stencil_rbgs_prolong"};
+                                    "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict", "patch_solve_mfma", "stencil_rbgs_prolong",
+                                    "stencil_rbgs_slabs", "stencil_slabs", "patch_solve_3pass"};
 
 template <typename T> struct DevBuf {
 	T     *p = nullptr;
@@ -748,7 +752,8 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 	}
 	auto launch = [&](LevelDev D) {
 		if (D.count == 0) return;
-		Timed t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : (MODE == MODE_JACOBI ? KC_JACOBI : KC_RESID_RESTRICT)),
+		Timed t(g, zs > 1 ? KC_STENCIL_SLABS
+		                  : (MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : (MODE == MODE_JACOBI ? KC_JACOBI : KC_RESID_RESTRICT))),
 		        (size_t) D.count * L.nc);
 		auto grid = [&](int z) { return dim3(8 * ((D.count * z + 7) / 8)); };
 		switch (zs) {
@@ -939,7 +944,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 		ps.coarse = prolong_from;
 		auto launch = [&](LevelDev D) {
 			if (D.count == 0) return;
-			Timed t(g, KC_RBGS_PROLONG, (size_t) D.count * L.nc);
+			Timed t(g, rbgsSlabs<N>(D.count) > 1 ? KC_RBGS_SLABS : KC_RBGS_PROLONG, (size_t) D.count * L.nc);
 			launchRbgsKernel<N, false, true>(g, D, u, f, out, ps);
 		};
 		// neighbours on other ranks receive this rank's face layers of u + P(coarse) (exchange under the interior)
@@ -949,7 +954,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 		return TE_OK;
 	}
 	if (zero_guess) { // a zero iterate has zero ghosts everywhere: nothing to exchange or build
-		Timed    t(g, KC_RBGS_ZERO, (size_t) L.P * L.nc);
+		Timed    t(g, rbgsSlabs<N>(L.P) > 1 ? KC_RBGS_SLABS : KC_RBGS_ZERO, (size_t) L.P * L.nc);
 		LevelDev D = L.dev();
 		D.xf_out   = xf_out;
 		launchRbgsKernel<N, true, false>(g, D, u, f, out, ProlongSrc());
@@ -958,7 +963,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 	}
 	auto launch = [&](LevelDev D) {
 		if (D.count == 0) return;
-		Timed t(g, KC_RBGS, (size_t) D.count * L.nc);
+		Timed t(g, rbgsSlabs<N>(D.count) > 1 ? KC_RBGS_SLABS : KC_RBGS, (size_t) D.count * L.nc);
 		launchRbgsKernel<N, false, false>(g, D, u, f, out, ProlongSrc());
 	};
 	int rc = withGhosts<N>(g, L, u, launch, xf_in, xf_out);
@@ -1095,7 +1100,7 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 			return TE_OK;
 		}
 		{
-			Timed t(g, KC_PS_MFMA, total);
+			Timed t(g, KC_PS_3PASS, total);
 			if (zero_guess)
 				hipLaunchKernelGGL((k_ps_xy<false, false>), gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, f,
 				                   (const double *) nullptr, s1);
@@ -1104,11 +1109,11 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 				                   (const double *) L.corr.p, s1);
 		}
 		{
-			Timed t(g, KC_PS_MFMA, total);
+			Timed t(g, KC_PS_3PASS, total);
 			hipLaunchKernelGGL(k_ps_z, gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p, L.zero_mode.p, L.rh2.p, s1, s0);
 		}
 		{
-			Timed t(g, KC_PS_MFMA, total);
+			Timed t(g, KC_PS_3PASS, total);
 			hipLaunchKernelGGL(k_ps_xy<true>, gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, s0, (const double *) nullptr, u);
 		}
 		HIPCHK(hipGetLastError());

@@ -18,11 +18,13 @@ import sys
 
 import re
 
-CLASS = [(r"k_rbgs3d<\d+, true", "stencil_rbgs_zero"), (r"k_rbgs3d<\d+, false, true", "stencil_rbgs_prolong"),
+CLASS = [(r"k_rbgs3d<\d+, \w+, \w+, [24]>", "stencil_rbgs_slabs"), (r"k_stencil3d<\d+, \d, [24]>", "stencil_slabs"),
+         (r"k_rbgs3d<\d+, true", "stencil_rbgs_zero"), (r"k_rbgs3d<\d+, false, true", "stencil_rbgs_prolong"),
          (r"k_rbgs3d<", "stencil_rbgs"), (r"k_stencil3d<\d+, 0,", "stencil_apply"), (r"k_stencil3d<\d+, 1,", "stencil_resid"),
          (r"k_stencil3d<\d+, 2,", "stencil_jacobi"), (r"k_stencil3d<\d+, 3,", "resid_restrict"),
          (r"k_restrict3d", "restrict"), (r"k_prolong3d", "prolong_add"), (r"k_vecop", "vecop"),
-         (r"k_dst_axis3d", "dst_axis"), (r"k_patch_rhs3d|k_face_corr3d", "patch_rhs"), (r"k_ps_", "patch_solve_mfma")]
+         (r"k_dst_axis3d", "dst_axis"), (r"k_patch_rhs3d|k_face_corr3d", "patch_rhs"), (r"k_ps_sym|k_ps_fused", "patch_solve_mfma"),
+         (r"k_ps_xy|k_ps_z", "patch_solve_3pass")]
 
 
 def klass(name):
