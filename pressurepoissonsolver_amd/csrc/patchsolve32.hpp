@@ -452,13 +452,8 @@ __global__ __launch_bounds__(512) void k_ps_fused(int P, const int32_t *__restri
 				}
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
-#ifdef PSF_NODIV
-					d0[r] *= -(exy0 + ez[mb][r]);
-					d1[r] *= -(exy1 + ez[mb][r]);
-#else
 					d0[r] /= -(exy0 + ez[mb][r]);
 					d1[r] /= -(exy1 + ez[mb][r]);
-#endif
 					if (zm && 16 * mb + g + 4 * r == 0) d0[r] = 0.0; // FftwPatchSolver.h:197
 				}
 				D[t][mb][0] = d0, D[t][mb][1] = d1;
