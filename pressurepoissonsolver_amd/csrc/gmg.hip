@@ -111,6 +111,8 @@ struct LevelHost {
 	DevBuf<double>  mats, lam, corr; // corr: [P][6][n^2] interface terms of the patch right-hand sides
 	DevBuf<double>  matsym;          // half matrices in MFMA fragment order (patchsolve32_sym.hpp), 32^3 patches
 	bool            sym_ok = false;  // every plan of the level has pure (DST-II/III or DCT-II/III) axes
+	DevBuf<int32_t> ps_list;         // otherwise: [patches with pure axes (n_pure) | the others]
+	int             n_pure = 0;
 	// scratch
 	std::unique_ptr<te_vec> u, f, r, t;
 
@@ -530,6 +532,17 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 				}
 			L->sym_ok = pure;
 			if ((rc = L->matsym.upload(fs))) return rc;
+			if (!pure) { // per-patch choice between k_ps_sym and k_ps_fused
+				std::vector<int32_t> lst, mixed;
+				for (int p = 0; p < P; p++) {
+					bool ok = true;
+					for (int a = 0; a < 3; a++) ok &= (((keys[plan[p]] >> (2 * a)) & 1) == ((keys[plan[p]] >> (2 * a + 1)) & 1));
+					(ok ? lst : mixed).push_back(p);
+				}
+				L->n_pure = (int) lst.size();
+				lst.insert(lst.end(), mixed.begin(), mixed.end());
+				if ((rc = L->ps_list.upload(lst))) return rc;
+			}
 		}
 		if ((rc = L->corr.alloc((size_t) std::max(P, 1) * NS * L->nf))) return rc;
 		if ((rc = L->plan.upload(plan)) || (rc = L->mats.upload(mats)) || (rc = L->lam.upload(lam))
@@ -1076,25 +1089,31 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 			Timed         t(g, KC_PS_MFMA, total);
 			const dim3    b512(512);
 			const double *cp = zero_guess ? (const double *) nullptr : (const double *) L.corr.p;
-			if (L.sym_ok && !(mode && !strcmp(mode, "1pass-dense"))) {
-				// pure axes: half-size transforms; one resident workgroup per CU walks over the patches
-				const dim3 gs(std::min(L.P, ncu));
-				double    *xo = g->in_cycle ? L.xfbuf[L.xf_cur ^ 1].p : nullptr;
+			// pure axes: half-size transforms, one resident workgroup per CU walks over the patches (k_ps_sym);
+			// patches with a mixed Dirichlet/Neumann axis: full transforms, one workgroup per patch (k_ps_fused)
+			const bool dense_only = mode && !strcmp(mode, "1pass-dense");
+			const int  n_sym = dense_only ? 0 : (L.sym_ok ? L.P : L.n_pure), n_mix = L.P - n_sym;
+			const int32_t *lst_sym = (n_sym > 0 && n_mix > 0) ? L.ps_list.p : nullptr;
+			const int32_t *lst_mix = (n_sym > 0 && n_mix > 0) ? L.ps_list.p + n_sym : nullptr;
+			if (n_sym > 0) {
+				const dim3 gs(std::min(n_sym, ncu));
+				double    *xo = (g->in_cycle && n_mix == 0) ? L.xfbuf[L.xf_cur ^ 1].p : nullptr; // (k_ps_fused does not export)
 				if (zero_guess)
-					hipLaunchKernelGGL(k_ps_sym<false>, gs, b512, PSS_LDS_BYTES, g->stream, L.P, L.plan.p, L.matsym.p, L.lam.p,
-					                   L.zero_mode.p, L.rh2.p, f, cp, u, xo);
+					hipLaunchKernelGGL(k_ps_sym<false>, gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
+					                   L.zero_mode.p, L.rh2.p, f, cp, u, xo, lst_sym);
 				else
-					hipLaunchKernelGGL(k_ps_sym<true>, gs, b512, PSS_LDS_BYTES, g->stream, L.P, L.plan.p, L.matsym.p, L.lam.p,
-					                   L.zero_mode.p, L.rh2.p, f, cp, u, xo);
+					hipLaunchKernelGGL(k_ps_sym<true>, gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
+					                   L.zero_mode.p, L.rh2.p, f, cp, u, xo, lst_sym);
 				if (xo) xfProduced(L, u);
-			} else {
-				const dim3 gf(8 * ((L.P + 7) / 8));
+			}
+			if (n_mix > 0) {
+				const dim3 gf(8 * ((n_mix + 7) / 8));
 				if (zero_guess)
-					hipLaunchKernelGGL(k_ps_fused<false>, gf, b512, PSF_LDS_BYTES, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p,
-					                   L.zero_mode.p, L.rh2.p, f, cp, u);
+					hipLaunchKernelGGL(k_ps_fused<false>, gf, b512, PSF_LDS_BYTES, g->stream, n_mix, L.plan.p, L.mats.p, L.lam.p,
+					                   L.zero_mode.p, L.rh2.p, f, cp, u, lst_mix);
 				else
-					hipLaunchKernelGGL(k_ps_fused<true>, gf, b512, PSF_LDS_BYTES, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p,
-					                   L.zero_mode.p, L.rh2.p, f, cp, u);
+					hipLaunchKernelGGL(k_ps_fused<true>, gf, b512, PSF_LDS_BYTES, g->stream, n_mix, L.plan.p, L.mats.p, L.lam.p,
+					                   L.zero_mode.p, L.rh2.p, f, cp, u, lst_mix);
 			}
 			HIPCHK(hipGetLastError());
 			return TE_OK;

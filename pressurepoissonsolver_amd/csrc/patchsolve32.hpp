@@ -303,13 +303,15 @@ template <bool CORR>
 __global__ __launch_bounds__(512) void k_ps_fused(int P, const int32_t *__restrict__ plan, const double *__restrict__ mats,
                                                   const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
                                                   const double *__restrict__ rh2, const double *__restrict__ in,
-                                                  const double *__restrict__ corr, double *__restrict__ out)
+                                                  const double *__restrict__ corr, double *__restrict__ out,
+                                                  const int32_t *__restrict__ list /* may be null: patches list[0..P) */)
 {
 	constexpr int N = 32, NN = N * N;
 	extern __shared__ __attribute__((aligned(16))) double xbuf[];
 	const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, g = l >> 4;
-	const int pid  = xcdRemap(blockIdx.x, P);
-	if (pid >= P) return;
+	const int slot = xcdRemap(blockIdx.x, P);
+	if (slot >= P) return;
+	const int pid = list ? list[slot] : slot;
 	const int     pl = plan[pid];
 	const double *M  = mats + (size_t) pl * 6 * NN;
 	PSF_STAMP(0);

@@ -47,7 +47,7 @@ constexpr int PSS_TAB       = PSS_RING + 8 * 128;                  // the curren
 constexpr int PSS_LDS_BYTES = (PSS_TAB + PSS_FRAG) * 8;            // 163840: all of a CU's LDS
 #ifdef PSF_TIMING
 static __device__ long long pss_stamp[8][12];
-#define PSS_STAMP(k) do { if (blockIdx.x == 100 && l == 0 && pid == (int) (blockIdx.x + 8 * gridDim.x)) pss_stamp[wave][k] = clock64(); } while (0)
+#define PSS_STAMP(k) do { if (blockIdx.x == 100 && l == 0 && it == (int) (blockIdx.x + 8 * gridDim.x)) pss_stamp[wave][k] = clock64(); } while (0)
 #else
 #define PSS_STAMP(k)
 #endif
@@ -58,12 +58,14 @@ struct PssPlane {
 	double ll[4], lh[4], hl[4], hh[4]; // [row half][column half][q]
 };
 
+// list (may be null): the kernel works on patches list[0..P) instead of 0..P (levels where only some patches
+// have pure axes; the others take k_ps_fused).
 template <bool CORR>
 __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict__ plan, const double *__restrict__ frag,
                                                 const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
                                                 const double *__restrict__ rh2, const double *__restrict__ in,
                                                 const double *__restrict__ corr, double *__restrict__ out,
-                                                double *__restrict__ xf_out)
+                                                double *__restrict__ xf_out, const int32_t *__restrict__ list)
 {
 	constexpr int N = 32, NN = N * N;
 	extern __shared__ __attribute__((aligned(16))) double xbuf[];
@@ -125,9 +127,11 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 	// planes in flight: slot 0 = plane z_0 then z_2 (then the z-face term), slot 1 = z_1 then z_3
 	PssPlane s0, s1;
 	double   c[2] = {0.0, 0.0};
-	int      pid  = blockIdx.x, cur_plan = -1;
-	if (pid < P) {
-		const Lane q = lane();
+	int      it = blockIdx.x, cur_plan = -1; // position in the walk; pid = the patch there
+	auto     patchAt = [&](int i) { return list ? list[i] : i; };
+	if (it < P) {
+		const Lane q   = lane();
+		const int  pid = patchAt(it);
 		loadPlane(q, s0, in + ((size_t) pid * N + zof(0)) * NN);
 		loadPlane(q, s1, in + ((size_t) pid * N + zof(1)) * NN);
 		if (CORR) loadRing(q, c, corr + (size_t) pid * 6 * NN, zof(0));
@@ -136,8 +140,8 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 	// memory latencies and holds up every store queued behind it (the memory pipeline is in order): the next
 	// patch's first two planes are requested apart, at the start and at the end of the second z stage.
 	auto prefetch = [&](int which) {
-		const int np = pid + gridDim.x;
-		if (np >= P) return;
+		if (it + (int) gridDim.x >= P) return;
+		const int  np = patchAt(it + gridDim.x);
 		const Lane qn = lane();
 		if (which == 0) {
 			loadPlane(qn, s0, in + ((size_t) np * N + zof(0)) * NN);
@@ -148,7 +152,8 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 	};
 
 #pragma unroll 1
-	for (; pid < P; pid += gridDim.x) {
+	for (; it < P; it += gridDim.x) {
+		const int pid = patchAt(it);
 		const int pl = plan[pid];
 		if (pl != cur_plan) { // (re)load the plan's fragment table; every wave is past the previous patch here
 			const double *src = frag + (size_t) pl * PSS_FRAG;

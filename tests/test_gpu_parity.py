@@ -152,6 +152,30 @@ def test_patch_solve_variants_agree(case, monkeypatch):
     assert rel(got["1pass"][1], got["3pass"][1]) <= 1e-13
 
 
+def test_patch_solve_split_between_pure_and_mixed_axes(monkeypatch):
+    """Neumann boundaries: patches that touch the boundary have a Dirichlet(interface)/Neumann axis (type-IV
+    transforms, k_ps_fused), interior patches have pure DST axes (k_ps_sym); the level is split per patch.
+    4^3 patches of 32^3: 8 interior + 56 boundary."""
+    m, H, levels = util.setup("uniform", 32, 2, neumann=True, dim=3)
+    g, L = capi.GMG(H), levels[0]
+    u = util.rand_vec(L.size, 43)
+    f = util.rand_vec(L.size, 53) / L.a["h"].min() ** 2
+    got = {}
+    for mode in ("1pass", "3pass"):
+        monkeypatch.setenv("TE_PS_MODE", mode)
+        du, df, dc = g.new_vector(0, u), g.new_vector(0, f), g.new_vector(0)
+        g.smooth(df, du, level=0, smoother=capi.SMOOTH_PATCH_SOLVE)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, dc)
+        got[mode] = (du.download(), dc.download())
+    assert rel(got["1pass"][0], orc.smooth(L, f, u)) <= 1e-11
+    assert rel(got["1pass"][0], got["3pass"][0]) <= 1e-13
+    assert rel(got["1pass"][1], got["3pass"][1]) <= 1e-12
+    # the mixed patches alone run the same MFMA sequence as the three-pass kernels
+    ids = np.asarray(L.a["id"]) if "id" in L.a else None
+    diff = np.abs(got["1pass"][0] - got["3pass"][0]).reshape(L.P, -1).max(axis=1)
+    assert (diff == 0).sum() >= 56 and (diff > 0).sum() <= 8
+
+
 def test_blas1(case):
     g, L = case["g"], case["levels"][0]
     a, b, c = (util.rand_vec(L.size, s) for s in (60, 61, 62))

@@ -92,14 +92,14 @@ int main(int argc, char **argv)
 	};
 	for (int skew = 0; skew <= 0; skew++) {
 		printf("skew %d\n", skew);
-		timeit("sym zero-guess", [&] { hipLaunchKernelGGL(k_ps_sym<false>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, (const double *) nullptr, out, s0); });
+		timeit("sym zero-guess", [&] { hipLaunchKernelGGL(k_ps_sym<false>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, (const double *) nullptr, out, s0, (const int32_t *) nullptr); });
 		sstamps();
-		timeit("sym with corr", [&] { hipLaunchKernelGGL(k_ps_sym<true>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, corr, out, s0); });
+		timeit("sym with corr", [&] { hipLaunchKernelGGL(k_ps_sym<true>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, corr, out, s0, (const int32_t *) nullptr); });
 		sstamps();
 	}
-	timeit("fused zero-guess", [&] { hipLaunchKernelGGL(k_ps_fused<false>, gf, dim3(512), PSF_LDS_BYTES, 0, P, plan, mats, lam, zm, rh2, in, (const double *) nullptr, out); });
+	timeit("fused zero-guess", [&] { hipLaunchKernelGGL(k_ps_fused<false>, gf, dim3(512), PSF_LDS_BYTES, 0, P, plan, mats, lam, zm, rh2, in, (const double *) nullptr, out, (const int32_t *) nullptr); });
 	stamps();
-	timeit("fused with corr", [&] { hipLaunchKernelGGL(k_ps_fused<true>, gf, dim3(512), PSF_LDS_BYTES, 0, P, plan, mats, lam, zm, rh2, in, corr, out); });
+	timeit("fused with corr", [&] { hipLaunchKernelGGL(k_ps_fused<true>, gf, dim3(512), PSF_LDS_BYTES, 0, P, plan, mats, lam, zm, rh2, in, corr, out, (const int32_t *) nullptr); });
 	stamps();
 	timeit("xy fwd zero", [&] { hipLaunchKernelGGL(k_ps_xy<false>, dim3(P), dim3(256), 0, 0, P, plan, mats, in, (const double *) nullptr, out); });
 	timeit("xy fwd corr", [&] { hipLaunchKernelGGL((k_ps_xy<false, true>), dim3(P), dim3(256), 0, 0, P, plan, mats, in, corr, out); });
