@@ -54,6 +54,21 @@ static __device__ long long pss_stamp[8][12];
 
 // One plane as the A operand of the y transform, A[i <-> x][k <-> y]: lane (j, g) holds rows y = 4q+g ("l") and
 // 31-y ("h"), q = 0..3, of columns x = j ("l") and 31-j ("h"). Sixteen lanes read 128 contiguous bytes.
+// n / d for well-scaled operands (eigenvalues of the patch operator: no denormals, no overflow): hardware
+// reciprocal, two Newton steps, one residual correction -- the sequence of the IEEE division without its
+// scaling and fix-up instructions, a third of the issue cycles. The z stages are bound by these divisions
+// (32 per lane and slab on the vector ALU) rather than by their 32 MFMAs.
+__device__ __forceinline__ double pssDiv(double n, double d)
+{
+	double x = __builtin_amdgcn_rcp(d);
+	double e = __builtin_fma(-d, x, 1.0);
+	x        = __builtin_fma(x, e, x);
+	e        = __builtin_fma(-d, x, 1.0);
+	x        = __builtin_fma(x, e, x);
+	const double q = n * x;
+	return __builtin_fma(__builtin_fma(-d, q, n), x, q);
+}
+
 struct PssPlane {
 	double ll[4], lh[4], hl[4], hh[4]; // [row half][column half][q]
 };
@@ -259,42 +274,51 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 			}
 			const bool zmp = zero_mode[pl] != 0;
 			if (fetch_next) prefetch(0);
+			// three passes over the wave's two slabs (forward, divide, inverse) rather than slab by slab: the divisions of
+			// one slab (vector ALU) then have the other slab's MFMAs to hide behind, inside the same wave
+			v4f64 d[2][2][2]; // [slab][kz parity][ky parity]: rows kz = 2 (g + 4r) + parity
 #pragma unroll
 			for (int t = 0; t < 2; t++) {
-				const int    sl = 2 * wave + t, kx = 2 * sl + half;
-				double      *sp = xbuf + sl * PSS_SLAB + 2 * j;
-				const double lx = ring[kx];
-				const double exy0 = lx + ly.x, exy1 = lx + ly.y;
-				const bool   zm   = zmp && kx == 0 && j == 0;
-				v4f64        d[2][2]; // [kz parity][ky parity]: rows kz = 2 (g + 4r) + parity
-				d[0][0] = d[0][1] = d[1][0] = d[1][1] = v4f64{0, 0, 0, 0};
+				const double *sp = xbuf + (2 * wave + t) * PSS_SLAB + 2 * j;
+				d[t][0][0] = d[t][0][1] = d[t][1][0] = d[t][1][1] = v4f64{0, 0, 0, 0};
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
 					const double2 vl = *reinterpret_cast<const double2 *>(sp + (4 * k + g) * N);
 					const double2 vh = *reinterpret_cast<const double2 *>(sp + (N - 1 - 4 * k - g) * N);
 					const double  a0 = frg(q, 2, 0, k), a1 = frg(q, 2, 1, k);
-					d[0][0] = mfma_f64(a0, vl.x + vh.x, d[0][0]);
-					d[0][1] = mfma_f64(a0, vl.y + vh.y, d[0][1]);
-					d[1][0] = mfma_f64(a1, vl.x - vh.x, d[1][0]);
-					d[1][1] = mfma_f64(a1, vl.y - vh.y, d[1][1]);
+					d[t][0][0] = mfma_f64(a0, vl.x + vh.x, d[t][0][0]);
+					d[t][0][1] = mfma_f64(a0, vl.y + vh.y, d[t][0][1]);
+					d[t][1][0] = mfma_f64(a1, vl.x - vh.x, d[t][1][0]);
+					d[t][1][1] = mfma_f64(a1, vl.y - vh.y, d[t][1][1]);
 				}
+			}
+#pragma unroll
+			for (int t = 0; t < 2; t++) {
+				const int    kx = 2 * (2 * wave + t) + half;
+				const double lx = ring[kx];
+				const double exy0 = lx + ly.x, exy1 = lx + ly.y;
+				const bool   zm   = zmp && kx == 0 && j == 0;
 #pragma unroll
 				for (int p = 0; p < 2; p++)
 #pragma unroll
 					for (int r = 0; r < 4; r++) {
-						d[p][0][r] /= -(exy0 + ez[p][r]);
-						d[p][1][r] /= -(exy1 + ez[p][r]);
-						if (zm && p == 0 && g + 4 * r == 0) d[p][0][r] = 0.0; // FftwPatchSolver.h:197
+						d[t][p][0][r] = pssDiv(d[t][p][0][r], -(exy0 + ez[p][r]));
+						d[t][p][1][r] = pssDiv(d[t][p][1][r], -(exy1 + ez[p][r]));
+						if (zm && p == 0 && g + 4 * r == 0) d[t][p][0][r] = 0.0; // FftwPatchSolver.h:197
 					}
-				v4f64 pz[2], qz[2];
+			}
+#pragma unroll
+			for (int t = 0; t < 2; t++) {
+				double *sp = xbuf + (2 * wave + t) * PSS_SLAB + 2 * j;
+				v4f64   pz[2], qz[2];
 				pz[0] = pz[1] = qz[0] = qz[1] = v4f64{0, 0, 0, 0};
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
 					const double a0 = frg(q, 5, 0, r), a1 = frg(q, 5, 1, r);
-					pz[0] = mfma_f64(a0, d[0][0][r], pz[0]);
-					pz[1] = mfma_f64(a0, d[0][1][r], pz[1]);
-					qz[0] = mfma_f64(a1, d[1][0][r], qz[0]);
-					qz[1] = mfma_f64(a1, d[1][1][r], qz[1]);
+					pz[0] = mfma_f64(a0, d[t][0][0][r], pz[0]);
+					pz[1] = mfma_f64(a0, d[t][0][1][r], pz[1]);
+					qz[0] = mfma_f64(a1, d[t][1][0][r], qz[0]);
+					qz[1] = mfma_f64(a1, d[t][1][1][r], qz[1]);
 				}
 				// rows z = g + 4r (P + Q) and 31 - z (P - Q); every read of this slab is complete (same wave, in order)
 #pragma unroll
