@@ -78,9 +78,13 @@ typedef struct {
 	int32_t smoother;   /* TE_SMOOTH_* */
 	double  omega;      /* Jacobi weight */
 	int32_t exact_coarse; /* pointwise smoothers: exact patch solve on a 1-patch coarsest level */
-	int32_t fuse;         /* 1 (default): inside te_vcycle use the fused residual+restrict kernel and the
-	                         zero-guess first sweep (bit-identical results, fewer HBM passes); 0: one kernel
-	                         per reference call (apply, scaleThenAdd, restrict, set, ...) */
+	int32_t fuse;         /* 0: one kernel per reference call (apply, scaleThenAdd, restrict, set, ...);
+	                         1: inside te_vcycle use the fused kernels whose results are BIT-IDENTICAL to 0
+	                            (residual+restrict, zero-guess first sweep, sweep on u + P e);
+	                         2 (default): additionally, with one RB-GS pre-sweep on a uniformly refined 3D level,
+	                            the sweep from the zero iterate, the residual and its restriction are one pass over f;
+	                            the coarse right-hand side differs from 1 by a few ulp along patch faces (the ghost
+	                            term of the residual is added separately), independent of the partition */
 } te_cycle_opts;
 
 #define TE_SMOOTH_PATCH_SOLVE 0 /* reference: FFTBlockJacobiSmoother.h:55-58 (block Jacobi, exact patch solves) */

@@ -40,12 +40,13 @@ enum KClass : int {
 	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_RBGS_ZERO, KC_RESID_RESTRICT, KC_PS_MFMA, KC_RBGS_PROLONG,
 	// launches on levels with few patches run other instantiations (z-slabs, split patches): classes of their own, so
 	// that a class above is one kernel symbol and its average duration is the one rocprofv3 --stats reports
-	KC_RBGS_SLABS, KC_STENCIL_SLABS, KC_PS_3PASS, KC_COUNT
+	KC_RBGS_SLABS, KC_STENCIL_SLABS, KC_PS_3PASS, KC_ZERO_RESID, KC_FIXUP, KC_COUNT
 };
 const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_jacobi", "stencil_rbgs",
                                     "cf_ghost", "restrict", "prolong_add", "patch_rhs", "dst_axis",
                                     "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict", "patch_solve_mfma", "stencil_rbgs_prolong",
-                                    "stencil_rbgs_slabs", "stencil_slabs", "patch_solve_3pass"};
+                                    "stencil_rbgs_slabs", "stencil_slabs", "patch_solve_3pass", "rbgs_zero_resid_restrict",
+                                    "restrict_fixup"};
 
 template <typename T> struct DevBuf {
 	T     *p = nullptr;
@@ -84,6 +85,11 @@ struct LevelHost {
 	// ghost exchange, and all ranks must agree on that); fuse2d = additionally all parents are local (rank-local:
 	// residual+restrict in one pass; peers see the same exchanges either way)
 	bool   lds2d = false, fuse2d = false;
+	// 3D: the fused pre-sweep + residual + restriction (opts.fuse = 2) applies: a uniform refinement step (every patch
+	// of the GLOBAL level is an octant child, none has a coarse/fine face) with at least 256 patches in total.
+	// Decided from the global tables, so it is the same on every rank and for every partition: sharded runs take the
+	// same arithmetic path as the single-rank run.
+	bool   fuse2_ok = false;
 	size_t nc = 0, nf = 0;
 	// stencil tables
 	DevBuf<int32_t> face_kind, face_src;
@@ -449,6 +455,14 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	}
 	L->nslots = nslots;
 	L->lds2d  = (D == 2 && n <= 64 && n % 2 == 0 && !getenv("TE_2D_SIMPLE"));
+	if (D == 3 && li + 1 < (int) H.levels.size() && lv.P_global >= 256) { // see LevelHost::fuse2_ok: global facts only
+		bool ok = true;
+		for (int gp = 0; gp < lv.P_global && ok; gp++) {
+			ok &= lv.g_orth_on_parent[gp] >= 0;
+			for (int s = 0; s < NS && ok; s++) ok &= lv.g_nbr_kind[(size_t) gp * NS + s] <= NBR_NORMAL;
+		}
+		L->fuse2_ok = ok;
+	}
 	L->ncf    = (int) cfs.size();
 	int rc;
 	{
@@ -984,6 +998,49 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
+// opts.fuse = 2: first pre-smoothing sweep from a zero iterate + residual + restriction (march3d.hpp,
+// k_rbgs_zero_resid3d / k_restrict_fixup3d). out = S(0, f) with its x faces in xf_out, coarse = AvgRstr(f - A out).
+template <int N> int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out)
+{
+	RestrictDst rd;
+	rd.parent     = L.parent.p;
+	rd.orth       = L.orth.p;
+	rd.coarse     = coarse;
+	rd.remote     = L.upbuf.p;
+	rd.remote_off = L.up_off.p;
+	int rc;
+	if (L.P > 0) {
+		Timed    t(g, KC_ZERO_RESID, (size_t) L.P * L.nc);
+		LevelDev D = L.dev();
+		D.xf_out   = xf_out;
+		hipLaunchKernelGGL(k_rbgs_zero_resid3d<N>, dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, f, out, rd);
+	}
+	if ((rc = prepareGhosts<N>(g, L, out))) return rc; // the new face layers of neighbours on other ranks (no-op on one rank)
+	if (L.P > 0) {
+		Timed    t(g, KC_FIXUP, (size_t) L.P * 6 * L.nf);
+		LevelDev D = L.dev();
+		D.xf       = xf_out;
+		hipLaunchKernelGGL(k_restrict_fixup3d<N>, dim3(L.P), dim3(256), 0, g->stream, D, out, rd);
+	}
+	// children whose parent lives on another rank: ship the finished blocks (as residRestrictN)
+	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
+	if (L.n_down > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 8);
+		hipLaunchKernelGGL(k_restrict_unpack3d<N>, dim3(L.n_down), dim3(256), 0, g->stream, L.down_desc.p, L.down_off.p,
+		                   L.downbuf.p, coarse);
+	}
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+int zeroSweepResid(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out)
+{
+	switch (L.n) {
+		case 4: return zeroSweepResidN<4>(g, L, f, out, coarse, xf_out);
+		case 8: return zeroSweepResidN<8>(g, L, f, out, coarse, xf_out);
+		case 16: return zeroSweepResidN<16>(g, L, f, out, coarse, xf_out);
+		default: return zeroSweepResidN<32>(g, L, f, out, coarse, xf_out);
+	}
+}
 int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false,
                const double *prolong_from = nullptr, const double *xf_in = nullptr, double *xf_out = nullptr)
 {
@@ -1349,10 +1406,13 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		return materialise();
 	}
 	LevelHost &C       = *g->levels[l + 1];
+	bool       have_coarse_f = false;
 	auto       descend = [&]() -> int {
         int r = materialise();
         if (r) return r;
-        if (o->fuse && (L.dim == 3 || L.fuse2d)) {
+        if (have_coarse_f) { // the fused pre-sweep already left AvgRstr(f - A u) in C.f
+            have_coarse_f = false;
+        } else if (o->fuse && (L.dim == 3 || L.fuse2d)) {
             if ((r = residRestrict(g, L, u->d, f->d, C.f->d, xfFor(L, u->d)))) return r;
         } else {
             if ((r = launchStencil<MODE_RESID>(g, L, u->d, f->d, L.r->d, 0.0, RestrictDst(), xfFor(L, u->d)))) return r; // prepCoarser: r = f - A u
@@ -1371,7 +1431,19 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         L.xf_valid_for = nullptr; // u changes in place
         return doProlong(g, l, C.u->d, u->d);
 	};
-	if ((rc = smooth(o->pre_sweeps, false))) return rc;
+	// opts.fuse = 2: one pre-smoothing RB-GS sweep from the zero iterate, the residual and its restriction in one
+	// pass over f (plus a pass over the face layers). All ranks take the same decision on a level or the ones
+	// that do not would wait for ghost faces nobody sends: it rests on facts every rank knows (dimension, options,
+	// global patch count) and on fuse2_ok, which the hierarchy builder sets identically on all ranks.
+	if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_RBGS && L.fuse2_ok && !getenv("TE_NO_FUSE2")) {
+		u_zero = false;
+		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p))) return rc;
+		xfProduced(L, L.t->d);
+		swapData(u, L.t.get());
+		have_coarse_f = true;
+	} else if ((rc = smooth(o->pre_sweeps, false))) {
+		return rc;
+	}
 	next_sweeps = (o->cycle_type == 1) ? o->mid_sweeps : o->post_sweeps;
 	if ((rc = descend())) return rc;
 	if (o->cycle_type == 1) {
@@ -1392,7 +1464,7 @@ void te_cycle_opts_default(te_cycle_opts *o)
 	o->smoother     = TE_SMOOTH_PATCH_SOLVE;
 	o->omega        = 6.0 / 7.0;
 	o->exact_coarse = 1;
-	o->fuse         = 1;
+	o->fuse         = 2;
 }
 
 int te_gmg_create(const te_hier *h, int device, te_gmg **out)

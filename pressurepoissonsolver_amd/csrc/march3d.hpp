@@ -486,4 +486,238 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	}
 	step(std::integral_constant<int, 0>{}, z1); // black update and store of the last plane (and, inside a patch, the red values above it)
 }
+
+// ---- pre-smoothing sweep from a zero iterate + residual + restriction in one pass (opts.fuse = 2) --------------
+// Cycle.h:57-65 for the first sweep of a cycle: u = S(0, f); coarse f = AvgRstr(f - A u). The sweep of a patch
+// needs no neighbour data at all (every ghost of a zero iterate is zero), and the residual of every cell that
+// is not on a patch face with a neighbour needs only this patch's new values: k_rbgs_zero_resid3d therefore
+// writes u (8 B/site) and the restricted residual (1 B/site) from one read of f (8 B/site) -- 17 B/site
+// instead of 16 + 17 for the sweep and the residual+restrict kernel. On faces with a neighbour the residual
+// is formed with a zero ghost; k_restrict_fixup3d then adds the missing term -g/h^2 (g = the neighbour's new
+// face value) to the coarse cells along the patch faces, from the face layers alone (x faces from the compact
+// columns the sweep exported). That is the one fusion that is NOT bit-identical to the unfused sequence: the
+// ghost term enters the coarse value by a separate addition (differences of a few ulp in coarse f along
+// patch faces; sharded runs still equal single-rank runs bit for bit). Levels of octant children with local
+// parents and no coarse/fine faces only; z-slabs do not apply (the residual would need two more planes).
+//
+// Pipeline per step z: red update of plane z (f only), black update of plane z-1 (new red values), residual of
+// plane z-2 (its z-neighbours z-3 and z-1 are final), restriction over plane pairs. Four LDS planes rotate:
+// plane z-2 is still being read (residual) while the fastest waves already write plane z+1.
+template <int N>
+__global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L, const double *__restrict__ f,
+                                                                     double *__restrict__ out, RestrictDst rd)
+{
+	using T           = Tile3<N>;
+	constexpr int TPB = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
+	constexpr int NN  = N * N, NNN = N * N * N;
+	const int     slot = xcdRemap(blockIdx.x, L.count);
+	if (slot >= L.count) return;
+	const int pid = L.order ? L.order[L.first + slot] : L.first + slot;
+	const int tid = threadIdx.x;
+
+	__shared__ __attribute__((aligned(16))) double tile[4][T::LSZ];
+	__shared__ double idiag[27];
+
+	const int32_t *fk  = L.face_kind + (size_t) pid * 6;
+	const double   rhx = L.rh2[(size_t) pid * 3], rhy = L.rh2[(size_t) pid * 3 + 1], rhz = L.rh2[(size_t) pid * 3 + 2];
+	const double2 *fp2 = reinterpret_cast<const double2 *>(f + (size_t) pid * NNN);
+	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
+
+	if (tid < 27) {
+		double kf[3];
+		int    cls[3] = {tid % 3, (tid / 3) % 3, tid / 9};
+#pragma unroll
+		for (int ax = 0; ax < 3; ax++) {
+			kf[ax] = 2.0;
+			if (cls[ax] != 1) {
+				int kind = fk[2 * ax + (cls[ax] == 2)];
+				if (kind == FACE_DIRICHLET) kf[ax] = 3.0;
+				if (kind == FACE_NEUMANN) kf[ax] = 1.0;
+			}
+		}
+		idiag[tid] = 1.0 / (kf[0] * rhx + kf[1] * rhy + kf[2] * rhz);
+	}
+	for (int i = tid; i < 4 * T::LSZ; i += TPB) (&tile[0][0])[i] = 0.0; // halo ring stays zero: ghosts of a zero iterate
+
+	const bool act = (T::NT == TPB) || tid < T::NT;
+	const int  X = act ? tid % H : 0, Yp = act ? tid / H : 0;
+	int        q[2], lds[2], dix[2][2];
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		q[k]   = (2 * Yp + k) * H + X;
+		lds[k] = (2 * Yp + k + 1) * LW + 2 * X + 2;
+	}
+	{
+		const int cy0 = (Yp == 0) ? 0 : 1, cy1 = (Yp == H - 1) ? 2 : 1;
+		const int cx0 = (X == 0) ? 0 : 1, cx1 = (X == H - 1) ? 2 : 1;
+		dix[0][0] = cx0 + 3 * cy0, dix[0][1] = cx1 + 3 * cy0, dix[1][0] = cx0 + 3 * cy1, dix[1][1] = cx1 + 3 * cy1;
+	}
+	// ghost of the residual's stencil on each side, as a multiple of the cell just inside: -1 Dirichlet, +1 Neumann
+	// (StarPatchOp.h:39-65); 0 on faces with a neighbour (that term is k_restrict_fixup3d's)
+	auto phys = [&](int s) { return fk[s] == FACE_DIRICHLET ? -1.0 : (fk[s] == FACE_NEUMANN ? 1.0 : 0.0); };
+	const double gW = (X == 0) ? phys(0) : 0.0, gE = (X == H - 1) ? phys(1) : 0.0;
+	const double gS = (Yp == 0) ? phys(2) : 0.0, gN = (Yp == H - 1) ? phys(3) : 0.0;
+	const double gB = phys(4), gT = phys(5);
+
+	// fused restriction target (see k_stencil3d<MODE_RESID_RESTRICT>): the parent's octant, or the block this rank
+	// ships to the parent's rank; no copy-through patches on these levels
+	const int pa = rd.parent[pid], rorth = rd.orth[pid];
+	double   *rdst;
+	int       rsz;
+	if (pa >= 0) {
+		rdst = rd.coarse + (size_t) pa * NNN + ((rorth & 1) ? H : 0) + N * ((rorth & 2) ? H : 0) + NN * ((rorth & 4) ? H : 0) + X + N * Yp;
+		rsz  = NN;
+	} else {
+		rdst = rd.remote + rd.remote_off[-(pa + 2)] + X + H * Yp;
+		rsz  = H * H;
+	}
+	double racc = 0.0;
+
+	// new iterate: u3 = plane z-3, u2 = z-2, u1 = z-1, u0 = z (all start from zero); right-hand sides alongside
+	double2 u3[2], u2[2], u1[2], u0[2], f2[2], f1[2], f0[2], fn[2];
+	const double2 zero2 = double2{0.0, 0.0};
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		u3[k] = u2[k] = u1[k] = u0[k] = zero2;
+		f2[k] = f1[k] = zero2;
+		f0[k] = fp2[q[k]];
+	}
+	__syncthreads(); // idiag and the zeroed tiles
+
+	int bz = 0; // z % 4
+	auto step = [&](auto zpar, int z) {
+		constexpr int ZPAR = decltype(zpar)::value;
+		const int     zc   = (z + 1 < N) ? z + 1 : N - 1;
+#pragma unroll
+		for (int k = 0; k < 2; k++) fn[k] = fp2[zc * NP + q[k]];
+		double *tz = tile[bz];            // plane z
+		double *t1 = tile[(bz + 3) & 3];  // plane z-1
+		double *t2 = tile[(bz + 2) & 3];  // plane z-2
+		ldsBarrier(); // plane z's buffer was last read (residual of plane z-4) two steps ago
+		if (z < N) { // red cells of plane z: every neighbour is zero
+			const int cz9 = (z == 0) ? 0 : (z == N - 1 ? 18 : 9);
+			relaxCell<N, 0, (0 + ZPAR) & 1, true>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, u0, u1, u1, f0);
+			relaxCell<N, 1, (1 + ZPAR) & 1, true>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, u0, u1, u1, f0);
+			// (the buffer still holds an older plane at the black cells: nobody reads them before step z+1 rewrites them)
+		}
+		if (z > 0 && z <= N) { // black cells of plane z-1 from the new red values
+			const int cz9 = (z - 1 == 0) ? 0 : (z - 1 == N - 1 ? 18 : 9);
+			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false>(t1, idiag, cz9, lds, dix, act, rhx, rhy, rhz, u1, u2, u0, f1);
+			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false>(t1, idiag, cz9, lds, dix, act, rhx, rhy, rhz, u1, u2, u0, f1);
+			if (act) {
+				op2[(z - 1) * NP + q[0]] = u1[0];
+				op2[(z - 1) * NP + q[1]] = u1[1];
+				if (L.xf_out) {
+					double *xo = L.xf_out + (size_t) pid * 2 * NN + N * (z - 1) + 2 * Yp;
+					if (X == 0) *reinterpret_cast<double2 *>(xo) = double2{u1[0].x, u1[1].x};
+					if (X == H - 1) *reinterpret_cast<double2 *>(xo + NN) = double2{u1[0].y, u1[1].y};
+				}
+			}
+		}
+		if (z > 1) { // residual of plane zr = z-2 (needs the black cells of this plane, written one step ago by all
+			// waves, and of plane z-1, just written by this thread's own registers) and its restriction
+			const int zr = z - 2;
+			// the black values of plane z-2 other waves wrote in the previous step are visible (barrier above)
+			const double2 ylo = *reinterpret_cast<const double2 *>(t2 + lds[0] - LW);
+			const double2 yhi = *reinterpret_cast<const double2 *>(t2 + lds[1] + LW);
+			double        a   = (zr & 1) ? racc : 0.0;
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				const double *t0 = t2 + lds[k];
+				const double2 c  = u2[k];
+				double2       ym = (k == 0) ? ylo : u2[0];
+				double2       yp = (k == 0) ? u2[1] : yhi;
+				if (k == 0) ym.x += gS * c.x, ym.y += gS * c.y;
+				if (k == 1) yp.x += gN * c.x, yp.y += gN * c.y;
+				const double xl = t0[-1] + gW * c.x, xr = t0[2] + gE * c.y;
+				const double2 below = (zr == 0) ? double2{gB * c.x, gB * c.y} : u3[k];
+				const double2 above = (zr == N - 1) ? double2{gT * c.x, gT * c.y} : u1[k];
+				double2       lap;
+				lap.x = (xl - 2 * c.x + c.y) * rhx;
+				lap.y = (c.x - 2 * c.y + xr) * rhx;
+				lap.x += (ym.x - 2 * c.x + yp.x) * rhy;
+				lap.y += (ym.y - 2 * c.y + yp.y) * rhy;
+				lap.x += (below.x - 2 * c.x + above.x) * rhz;
+				lap.y += (below.y - 2 * c.y + above.y) * rhz;
+				a += (f2[k].x - lap.x) / 8; // AvgRstr.h:95-102 order: x, then y, then z; each /2^D first
+				a += (f2[k].y - lap.y) / 8;
+			}
+			racc = a;
+			if ((zr & 1) && act) rdst[rsz * (zr >> 1)] = a;
+		}
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			u3[k] = u2[k];
+			u2[k] = u1[k];
+			u1[k] = u0[k];
+			u0[k] = zero2;
+			f2[k] = f1[k];
+			f1[k] = f0[k];
+			f0[k] = fn[k];
+		}
+		bz = (bz + 1) & 3;
+	};
+#pragma unroll 1
+	for (int z = 0; z < N; z += 2) {
+		step(std::integral_constant<int, 0>{}, z);
+		step(std::integral_constant<int, 1>{}, z + 1);
+	}
+	step(std::integral_constant<int, 0>{}, N);     // black of plane N-1, residual of plane N-2
+	step(std::integral_constant<int, 1>{}, N + 1); // residual of plane N-1
+}
+
+// Second half of the fusion above: the ghost terms of the residual along patch faces with a neighbour. One
+// workgroup per fine patch; per face, one thread per coarse face cell adds -(1/h^2)/8 times the four
+// neighbour values behind its 2x2 fine cells to the coarse cell (a coarse cell belongs to exactly one fine
+// patch; faces in the fixed order W,E,S,N,B,T with a barrier in between: deterministic and independent of the
+// partition). u = the new iterate (its ghost slots current), xf = its compact x faces (may be null).
+template <int N>
+__global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const double *__restrict__ u, RestrictDst rd)
+{
+	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
+	const int     p  = L.first + blockIdx.x; // (all patches: this kernel runs after the exchange)
+	const int     pa = rd.parent[p], o = rd.orth[p];
+	// the octant of the parent, or the H^3 block that travels to the parent's rank: base and strides
+	double   *cb;
+	int       c1 = 1, c2, c3;
+	if (pa >= 0) {
+		cb = rd.coarse + (size_t) pa * NNN + ((o & 1) ? H : 0) + N * ((o & 2) ? H : 0) + NN * ((o & 4) ? H : 0);
+		c2 = N, c3 = NN;
+	} else {
+		cb = rd.remote + rd.remote_off[-(pa + 2)];
+		c2 = H, c3 = H * H;
+	}
+	const int cs[3] = {c1, c2, c3};
+	for (int s = 0; s < 6; s++) {
+		const int kind = L.face_kind[(size_t) p * 6 + s], src = L.face_src[(size_t) p * 6 + s];
+		if (kind >= FACE_LOCAL) {
+			const int    ax = s >> 1;
+			const int    sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
+			const int    oth = (s & 1) ? 0 : (N - 1) * sn;             // the neighbour's facing layer
+			const double w   = -L.rh2[(size_t) p * 3 + ax];
+			for (int i = threadIdx.x; i < H * H; i += blockDim.x) {
+				const int ha = i % H, hb = i / H;
+				double    acc = 0.0;
+#pragma unroll
+				for (int db = 0; db < 2; db++)
+#pragma unroll
+					for (int da = 0; da < 2; da++) {
+						const int a = 2 * ha + da, b = 2 * hb + db;
+						double    g;
+						if (kind == FACE_GHOST)
+							g = L.ghost[(size_t) src * NN + a + N * b];
+						else if (ax == 0 && L.xf)
+							g = L.xf[((size_t) src * 2 + ((s & 1) ^ 1)) * NN + a + N * b];
+						else
+							g = u[(size_t) src * NNN + oth + a * sa + b * sb];
+						acc += (w * g) / 8;
+					}
+				// coarse cell (ha, hb) of the face: axes in order, the normal index 0 or H-1
+				const int ca = (ax == 0) ? 1 : 0, cbx = (ax == 2) ? 1 : 2;
+				cb[ha * cs[ca] + hb * cs[cbx] + ((s & 1) ? (H - 1) * cs[ax] : 0)] += acc;
+			}
+		}
+		__syncthreads();
+	}
+}
 } // namespace te

@@ -152,6 +152,37 @@ def test_patch_solve_variants_agree(case, monkeypatch):
     assert rel(got["1pass"][1], got["3pass"][1]) <= 1e-13
 
 
+@pytest.mark.parametrize("n,neumann", [(8, False), (8, True), (16, False), (32, False)])
+def test_fused_presweep_residual_restrict(n, neumann):
+    """opts.fuse = 2 (default): on uniformly refined levels with >= 256 patches the zero-guess RB-GS pre-sweep, the
+    residual and its restriction are one pass (k_rbgs_zero_resid3d) plus a fix-up of the coarse cells along patch
+    faces (k_restrict_fixup3d). Not bit-identical to fuse = 1 (the ghost term is added separately): a few ulp."""
+    m, H, levels = util.setup("uniform", n, 3, neumann=neumann, dim=3)  # 8^3 = 512 patches on the finest level
+    g, L = capi.GMG(H), levels[0]
+    f = util.rand_vec(L.size, 54) / L.a["h"].min() ** 2
+    got = {}
+    for fuse in (1, 2):
+        df, dc = g.new_vector(0, f), g.new_vector(0)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS, fuse=fuse), df, dc)
+        got[fuse] = dc.download()
+    assert not np.array_equal(got[1], got[2]) or n == 4  # the fused path really ran (it is not bit-identical)
+    assert rel(got[2], got[1]) <= 1e-13
+    if n <= 16:
+        o = orc.cycle_opts(smoother=2)
+        assert rel(got[2], orc.cycle(levels, o, f)) <= 1e-10
+    # W-cycle and two pre-sweeps fall back to the bit-identical path
+    for kw in (dict(cycle_type=1), dict(pre_sweeps=2)):
+        outs = []
+        for fuse in (1, 2):
+            df, dc = g.new_vector(0, f), g.new_vector(0)
+            g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS, fuse=fuse, **kw), df, dc)
+            outs.append(dc.download())
+        if "pre_sweeps" in kw:
+            assert np.array_equal(outs[0], outs[1])
+        else:
+            assert rel(outs[1], outs[0]) <= 1e-13
+
+
 def test_patch_solve_split_between_pure_and_mixed_axes(monkeypatch):
     """Neumann boundaries: patches that touch the boundary have a Dirichlet(interface)/Neumann axis (type-IV
     transforms, k_ps_fused), interior patches have pure DST axes (k_ps_sym); the level is split per patch.
