@@ -84,7 +84,9 @@ typedef struct {
 	                         2 (default): additionally, with one RB-GS pre-sweep on a uniformly refined 3D level,
 	                            the sweep from the zero iterate, the residual and its restriction are one pass over f;
 	                            the coarse right-hand side differs from 1 by a few ulp along patch faces (the ghost
-	                            term of the residual is added separately), independent of the partition */
+	                            term of the residual is added separately), independent of the partition; with one
+	                            block-Jacobi pre-sweep the residual after the exact patch solves is taken on the face
+	                            layers only (it vanishes inside a patch up to the rounding of the solve) */
 } te_cycle_opts;
 
 #define TE_SMOOTH_PATCH_SOLVE 0 /* reference: FFTBlockJacobiSmoother.h:55-58 (block Jacobi, exact patch solves) */

@@ -1020,7 +1020,7 @@ template <int N> int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, d
 		Timed    t(g, KC_FIXUP, (size_t) L.P * 6 * L.nf);
 		LevelDev D = L.dev();
 		D.xf       = xf_out;
-		hipLaunchKernelGGL(k_restrict_fixup3d<N>, dim3(L.P), dim3(256), 0, g->stream, D, out, rd);
+		hipLaunchKernelGGL((k_restrict_fixup3d<N, false>), dim3(L.P), dim3(256), 0, g->stream, D, out, rd);
 	}
 	// children whose parent lives on another rank: ship the finished blocks (as residRestrictN)
 	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
@@ -1031,6 +1031,51 @@ template <int N> int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, d
 	}
 	HIPCHK(hipGetLastError());
 	return TE_OK;
+}
+// opts.fuse = 2 with the block-Jacobi smoother: after an exact patch solve from the zero iterate the residual
+// vanishes inside every patch (A_patch u = f is what was solved) and equals -(g + m)/h^2 = -2 gamma/h^2 on the face
+// layers (the patch operator closes interface faces with ghost = -m, the level operator with the neighbour's g), so
+// coarse f = AvgRstr(f - A u) is k_restrict_fixup3d<OWN> applied to a zeroed coarse vector: no pass over u and f
+// at all. (What is dropped is the rounding noise of the solve, ~1e-13 |f|.) u: the new iterate, xf: its
+// compact x faces or null; coarse: the coarse level's f with `coarse_n` entries.
+template <int N> int interfaceResidRestrictN(te_gmg *g, LevelHost &L, const double *u, const double *xf, double *coarse, size_t coarse_n)
+{
+	RestrictDst rd;
+	rd.parent     = L.parent.p;
+	rd.orth       = L.orth.p;
+	rd.coarse     = coarse;
+	rd.remote     = L.upbuf.p;
+	rd.remote_off = L.up_off.p;
+	int rc;
+	if ((rc = prepareGhosts<N>(g, L, u))) return rc;
+	{
+		Timed t(g, KC_VECOP, coarse_n);
+		HIPCHK(hipMemsetAsync(coarse, 0, sizeof(double) * coarse_n, g->stream));
+		if (L.n_up > 0) HIPCHK(hipMemsetAsync(L.upbuf.p, 0, sizeof(double) * L.upbuf.n, g->stream));
+	}
+	if (L.P > 0) {
+		Timed    t(g, KC_FIXUP, (size_t) L.P * 6 * L.nf);
+		LevelDev D = L.dev();
+		D.xf       = xf;
+		hipLaunchKernelGGL((k_restrict_fixup3d<N, true>), dim3(L.P), dim3(256), 0, g->stream, D, u, rd);
+	}
+	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
+	if (L.n_down > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 8);
+		hipLaunchKernelGGL(k_restrict_unpack3d<N>, dim3(L.n_down), dim3(256), 0, g->stream, L.down_desc.p, L.down_off.p,
+		                   L.downbuf.p, coarse);
+	}
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+int interfaceResidRestrict(te_gmg *g, LevelHost &L, const double *u, const double *xf, double *coarse, size_t coarse_n)
+{
+	switch (L.n) {
+		case 4: return interfaceResidRestrictN<4>(g, L, u, xf, coarse, coarse_n);
+		case 8: return interfaceResidRestrictN<8>(g, L, u, xf, coarse, coarse_n);
+		case 16: return interfaceResidRestrictN<16>(g, L, u, xf, coarse, coarse_n);
+		default: return interfaceResidRestrictN<32>(g, L, u, xf, coarse, coarse_n);
+	}
 }
 int zeroSweepResid(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out)
 {
@@ -1440,6 +1485,13 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p))) return rc;
 		xfProduced(L, L.t->d);
 		swapData(u, L.t.get());
+		have_coarse_f = true;
+	} else if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_PATCH_SOLVE && L.fuse2_ok
+	           && !getenv("TE_NO_FUSE2")) {
+		// block Jacobi from the zero iterate: the residual lives on the face layers only (interfaceResidRestrictN)
+		u_zero = false;
+		if ((rc = smoothOnce(g, l, f, u, TE_SMOOTH_PATCH_SOLVE, o->omega, true))) return rc;
+		if ((rc = interfaceResidRestrict(g, L, u->d, xfFor(L, u->d), C.f->d, C.f->n))) return rc;
 		have_coarse_f = true;
 	} else if ((rc = smooth(o->pre_sweeps, false))) {
 		return rc;

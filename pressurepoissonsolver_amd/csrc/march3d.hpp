@@ -671,7 +671,10 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 // neighbour values behind its 2x2 fine cells to the coarse cell (a coarse cell belongs to exactly one fine
 // patch; faces in the fixed order W,E,S,N,B,T with a barrier in between: deterministic and independent of the
 // partition). u = the new iterate (its ghost slots current), xf = its compact x faces (may be null).
-template <int N>
+// OWN: the residual that is being completed was formed with the PATCH operator (exact patch solves: interface
+// faces closed as homogeneous Dirichlet, ghost = -m, StarPatchOp.h:204-319) rather than with a zero ghost, so
+// the missing term is -(g + m)/h^2 = -2 gamma/h^2 with m = this patch's own face value.
+template <int N, bool OWN>
 __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const double *__restrict__ u, RestrictDst rd)
 {
 	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
@@ -710,6 +713,12 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 							g = L.xf[((size_t) src * 2 + ((s & 1) ^ 1)) * NN + a + N * b];
 						else
 							g = u[(size_t) src * NNN + oth + a * sa + b * sb];
+						if (OWN) {
+							if (ax == 0 && L.xf)
+								g += L.xf[((size_t) p * 2 + (s & 1)) * NN + a + N * b];
+							else
+								g += u[(size_t) p * NNN + ((s & 1) ? (N - 1) * sn : 0) + a * sa + b * sb];
+						}
 						acc += (w * g) / 8;
 					}
 				// coarse cell (ha, hb) of the face: axes in order, the normal index 0 or H-1

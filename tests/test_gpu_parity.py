@@ -170,6 +170,15 @@ def test_fused_presweep_residual_restrict(n, neumann):
     if n <= 16:
         o = orc.cycle_opts(smoother=2)
         assert rel(got[2], orc.cycle(levels, o, f)) <= 1e-10
+    # block-Jacobi smoother: the residual after exact patch solves from zero is taken on the face layers only
+    outs = []
+    for fuse in (1, 2):
+        df, dc = g.new_vector(0, f), g.new_vector(0)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE, fuse=fuse), df, dc)
+        outs.append(dc.download())
+    assert rel(outs[1], outs[0]) <= 1e-11
+    if n <= 16:
+        assert rel(outs[1], orc.cycle(levels, orc.cycle_opts(smoother=0), f)) <= 1e-10
     # W-cycle and two pre-sweeps fall back to the bit-identical path
     for kw in (dict(cycle_type=1), dict(pre_sweeps=2)):
         outs = []
