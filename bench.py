@@ -5,7 +5,7 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one GMG V(1,1) cycle (GMG/Cycle.h:116-126 semantics: zero u, pre-smooth, residual,
-restrict, recurse, prolong-add, post-smooth) over the whole 512^3 grid, 16^3 patches of 32^3
+restrict, recurse, prolong-add, post-smooth; default options: te_cycle_opts.fuse = 2) over the whole 512^3 grid, 16^3 patches of 32^3
 (apps/3d/steady -n 32 --mesh 4uni.bin --divide 1). Inputs are resident in HBM before the timed
 region. N > 1: one rank per GPU (torch.distributed, backend nccl == RCCL); the same 512^3
 problem is sharded by contiguous Morton ranges of patches (strong scaling).
@@ -42,6 +42,8 @@ ALG_BYTES = {
     "stencil_rbgs_zero": 16.0,   # first sweep from a zero guess: read f, write u
     "stencil_rbgs_prolong": 25.0,  # post-sweep on u + P(coarse): read u, f, coarse (8/8); write u
     "patch_solve_mfma": 16.0,    # single-pass exact patch solve: read f, write u (+ face terms, not counted)
+    "rbgs_zero_resid_restrict": 17.0,  # fuse = 2: sweep from zero + residual + restriction: read f, write u and 1/8
+    "restrict_fixup": 12.0,      # per face cell: read the neighbour's value (8), update a coarse cell per 2x2 (16/4)
     # levels with few patches run other instantiations, timed as classes of their own (one class = one kernel
     # symbol for the large levels); they only become "dominant" for small problems (--size 256):
     "stencil_rbgs_slabs": 20.5,  # z-slab RB-GS: a V(1,1) launches as many zero-guess (16) as fused-prolong (25) sweeps
