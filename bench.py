@@ -44,6 +44,9 @@ ALG_BYTES = {
     "patch_solve_mfma": 16.0,    # single-pass exact patch solve: read f, write u (+ face terms, not counted)
     "rbgs_zero_resid_restrict": 17.0,  # fuse = 2: sweep from zero + residual + restriction: read f, write u and 1/8
     "restrict_fixup": 12.0,      # per face cell: read the neighbour's value (8), update a coarse cell per 2x2 (16/4)
+    # fuse = 3 (default): the iterate between the two sweeps exists only as its six face layers (6/32 of a vector)
+    "rbgs_zero_resid_restrict_faces": 10.5,  # read f (8); write the face layers (1.5) and coarse f (1)
+    "rbgs_resweep_prolong": 18.5,            # read f (8), coarse (1), neighbours' face layers (1.5); write u (8)
     # levels with few patches run other instantiations, timed as classes of their own (one class = one kernel
     # symbol for the large levels); they only become "dominant" for small problems (--size 256):
     "stencil_rbgs_slabs": 20.5,  # z-slab RB-GS: a V(1,1) launches as many zero-guess (16) as fused-prolong (25) sweeps

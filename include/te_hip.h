@@ -81,7 +81,10 @@ typedef struct {
 	int32_t fuse;         /* 0: one kernel per reference call (apply, scaleThenAdd, restrict, set, ...);
 	                         1: inside te_vcycle use the fused kernels whose results are BIT-IDENTICAL to 0
 	                            (residual+restrict, zero-guess first sweep, sweep on u + P e);
-	                         2 (default): additionally, with one RB-GS pre-sweep on a uniformly refined 3D level,
+	                         3 (default): 2, and with exactly one RB-GS pre-sweep and a post-sweep in a V-cycle the
+	                            iterate between them is never stored: the post-sweep kernel recomputes it from f
+	                            (bit-identical to 2);
+	                         2: additionally to 1, with one RB-GS pre-sweep on a uniformly refined 3D level,
 	                            the sweep from the zero iterate, the residual and its restriction are one pass over f;
 	                            the coarse right-hand side differs from 1 by a few ulp along patch faces (the ghost
 	                            term of the residual is added separately), independent of the partition; with one

@@ -40,13 +40,13 @@ enum KClass : int {
 	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_RBGS_ZERO, KC_RESID_RESTRICT, KC_PS_MFMA, KC_RBGS_PROLONG,
 	// launches on levels with few patches run other instantiations (z-slabs, split patches): classes of their own, so
 	// that a class above is one kernel symbol and its average duration is the one rocprofv3 --stats reports
-	KC_RBGS_SLABS, KC_STENCIL_SLABS, KC_PS_3PASS, KC_ZERO_RESID, KC_FIXUP, KC_COUNT
+	KC_RBGS_SLABS, KC_STENCIL_SLABS, KC_PS_3PASS, KC_ZERO_RESID, KC_FIXUP, KC_RESWEEP, KC_ZERO_RESID_FACES, KC_COUNT
 };
 const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_jacobi", "stencil_rbgs",
                                     "cf_ghost", "restrict", "prolong_add", "patch_rhs", "dst_axis",
                                     "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict", "patch_solve_mfma", "stencil_rbgs_prolong",
                                     "stencil_rbgs_slabs", "stencil_slabs", "patch_solve_3pass", "rbgs_zero_resid_restrict",
-                                    "restrict_fixup"};
+                                    "restrict_fixup", "rbgs_resweep_prolong", "rbgs_zero_resid_restrict_faces"};
 
 template <typename T> struct DevBuf {
 	T     *p = nullptr;
@@ -148,10 +148,14 @@ struct LevelHost {
 		L.count     = P;
 		L.xf        = nullptr;
 		L.xf_out    = nullptr;
+		L.f6        = nullptr;
+		L.f6_out    = nullptr;
 		return L;
 	}
 	// compact x-face columns of the level's current iterate inside te_vcycle (ping-pong with the sweeps'
 	// out-of-place output); xf_valid_for = the data pointer they describe, or null
+	DevBuf<double> f6buf;            // [P][6][n^2]: the six face layers of an iterate that is never stored (opts.fuse = 3)
+	const double  *pack_f6 = nullptr; // set while that iterate is the one whose faces travel to other ranks
 	DevBuf<double> xfbuf[2];
 	int            xf_cur       = 0;
 	const double  *xf_valid_for = nullptr;
@@ -477,7 +481,8 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		ord.insert(ord.end(), bnd.begin(), bnd.end());
 		if ((rc = L->order.upload(ord))) return rc;
 	}
-	if (D == 3 && ((rc = L->xfbuf[0].alloc((size_t) std::max(P, 1) * 2 * L->nf)) || (rc = L->xfbuf[1].alloc((size_t) std::max(P, 1) * 2 * L->nf))))
+	if (D == 3 && ((rc = L->xfbuf[0].alloc((size_t) std::max(P, 1) * 2 * L->nf)) || (rc = L->xfbuf[1].alloc((size_t) std::max(P, 1) * 2 * L->nf))
+	               || (rc = L->f6buf.alloc((size_t) std::max(P, 1) * 6 * L->nf))))
 		return rc;
 	if ((rc = L->face_kind.upload(fk)) || (rc = L->face_src.upload(fs)) || (rc = L->face_kadj.upload(kadj))
 	    || (rc = L->rh2.upload(rh2)) || (rc = L->cf_desc.upload(cfd)) || (rc = L->cf_slots.upload(cfs))
@@ -716,7 +721,10 @@ template <int N> void packFaces(te_gmg *g, LevelHost &L, const double *u, const 
 {
 	Timed      t(g, KC_PACK, (size_t) L.nremote * L.nf);
 	const dim3 grid(L.nremote), blk(N * N < 256 ? N * N : 256);
-	if (ps)
+	if (L.pack_f6) { // the iterate exists only as its face layers
+		ProlongSrc none{nullptr, nullptr, nullptr};
+		hipLaunchKernelGGL(k_pack_faces6_3d<N>, grid, blk, 0, g->stream, L.send_faces.p, L.pack_f6, ps ? *ps : none, L.sendbuf.p);
+	} else if (ps)
 		hipLaunchKernelGGL(k_pack_faces_prolong3d<N>, grid, blk, 0, g->stream, L.send_faces.p, u, *ps, L.sendbuf.p);
 	else
 		hipLaunchKernelGGL(k_pack_faces3d<N>, grid, blk, 0, g->stream, L.send_faces.p, u, L.sendbuf.p);
@@ -1000,7 +1008,9 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 }
 // opts.fuse = 2: first pre-smoothing sweep from a zero iterate + residual + restriction (march3d.hpp,
 // k_rbgs_zero_resid3d / k_restrict_fixup3d). out = S(0, f) with its x faces in xf_out, coarse = AvgRstr(f - A out).
-template <int N> int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out)
+// store_u = false (opts.fuse = 3): the new iterate is left in L.f6buf as its six face layers only
+template <int N>
+int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out, bool store_u)
 {
 	RestrictDst rd;
 	rd.parent     = L.parent.p;
@@ -1010,16 +1020,29 @@ template <int N> int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, d
 	rd.remote_off = L.up_off.p;
 	int rc;
 	if (L.P > 0) {
-		Timed    t(g, KC_ZERO_RESID, (size_t) L.P * L.nc);
-		LevelDev D = L.dev();
-		D.xf_out   = xf_out;
-		hipLaunchKernelGGL(k_rbgs_zero_resid3d<N>, dim3(8 * ((L.P + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, f, out, rd);
+		Timed      t(g, store_u ? KC_ZERO_RESID : KC_ZERO_RESID_FACES, (size_t) L.P * L.nc);
+		LevelDev   D = L.dev();
+		const dim3 grid(8 * ((L.P + 7) / 8)), blk(Tile3<N>::TPB);
+		if (store_u) {
+			D.xf_out = xf_out;
+			hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, true>), grid, blk, 0, g->stream, D, f, out, rd);
+		} else {
+			D.f6_out = L.f6buf.p;
+			hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false>), grid, blk, 0, g->stream, D, f, out, rd);
+		}
 	}
-	if ((rc = prepareGhosts<N>(g, L, out))) return rc; // the new face layers of neighbours on other ranks (no-op on one rank)
+	// the new face layers of neighbours on other ranks (no-op on one rank)
+	L.pack_f6 = store_u ? nullptr : L.f6buf.p;
+	rc        = prepareGhosts<N>(g, L, out);
+	L.pack_f6 = nullptr;
+	if (rc) return rc;
 	if (L.P > 0) {
 		Timed    t(g, KC_FIXUP, (size_t) L.P * 6 * L.nf);
 		LevelDev D = L.dev();
-		D.xf       = xf_out;
+		if (store_u)
+			D.xf = xf_out;
+		else
+			D.f6 = L.f6buf.p;
 		hipLaunchKernelGGL((k_restrict_fixup3d<N, false>), dim3(L.P), dim3(256), 0, g->stream, D, out, rd);
 	}
 	// children whose parent lives on another rank: ship the finished blocks (as residRestrictN)
@@ -1031,6 +1054,37 @@ template <int N> int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, d
 	}
 	HIPCHK(hipGetLastError());
 	return TE_OK;
+}
+// opts.fuse = 3, post-smoothing: out = S(v + P(prolong_from), f) with v = S(0, f) recomputed (its faces in L.f6buf)
+template <int N> int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from, double *xf_out)
+{
+	ProlongSrc ps;
+	ps.parent = L.parent.p;
+	ps.orth   = L.orth.p;
+	ps.coarse = prolong_from;
+	auto launch = [&](LevelDev D) {
+		if (D.count == 0) return;
+		Timed t(g, KC_RESWEEP, (size_t) D.count * L.nc);
+		D.f6 = L.f6buf.p;
+		if constexpr (N >= 4)
+			hipLaunchKernelGGL(k_rbgs_resweep_prolong3d<N>, dim3(8 * ((D.count + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, f,
+			                   out, ps);
+	};
+	L.pack_f6 = L.f6buf.p; // neighbours on other ranks receive the face layers of v + P(coarse)
+	int rc    = withGhosts<N>(g, L, out /* unused: the faces come from pack_f6 */, launch, nullptr, xf_out, &ps);
+	L.pack_f6 = nullptr;
+	if (rc) return rc;
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+int resweepProlong(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from, double *xf_out)
+{
+	switch (L.n) {
+		case 4: return resweepProlongN<4>(g, L, f, out, prolong_from, xf_out);
+		case 8: return resweepProlongN<8>(g, L, f, out, prolong_from, xf_out);
+		case 16: return resweepProlongN<16>(g, L, f, out, prolong_from, xf_out);
+		default: return resweepProlongN<32>(g, L, f, out, prolong_from, xf_out);
+	}
 }
 // opts.fuse = 2 with the block-Jacobi smoother: after an exact patch solve from the zero iterate the residual
 // vanishes inside every patch (A_patch u = f is what was solved) and equals -(g + m)/h^2 = -2 gamma/h^2 on the face
@@ -1077,13 +1131,13 @@ int interfaceResidRestrict(te_gmg *g, LevelHost &L, const double *u, const doubl
 		default: return interfaceResidRestrictN<32>(g, L, u, xf, coarse, coarse_n);
 	}
 }
-int zeroSweepResid(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out)
+int zeroSweepResid(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out, bool store_u)
 {
 	switch (L.n) {
-		case 4: return zeroSweepResidN<4>(g, L, f, out, coarse, xf_out);
-		case 8: return zeroSweepResidN<8>(g, L, f, out, coarse, xf_out);
-		case 16: return zeroSweepResidN<16>(g, L, f, out, coarse, xf_out);
-		default: return zeroSweepResidN<32>(g, L, f, out, coarse, xf_out);
+		case 4: return zeroSweepResidN<4>(g, L, f, out, coarse, xf_out, store_u);
+		case 8: return zeroSweepResidN<8>(g, L, f, out, coarse, xf_out, store_u);
+		case 16: return zeroSweepResidN<16>(g, L, f, out, coarse, xf_out, store_u);
+		default: return zeroSweepResidN<32>(g, L, f, out, coarse, xf_out, store_u);
 	}
 }
 int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false,
@@ -1417,6 +1471,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         return vecop<VOP_SET>(u, nullptr, nullptr, 0.0, 0.0, 0.0);
 	};
 	const double *pending_prolong = nullptr; // coarse correction still to be added to u
+	bool          u_unstored      = false;   // opts.fuse = 3: u = S(0, f) exists only as its face layers (L.f6buf)
 	int           next_sweeps     = 0;       // sweeps that follow the descend() in progress
 	auto smooth = [&](int sweeps, bool at_coarsest) -> int {
 		int sm = o->smoother;
@@ -1430,7 +1485,12 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 					if ((r = patchSolve(g, L, f->d, u->d, false, c))) return r;
 					continue;
 				}
-				if ((r = launchRbgs(g, L, u->d, f->d, L.t->d, false, c, xfFor(L, u->d), L.xfbuf[L.xf_cur ^ 1].p))) return r;
+				if (u_unstored) {
+					u_unstored = false;
+					if ((r = resweepProlong(g, L, f->d, L.t->d, c, L.xfbuf[L.xf_cur ^ 1].p))) return r;
+				} else if ((r = launchRbgs(g, L, u->d, f->d, L.t->d, false, c, xfFor(L, u->d), L.xfbuf[L.xf_cur ^ 1].p))) {
+					return r;
+				}
 				xfProduced(L, L.t->d);
 				swapData(u, L.t.get());
 				continue;
@@ -1482,9 +1542,17 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	// global patch count) and on fuse2_ok, which the hierarchy builder sets identically on all ranks.
 	if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_RBGS && L.fuse2_ok && !getenv("TE_NO_FUSE2")) {
 		u_zero = false;
-		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p))) return rc;
-		xfProduced(L, L.t->d);
-		swapData(u, L.t.get());
+		// opts.fuse = 3: if exactly this sweep, the descent and a fused post-sweep follow, the iterate in between is
+		// never stored: the post-sweep kernel recomputes it from f (bit-identical to fuse = 2; a rank-local choice,
+		// the peers see the same exchanges)
+		u_unstored = o->fuse >= 3 && o->cycle_type == 0 && o->post_sweeps >= 1 && L.prolong_fusable && L.n >= 4 && !getenv("TE_NO_FUSE3");
+		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p, !u_unstored))) return rc;
+		if (u_unstored) {
+			L.xf_valid_for = nullptr;
+		} else {
+			xfProduced(L, L.t->d);
+			swapData(u, L.t.get());
+		}
 		have_coarse_f = true;
 	} else if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_PATCH_SOLVE && L.fuse2_ok
 	           && !getenv("TE_NO_FUSE2")) {
@@ -1516,7 +1584,7 @@ void te_cycle_opts_default(te_cycle_opts *o)
 	o->smoother     = TE_SMOOTH_PATCH_SOLVE;
 	o->omega        = 6.0 / 7.0;
 	o->exact_coarse = 1;
-	o->fuse         = 2;
+	o->fuse         = 3;
 }
 
 int te_gmg_create(const te_hier *h, int device, te_gmg **out)

@@ -46,6 +46,10 @@ struct LevelDev {
 	// xf (may be null) belongs to the input iterate u; xf_out (may be null) is filled for the output.
 	const double *xf;
 	double       *xf_out;
+	// all six face layers of an iterate that is never stored as a whole (opts.fuse = 3): [P][6][N*N], a face cell at
+	// a + N b with (a, b) the two other axes in order (the ghost-slot layout). f6 belongs to the input, f6_out is filled.
+	const double *f6;
+	double       *f6_out;
 };
 
 // Blocks b, b+8, b+16, ... share an XCD (observed round-robin dispatch); give every XCD one
@@ -152,6 +156,39 @@ __device__ __forceinline__ HaloSrc haloSrc(int tid, const int32_t *fk, const int
 		}
 		if (kind == FACE_DIRICHLET) h.s = dir_sign;
 		if (kind == FACE_NEUMANN) h.s = neu_sign;
+	}
+	return h;
+}
+
+// The same two helpers for an iterate that exists only as its six face layers (LevelDev.f6) -- the relaxation kernels
+// fold physical faces into the diagonal, so those contribute 0.
+template <int N>
+__device__ __forceinline__ PlaneSrc zPlaneSrc6(int kind, int src, bool top, const double *f6, const double *ghost)
+{
+	constexpr int NN = N * N;
+	PlaneSrc      r;
+	const double *p = f6; // harmless valid address where nothing applies (scale 0)
+	r.s             = 0.0;
+	if (kind == FACE_LOCAL) p = f6 + ((size_t) src * 6 + (top ? 4 : 5)) * NN, r.s = 1.0;
+	if (kind == FACE_GHOST) p = ghost + (size_t) src * NN, r.s = 1.0;
+	r.p = reinterpret_cast<const double2 *>(p);
+	return r;
+}
+template <int N>
+__device__ __forceinline__ HaloSrc haloSrc6(int tid, const int32_t *fk, const int32_t *fs, const double *f6, const double *ghost)
+{
+	constexpr int NN = N * N, LW = Tile2<N>::LW;
+	HaloSrc       h;
+	h.p      = f6;
+	h.stride = 0;
+	h.s      = 0.0;
+	h.lds    = -1;
+	if (tid < 4 * N) {
+		const int side = tid / N, t = tid % N;
+		const int kind = fk[side], src = fs[side];
+		h.lds = (side == 0) ? (t + 1) * LW + 1 : (side == 1) ? (t + 1) * LW + N + 2 : (side == 2) ? t + 2 : (N + 1) * LW + t + 2;
+		if (kind == FACE_LOCAL) h.p = f6 + ((size_t) src * 6 + (side ^ 1)) * NN + t, h.stride = N, h.s = 1.0;
+		if (kind == FACE_GHOST) h.p = ghost + (size_t) src * NN + t, h.stride = N, h.s = 1.0;
 	}
 	return h;
 }

@@ -503,7 +503,9 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 // Pipeline per step z: red update of plane z (f only), black update of plane z-1 (new red values), residual of
 // plane z-2 (its z-neighbours z-3 and z-1 are final), restriction over plane pairs. Four LDS planes rotate:
 // plane z-2 is still being read (residual) while the fastest waves already write plane z+1.
-template <int N>
+// STORE_U = false (opts.fuse = 3): the new iterate is not stored at all, only its six face layers (L.f6_out): the
+// post-smoothing kernel k_rbgs_resweep_prolong3d recomputes it from f, everything else reads faces.
+template <int N, bool STORE_U>
 __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L, const double *__restrict__ f,
                                                                      double *__restrict__ out, RestrictDst rd)
 {
@@ -604,13 +606,26 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 			const int cz9 = (z - 1 == 0) ? 0 : (z - 1 == N - 1 ? 18 : 9);
 			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false>(t1, idiag, cz9, lds, dix, act, rhx, rhy, rhz, u1, u2, u0, f1);
 			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false>(t1, idiag, cz9, lds, dix, act, rhx, rhy, rhz, u1, u2, u0, f1);
-			if (act) {
+			if (act && STORE_U) {
 				op2[(z - 1) * NP + q[0]] = u1[0];
 				op2[(z - 1) * NP + q[1]] = u1[1];
 				if (L.xf_out) {
 					double *xo = L.xf_out + (size_t) pid * 2 * NN + N * (z - 1) + 2 * Yp;
 					if (X == 0) *reinterpret_cast<double2 *>(xo) = double2{u1[0].x, u1[1].x};
 					if (X == H - 1) *reinterpret_cast<double2 *>(xo + NN) = double2{u1[0].y, u1[1].y};
+				}
+			}
+			if (act && !STORE_U) { // the six face layers only: W,E at y + N z; S,N at x + N z; B,T at x + N y
+				double   *fo = L.f6_out + (size_t) pid * 6 * NN;
+				const int zz = z - 1;
+				if (X == 0) *reinterpret_cast<double2 *>(fo + 0 * NN + N * zz + 2 * Yp) = double2{u1[0].x, u1[1].x};
+				if (X == H - 1) *reinterpret_cast<double2 *>(fo + 1 * NN + N * zz + 2 * Yp) = double2{u1[0].y, u1[1].y};
+				if (Yp == 0) *reinterpret_cast<double2 *>(fo + 2 * NN + N * zz + 2 * X) = u1[0];
+				if (Yp == H - 1) *reinterpret_cast<double2 *>(fo + 3 * NN + N * zz + 2 * X) = u1[1];
+				if (zz == 0 || zz == N - 1) {
+					double *zo = fo + (zz == 0 ? 4 : 5) * NN + 2 * X;
+					*reinterpret_cast<double2 *>(zo + N * (2 * Yp))     = u1[0];
+					*reinterpret_cast<double2 *>(zo + N * (2 * Yp + 1)) = u1[1];
 				}
 			}
 		}
@@ -670,7 +685,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 // workgroup per fine patch; per face, one thread per coarse face cell adds -(1/h^2)/8 times the four
 // neighbour values behind its 2x2 fine cells to the coarse cell (a coarse cell belongs to exactly one fine
 // patch; faces in the fixed order W,E,S,N,B,T with a barrier in between: deterministic and independent of the
-// partition). u = the new iterate (its ghost slots current), xf = its compact x faces (may be null).
+// partition). u = the new iterate (its ghost slots current); L.xf = its compact x faces, or L.f6 = all six face
+// layers when u itself was never stored (either may be null).
 // OWN: the residual that is being completed was formed with the PATCH operator (exact patch solves: interface
 // faces closed as homogeneous Dirichlet, ghost = -m, StarPatchOp.h:204-319) rather than with a zero ghost, so
 // the missing term is -(g + m)/h^2 = -2 gamma/h^2 with m = this patch's own face value.
@@ -709,6 +725,8 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 						double    g;
 						if (kind == FACE_GHOST)
 							g = L.ghost[(size_t) src * NN + a + N * b];
+						else if (L.f6)
+							g = L.f6[((size_t) src * 6 + (s ^ 1)) * NN + a + N * b];
 						else if (ax == 0 && L.xf)
 							g = L.xf[((size_t) src * 2 + ((s & 1) ^ 1)) * NN + a + N * b];
 						else
@@ -728,5 +746,264 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 		}
 		__syncthreads();
 	}
+}
+
+// ---- opts.fuse = 3: the post-smoothing sweep recomputes the pre-smoothed iterate instead of reading it ---------
+// With one pre- and one post-sweep the iterate between them, v = S(0, f), is a cheap function of f alone (red
+// cells: -f/diag; black cells: their six red neighbours), and the post sweep reads f anyway. So
+// k_rbgs_zero_resid3d<N, false> stores only v's six face layers (for the neighbours' ghosts, the fix-up and the
+// exchange), and this kernel recomputes v plane by plane two planes ahead of the sweep, adds P(coarse) and
+// relaxes: read f, 1/8 coarse and the neighbours' face layers, write u -- 18.5 B/site instead of 25, and the
+// pre-sweep kernel writes 2.5 instead of 9.5 B/site. v is formed by the same instructions as in the pre-sweep
+// kernel and v + P e as in k_rbgs3d<N, false, true>, so the result is bit-identical to opts.fuse = 2.
+//
+// Step z (one barrier, as in k_rbgs3d): before it, red values of plane z+3 (registers only), the red values
+// of plane z+2 into their LDS plane, the iterate of plane z (w = v + P e) into its LDS plane; after it, black
+// values of plane z+2 (its z-neighbours z+1 and z+3 are registers of the same lane) -> w(z+2), then the sweep's
+// red update of plane z and black update of plane z-1 exactly as in k_rbgs3d.
+template <int N>
+__global__ void k_pack_faces6_3d(const int32_t *__restrict__ faces, const double *__restrict__ f6, ProlongSrc ps,
+                                 double *__restrict__ sendbuf)
+{
+	constexpr int NN = N * N, H = N / 2;
+	const int     p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
+	const int     ax = s >> 1;
+	const int     sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
+	const double *fp = f6 + ((size_t) p * 6 + s) * NN;
+	const double *cp = ps.coarse ? coarseOctant<N>(ps, p) + ((s & 1) ? (H - 1) * sn : 0) : nullptr;
+	double       *o  = sendbuf + (size_t) blockIdx.x * NN;
+	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+		const int a = i % N, b = i / N;
+		o[i] = cp ? fp[i] + cp[(a / 2) * sa + (b / 2) * sb] : fp[i];
+	}
+}
+
+template <int N>
+__global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelDev L, const double *__restrict__ f,
+                                                                          double *__restrict__ out, ProlongSrc ps)
+{
+	using T           = Tile3<N>;
+	constexpr int TPB = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
+	constexpr int NN  = N * N, NNN = N * N * N;
+	static_assert(N >= 4, "the pipeline looks three planes ahead");
+	const int     slot = xcdRemap(blockIdx.x, L.count);
+	if (slot >= L.count) return;
+	const int pid = L.order ? L.order[L.first + slot] : L.first + slot;
+	const int tid = threadIdx.x;
+
+	__shared__ __attribute__((aligned(16))) double tileS[3][T::LSZ]; // the sweep's planes z-1, z, z+1 (as k_rbgs3d)
+	__shared__ __attribute__((aligned(16))) double tileV[2][T::LSZ]; // red values of the recomputed plane z+2
+	__shared__ double idiag[27];
+
+	const int32_t *fk  = L.face_kind + (size_t) pid * 6;
+	const int32_t *fs  = L.face_src + (size_t) pid * 6;
+	const double   rhx = L.rh2[(size_t) pid * 3], rhy = L.rh2[(size_t) pid * 3 + 1], rhz = L.rh2[(size_t) pid * 3 + 2];
+	const double2 *fp2 = reinterpret_cast<const double2 *>(f + (size_t) pid * NNN);
+	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
+
+	if (tid < 27) {
+		double kf[3];
+		int    cls[3] = {tid % 3, (tid / 3) % 3, tid / 9};
+#pragma unroll
+		for (int ax = 0; ax < 3; ax++) {
+			kf[ax] = 2.0;
+			if (cls[ax] != 1) {
+				int kind = fk[2 * ax + (cls[ax] == 2)];
+				if (kind == FACE_DIRICHLET) kf[ax] = 3.0;
+				if (kind == FACE_NEUMANN) kf[ax] = 1.0;
+			}
+		}
+		idiag[tid] = 1.0 / (kf[0] * rhx + kf[1] * rhy + kf[2] * rhz);
+	}
+	for (int i = tid; i < 2 * T::LSZ; i += TPB) (&tileV[0][0])[i] = 0.0; // its halo ring stays zero: ghosts of a zero iterate
+
+	const HaloSrc  hs  = haloSrc6<N>(tid, fk, fs, L.f6, L.ghost);
+	const PlaneSrc bot = zPlaneSrc6<N>(fk[4], fs[4], false, L.f6, L.ghost);
+	const PlaneSrc top = zPlaneSrc6<N>(fk[5], fs[5], true, L.f6, L.ghost);
+
+	const bool act = (T::NT == TPB) || tid < T::NT;
+	const int  X = act ? tid % H : 0, Yp = act ? tid / H : 0;
+	int        q[2], lds[2], dix[2][2];
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		q[k]   = (2 * Yp + k) * H + X;
+		lds[k] = (2 * Yp + k + 1) * LW + 2 * X + 2;
+	}
+	{
+		const int cy0 = (Yp == 0) ? 0 : 1, cy1 = (Yp == H - 1) ? 2 : 1;
+		const int cx0 = (X == 0) ? 0 : 1, cx1 = (X == H - 1) ? 2 : 1;
+		dix[0][0] = cx0 + 3 * cy0, dix[0][1] = cx1 + 3 * cy0, dix[1][0] = cx0 + 3 * cy1, dix[1][1] = cx1 + 3 * cy1;
+	}
+
+	// coarse-correction sources (as k_rbgs3d<N, false, true>)
+	const double *cown = coarseOctant<N>(ps, pid), *chalo = cown, *cbot = cown, *ctop = cown;
+	double        shalo = 0.0, sbot = 0.0, stop = 0.0;
+	const int     cq = X + N * Yp;
+	if (tid < 4 * N) {
+		const int side = tid / N, t = tid % N;
+		if (fk[side] == FACE_LOCAL) {
+			const double *cn = coarseOctant<N>(ps, fs[side]);
+			const int     cx = (side == 0) ? H - 1 : (side == 1 ? 0 : t / 2);
+			const int     cy = (side == 2) ? H - 1 : (side == 3 ? 0 : t / 2);
+			chalo = cn + cx + N * cy;
+			shalo = 1.0;
+		}
+	}
+	if (fk[4] == FACE_LOCAL) cbot = coarseOctant<N>(ps, fs[4]) + NN * (H - 1), sbot = 1.0;
+	if (fk[5] == FACE_LOCAL) ctop = coarseOctant<N>(ps, fs[5]), stop = 1.0;
+
+	const double2 zero2 = double2{0.0, 0.0};
+	auto cz9of = [](int z) { return (z == 0) ? 0 : (z == N - 1 ? 18 : 9); };
+	// red values of a plane from its right-hand side alone: (0 - f) / diag at the red cells, 0 elsewhere
+	// (the arithmetic of relaxCell<..., ZERO_NBRS = true>)
+	auto redOf = [&](auto zpar, int z, const double2(&rhs)[2], double2(&dst)[2]) {
+		constexpr int ZP = decltype(zpar)::value;
+		const int     c9 = cz9of(z);
+		dst[0] = dst[1] = zero2;
+		if ((0 + ZP) & 1)
+			dst[0].y = (0.0 - rhs[0].y) * idiag[dix[0][1] + c9];
+		else
+			dst[0].x = (0.0 - rhs[0].x) * idiag[dix[0][0] + c9];
+		if ((1 + ZP) & 1)
+			dst[1].y = (0.0 - rhs[1].y) * idiag[dix[1][1] + c9];
+		else
+			dst[1].x = (0.0 - rhs[1].x) * idiag[dix[1][0] + c9];
+	};
+	auto putRed = [&](auto zpar, double *tv, const double2(&src)[2]) { // the red cells of a plane into its LDS plane
+		constexpr int ZP = decltype(zpar)::value;
+		if (!act) return;
+		tv[lds[0] + ((0 + ZP) & 1)] = ((0 + ZP) & 1) ? src[0].y : src[0].x;
+		tv[lds[1] + ((1 + ZP) & 1)] = ((1 + ZP) & 1) ? src[1].y : src[1].x;
+	};
+	auto fillBlack = [&](auto zpar, int z, double *tv, double2(&cen)[2], const double2(&below)[2], const double2(&above)[2],
+	                     const double2(&rhs)[2]) {
+		constexpr int ZP = decltype(zpar)::value;
+		relaxCell<N, 0, (1 + 0 + ZP) & 1, false>(tv, idiag, cz9of(z), lds, dix, act, rhx, rhy, rhz, cen, below, above, rhs);
+		relaxCell<N, 1, (1 + 1 + ZP) & 1, false>(tv, idiag, cz9of(z), lds, dix, act, rhx, rhy, rhz, cen, below, above, rhs);
+	};
+	using P0 = std::integral_constant<int, 0>;
+	using P1 = std::integral_constant<int, 1>;
+
+	// right-hand sides of planes z-1 .. z+3 (fn: z+4 in flight), recomputed planes r1 = v(z+1) (red entries are
+	// what is read), r2 = red(z+2) -> v(z+2), r3 = red(z+3); the sweep's planes as in k_rbgs3d
+	double2 fm[2], f0[2], f1[2], f2[2], f3[2], fn[2], r1[2], r2[2], r3[2];
+	double2 umm[2], um[2], uc[2], un[2], un2[2];
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		fm[k] = zero2;
+		f0[k] = fp2[0 * NP + q[k]];
+		f1[k] = fp2[1 * NP + q[k]];
+		f2[k] = fp2[2 * NP + q[k]];
+		f3[k] = fp2[3 * NP + q[k]];
+		umm[k] = zero2;
+	}
+	__syncthreads(); // idiag, zeroed tileV
+	{ // prologue: v(0), v(1)
+		double2 v0[2], v1[2];
+		redOf(P0{}, 0, f0, v0);
+		redOf(P1{}, 1, f1, v1);
+		redOf(P0{}, 2, f2, r2);
+		putRed(P0{}, tileV[0], v0);
+		putRed(P1{}, tileV[1], v1);
+		ldsBarrier();
+		const double2 none[2] = {zero2, zero2};
+		fillBlack(P0{}, 0, tileV[0], v0, none, v1, f0);
+		fillBlack(P1{}, 1, tileV[1], v1, v0, r2, f1);
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			const double  c0 = cown[cq], cb = sbot * cbot[cq]; // planes 0 and 1 share coarse plane 0
+			const double2 a  = bot.p[q[k]];
+			uc[k] = double2{v0[k].x + c0, v0[k].y + c0};
+			un[k] = double2{v1[k].x + c0, v1[k].y + c0};
+			um[k] = double2{bot.s * a.x, bot.s * a.y};
+			um[k].x += bot.s * cb, um[k].y += bot.s * cb;
+			r1[k] = v1[k];
+		}
+		ldsBarrier(); // both red planes have been read: step 0 rewrites the first one
+	}
+	double hv = hs.s * (hs.p[0] + shalo * chalo[0]);
+
+	int bz = 0; // z % 3
+	auto step = [&](auto zpar, int z) {
+		constexpr int ZPAR = decltype(zpar)::value;
+		using ZQ          = std::integral_constant<int, 1 - ZPAR>;
+		// loads for the coming steps
+		const int zf = (z + 4 < N) ? z + 4 : N - 1, zc = (z + 1 < N) ? z + 1 : N - 1;
+#pragma unroll
+		for (int k = 0; k < 2; k++) fn[k] = fp2[zf * NP + q[k]];
+		const double hvn = hs.s * (hs.p[zc * hs.stride] + shalo * chalo[NN * (zc >> 1)]);
+		const double c2  = (z + 2 < N) ? cown[NN * ((z + 2) >> 1) + cq] : stop * ctop[cq];
+		double2      tg[2];
+#pragma unroll
+		for (int k = 0; k < 2; k++) tg[k] = top.p[q[k]]; // the top neighbour's plane (used on the last steps only)
+		// before the barrier: red values two and three planes ahead, this plane of the iterate into LDS
+		double *tvz = tileV[z & 1];
+		if (z + 3 < N)
+			redOf(ZQ{}, z + 3, f3, r3);
+		else
+			r3[0] = r3[1] = zero2;
+		if (z + 2 < N) putRed(zpar, tvz, r2);
+		double *tz = tileS[bz];
+		double *tm = tileS[bz == 0 ? 2 : bz - 1];
+		if (z < N) {
+			if (act) {
+				*reinterpret_cast<double2 *>(tz + lds[0]) = uc[0];
+				*reinterpret_cast<double2 *>(tz + lds[1]) = uc[1];
+			}
+			if (hs.lds >= 0) tz[hs.lds] = hv;
+		}
+		ldsBarrier();
+		// the iterate two planes ahead: black values of the recomputed plane, plus the coarse correction
+		if (z + 2 < N) {
+			fillBlack(zpar, z + 2, tvz, r2, r1, r3, f2);
+#pragma unroll
+			for (int k = 0; k < 2; k++) un2[k] = double2{r2[k].x + c2, r2[k].y + c2};
+		} else {
+#pragma unroll
+			for (int k = 0; k < 2; k++) un2[k] = double2{top.s * (tg[k].x + c2), top.s * (tg[k].y + c2)};
+		}
+		// the sweep itself (k_rbgs3d)
+		if (z < N) {
+			const int cz9 = cz9of(z);
+			relaxCell<N, 0, (0 + ZPAR) & 1, false>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, uc, um, un, f0);
+			relaxCell<N, 1, (1 + ZPAR) & 1, false>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, uc, um, un, f0);
+		}
+		if (z > 0) {
+			const int cz9 = cz9of(z - 1);
+			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
+			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
+			if (act) {
+				op2[(z - 1) * NP + q[0]] = um[0];
+				op2[(z - 1) * NP + q[1]] = um[1];
+				if (L.xf_out) {
+					double *xo = L.xf_out + (size_t) pid * 2 * NN + N * (z - 1) + 2 * Yp;
+					if (X == 0) *reinterpret_cast<double2 *>(xo) = double2{um[0].x, um[1].x};
+					if (X == H - 1) *reinterpret_cast<double2 *>(xo + NN) = double2{um[0].y, um[1].y};
+				}
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			umm[k] = um[k];
+			um[k]  = uc[k];
+			uc[k]  = un[k];
+			un[k]  = un2[k];
+			fm[k]  = f0[k];
+			f0[k]  = f1[k];
+			f1[k]  = f2[k];
+			f2[k]  = f3[k];
+			f3[k]  = fn[k];
+			r1[k]  = r2[k];
+			r2[k]  = r3[k];
+		}
+		hv = hvn;
+		bz = (bz == 2) ? 0 : bz + 1;
+	};
+#pragma unroll 1
+	for (int z = 0; z < N; z += 2) {
+		step(P0{}, z);
+		step(P1{}, z + 1);
+	}
+	step(P0{}, N);
 }
 } // namespace te

@@ -161,12 +161,14 @@ def test_fused_presweep_residual_restrict(n, neumann):
     g, L = capi.GMG(H), levels[0]
     f = util.rand_vec(L.size, 54) / L.a["h"].min() ** 2
     got = {}
-    for fuse in (1, 2):
+    for fuse in (1, 2, 3):
         df, dc = g.new_vector(0, f), g.new_vector(0)
         g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS, fuse=fuse), df, dc)
         got[fuse] = dc.download()
     assert not np.array_equal(got[1], got[2]) or n == 4  # the fused path really ran (it is not bit-identical)
     assert rel(got[2], got[1]) <= 1e-13
+    # fuse = 3 never stores the iterate between the two sweeps (the post-sweep kernel recomputes it from f): same bits
+    assert np.array_equal(got[3], got[2])
     if n <= 16:
         o = orc.cycle_opts(smoother=2)
         assert rel(got[2], orc.cycle(levels, o, f)) <= 1e-10
