@@ -9,11 +9,12 @@ g = capi.GMG(H)
 t = H.tables(0)
 f, exact = problems.init_dirichlet(t, n)
 for sm in (capi.SMOOTH_RBGS, capi.SMOOTH_PATCH_SOLVE):
-    b = g.new_vector(0, f); x = g.new_vector(0)
     o = g.default_opts(smoother=sm)
-    g.sync(); t0=time.time()
-    its, rr = g.bicgstab(x, b, o, tol=1e-12)
-    g.sync(); dt=time.time()-t0
+    for rep in range(2):  # the first solve pays one-time costs (code load, lazy attributes)
+        b = g.new_vector(0, f); x = g.new_vector(0)
+        g.sync(); t0=time.time()
+        its, rr = g.bicgstab(x, b, o, tol=1e-12)
+        g.sync(); dt=time.time()-t0
     err = np.linalg.norm(x.download()-exact)/np.linalg.norm(exact)
     print('smoother',sm,'its',its,'rr %.2e'%rr,'time %.1f ms'%(dt*1e3),'per it %.2f ms'%(dt*1e3/max(its,1)),'err %.3e'%err)
 for sm in (capi.SMOOTH_RBGS, capi.SMOOTH_PATCH_SOLVE):
