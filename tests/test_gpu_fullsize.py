@@ -75,8 +75,23 @@ def test_cycle_contraction_and_fusion(big):
             g.residual(x, f, r)
             assert r.twoNorm() <= bound * fn
             outs.append(x)
+        ref = g.new_vector(0)
+        ref.copy(outs[1])
         outs[0].addScaled(-1.0, outs[1])
         assert outs[0].infNorm() == 0.0  # fused == unfused, bit for bit
+        # fuse = 2 / 3 (default): pre-sweep + residual + restriction in one pass, intermediate iterate never stored:
+        # same cycle to rounding (RB-GS: a few ulp in the coarse right-hand sides; block Jacobi: the solve's own rounding)
+        hi = {}
+        for fuse in (2, 3):
+            x = g.new_vector(0)
+            g.cycle(g.default_opts(smoother=sm, fuse=fuse), f, x)
+            hi[fuse] = x
+        d = g.new_vector(0)
+        d.copy(hi[3])
+        d.addScaled(-1.0, hi[2])
+        assert d.infNorm() == 0.0  # 3 == 2 bit for bit
+        hi[3].addScaled(-1.0, ref)
+        assert hi[3].twoNorm() <= (1e-13 if sm == capi.SMOOTH_RBGS else 1e-11) * ref.twoNorm()
         results[sm] = True
     assert len(results) == 2
 
