@@ -186,6 +186,7 @@ struct te_gmg {
 	hipEvent_t  ev_pack = nullptr, ev_recv = nullptr;
 	bool        overlap = true;
 	bool        in_cycle = false; // te_vcycle in progress: the levels' xf_valid_for bookkeeping is trustworthy
+	bool        no_xf_export = false; // the patch solve in progress is the last kernel on its level: nobody reads its x faces
 	int                                     dim = 3, n = 0;
 	std::vector<std::unique_ptr<LevelHost>> levels;
 	DevBuf<double>                          partial, result;
@@ -1253,7 +1254,7 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 			const int32_t *lst_mix = (n_sym > 0 && n_mix > 0) ? L.ps_list.p + n_sym : nullptr;
 			if (n_sym > 0) {
 				const dim3 gs(std::min(n_sym, ncu));
-				double    *xo = (g->in_cycle && n_mix == 0) ? L.xfbuf[L.xf_cur ^ 1].p : nullptr; // (k_ps_fused does not export)
+				double    *xo = (g->in_cycle && n_mix == 0 && !g->no_xf_export) ? L.xfbuf[L.xf_cur ^ 1].p : nullptr; // (k_ps_fused does not export)
 				if (zero_guess)
 					hipLaunchKernelGGL(k_ps_sym<false>, gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
 					                   L.zero_mode.p, L.rh2.p, f, cp, u, xo, lst_sym);
@@ -1473,7 +1474,9 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	const double *pending_prolong = nullptr; // coarse correction still to be added to u
 	bool          u_unstored      = false;   // opts.fuse = 3: u = S(0, f) exists only as its face layers (L.f6buf)
 	int           next_sweeps     = 0;       // sweeps that follow the descend() in progress
-	auto smooth = [&](int sweeps, bool at_coarsest) -> int {
+	// final_call: the post-smoothing of this level -- nobody reads the x-face columns of its last sweep's result
+	// (they serve the NEXT kernel on the same level), so that sweep does not export them
+	auto smooth = [&](int sweeps, bool at_coarsest, bool final_call = false) -> int {
 		int sm = o->smoother;
 		if (at_coarsest && o->exact_coarse && L.P_global == 1) sm = TE_SMOOTH_PATCH_SOLVE;
 		for (int i = 0; i < sweeps; i++) {
@@ -1481,17 +1484,25 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 			if (pending_prolong) {
 				const double *c = pending_prolong;
 				pending_prolong = nullptr;
+				const bool last = final_call && i == sweeps - 1;
 				if (sm == TE_SMOOTH_PATCH_SOLVE) { // reads u + P c on the face layers only, then overwrites u
-					if ((r = patchSolve(g, L, f->d, u->d, false, c))) return r;
+					g->no_xf_export = last;
+					r               = patchSolve(g, L, f->d, u->d, false, c);
+					g->no_xf_export = false;
+					if (r) return r;
 					continue;
 				}
+				double *xo = last ? nullptr : L.xfbuf[L.xf_cur ^ 1].p;
 				if (u_unstored) {
 					u_unstored = false;
-					if ((r = resweepProlong(g, L, f->d, L.t->d, c, L.xfbuf[L.xf_cur ^ 1].p))) return r;
-				} else if ((r = launchRbgs(g, L, u->d, f->d, L.t->d, false, c, xfFor(L, u->d), L.xfbuf[L.xf_cur ^ 1].p))) {
+					if ((r = resweepProlong(g, L, f->d, L.t->d, c, xo))) return r;
+				} else if ((r = launchRbgs(g, L, u->d, f->d, L.t->d, false, c, xfFor(L, u->d), xo))) {
 					return r;
 				}
-				xfProduced(L, L.t->d);
+				if (xo)
+					xfProduced(L, L.t->d);
+				else
+					L.xf_valid_for = nullptr;
 				swapData(u, L.t.get());
 				continue;
 			}
@@ -1571,7 +1582,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		next_sweeps = o->post_sweeps;
 		if ((rc = descend())) return rc;
 	}
-	return smooth(o->post_sweeps, false);
+	return smooth(o->post_sweeps, false, true);
 }
 } // namespace
 
