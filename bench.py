@@ -113,6 +113,11 @@ def cpu_baseline(sample, smoother_id):
 
 def main():
     a = parse()
+    # stdout carries exactly one JSON line: everything else that libraries print there (e.g. Gloo's connection
+    # banner from C++) goes to stderr
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -247,7 +252,7 @@ def main():
     reduction = float(np.sqrt(rn / fn))
 
     if rank == 0 and not rows:  # TE_BENCH_NOPROFILE=1 (tooling): wall time only
-        print(json.dumps({"ms_per_step": ms_per_step, "value": value}), flush=True)
+        print(json.dumps({"ms_per_step": ms_per_step, "value": value}), file=json_out, flush=True)
     elif rank == 0:
         dom = max(((k, v) for k, v in rows.items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
         name, st = dom
@@ -291,7 +296,7 @@ def main():
             from oracle import build as obuild
             obuild.build_oracle()
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample, sm)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
