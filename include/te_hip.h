@@ -175,6 +175,12 @@ int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank,
 /* moves n doubles through the active exchange back-end with this rank as its own peer (diagnostic) */
 int te_gmg_exchange_selftest(te_gmg *g, int n);
 
+/* Domain<D>::integrate (Domain.h:258-278) and Domain<D>::volume (:237-251), this rank's part (the host adds the
+ * ranks as it does for norms): sum over local patches of (sum of the patch's cells) * (cell volume), resp. of the
+ * patch volumes. What the drivers need for pure-Neumann problems (apps/3d/steady.cpp:330-334, 539-549). */
+int te_integrate(te_gmg *g, int level, const te_vec *v, double *out);
+int te_volume(te_gmg *g, int level, double *out);
+
 /* kernel timing hooks for bench.py: HIP-event time of the last te_vcycle's dominant kernel */
 int te_gmg_profile(te_gmg *g, int enable);
 /* name[i] (<=63 chars), calls[i], total_ms[i] (HIP events on the solver stream), cells[i]

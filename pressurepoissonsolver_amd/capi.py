@@ -106,6 +106,8 @@ SYMBOLS = {
     "te_gmg_profile_rows": (_I, [_P, _I, _P, _P, _P, _P]),
     "te_gmg_profile_reset": (_I, [_P]),
     "te_gmg_profile_select": (_I, [_P, C.c_char_p]),
+    "te_integrate": (_I, [_P, _I, _P, _P]),
+    "te_volume": (_I, [_P, _I, _P]),
 }
 
 _lib = None
@@ -364,6 +366,18 @@ class GMG:
         check(lib().te_bicgstab(self.h, C.byref(opts) if opts is not None else None, x.h, b.h, max_it, tol,
                                 C.byref(its), C.byref(rr)))
         return its.value, rr.value
+
+    def integrate(self, v, level=0):
+        """Domain<D>::integrate (Domain.h:258-278), this rank's part"""
+        out = C.c_double()
+        check(lib().te_integrate(self.h, level, v.h, C.byref(out)))
+        return out.value
+
+    def volume(self, level=0):
+        """Domain<D>::volume (Domain.h:237-251), this rank's part"""
+        out = C.c_double()
+        check(lib().te_volume(self.h, level, C.byref(out)))
+        return out.value
 
     def profile(self, enable=True): check(lib().te_gmg_profile(self.h, int(enable)))
     def profile_reset(self): check(lib().te_gmg_profile_reset(self.h))

@@ -154,6 +154,8 @@ struct LevelHost {
 	}
 	// compact x-face columns of the level's current iterate inside te_vcycle (ping-pong with the sweeps'
 	// out-of-place output); xf_valid_for = the data pointer they describe, or null
+	DevBuf<double> cellvol;          // [P] product of the spacings (te_integrate)
+	std::vector<double> patch_vol;   // [P] product of the patch lengths (te_volume)
 	DevBuf<double> f6buf;            // [P][6][n^2]: the six face layers of an iterate that is never stored (opts.fuse = 3)
 	const double  *pack_f6 = nullptr; // set while that iterate is the one whose faces travel to other ranks
 	DevBuf<double> xfbuf[2];
@@ -402,7 +404,8 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	}
 
 	std::vector<int32_t> fk(P * NS), fs(P * NS, -1), cfd, cfs, plan(P, 0);
-	std::vector<double>  kadj(P * NS, 0.0), rh2(P * 3);
+	std::vector<double>  kadj(P * NS, 0.0), rh2(P * 3), cellvol(P);
+	L->patch_vol.assign(P, 0.0);
 	std::map<int, int>   plan_of_key;
 	std::vector<int>     keys;
 	int                  nslots = nremote;
@@ -410,10 +413,15 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		const int gp  = lv.l2g[p];
 		int       key = 0;
 		rh2[p * 3 + 2] = 0.0;
+		double cv = 1.0, pv = 1.0; // Domain.h:270-272 (patch_sum *= spacings[i]), :242-245
 		for (int a = 0; a < D; a++) {
 			double h       = lv.g_lengths[(size_t) gp * D + a] / n;
 			rh2[p * 3 + a] = 1.0 / (h * h);
+			cv *= h;
+			pv *= h * n;
 		}
+		cellvol[p]      = cv;
+		L->patch_vol[p] = pv;
 		for (int s = 0; s < NS; s++) {
 			const size_t gf   = (size_t) gp * NS + s;
 			const int    kind = lv.g_nbr_kind[gf];
@@ -485,6 +493,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	if (D == 3 && ((rc = L->xfbuf[0].alloc((size_t) std::max(P, 1) * 2 * L->nf)) || (rc = L->xfbuf[1].alloc((size_t) std::max(P, 1) * 2 * L->nf))
 	               || (rc = L->f6buf.alloc((size_t) std::max(P, 1) * 6 * L->nf))))
 		return rc;
+	if ((rc = L->cellvol.upload(cellvol))) return rc;
 	if ((rc = L->face_kind.upload(fk)) || (rc = L->face_src.upload(fs)) || (rc = L->face_kadj.upload(kadj))
 	    || (rc = L->rh2.upload(rh2)) || (rc = L->cf_desc.upload(cfd)) || (rc = L->cf_slots.upload(cfs))
 	    || (rc = L->ghost.alloc((size_t) std::max(nslots, 1) * L->nf)))
@@ -1958,6 +1967,34 @@ int te_gmg_profile(te_gmg *g, int enable)
 	if (!g) return te::fail(TE_EINVAL, "te_gmg_profile: null");
 	drainEvents(g);
 	g->profiling = enable != 0;
+	return TE_OK;
+}
+int te_integrate(te_gmg *g, int level, const te_vec *v, double *out)
+{
+	int rc;
+	if (!out) return te::fail(TE_EINVAL, "te_integrate: null result");
+	if ((rc = checkLevelVec(g, level, v, "te_integrate"))) return rc;
+	LevelHost &L = *g->levels[level];
+	*out         = 0.0;
+	if (L.P == 0) return TE_OK;
+	DevBuf<double> part;
+	if ((rc = part.alloc(L.P))) return rc;
+	hipLaunchKernelGGL(k_patch_integrals, dim3(L.P), dim3(256), 0, g->stream, (int) L.nc, v->d, L.cellvol.p, part.p);
+	HIPCHK(hipGetLastError());
+	std::vector<double> h(L.P);
+	HIPCHK(hipMemcpyAsync(h.data(), part.p, sizeof(double) * L.P, hipMemcpyDeviceToHost, g->stream));
+	HIPCHK(hipStreamSynchronize(g->stream));
+	double sum = 0.0;
+	for (double x : h) sum += x; // patch order, as the reference's loop over its patch map
+	*out = sum;
+	return TE_OK;
+}
+int te_volume(te_gmg *g, int level, double *out)
+{
+	if (!g || !out || level < 0 || level >= (int) g->levels.size()) return te::fail(TE_EINVAL, "te_volume: bad argument");
+	double sum = 0.0;
+	for (double x : g->levels[level]->patch_vol) sum += x;
+	*out = sum;
 	return TE_OK;
 }
 int te_gmg_profile_select(te_gmg *g, const char *name)

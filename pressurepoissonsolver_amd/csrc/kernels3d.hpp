@@ -633,6 +633,20 @@ __global__ __launch_bounds__(256) void k_reduce_final2(int nparts, const double 
 		result[1] = b;
 	}
 }
+// Domain::integrate (Domain.h:258-278): per patch, the sum of its cells times the cell volume; one workgroup per
+// patch (cells summed in a fixed order), the per-patch values are added on the host in patch order.
+// vol[p] = product of the patch's spacings.
+__global__ __launch_bounds__(256) void k_patch_integrals(int nc, const double *__restrict__ v, const double *__restrict__ vol,
+                                                         double *__restrict__ out)
+{
+	const double *p = v + (size_t) blockIdx.x * nc;
+	double        acc = 0.0;
+	for (int i = threadIdx.x; i < nc; i += blockDim.x) acc += p[i];
+	double dummy = 0.0;
+	blockReduce2(acc, dummy);
+	if (threadIdx.x == 0) out[blockIdx.x] = acc * vol[blockIdx.x];
+}
+
 // s = resid; s += ap * (-alpha)          (BiCGStab.h:79-80)
 __global__ __launch_bounds__(256) void k_bicg_s(size_t n2, double2 *__restrict__ s, const double2 *__restrict__ resid,
                                                 const double2 *__restrict__ ap, double malpha)

@@ -42,7 +42,25 @@ def trig2d_rhs(x, y):
     return -5 * np.pi ** 2 * trig2d_exact(x, y)
 
 
+def trig_normal(x, y, z):
+    """d/dx, d/dy, d/dz of trig_exact (apps/3d/steady.cpp:266-284)"""
+    x, y, z = x + .3, y + .3, z + .3
+    pi = np.pi
+    return (pi * np.cos(pi * x) * np.cos(2.0 / 3 * pi * y) * np.sin(5.0 / 6 * pi * z),
+            -2.0 / 3 * pi * np.sin(pi * x) * np.sin(2.0 / 3 * pi * y) * np.sin(5.0 / 6 * pi * z),
+            5.0 / 6 * pi * np.sin(pi * x) * np.cos(2.0 / 3 * pi * y) * np.cos(5.0 / 6 * pi * z))
+
+
+def gauss_normal(x, y, z):
+    """apps/3d/steady.cpp:243-251"""
+    pi = np.pi
+    return (-10 * pi * np.sin(10 * pi * x) * np.exp(np.cos(10 * pi * x)) + 0 * y,
+            11 * pi * np.sin(11 * pi * y) * np.exp(np.cos(11 * pi * y)) + 0 * x,
+            -12 * pi * np.sin(12 * pi * z) * np.exp(np.cos(12 * pi * z)) + 0 * x)
+
+
 PROBLEMS = {"trig": (trig_rhs, trig_exact), "gauss": (gauss_rhs, gauss_exact)}
+NORMALS = {"trig": trig_normal, "gauss": gauss_normal}
 PROBLEMS_2D = {"trig": (trig2d_rhs, trig2d_exact)}
 
 
@@ -108,6 +126,31 @@ def init_dirichlet(tables, n, problem="trig", patches=None):
             c = cc[k][tuple(sl)].copy()
             c[..., ax] += (0.5 if up else -0.5) * h[k, ax]  # the boundary face itself
             f[k][tuple(sl)] -= 2 * efun(c[..., 0], c[..., 1], c[..., 2]) / h[k, ax] ** 2
+    return f.ravel(), ex.ravel()
+
+
+def init_neumann(tables, n, problem="trig", patches=None):
+    """(f, exact) flat vectors for Neumann physical boundaries, Init::initNeumann (Init.cpp:56-150): the normal
+    derivative on the boundary face enters the adjacent cells as +g_n/h on low sides, -g_n/h on high sides."""
+    ffun, efun = PROBLEMS[problem]
+    nfun = NORMALS[problem]
+    if patches is None:
+        patches = np.arange(len(tables["id"]))
+    cc = cell_centres(tables, n, patches)
+    f = ffun(cc[..., 0], cc[..., 1], cc[..., 2])
+    ex = efun(cc[..., 0], cc[..., 1], cc[..., 2])
+    h = tables["lengths"][patches] / n
+    for k, p in enumerate(patches):
+        for s in range(6):
+            if tables["nbr_kind"][p, s] != 0:
+                continue
+            ax, up = s // 2, s & 1
+            sl = [slice(None)] * 3
+            sl[2 - ax] = -1 if up else 0
+            c = cc[k][tuple(sl)].copy()
+            c[..., ax] += (0.5 if up else -0.5) * h[k, ax]  # the boundary face itself (getXYZ with index -1 / n)
+            gn = nfun(c[..., 0], c[..., 1], c[..., 2])[ax]
+            f[k][tuple(sl)] += (-1.0 if up else 1.0) * gn / h[k, ax]
     return f.ravel(), ex.ravel()
 
 

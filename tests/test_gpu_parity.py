@@ -274,9 +274,41 @@ def test_cycle_sweep_counts(case, sweeps):
         assert rel(du.download(), want) <= 1e-10
 
 
+def test_neumann_solve_with_zero_mean_rhs(case):
+    """Pure-Neumann problems as the driver runs them (apps/3d/steady.cpp:318-334, 539-549): Init::initNeumann,
+    f -= integrate(f)/volume, BiCGStab + GMG, error measured after shifting the means together.
+    te_integrate / te_volume are Domain<D>::integrate / volume (Domain.h:237-278)."""
+    if not case["neumann"] or case["dim"] != 3:
+        pytest.skip("3D Neumann cases")
+    g, levels, H, n = case["g"], case["levels"], case["H"], case["n"]
+    t = H.tables(0)
+    f, exact = problems.init_neumann(t, n)
+    cell = np.prod(t["lengths"] / n, axis=1)
+    df, de = g.new_vector(0, f), g.new_vector(0, exact)
+    vol = g.volume()
+    assert abs(vol - np.sum(np.prod(t["lengths"], axis=1))) <= 1e-14 * vol
+    want = np.sum(f.reshape(len(cell), -1).sum(axis=1) * cell)
+    assert abs(g.integrate(df) - want) <= 1e-12 * np.abs(f).sum() * cell.max()
+    df.shift(-g.integrate(df) / vol)
+    fz = df.download()
+    for sm in (capi.SMOOTH_PATCH_SOLVE, capi.SMOOTH_RBGS):
+        dx = g.new_vector(0)
+        its, rr = g.bicgstab(dx, df, g.default_opts(smoother=sm), tol=1e-10)
+        assert rr <= 1e-10 and its <= 40
+        x_ref, its_ref, rr_ref = orc.bicgstab(levels, orc.cycle_opts(smoother=sm), fz, tol=1e-10)
+        assert abs(its - its_ref) <= 2
+        # compare after removing the (arbitrary) constant, as the driver does for its error norm
+        uavg, eavg = g.integrate(dx) / vol, g.integrate(de) / vol
+        x = dx.download()
+        xr = x_ref - np.sum(x_ref.reshape(len(cell), -1).sum(axis=1) * cell) / vol
+        assert rel(x - uavg, xr) <= 1e-6
+        err = rel(x - uavg, exact - eavg)
+        assert err <= 12.0 * (t["lengths"][:, 0].min() / n) ** 2  # second order in h
+
+
 def test_bicgstab_trig(case):
     if case["neumann"]:
-        pytest.skip("pure-Neumann solves need the drivers' null-space handling (apps/3d/steady.cpp:330-334)")
+        pytest.skip("pure-Neumann solves: test_neumann_solve_with_zero_mean_rhs")
     g, levels, H = case["g"], case["levels"], case["H"]
     init = problems.init_dirichlet if case["dim"] == 3 else problems.init_dirichlet_2d
     f, exact = init(H.tables(0), case["n"])
