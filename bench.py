@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--smoother", default="rbgs", choices=["rbgs", "jacobi", "patch_solve"])
     ap.add_argument("--dim", type=int, default=3, choices=[2, 3], help="2: the 2D twin (config C5: --dim 2 --size 4096 --patch 64)")
     ap.add_argument("--patch", type=int, default=32, help="cells per axis per patch")
+    ap.add_argument("--mesh", default=None, help="octree file instead of the uniform grid (config C4: tests/golden/2refine.bin "
+                                                 "--divide 2 or 3); --size is ignored")
+    ap.add_argument("--divide", type=int, default=0, help="refineLeaves passes over --mesh (apps/3d/steady --divide)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=128, help="cells per axis of the CPU baseline sample")
     return ap.parse_args()
@@ -149,9 +152,13 @@ def main():
     from pressurepoissonsolver_amd import dist as tedist
 
     n = a.patch
-    assert a.size % n == 0 and (a.size // n) & (a.size // n - 1) == 0, "--size must be patch * 2^k"
-    div = int(round(np.log2(a.size // n)))
-    mesh = capi.Mesh.uniform(a.dim, div)
+    if a.mesh:
+        mesh = capi.Mesh.read(a.mesh, a.dim)
+        for _ in range(a.divide):
+            mesh.refine_leaves()
+    else:
+        assert a.size % n == 0 and (a.size // n) & (a.size // n - 1) == 0, "--size must be patch * 2^k"
+        mesh = capi.Mesh.uniform(a.dim, int(round(np.log2(a.size // n))))
     H = capi.Hierarchy(mesh, n, rank=rank, nranks=world)
     g = capi.GMG(H, device=local_rank)
     exchange_backend = "none"
@@ -268,12 +275,13 @@ def main():
                 traffic = None
         b_alg = vcycle_alg_bytes_per_finest_cell(cells_global)
         out = {
-            "metric": "V-cycle lattice-site updates/sec, 512^3 3D Poisson" if (a.size == 512 and a.dim == 3) else
-                      f"V-cycle lattice-site updates/sec, {a.size}^{a.dim} {a.dim}D Poisson",
+            "metric": "V-cycle lattice-site updates/sec, 512^3 3D Poisson" if (a.size == 512 and a.dim == 3 and not a.mesh) else
+                      (f"V-cycle lattice-site updates/sec, {os.path.basename(a.mesh)} --divide {a.divide}, {a.dim}D Poisson" if a.mesh else
+                       f"V-cycle lattice-site updates/sec, {a.size}^{a.dim} {a.dim}D Poisson"),
             "value": value, "unit": "lattice-site updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"apps/{a.dim}d/steady-equivalent: {a.size}^{a.dim} uniform, {cells_global[0] // n ** a.dim} "
+            "config": {"workload": f"apps/{a.dim}d/steady-equivalent: " + (f"{os.path.basename(a.mesh)} --divide {a.divide}" if a.mesh else f"{a.size}^{a.dim} uniform") + f", {cells_global[0] // n ** a.dim} "
                                    f"patches of {n}^{a.dim}, {H.num_levels} levels, V(1,1), smoother={a.smoother}, "
                                    "Dirichlet, f ~ U(-1,1) splitmix64(0x5EED + patch id)",
                        "parallelism": f"patch-sharded x{world} (Morton ranges)", "exchange": exchange_backend,
