@@ -81,6 +81,9 @@ struct ExPlan {
 struct LevelHost {
 	int    dim = 3, n = 0, P = 0, P_global = 0;
 	bool   prolong_fusable = false; // every patch is an octant child of a LOCAL parent and there is no coarse/fine face
+	// refined levels: every patch has a LOCAL parent (octant children and patches that copy through), coarse/fine
+	// faces allowed: the RB-GS sweep on u + P e has a variant for that (k_rbgs3d<..., CFP>)
+	bool   prolong_fusable_cf = false, has_copy = false;
 	// 2D: lds2d = patches fit in LDS (the same on every rank: it decides whether the zero-guess sweep skips its
 	// ghost exchange, and all ranks must agree on that); fuse2d = additionally all parents are local (rank-local:
 	// residual+restrict in one pass; peers see the same exchanges either way)
@@ -651,6 +654,8 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		L->Pc      = cv.P;
 		L->prolong_fusable = (D == 3 && L->ncf == 0 && up.empty() && down.empty()
 		                      && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
+		L->has_copy           = std::any_of(orth.begin(), orth.end(), [](int32_t o) { return o < 0; });
+		L->prolong_fusable_cf = (D == 3 && up.empty() && down.empty() && !getenv("TE_NO_CFP"));
 		if (D == 2 && L->lds2d && up.empty() && down.empty()) {
 			L->fuse2d          = true;
 			L->prolong_fusable = (L->nslots == 0 && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
@@ -748,8 +753,12 @@ template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u, con
 	}
 	if (L.ncf == 0) return TE_OK;
 	Timed t(g, KC_CFGHOST, (size_t) L.ncf * L.nf);
-	hipLaunchKernelGGL(k_cf_ghost3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
-	                   L.cf_slots.p, u, L.ghost.p);
+	if (ps)
+		hipLaunchKernelGGL(k_cf_ghost_prolong3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
+		                   L.cf_slots.p, u, *ps, L.ghost.p);
+	else
+		hipLaunchKernelGGL(k_cf_ghost3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
+		                   L.cf_slots.p, u, L.ghost.p);
 	return TE_OK;
 }
 // Run `launch(subset)` over all patches of the level with current ghosts. With off-rank neighbours the
@@ -780,8 +789,12 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 	HIPCHK(hipStreamWaitEvent(g->stream, g->ev_recv, 0));
 	if (L.ncf > 0) {
 		Timed t(g, KC_CFGHOST, (size_t) L.ncf * L.nf);
-		hipLaunchKernelGGL(k_cf_ghost3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p, L.cf_slots.p,
-		                   u, L.ghost.p);
+		if (ps)
+			hipLaunchKernelGGL(k_cf_ghost_prolong3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
+			                   L.cf_slots.p, u, *ps, L.ghost.p);
+		else
+			hipLaunchKernelGGL(k_cf_ghost3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
+			                   L.cf_slots.p, u, L.ghost.p);
 	}
 	launch(L.devPart(true)); // boundary
 	return TE_OK;
@@ -987,8 +1000,15 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 		ps.parent = L.parent.p;
 		ps.orth   = L.orth.p;
 		ps.coarse = prolong_from;
+		const bool cfp = (L.ncf > 0 || L.has_copy); // refined level: copy-through patches / coarse-fine ghost slots
 		auto launch = [&](LevelDev D) {
 			if (D.count == 0) return;
+			if (cfp) {
+				Timed t(g, KC_RBGS_PROLONG, (size_t) D.count * L.nc);
+				hipLaunchKernelGGL((k_rbgs3d<N, false, true, 1, true>), dim3(8 * ((D.count + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream,
+				                   D, u, f, out, ps);
+				return;
+			}
 			Timed t(g, rbgsSlabs<N>(D.count) > 1 ? KC_RBGS_SLABS : KC_RBGS_PROLONG, (size_t) D.count * L.nc);
 			launchRbgsKernel<N, false, true>(g, D, u, f, out, ps);
 		};
@@ -1547,9 +1567,9 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         if ((r = visit(g, o, l + 1, C.f.get(), C.u.get(), o->fuse != 0))) return r;
         // prepFiner (Cycle.h:74-80). When the very next step is an RB-GS sweep on a level without ghost
         // slots, that sweep reads u + P(coarse u) on the fly instead (same bits, one HBM pass less).
-        if (o->fuse && L.prolong_fusable && next_sweeps > 0
-            && (o->smoother == TE_SMOOTH_RBGS
-                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.dim == 3 && L.n == 32 && !getenv("TE_PS_SLOW")))) {
+        if (o->fuse && next_sweeps > 0
+            && ((o->smoother == TE_SMOOTH_RBGS && (L.prolong_fusable || L.prolong_fusable_cf))
+                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.prolong_fusable && L.dim == 3 && L.n == 32 && !getenv("TE_PS_SLOW")))) {
             pending_prolong = C.u->d;
             return TE_OK;
         }

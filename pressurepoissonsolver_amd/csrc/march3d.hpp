@@ -220,6 +220,63 @@ template <int N> __device__ __forceinline__ const double *coarseOctant(const Pro
 	return ps.coarse + (size_t) ps.parent[p] * NNN + ((o & 1) ? H : 0) + N * ((o & 2) ? H : 0) + NN * ((o & 4) ? H : 0);
 }
 
+// P(coarse) at one cell of patch p: the octant of the parent, or (orth < 0, the patch copies through) the same cell
+template <int N> __device__ __forceinline__ double coarseAtCell(const ProlongSrc &ps, int p, int cell)
+{
+	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
+	const int     o = ps.orth[p];
+	const double *c = ps.coarse + (size_t) ps.parent[p] * NNN;
+	if (o < 0) return c[cell];
+	const int x = cell % N, y = (cell / N) % N, z = cell / NN;
+	return c[((o & 1) ? H : 0) + (x >> 1) + N * (((o & 2) ? H : 0) + (y >> 1)) + NN * (((o & 4) ? H : 0) + (z >> 1))];
+}
+
+// k_cf_ghost3d for the iterate u + P(coarse u) that is never stored: every value of u it reads gets its patch's
+// correction added first (remote raw layers arrive corrected: the sender packs u + P e). Same weights
+// (TriLinInterp.cpp:85-170), same order of operations on the corrected values.
+template <int N>
+__global__ void k_cf_ghost_prolong3d(const int32_t *__restrict__ desc, const int32_t *__restrict__ slots,
+                                     const double *__restrict__ u, ProlongSrc ps, double *__restrict__ ghost)
+{
+	constexpr int  NN = N * N, NNN = N * N * N;
+	const int32_t *d  = desc + (size_t) blockIdx.x * 8;
+	const int      p = d[0], s = d[1], kind = d[2], q = d[3];
+	const int      ax   = s >> 1;
+	const int      sa   = (ax == 0) ? N : 1;
+	const int      sb   = (ax == 2) ? N : NN;
+	const int      sn   = (ax == 0) ? 1 : (ax == 1 ? N : NN);
+	const int      mine = (s & 1) ? (N - 1) * sn : 0;
+	const int      oth  = (s & 1) ? 0 : (N - 1) * sn;
+	double        *g    = ghost + (size_t) slots[blockIdx.x] * NN;
+	auto           U    = [&](int patch, int cell) { return u[(size_t) patch * NNN + cell] + coarseAtCell<N>(ps, patch, cell); };
+	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+		const int a = i % N, b = i / N;
+		double    m = U(p, mine + a * sa + b * sb);
+		double    gamma;
+		if (kind == 2) {
+			const int a0 = a & ~1, b0 = b & ~1;
+			double    sum = 0;
+			for (int bb = 0; bb < 2; bb++)
+				for (int aa = 0; aa < 2; aa++)
+					if (a0 + aa != a || b0 + bb != b) sum += U(p, mine + (a0 + aa) * sa + (b0 + bb) * sb);
+			const int ca = (a + ((q & 1) ? N : 0)) / 2, cb = (b + ((q & 2) ? N : 0)) / 2;
+			double    C  = d[4] >= 0 ? U(d[4], oth + ca * sa + cb * sb) : ghost[(size_t) (-(d[4] + 2)) * NN + ca + N * cb];
+			gamma        = (11 * m - sum) / 12.0 + 4.0 * C / 12.0;
+		} else {
+			const int qa = (a >= N / 2), qb = (b >= N / 2);
+			const int nbq = d[4 + qa + 2 * qb];
+			const int fa = 2 * (a - qa * (N / 2)), fb = 2 * (b - qb * (N / 2));
+			double    sum = 0;
+			for (int bb = 0; bb < 2; bb++)
+				for (int aa = 0; aa < 2; aa++)
+					sum += 1.0 / 6.0 * (nbq >= 0 ? U(nbq, oth + (fa + aa) * sa + (fb + bb) * sb)
+					                             : ghost[(size_t) (-(nbq + 2)) * NN + (fa + aa) + N * (fb + bb)]);
+			gamma = 2.0 / 6.0 * m + sum;
+		}
+		g[i] = 2 * gamma - m;
+	}
+}
+
 // k_pack_faces3d for the iterate u + P(coarse u) that is never stored (see ProlongSrc): the face layers other
 // ranks need, with this rank's coarse correction added on the way out.
 template <int N>
@@ -230,9 +287,17 @@ __global__ void k_pack_faces_prolong3d(const int32_t *__restrict__ faces, const 
 	const int     p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
 	const int     ax = s >> 1;
 	const int     sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
-	const double *up = u + (size_t) p * NNN + ((s & 1) ? (N - 1) * sn : 0);
+	const int     face = (s & 1) ? (N - 1) * sn : 0;
+	const double *up   = u + (size_t) p * NNN + face;
+	double       *o    = sendbuf + (size_t) blockIdx.x * NN;
+	if (ps.orth[p] < 0) { // copy-through patch: the correction is the same-size coarse patch
+		for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+			const int cell = (i % N) * sa + (i / N) * sb;
+			o[i]           = up[cell] + coarseAtCell<N>(ps, p, face + cell);
+		}
+		return;
+	}
 	const double *cp = coarseOctant<N>(ps, p) + ((s & 1) ? (H - 1) * sn : 0);
-	double       *o  = sendbuf + (size_t) blockIdx.x * NN;
 	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
 		const int a = i % N, b = i / N;
 		o[i] = up[a * sa + b * sb] + cp[(a / 2) * sa + (b / 2) * sb];
@@ -283,7 +348,10 @@ __device__ __forceinline__ void relaxCell(double *tl, const double *idiag, int c
 // ZS > 1 (levels with few patches): a patch is split into ZS z-slabs, one workgroup each. A slab [z0, z1) needs
 // the new red values of planes z0-1 and z1, which depend on old values only: they are recomputed (never
 // stored), so the result is bit-identical to the whole-patch sweep at 2/(N/ZS) extra arithmetic and reads.
-template <int N, bool ZERO, bool PROLONG, int ZS = 1>
+// CFP (with PROLONG, ZS = 1): the level is refined -- some patches copy through to the coarser level (orth < 0: their
+// correction is the same-size coarse patch, cell by cell) and coarse/fine ghost slots exist (filled from u + P e
+// by k_cf_ghost_prolong3d).
+template <int N, bool ZERO, bool PROLONG, int ZS = 1, bool CFP = false>
 __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const double *__restrict__ u,
                                                           const double *__restrict__ f,
                                                           double *__restrict__ out, ProlongSrc ps)
@@ -356,29 +424,70 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	const double *cown = nullptr, *chalo = nullptr, *cbot = nullptr, *ctop = nullptr;
 	double        shalo = 0.0, sbot = 0.0, stop = 0.0;
 	const int     cq = X + N * Yp; // in-plane coarse offset of this thread's cells (both rows share it)
+	// CFP: copy-through patches (own / bottom / top neighbour) are addressed cell by cell; hsh = z shift of the halo's
+	// coarse index (0 for a copy-through neighbour)
+	bool          cpo = false, cpb = false, cpt = false;
+	const double *yown = nullptr, *ybot = nullptr, *ytop = nullptr;
+	int           hsh = 1;
+	static_assert(!CFP || (PROLONG && ZS == 1), "CFP is a variant of the fused-prolongation sweep without z-slabs");
 	if (PROLONG) {
-		cown  = coarseOctant<N>(ps, pid);
+		if (CFP && ps.orth[pid] < 0) {
+			cpo  = true;
+			yown = ps.coarse + (size_t) ps.parent[pid] * NNN;
+			cown = yown;
+		} else {
+			cown = coarseOctant<N>(ps, pid);
+		}
 		chalo = cbot = ctop = cown; // harmless valid address where no correction applies (scale 0)
 		if (tid < 4 * N) {
 			const int side = tid / N, t = tid % N;
 			if (fk[side] == FACE_LOCAL) {
-				const double *cn = coarseOctant<N>(ps, fs[side]);
-				// the neighbour's facing cell: west (N-1,t) east (0,t) south (t,N-1) north (t,0)
-				const int cx = (side == 0) ? H - 1 : (side == 1 ? 0 : t / 2);
-				const int cy = (side == 2) ? H - 1 : (side == 3 ? 0 : t / 2);
-				chalo = cn + cx + N * cy;
+				if (CFP && ps.orth[fs[side]] < 0) { // the neighbour's facing cell in its same-size coarse patch
+					const int nbr = (side == 0) ? t * N + (N - 1) : (side == 1 ? t * N : (side == 2 ? (N - 1) * N + t : t));
+					chalo = ps.coarse + (size_t) ps.parent[fs[side]] * NNN + nbr;
+					hsh   = 0;
+				} else {
+					const double *cn = coarseOctant<N>(ps, fs[side]);
+					// the neighbour's facing cell: west (N-1,t) east (0,t) south (t,N-1) north (t,0)
+					const int cx = (side == 0) ? H - 1 : (side == 1 ? 0 : t / 2);
+					const int cy = (side == 2) ? H - 1 : (side == 3 ? 0 : t / 2);
+					chalo = cn + cx + N * cy;
+				}
 				shalo = 1.0;
 			}
 		}
 		if (fk[4] == FACE_LOCAL) {
-			cbot = coarseOctant<N>(ps, fs[4]) + NN * (H - 1);
+			if (CFP && ps.orth[fs[4]] < 0)
+				cpb = true, ybot = ps.coarse + (size_t) ps.parent[fs[4]] * NNN + NN * (N - 1);
+			else
+				cbot = coarseOctant<N>(ps, fs[4]) + NN * (H - 1);
 			sbot = 1.0;
 		}
 		if (fk[5] == FACE_LOCAL) {
-			ctop = coarseOctant<N>(ps, fs[5]);
+			if (CFP && ps.orth[fs[5]] < 0)
+				cpt = true, ytop = ps.coarse + (size_t) ps.parent[fs[5]] * NNN;
+			else
+				ctop = coarseOctant<N>(ps, fs[5]);
 			stop = 1.0;
 		}
 	}
+	// the correction of this thread's two cells of row k: plane z of the own patch / the bottom / top neighbour's
+	// facing plane (CFP only; the uniform case uses the scalar forms below)
+	auto ownC = [&](int k, int z) {
+		if (cpo) return *reinterpret_cast<const double2 *>(yown + (size_t) z * NN + (2 * Yp + k) * N + 2 * X);
+		const double c = cown[NN * (z >> 1) + cq];
+		return double2{c, c};
+	};
+	auto botC = [&](int k) {
+		if (cpb) return *reinterpret_cast<const double2 *>(ybot + (2 * Yp + k) * N + 2 * X);
+		const double c = cbot[cq];
+		return double2{c, c};
+	};
+	auto topC = [&](int k) {
+		if (cpt) return *reinterpret_cast<const double2 *>(ytop + (2 * Yp + k) * N + 2 * X);
+		const double c = ctop[cq];
+		return double2{c, c};
+	};
 
 	// planes: umm = z-2, um = z-1, uc = z, un = z+1, un2 = z+2 (values are updated in place); start at z = zs
 	double2 umm[2], um[2], uc[2], un[2], un2[2], fm[2], fc[2], fn[2];
@@ -391,11 +500,16 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 			double2 a = pm[q[k]];
 			um[k]     = double2{sm * a.x, sm * a.y};
 			un[k]     = up2[(zs + 1) * NP + q[k]];
-			if (PROLONG) {
+			if (PROLONG && !CFP) {
 				const double c0 = cown[NN * (zs >> 1) + cq], c1 = cown[NN * ((zs + 1) >> 1) + cq];
 				const double cb = (zs > 0) ? cown[NN * ((zs - 1) >> 1) + cq] : sbot * cbot[cq];
 				uc[k].x += c0, uc[k].y += c0, un[k].x += c1, un[k].y += c1;
 				um[k].x += sm * cb, um[k].y += sm * cb;
+			}
+			if (PROLONG && CFP) { // zs = 0
+				const double2 c0 = ownC(k, 0), c1 = ownC(k, 1), cb = botC(k);
+				uc[k].x += c0.x, uc[k].y += c0.y, un[k].x += c1.x, un[k].y += c1.y;
+				um[k].x += sm * (sbot * cb.x), um[k].y += sm * (sbot * cb.y);
 			}
 		} else {
 			uc[k] = um[k] = un[k] = un2[k] = double2{0.0, 0.0};
@@ -404,7 +518,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		umm[k] = double2{0.0, 0.0};
 		fm[k]  = double2{0.0, 0.0};
 	}
-	double hv = ZERO ? 0.0 : hs.s * (hs.p[zs * hs.stride] + (PROLONG ? shalo * chalo[NN * (zs >> 1)] : 0.0));
+	double hv = ZERO ? 0.0 : hs.s * (hs.p[zs * hs.stride] + (PROLONG ? shalo * chalo[NN * (zs >> hsh)] : 0.0));
 	__syncthreads(); // idiag (and the zeroed tiles)
 
 	int bz = 0; // z % 3
@@ -420,15 +534,20 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 #pragma unroll
 			for (int k = 0; k < 2; k++) {
 				double2 a = pn[q[k]];
-				if (PROLONG) { // plane z+2 of the patch, or the top neighbour's plane 0
+				if (PROLONG && !CFP) { // plane z+2 of the patch, or the top neighbour's plane 0
 					const double *cp = (z + 2 < N) ? cown + NN * ((z + 2) >> 1) : ctop;
 					const double  cs = (z + 2 < N) ? 1.0 : stop;
 					const double  c  = cs * cp[cq];
 					a.x += c, a.y += c;
 				}
+				if (PROLONG && CFP) {
+					const double2 c  = (z + 2 < N) ? ownC(k, z + 2) : topC(k);
+					const double  cs = (z + 2 < N) ? 1.0 : stop;
+					a.x += cs * c.x, a.y += cs * c.y;
+				}
 				un2[k] = double2{sn * a.x, sn * a.y};
 			}
-			hvn = hs.s * (hs.p[zc * hs.stride] + (PROLONG ? shalo * chalo[NN * (zc >> 1)] : 0.0));
+			hvn = hs.s * (hs.p[zc * hs.stride] + (PROLONG ? shalo * chalo[NN * (zc >> hsh)] : 0.0));
 		}
 #pragma unroll
 		for (int k = 0; k < 2; k++) fn[k] = fp2[zc * NP + q[k]];
