@@ -1568,8 +1568,9 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         // prepFiner (Cycle.h:74-80). When the very next step is an RB-GS sweep on a level without ghost
         // slots, that sweep reads u + P(coarse u) on the fly instead (same bits, one HBM pass less).
         if (o->fuse && next_sweeps > 0
-            && ((o->smoother == TE_SMOOTH_RBGS && (L.prolong_fusable || L.prolong_fusable_cf))
-                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.prolong_fusable && L.dim == 3 && L.n == 32 && !getenv("TE_PS_SLOW")))) {
+            && (L.prolong_fusable || L.prolong_fusable_cf)
+            && (o->smoother == TE_SMOOTH_RBGS
+                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.dim == 3 && L.n == 32 && !getenv("TE_PS_SLOW")))) {
             pending_prolong = C.u->d;
             return TE_OK;
         }

@@ -42,11 +42,8 @@ __global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *_
 	const int     mine = (s & 1) ? (N - 1) * sn : 0, oth = (s & 1) ? 0 : (N - 1) * sn;
 	const double  rh = L.rh2[(size_t) p * 3 + ax];
 	double       *c  = corr + ((size_t) p * 6 + s) * NN;
-	const double *cm = nullptr, *cn = nullptr; // coarse octants of this patch / of the neighbour
-	if (PROLONG && kind >= FACE_LOCAL) { // a ghost slot (neighbour on another rank) holds u + P e already: the sender adds it
-		cm = coarseOctant<N>(ps, p);
-		if (kind == FACE_LOCAL) cn = coarseOctant<N>(ps, src);
-	}
+	// PROLONG: P e at a cell through coarseAtCell (octant children and patches that copy through alike); a ghost slot
+	// (neighbour on another rank, coarse/fine face) holds values of u + P e already
 	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
 		double v = 0.0;
 		if (kind >= FACE_LOCAL) {
@@ -61,10 +58,8 @@ __global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *_
 				gh = (kind == FACE_LOCAL) ? u[(size_t) src * NNN + oth + cell] : L.ghost[(size_t) src * NN + i];
 			}
 			if (PROLONG) {
-				// coarse cell of fine (x, y, z): x/2 + N (y/2) + N^2 (z/2); on the face layer the normal index is 0 or N-1
-				const int ccell = (a / 2) * sa + (b / 2) * sb;
-				m += cm[ccell + ((s & 1) ? (N / 2 - 1) * sn : 0)];
-				if (kind == FACE_LOCAL) gh += cn[ccell + ((s & 1) ? 0 : (N / 2 - 1) * sn)];
+				m += coarseAtCell<N>(ps, p, mine + cell);
+				if (kind == FACE_LOCAL) gh += coarseAtCell<N>(ps, src, oth + cell);
 			}
 			v = 2.0 * rh * (0.5 * m + 0.5 * gh);
 		}
