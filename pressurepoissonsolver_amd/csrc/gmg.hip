@@ -88,10 +88,9 @@ struct LevelHost {
 	// ghost exchange, and all ranks must agree on that); fuse2d = additionally all parents are local (rank-local:
 	// residual+restrict in one pass; peers see the same exchanges either way)
 	bool   lds2d = false, fuse2d = false;
-	// 3D: the fused pre-sweep + residual + restriction (opts.fuse = 2) applies: a uniform refinement step (every patch
-	// of the GLOBAL level is an octant child, none has a coarse/fine face) with at least 256 patches in total.
-	// Decided from the global tables, so it is the same on every rank and for every partition: sharded runs take the
-	// same arithmetic path as the single-rank run.
+	// 3D: the fused pre-sweep + residual + restriction (opts.fuse = 2) applies: a level with at least 256 patches in
+	// total. A global fact, so it is the same on every rank and for every partition: sharded runs take the same
+	// arithmetic path as the single-rank run.
 	bool   fuse2_ok = false;
 	size_t nc = 0, nf = 0;
 	// stencil tables
@@ -471,14 +470,9 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	}
 	L->nslots = nslots;
 	L->lds2d  = (D == 2 && n <= 64 && n % 2 == 0 && !getenv("TE_2D_SIMPLE"));
-	if (D == 3 && li + 1 < (int) H.levels.size() && lv.P_global >= 256) { // see LevelHost::fuse2_ok: global facts only
-		bool ok = true;
-		for (int gp = 0; gp < lv.P_global && ok; gp++) {
-			ok &= lv.g_orth_on_parent[gp] >= 0;
-			for (int s = 0; s < NS && ok; s++) ok &= lv.g_nbr_kind[(size_t) gp * NS + s] <= NBR_NORMAL;
-		}
-		L->fuse2_ok = ok;
-	}
+	// see LevelHost::fuse2_ok: a global fact only. (Refined levels qualify: patches that copy through and
+	// coarse/fine faces -- whose ghost slots carry the interpolated value -- are handled by both kernels.)
+	L->fuse2_ok = (D == 3 && li + 1 < (int) H.levels.size() && lv.P_global >= 256 && !getenv("TE_NO_FUSE2"));
 	L->ncf    = (int) cfs.size();
 	int rc;
 	{

@@ -683,9 +683,12 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 	// fused restriction target (see k_stencil3d<MODE_RESID_RESTRICT>): the parent's octant, or the block this rank
 	// ships to the parent's rank; no copy-through patches on these levels
 	const int pa = rd.parent[pid], rorth = rd.orth[pid];
-	double   *rdst;
-	int       rsz;
-	if (pa >= 0) {
+	double   *rdst = nullptr;
+	double2  *rcpy = nullptr; // a patch that copies through (orth < 0): the residual itself goes to the same-size coarse patch
+	int       rsz  = 0;
+	if (rorth < 0) {
+		rcpy = reinterpret_cast<double2 *>(pa >= 0 ? rd.coarse + (size_t) pa * NNN : rd.remote + rd.remote_off[-(pa + 2)]);
+	} else if (pa >= 0) {
 		rdst = rd.coarse + (size_t) pa * NNN + ((rorth & 1) ? H : 0) + N * ((rorth & 2) ? H : 0) + NN * ((rorth & 4) ? H : 0) + X + N * Yp;
 		rsz  = NN;
 	} else {
@@ -773,11 +776,13 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 				lap.y += (ym.y - 2 * c.y + yp.y) * rhy;
 				lap.x += (below.x - 2 * c.x + above.x) * rhz;
 				lap.y += (below.y - 2 * c.y + above.y) * rhz;
-				a += (f2[k].x - lap.x) / 8; // AvgRstr.h:95-102 order: x, then y, then z; each /2^D first
-				a += (f2[k].y - lap.y) / 8;
+				const double2 r = double2{f2[k].x - lap.x, f2[k].y - lap.y};
+				if (rcpy && act) rcpy[zr * NP + q[k]] = r; // (wave-uniform) AvgRstr.h:103-107
+				a += r.x / 8; // AvgRstr.h:95-102 order: x, then y, then z; each /2^D first
+				a += r.y / 8;
 			}
 			racc = a;
-			if ((zr & 1) && act) rdst[rsz * (zr >> 1)] = a;
+			if (rdst && (zr & 1) && act) rdst[rsz * (zr >> 1)] = a;
 		}
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
@@ -826,6 +831,32 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 		c2 = H, c3 = H * H;
 	}
 	const int cs[3] = {c1, c2, c3};
+	if (o < 0) { // the patch copies through: every face cell's term goes to the same cell of the same-size coarse patch
+		double *cc = pa >= 0 ? rd.coarse + (size_t) pa * NNN : rd.remote + rd.remote_off[-(pa + 2)];
+		for (int s = 0; s < 6; s++) {
+			const int kind = L.face_kind[(size_t) p * 6 + s], src = L.face_src[(size_t) p * 6 + s];
+			if (kind >= FACE_LOCAL) {
+				const int    ax = s >> 1;
+				const int    sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
+				const int    mine = (s & 1) ? (N - 1) * sn : 0, oth = (s & 1) ? 0 : (N - 1) * sn;
+				const double w = -L.rh2[(size_t) p * 3 + ax];
+				for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+					const int cell = (i % N) * sa + (i / N) * sb;
+					double    g;
+					if (kind == FACE_GHOST)
+						g = L.ghost[(size_t) src * NN + i];
+					else if (ax == 0 && L.xf) // compact x-face columns instead of a stride-N gather
+						g = L.xf[((size_t) src * 2 + ((s & 1) ^ 1)) * NN + i];
+					else
+						g = u[(size_t) src * NNN + oth + cell];
+					if (OWN) g += (ax == 0 && L.xf) ? L.xf[((size_t) p * 2 + (s & 1)) * NN + i] : u[(size_t) p * NNN + mine + cell];
+					cc[mine + cell] += w * g;
+				}
+			}
+			__syncthreads();
+		}
+		return;
+	}
 	for (int s = 0; s < 6; s++) {
 		const int kind = L.face_kind[(size_t) p * 6 + s], src = L.face_src[(size_t) p * 6 + s];
 		if (kind >= FACE_LOCAL) {

@@ -152,12 +152,15 @@ def test_patch_solve_variants_agree(case, monkeypatch):
     assert rel(got["1pass"][1], got["3pass"][1]) <= 1e-13
 
 
-@pytest.mark.parametrize("n,neumann", [(4, False), (8, False), (8, True), (16, False), (32, False)])
-def test_fused_presweep_residual_restrict(n, neumann):
+@pytest.mark.parametrize("n,neumann,mesh,div", [(4, False, "uniform", 3), (8, False, "uniform", 3), (8, True, "uniform", 3),
+                                                (16, False, "uniform", 3), (32, False, "uniform", 3),
+                                                # refined: patches that copy through, coarse/fine faces (960 patches)
+                                                (8, False, "2refine.bin", 2), (8, True, "2refine.bin", 2)])
+def test_fused_presweep_residual_restrict(n, neumann, mesh, div):
     """opts.fuse = 2 (default): on uniformly refined levels with >= 256 patches the zero-guess RB-GS pre-sweep, the
     residual and its restriction are one pass (k_rbgs_zero_resid3d) plus a fix-up of the coarse cells along patch
     faces (k_restrict_fixup3d). Not bit-identical to fuse = 1 (the ghost term is added separately): a few ulp."""
-    m, H, levels = util.setup("uniform", n, 3, neumann=neumann, dim=3)  # 8^3 = 512 patches on the finest level
+    m, H, levels = util.setup(mesh, n, div, neumann=neumann, dim=3)  # uniform: 8^3 = 512 patches on the finest level
     g, L = capi.GMG(H), levels[0]
     f = util.rand_vec(L.size, 54) / L.a["h"].min() ** 2
     got = {}
