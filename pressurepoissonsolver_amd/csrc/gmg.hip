@@ -767,7 +767,10 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 		D.xf_out = xf_out;
 		launch_(D);
 	};
-	if (L.nremote == 0 || !g->overlap || L.n_int == 0) {
+	// (levels with few local patches: nothing worth hiding under the exchange, and the second stream and its two
+	// events only add host calls and latency)
+	const char *omin = getenv("TE_OVERLAP_MIN"); // tests set 0 so that their small levels take the overlapped path
+	if (L.nremote == 0 || !g->overlap || L.n_int == 0 || L.P < (omin ? atoi(omin) : 128)) {
 		int rc = prepareGhosts<N>(g, L, u, ps);
 		if (rc) return rc;
 		launch(L.dev());

@@ -45,7 +45,11 @@ def shard_run(mesh, n, nranks, fn, dim=3):
 @pytest.mark.parametrize("name,divides,n,dim", [("uniform", 2, 8, 3), ("uniform", 3, 4, 3), ("uniform", 3, 8, 2),
                                                 # refined trees: coarse/fine faces cut by rank boundaries (config C4)
                                                 ("2refine.bin", 1, 8, 3), ("2d2ref.bin", 2, 8, 2)])
-def test_sharded_ops_equal_single_rank(nranks, name, divides, n, dim):
+def test_sharded_ops_equal_single_rank(nranks, name, divides, n, dim, monkeypatch):
+    # levels with fewer than 128 local patches skip the interior/boundary overlap by default: these small meshes must
+    # exercise it (the 8-rank run keeps the default, i.e. covers the non-overlapped path too)
+    if nranks != 8:
+        monkeypatch.setenv("TE_OVERLAP_MIN", "0")
     mesh = util.mesh(name, divides, dim)
     H1 = capi.Hierarchy(mesh, n)
     g1 = capi.GMG(H1)
