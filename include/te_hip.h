@@ -113,6 +113,11 @@ void   te_vec_destroy(te_vec *v);
 size_t te_vec_size(const te_vec *v);                 /* doubles (local patches * n^dim) */
 int    te_vec_upload(te_vec *v, const double *host); /* Vector<D>::getLocalData write path */
 int    te_vec_download(const te_vec *v, double *host);
+/* Vector<D>::getLocalData(i) (Vector.h:214-215, PetscVector.h:87-98) for patches [first_patch, first_patch+npatches):
+ * host holds npatches * n^dim doubles in the same layout. The per-patch data plane of the C++ adaptor
+ * (HipVector::getLocalData) and of Init-style fill loops (apps/shared/Init.cpp:152-245). */
+int    te_vec_upload_patches(te_vec *v, int first_patch, int npatches, const double *host);
+int    te_vec_download_patches(const te_vec *v, int first_patch, int npatches, double *host);
 void  *te_vec_device_ptr(te_vec *v);
 
 /* Vector<D> BLAS-1 virtuals, Vector.h:190-321 (same names, same argument order) */
@@ -135,6 +140,10 @@ int te_vec_dot(const te_vec *v, const te_vec *b, double *out);
 /* Operator<D>::apply (Operators/Operator.h:37) as SchurDomainOp / DomainWrapOp implement it:
  * f = A u through SchurHelper::apply (SchurHelper.h:360-376) */
 int te_apply(te_gmg *g, int level, const te_vec *u, te_vec *f);
+/* PatchOperator<D>::apply without interface values, StarPatchOp.h:204-319 (SevenPtPatchOperator.cpp:247-409,
+ * FivePtPatchOperator.h:172-261): f = A_patch u per patch, faces with a neighbour closed as homogeneous
+ * Dirichlet. The operator the exact patch solves invert; the reference uses it in PatchSolvers/BiCGStabSolver.h:82-85. */
+int te_patch_apply(te_gmg *g, int level, const te_vec *u, te_vec *f);
 /* r = f - A u  (Cycle.h:60-61 fused: apply + scaleThenAdd(-1, f)) */
 int te_residual(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *r);
 /* GMG::Smoother<D>::smooth(f, u) (GMG/Smoother.h:39), `sweeps` times */
@@ -148,7 +157,10 @@ int te_prolong_add(te_gmg *g, int fine_level, const te_vec *coarse, te_vec *fine
 /* GMG::Cycle<D>::apply(f, u) (GMG/Cycle.h:116-126) on level 0 */
 int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u);
 /* BiCGStab<D>::solve(vg, A, x, b, Mr, max_it, tol) (BiCGStab.h:45-106). Mr = te_vcycle when
- * `o` is non-NULL. Single-rank only (multi-rank callers drive te_vec_* themselves). */
+ * `o` is non-NULL. On a sharded hierarchy every rank calls it; the scalars of an iteration are summed over
+ * the ranks (Vector.h:294,319) by ncclAllReduce on the solver stream (te_gmg_use_rccl) or by the
+ * te_gmg_set_allreduce callback, batched as BiCGStab.h:71-97 allows: 1 + 2 + 2 doubles per iteration.
+ * TE_ESTATE when several ranks exist and neither is set. */
 int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, int max_it,
                 double tol, int *iterations, double *rel_resid);
 
@@ -172,6 +184,19 @@ int te_gmg_set_exchange(te_gmg *g, te_exchange_fn fn, void *user);
  * ncclUniqueId produced by te_rccl_unique_id on rank 0 and broadcast by the host. */
 int te_rccl_unique_id(const char *libpath, char *id128);
 int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank, int nranks);
+/* Sum (op 0) or maximum (op 1) of vals[0..n) over all ranks, in place, the same result on every rank: the
+ * MPI_Allreduce of Vector.h:294,306,319 for hosts that registered an exchange callback (with te_gmg_use_rccl the
+ * library reduces on the device itself). Used by te_bicgstab and te_gmg_verify_schedule. */
+typedef int (*te_allreduce_fn)(void *user, double *vals, int n, int op);
+int te_gmg_set_allreduce(te_gmg *g, te_allreduce_fn fn, void *user);
+/* Dry run of one te_vcycle with options `o` that records every exchange each rank would issue (tag, level, peer,
+ * counts) and compares, through one reduction over the ranks, what every rank sends with what its peer expects,
+ * pair by pair and in order. TE_ESTATE on ALL ranks when the ranks would issue different sequences (different
+ * options or hierarchies) -- instead of a hang inside RCCL in the middle of a cycle. te_vcycle runs it by itself the
+ * first time it sees a set of options on a sharded hierarchy (TE_NO_VERIFY skips that). Collective.
+ * Independently, a watchdog thread ends the process (exit status 86, message on stderr) when an exchange has not
+ * completed TE_EXCHANGE_TIMEOUT seconds (default 300; 0 = off) after it was issued. */
+int te_gmg_verify_schedule(te_gmg *g, const te_cycle_opts *o);
 /* moves n doubles through the active exchange back-end with this rank as its own peer (diagnostic) */
 int te_gmg_exchange_selftest(te_gmg *g, int n);
 

@@ -41,6 +41,8 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, 
                           C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                           C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p)
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+
 # every symbol include/te_hip.h declares: (restype, argtypes)
 _P = C.c_void_p
 _D = C.c_double
@@ -77,6 +79,8 @@ SYMBOLS = {
     "te_vec_size": (C.c_size_t, [_P]),
     "te_vec_upload": (_I, [_P, _P]),
     "te_vec_download": (_I, [_P, _P]),
+    "te_vec_upload_patches": (_I, [_P, _I, _I, _P]),
+    "te_vec_download_patches": (_I, [_P, _I, _I, _P]),
     "te_vec_device_ptr": (_P, [_P]),
     "te_vec_set": (_I, [_P, _D]),
     "te_vec_scale": (_I, [_P, _D]),
@@ -92,6 +96,7 @@ SYMBOLS = {
     "te_vec_inf_norm": (_I, [_P, _PD]),
     "te_vec_dot": (_I, [_P, _P, _PD]),
     "te_apply": (_I, [_P, _I, _P, _P]),
+    "te_patch_apply": (_I, [_P, _I, _P, _P]),
     "te_residual": (_I, [_P, _I, _P, _P, _P]),
     "te_smooth": (_I, [_P, _I, _P, _P, _I, _D, _I]),
     "te_restrict": (_I, [_P, _I, _P, _P]),
@@ -101,6 +106,8 @@ SYMBOLS = {
     "te_gmg_set_exchange": (_I, [_P, EXCHANGE_FN, _P]),
     "te_rccl_unique_id": (_I, [C.c_char_p, C.c_char_p]),
     "te_gmg_use_rccl": (_I, [_P, C.c_char_p, C.c_char_p, _I, _I]),
+    "te_gmg_set_allreduce": (_I, [_P, ALLREDUCE_FN, _P]),
+    "te_gmg_verify_schedule": (_I, [_P, C.POINTER(CycleOpts)]),
     "te_gmg_exchange_selftest": (_I, [_P, _I]),
     "te_gmg_profile": (_I, [_P, _I]),
     "te_gmg_profile_rows": (_I, [_P, _I, _P, _P, _P, _P]),
@@ -271,6 +278,19 @@ class Vec:
         check(lib().te_vec_download(self.h, _ptr(out)))
         return out
 
+    def upload_patches(self, first, a):
+        """Vector<D>::getLocalData(i) write path for a run of patches"""
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        nc = self.gmg.hier.n ** self.gmg.hier.dim
+        if a.size % nc:
+            raise ValueError("upload_patches: not a whole number of patches")
+        check(lib().te_vec_upload_patches(self.h, first, a.size // nc, _ptr(a.ravel())))
+
+    def download_patches(self, first, count):
+        out = np.empty(count * self.gmg.hier.n ** self.gmg.hier.dim, np.float64)
+        check(lib().te_vec_download_patches(self.h, first, count, _ptr(out)))
+        return out
+
     def device_ptr(self):
         return lib().te_vec_device_ptr(self.h)
 
@@ -353,6 +373,23 @@ class GMG:
 
     def apply(self, u, f, level=0): check(lib().te_apply(self.h, level, u.h, f.h))
     def residual(self, u, f, r, level=0): check(lib().te_residual(self.h, level, u.h, f.h, r.h))
+    def patch_apply(self, u, f, level=0): check(lib().te_patch_apply(self.h, level, u.h, f.h))
+    def verify_schedule(self, opts): check(lib().te_gmg_verify_schedule(self.h, C.byref(opts)))
+
+    def set_allreduce(self, fn):
+        """fn(list of floats, op) -> list of floats (op 0 sum, 1 max), the same on every rank"""
+        def cb(user, vals, n, op):
+            try:
+                out = fn([vals[i] for i in range(n)], op)
+                for i in range(n):
+                    vals[i] = out[i]
+                return 0
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._ar = ALLREDUCE_FN(cb)
+        check(lib().te_gmg_set_allreduce(self.h, self._ar, None))
 
     def smooth(self, f, u, level=0, smoother=SMOOTH_PATCH_SOLVE, omega=6.0 / 7.0, sweeps=1):
         check(lib().te_smooth(self.h, level, f.h, u.h, smoother, omega, sweeps))

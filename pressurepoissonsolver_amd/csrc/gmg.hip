@@ -9,12 +9,19 @@
 #include "patchsolve32_sym.hpp"
 #include <algorithm>
 #include <array>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <set>
+#include <thread>
 #include <tuple>
+#include <unistd.h>
 #include <vector>
 
 using namespace te;
@@ -95,6 +102,10 @@ struct LevelHost {
 	size_t nc = 0, nf = 0;
 	// stencil tables
 	DevBuf<int32_t> face_kind, face_src;
+	// the same with every neighbour face closed as homogeneous Dirichlet: the PATCH operator, StarPatchOp::apply
+	// (StarPatchOp.h:204-319); patch_local selects it for one launch (te_patch_apply)
+	DevBuf<int32_t> face_kind_patch;
+	bool            patch_local = false;
 	DevBuf<double>  face_kadj, rh2, ghost;
 	int             nslots = 0;
 	// coarse/fine faces
@@ -129,7 +140,7 @@ struct LevelHost {
 		Level2D L;
 		L.P         = P;
 		L.n         = n;
-		L.face_kind = face_kind.p;
+		L.face_kind = patch_local ? face_kind_patch.p : face_kind.p;
 		L.face_src  = face_src.p;
 		L.face_kadj = face_kadj.p;
 		L.rh2       = rh2.p;
@@ -140,7 +151,7 @@ struct LevelHost {
 	{
 		LevelDev L;
 		L.P         = P;
-		L.face_kind = face_kind.p;
+		L.face_kind = patch_local ? face_kind_patch.p : face_kind.p;
 		L.face_src  = face_src.p;
 		L.face_kadj = face_kadj.p;
 		L.rh2       = rh2.p;
@@ -198,6 +209,32 @@ struct te_gmg {
 	int                                     red_blocks  = 1024;
 	te_exchange_fn                          exchange    = nullptr;
 	void                                   *exchange_user = nullptr;
+	int                                     rank = 0, nranks = 1;
+	// sum / max of a few host scalars over the ranks (Vector.h:294,306,319 MPI_Allreduce); with the native RCCL
+	// back-end the library reduces on the device instead (ncclAllReduce on the solver stream)
+	te_allreduce_fn                         allreduce      = nullptr;
+	void                                   *allreduce_user = nullptr;
+	// schedule check (te_gmg_verify_schedule): exchanges are recorded instead of performed
+	bool recording = false;
+	struct ExRec {
+		int     tag, level, peer;
+		int64_t send_cnt, recv_cnt;
+	};
+	std::vector<ExRec>         record;
+	int                        cur_level = 0;
+	std::set<uint64_t>         verified_opts;
+	// watchdog: an exchange that has not completed TE_EXCHANGE_TIMEOUT seconds after it was issued ends the process
+	struct Watchdog {
+		std::thread                           th;
+		std::mutex                            mu;
+		std::atomic<bool>                     stop{false};
+		bool                                  pending = false;
+		std::chrono::steady_clock::time_point since;
+		hipEvent_t                            ev = nullptr;
+		bool                                  ev_recorded = false;
+		double                                timeout_s = 300.0;
+		int                                   tag = 0, level = 0;
+	} wd;
 	// optional: RCCL point-to-point called straight from this library (no host callback per exchange)
 	struct Rccl {
 		void *lib = nullptr, *comm = nullptr;
@@ -206,6 +243,7 @@ struct te_gmg {
 		int (*Send)(const void *, size_t, int, int, void *, hipStream_t)             = nullptr;
 		int (*Recv)(void *, size_t, int, int, void *, hipStream_t)                   = nullptr;
 		int (*CommDestroy)(void *)                                                   = nullptr;
+		int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
 		const char *(*GetErrorString)(int)                                           = nullptr;
 	} rccl;
 	// profiling
@@ -491,6 +529,12 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	               || (rc = L->f6buf.alloc((size_t) std::max(P, 1) * 6 * L->nf))))
 		return rc;
 	if ((rc = L->cellvol.upload(cellvol))) return rc;
+	{
+		std::vector<int32_t> fkp(fk);
+		for (auto &k : fkp)
+			if (k >= FACE_LOCAL) k = FACE_DIRICHLET;
+		if ((rc = L->face_kind_patch.upload(fkp))) return rc;
+	}
 	if ((rc = L->face_kind.upload(fk)) || (rc = L->face_src.upload(fs)) || (rc = L->face_kadj.upload(kadj))
 	    || (rc = L->rh2.upload(rh2)) || (rc = L->cf_desc.upload(cfd)) || (rc = L->cf_slots.upload(cfs))
 	    || (rc = L->ghost.alloc((size_t) std::max(nslots, 1) * L->nf)))
@@ -694,11 +738,86 @@ int newVec(te_gmg *g, int level, te_vec **out)
 inline bool sameShape(const te_vec *a, const te_vec *b) { return a && b && a->g == b->g && a->level == b->level; }
 
 // ------------------------------------------------------------------------------ launches
+// Watchdog (multi-rank only): a peer that never posts its half of an exchange leaves RCCL (or the host callback)
+// waiting for ever, with no error. Every exchange arms a deadline and records an event behind itself on its
+// stream; a thread polls the event and ends the PROCESS (exit status 86, message on stderr) when the deadline
+// passes first -- the launcher (torchrun, mpirun) then takes the job down instead of hanging the node.
+void watchdogLoop(te_gmg *g)
+{
+	auto &w = g->wd;
+	while (!w.stop.load()) {
+		std::this_thread::sleep_for(std::chrono::milliseconds(50));
+		std::lock_guard<std::mutex> lk(w.mu);
+		if (!w.pending) continue;
+		if (w.ev_recorded && hipEventQuery(w.ev) == hipSuccess) {
+			w.pending = false;
+			continue;
+		}
+		const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - w.since).count();
+		if (waited > w.timeout_s) {
+			fprintf(stderr,
+			        "te_hip watchdog: rank %d: exchange (tag %d, level %d) has not completed after %.0f s -- a peer is "
+			        "missing or issued a different exchange sequence; ending the process\n",
+			        g->rank, w.tag, w.level, waited);
+			fflush(stderr);
+			_exit(86);
+		}
+	}
+}
+void watchdogStart(te_gmg *g)
+{
+	auto &w = g->wd;
+	if (w.th.joinable() || g->nranks < 2) return;
+	if (const char *t = getenv("TE_EXCHANGE_TIMEOUT")) w.timeout_s = atof(t);
+	if (w.timeout_s <= 0) return; // TE_EXCHANGE_TIMEOUT=0 disables it
+	if (hipEventCreateWithFlags(&w.ev, hipEventDisableTiming) != hipSuccess) return;
+	w.th = std::thread(watchdogLoop, g);
+}
+void watchdogStop(te_gmg *g)
+{
+	auto &w = g->wd;
+	if (!w.th.joinable()) return;
+	w.stop.store(true);
+	w.th.join();
+	if (w.ev) (void) hipEventDestroy(w.ev);
+	w.ev = nullptr;
+}
+struct WatchdogArm { // around the issue of one exchange: deadline from the first exchange still outstanding
+	te_gmg     *g;
+	hipStream_t stream;
+	WatchdogArm(te_gmg *g_, hipStream_t st, int tag) : g(g_), stream(st)
+	{
+		auto &w = g->wd;
+		if (!w.th.joinable()) return;
+		std::lock_guard<std::mutex> lk(w.mu);
+		if (!w.pending) {
+			w.pending = true;
+			w.since   = std::chrono::steady_clock::now();
+		}
+		w.ev_recorded = false; // a blocking host callback is covered too: no event yet, only the deadline
+		w.tag         = tag;
+		w.level       = g->cur_level;
+	}
+	~WatchdogArm()
+	{
+		auto &w = g->wd;
+		if (!w.th.joinable()) return;
+		std::lock_guard<std::mutex> lk(w.mu);
+		w.ev_recorded = (hipEventRecord(w.ev, stream) == hipSuccess);
+	}
+};
+
 int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double *recv, hipStream_t stream = nullptr)
 {
 	if (!stream) stream = g->stream;
 	const bool timed = (stream == g->stream);
 	if (pl.empty()) return TE_OK;
+	if (g->recording) { // te_gmg_verify_schedule: who would talk to whom, in which order; nothing moves
+		for (size_t i = 0; i < pl.peers.size(); i++)
+			g->record.push_back({tag, g->cur_level, pl.peers[i], pl.send_cnt[i], pl.recv_cnt[i]});
+		return TE_OK;
+	}
+	WatchdogArm arm(g, stream, tag);
 	if (g->rccl.comm) {
 		// one RCCL group per exchange, enqueued on the solver stream behind the pack kernel: every
 		// send/recv of the exchange progresses together over the direct xGMI links, no host round trip
@@ -723,6 +842,27 @@ int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double 
 	if (rc) return te::fail(TE_ESTATE, "exchange callback failed with status " + std::to_string(rc));
 	return TE_OK;
 }
+// Sum (op 0) or maximum (op 1) over the ranks of n (<= 4) doubles that the solver stream has left in g->result;
+// returns them in g->result_host. One rank: a copy. Replaces the MPI_Allreduce of Vector.h:294,306,319.
+int finishReduce(te_gmg *g, int n, int op, bool global)
+{
+	if (global && g->nranks > 1 && g->rccl.comm) {
+		constexpr int ncclFloat64 = 8, ncclSum = 0, ncclMax = 2;
+		WatchdogArm   arm(g, g->stream, 100 + op);
+		int rc = g->rccl.AllReduce(g->result.p, g->result.p, (size_t) n, ncclFloat64, op ? ncclMax : ncclSum, g->rccl.comm, g->stream);
+		if (rc) return te::fail(TE_ESTATE, std::string("ncclAllReduce failed: ") + g->rccl.GetErrorString(rc));
+	}
+	HIPCHK(hipMemcpyAsync(g->result_host, g->result.p, n * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+	HIPCHK(hipStreamSynchronize(g->stream));
+	if (global && g->nranks > 1 && !g->rccl.comm) {
+		if (!g->allreduce)
+			return te::fail(TE_ESTATE, "a reduction over ranks needs te_gmg_use_rccl or te_gmg_set_allreduce");
+		WatchdogArm arm(g, g->stream, 100 + op);
+		int rc = g->allreduce(g->allreduce_user, g->result_host, n, op);
+		if (rc) return te::fail(TE_ESTATE, "allreduce callback failed with status " + std::to_string(rc));
+	}
+	return TE_OK;
+}
 // make every ghost plane of `u` current: remote same-level faces (pack -> exchange -> ghost slots
 // [0, nremote)), then the coarse/fine planes. Replaces SchurHelper.h:145-150 updateInterfaceDist.
 // `ps`: the iterate is u + P(ps->coarse) (never stored): the faces are packed with the correction added.
@@ -740,6 +880,7 @@ template <int N> void packFaces(te_gmg *g, LevelHost &L, const double *u, const 
 }
 template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u, const ProlongSrc *ps = nullptr)
 {
+	if (L.patch_local) return TE_OK; // the patch operator reads no neighbour
 	if (L.nremote > 0) {
 		packFaces<N>(g, L, u, ps);
 		int rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p);
@@ -770,7 +911,7 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 	// (levels with few local patches: nothing worth hiding under the exchange, and the second stream and its two
 	// events only add host calls and latency)
 	const char *omin = getenv("TE_OVERLAP_MIN"); // tests set 0 so that their small levels take the overlapped path
-	if (L.nremote == 0 || !g->overlap || L.n_int == 0 || L.P < (omin ? atoi(omin) : 128)) {
+	if (L.patch_local || g->recording || L.nremote == 0 || !g->overlap || L.n_int == 0 || L.P < (omin ? atoi(omin) : 128)) {
 		int rc = prepareGhosts<N>(g, L, u, ps);
 		if (rc) return rc;
 		launch(L.dev());
@@ -833,6 +974,7 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 // ------------------------------------------------------------------------------ 2D launches
 int prepareGhosts2d(te_gmg *g, LevelHost &L, const double *u)
 {
+	if (L.patch_local) return TE_OK;
 	if (L.nremote > 0) {
 		{
 			Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
@@ -1411,13 +1553,19 @@ template <int OP> int vecop(te_vec *v, const te_vec *a, const te_vec *b, double 
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
-template <int OP> int reduce(const te_vec *a, const te_vec *b, double *out)
+template <int OP> int reduce(const te_vec *a, const te_vec *b, double *out, bool global = false)
 {
 	if (!a || !out || (OP == RED_DOT && !sameShape(a, b))) return te::fail(TE_EINVAL, "te_vec reduce: bad argument");
 	te_gmg *g = a->g;
-	if (a->n == 0) {
+	if (a->n == 0 && !(global && g->nranks > 1)) {
 		*out = 0.0;
 		return TE_OK;
+	}
+	if (a->n == 0) { // a rank without patches still takes part in the reduction over ranks
+		HIPCHK(hipMemsetAsync(g->result.p, 0, sizeof(double), g->stream));
+		int rc0 = finishReduce(g, 1, OP == RED_MAXABS ? 1 : 0, true);
+		*out = g->result_host[0];
+		return rc0;
 	}
 	const int blocks = gridFor(a->n / 2, 256, g->red_blocks);
 	{
@@ -1427,8 +1575,8 @@ template <int OP> int reduce(const te_vec *a, const te_vec *b, double *out)
 		                   b ? reinterpret_cast<const double2 *>(b->d) : nullptr, g->partial.p);
 		hipLaunchKernelGGL(k_reduce_final<OP>, dim3(1), dim3(256), 0, g->stream, blocks, g->partial.p, g->result.p);
 	}
-	HIPCHK(hipMemcpyAsync(g->result_host, g->result.p, sizeof(double), hipMemcpyDeviceToHost, g->stream));
-	HIPCHK(hipStreamSynchronize(g->stream));
+	int rc = finishReduce(g, 1, OP == RED_MAXABS ? 1 : 0, global);
+	if (rc) return rc;
 	*out = g->result_host[0];
 	return TE_OK;
 }
@@ -1491,6 +1639,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	const bool coarsest = (l == nl - 1);
 	LevelHost &L        = *g->levels[l];
 	int        rc;
+	g->cur_level        = l;
 	auto       materialise = [&]() -> int {
         if (!u_zero) return TE_OK;
         u_zero         = false;
@@ -1562,6 +1711,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
             if ((r = vecop<VOP_SET>(C.u.get(), nullptr, nullptr, 0.0, 0.0, 0.0))) return r;
         }
         if ((r = visit(g, o, l + 1, C.f.get(), C.u.get(), o->fuse != 0))) return r;
+        g->cur_level = l;
         // prepFiner (Cycle.h:74-80). When the very next step is an RB-GS sweep on a level without ghost
         // slots, that sweep reads u + P(coarse u) on the fly instead (same bits, one HBM pass less).
         if (o->fuse && next_sweeps > 0
@@ -1637,6 +1787,8 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 	g->device = device;
 	g->dim    = h->h.dim;
 	g->n      = h->h.n;
+	g->rank   = h->h.rank;
+	g->nranks = h->h.nranks;
 	memset(g->calls, 0, sizeof(g->calls));
 	memset(g->cells, 0, sizeof(g->cells));
 	memset(g->total_ms, 0, sizeof(g->total_ms));
@@ -1671,6 +1823,7 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 void te_gmg_destroy(te_gmg *g)
 {
 	if (!g) return;
+	watchdogStop(g);
 	(void) hipStreamSynchronize(g->stream);
 	if (g->comm_stream) (void) hipStreamSynchronize(g->comm_stream);
 	for (auto &L : g->levels) {
@@ -1706,6 +1859,14 @@ int   te_gmg_set_exchange(te_gmg *g, te_exchange_fn fn, void *user)
 	}
 	g->exchange      = fn;
 	g->exchange_user = user;
+	if (fn) watchdogStart(g);
+	return TE_OK;
+}
+int te_gmg_set_allreduce(te_gmg *g, te_allreduce_fn fn, void *user)
+{
+	if (!g) return te::fail(TE_EINVAL, "te_gmg_set_allreduce: null");
+	g->allreduce      = fn;
+	g->allreduce_user = user;
 	return TE_OK;
 }
 
@@ -1739,12 +1900,16 @@ int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank,
 	r.Send           = (int (*)(const void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclSend");
 	r.Recv           = (int (*)(void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclRecv");
 	r.CommDestroy    = (int (*)(void *)) rcclSym(lib, "ncclCommDestroy");
+	r.AllReduce      = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclAllReduce");
 	r.GetErrorString = (const char *(*) (int) ) rcclSym(lib, "ncclGetErrorString");
-	if (!init || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.CommDestroy || !r.GetErrorString)
+	if (!init || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.CommDestroy || !r.GetErrorString || !r.AllReduce)
 		return te::fail(TE_EIO, "te_gmg_use_rccl: RCCL symbols missing in " + std::string(libpath));
 	int rc = init(&r.comm, nranks, id, rank);
 	if (rc) return te::fail(TE_ESTATE, std::string("ncclCommInitRank failed: ") + r.GetErrorString(rc));
+	if (nranks > 1 && (rank != g->rank || nranks != g->nranks))
+		return te::fail(TE_EINVAL, "te_gmg_use_rccl: rank / nranks differ from the hierarchy's");
 	g->rccl = r;
+	watchdogStart(g);
 	return TE_OK;
 }
 // moves n doubles from a scratch send buffer to a scratch receive buffer of level 0 through the same
@@ -1872,11 +2037,113 @@ int te_prolong_add(te_gmg *g, int fine_level, const te_vec *coarse, te_vec *fine
 		return rc;
 	return doProlong(g, fine_level, coarse->d, fine->d);
 }
+
+// Dry run of one te_vcycle with `o` on zero vectors in which every exchange is recorded instead of performed; the
+// per-pair summaries (how many messages, how many doubles, a hash of the (tag, level, count) sequence) are summed over
+// the ranks -- each entry has one contributor, the sum is exact -- and every rank checks that what r sends to q is
+// what q expects from r, in the same order. All ranks see the same matrix, so all of them fail, or none.
+static uint64_t mix64(uint64_t h, uint64_t v)
+{
+	h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+	h *= 0xBF58476D1CE4E5B9ull;
+	return h ^ (h >> 31);
+}
+static int verifySchedule(te_gmg *g, const te_cycle_opts *o)
+{
+	const int R = g->nranks;
+	if (R < 2) return TE_OK;
+	if (!g->rccl.comm && !g->allreduce)
+		return te::fail(TE_ESTATE, "te_gmg_verify_schedule: needs te_gmg_use_rccl or te_gmg_set_allreduce");
+	int     rc;
+	te_vec *f = nullptr, *u = nullptr;
+	if ((rc = newVec(g, 0, &f))) return rc;
+	if ((rc = newVec(g, 0, &u))) {
+		te_vec_destroy(f);
+		return rc;
+	}
+	const bool prof = g->profiling;
+	g->profiling    = false;
+	g->recording    = true;
+	g->record.clear();
+	for (auto &L : g->levels) L->xf_valid_for = nullptr;
+	g->in_cycle = getenv("TE_NO_XF") == nullptr;
+	rc          = visit(g, o, 0, f, u, o->fuse != 0);
+	g->in_cycle = false;
+	for (auto &L : g->levels) L->xf_valid_for = nullptr;
+	g->recording = false;
+	g->profiling = prof;
+	(void) hipStreamSynchronize(g->stream);
+	te_vec_destroy(f);
+	te_vec_destroy(u);
+	if (rc) return rc;
+	// [dir 0 = sent by row to column, 1 = expected by column from row][row][col][count, doubles, hash lo, hash hi]
+	std::vector<double>   m((size_t) 2 * R * R * 4, 0.0);
+	std::vector<uint64_t> hs((size_t) R, 0), hr((size_t) R, 0);
+	auto at = [&](int dir, int from, int to, int k) -> double & { return m[(((size_t) dir * R + from) * R + to) * 4 + k]; };
+	for (auto &e : g->record) {
+		if (e.peer < 0 || e.peer >= R) return te::fail(TE_ESTATE, "te_gmg_verify_schedule: peer out of range");
+		if (e.send_cnt > 0) {
+			at(0, g->rank, e.peer, 0) += 1;
+			at(0, g->rank, e.peer, 1) += (double) e.send_cnt;
+			hs[e.peer] = mix64(mix64(mix64(hs[e.peer], (uint64_t) e.tag), (uint64_t) e.level), (uint64_t) e.send_cnt);
+		}
+		if (e.recv_cnt > 0) {
+			at(1, e.peer, g->rank, 0) += 1;
+			at(1, e.peer, g->rank, 1) += (double) e.recv_cnt;
+			hr[e.peer] = mix64(mix64(mix64(hr[e.peer], (uint64_t) e.tag), (uint64_t) e.level), (uint64_t) e.recv_cnt);
+		}
+	}
+	for (int q = 0; q < R; q++) { // 2 x 24 bits of each hash: exact in a double
+		at(0, g->rank, q, 2) = (double) (hs[q] & 0xFFFFFF), at(0, g->rank, q, 3) = (double) ((hs[q] >> 24) & 0xFFFFFF);
+		at(1, q, g->rank, 2) = (double) (hr[q] & 0xFFFFFF), at(1, q, g->rank, 3) = (double) ((hr[q] >> 24) & 0xFFFFFF);
+	}
+	g->record.clear();
+	// sum over ranks, four doubles at a time through the same path as the solver's scalar reductions
+	for (size_t i = 0; i < m.size(); i += 4) {
+		HIPCHK(hipMemcpyAsync(g->result.p, &m[i], 4 * sizeof(double), hipMemcpyHostToDevice, g->stream));
+		if ((rc = finishReduce(g, 4, 0, true))) return rc;
+		for (int k = 0; k < 4; k++) m[i + k] = g->result_host[k];
+	}
+	for (int r = 0; r < R; r++)
+		for (int q = 0; q < R; q++)
+			for (int k = 0; k < 4; k++)
+				if (at(0, r, q, k) != at(1, r, q, k)) {
+					char buf[320];
+					snprintf(buf, sizeof buf,
+					         "te_gmg_verify_schedule: rank %d sends rank %d %.0f messages / %.0f doubles per cycle but rank %d "
+					         "expects %.0f / %.0f (or in another order): the ranks would issue different exchange sequences "
+					         "(different cycle options or hierarchies?)",
+					         r, q, at(0, r, q, 0), at(0, r, q, 1), q, at(1, r, q, 0), at(1, r, q, 1));
+					return te::fail(TE_ESTATE, buf);
+				}
+	return TE_OK;
+}
+static uint64_t optsKey(const te_cycle_opts *o)
+{
+	uint64_t h = 0;
+	for (int32_t v : {o->pre_sweeps, o->post_sweeps, o->coarse_sweeps, o->mid_sweeps, o->cycle_type, o->smoother, o->exact_coarse, o->fuse})
+		h = mix64(h, (uint64_t) (uint32_t) v);
+	return h;
+}
+int te_gmg_verify_schedule(te_gmg *g, const te_cycle_opts *o)
+{
+	if (!g || !o) return te::fail(TE_EINVAL, "te_gmg_verify_schedule: null argument");
+	int rc = verifySchedule(g, o);
+	if (rc == TE_OK) g->verified_opts.insert(optsKey(o));
+	return rc;
+}
 int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u)
 {
 	int rc;
 	if (!o) return te::fail(TE_EINVAL, "te_vcycle: null options");
 	if ((rc = checkLevelVec(g, 0, f, "te_vcycle")) || (rc = checkLevelVec(g, 0, u, "te_vcycle"))) return rc;
+	// several ranks: the first cycle with a new set of options checks that all ranks will issue matching exchange
+	// sequences (a mismatch would otherwise be a silent hang inside RCCL); TE_NO_VERIFY skips it
+	if (g->nranks > 1 && !g->recording && (g->rccl.comm || g->allreduce) && !g->verified_opts.count(optsKey(o))
+	    && !getenv("TE_NO_VERIFY")) {
+		if ((rc = verifySchedule(g, o))) return rc;
+		g->verified_opts.insert(optsKey(o));
+	}
 	if (!o->fuse && (rc = te_vec_set(u, 0.0))) return rc; // Cycle.h:118
 	for (auto &L : g->levels) L->xf_valid_for = nullptr;
 	g->in_cycle = getenv("TE_NO_XF") == nullptr;
@@ -1886,37 +2153,45 @@ int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u)
 	return rc;
 }
 
-// BiCGStab.h:45-106, statement for statement, on device vectors
+// BiCGStab.h:45-106, statement for statement, on device vectors. Several ranks: every scalar is summed over the
+// ranks (Vector.h:294,319) -- ncclAllReduce of the one or two doubles on the solver stream with the native RCCL
+// back-end, otherwise the te_gmg_set_allreduce callback -- so all ranks take the same branches.
 int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, int max_it, double tol,
                 int *iterations, double *rel_resid)
 {
 	int rc;
 	if ((rc = checkLevelVec(g, 0, x, "te_bicgstab")) || (rc = checkLevelVec(g, 0, b, "te_bicgstab"))) return rc;
+	if (g->nranks > 1 && !g->rccl.comm && !g->allreduce)
+		return te::fail(TE_ESTATE, "te_bicgstab on a sharded hierarchy needs te_gmg_use_rccl or te_gmg_set_allreduce");
 	te_vec *w[8] = {nullptr};
-	for (auto &p : w)
-		if ((rc = newVec(g, 0, &p))) return rc;
-	te_vec *resid = w[0], *ms = w[1], *mp = w[2], *rhat = w[3], *p = w[4], *ap = w[5], *as = w[6], *s = w[7];
 	auto    done = [&](int code) {
-        for (auto q : w) te_vec_destroy(q);
+        for (auto q : w)
+            if (q) te_vec_destroy(q);
         return code;
 	};
+	for (auto &p : w)
+		if ((rc = newVec(g, 0, &p))) return done(rc);
+	te_vec *resid = w[0], *ms = w[1], *mp = w[2], *rhat = w[3], *p = w[4], *ap = w[5], *as = w[6], *s = w[7];
 	double r0sq, rsq, rho, tmp, tmp2;
 #define TE_TRY(x)                \
 	if ((rc = (x))) return done(rc)
 	TE_TRY(te_apply(g, 0, x, resid));
 	TE_TRY(te_vec_scale_then_add(resid, -1, b));
-	TE_TRY(te_vec_two_norm_sq(resid, &r0sq));
+	TE_TRY(reduce<RED_SUMSQ>(resid, nullptr, &r0sq, true));
 	const double r0_norm = sqrt(r0sq);
 	TE_TRY(te_vec_copy(rhat, resid));
 	TE_TRY(te_vec_copy(p, resid));
-	TE_TRY(te_vec_dot(rhat, resid, &rho));
+	TE_TRY(reduce<RED_DOT>(rhat, resid, &rho, true));
 	int          num_its = 0;
 	const size_t n2      = x->n / 2;
 	const int    fat     = gridFor(n2, 256, 1 << 30), rb = gridFor(n2, 256, g->red_blocks / 2);
-	auto         two     = [&](double *a, double *b2) -> int { // fixed-order sum of the per-block pairs -> host
-        hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(256), 0, g->stream, rb, g->partial.p, g->result.p);
-        HIPCHK(hipMemcpyAsync(g->result_host, g->result.p, 2 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
-        HIPCHK(hipStreamSynchronize(g->stream));
+	auto         two     = [&](double *a, double *b2) -> int { // fixed-order sum of the per-block pairs -> all ranks -> host
+        if (n2 > 0)
+            hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(256), 0, g->stream, rb, g->partial.p, g->result.p);
+        else
+            HIPCHK(hipMemsetAsync(g->result.p, 0, 2 * sizeof(double), g->stream));
+        int r2 = finishReduce(g, 2, 0, true);
+        if (r2) return r2;
         *a  = g->result_host[0];
         *b2 = g->result_host[1];
         return TE_OK;
@@ -1931,7 +2206,7 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 		} else {
 			TE_TRY(te_apply(g, 0, p, ap));
 		}
-		TE_TRY(te_vec_dot(rhat, ap, &tmp));
+		TE_TRY(reduce<RED_DOT>(rhat, ap, &tmp, true));
 		const double alpha = rho / tmp;
 		if (n2 > 0) {
 			Timed t(g, KC_VECOP, x->n);
@@ -1946,25 +2221,21 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 		}
 		tmp = tmp2 = 0.0;
 		if (n2 > 0) {
-			{
-				Timed t(g, KC_REDUCE, x->n);
-				hipLaunchKernelGGL(k_bicg_omega, dim3(rb), dim3(256), 0, g->stream, n2, (const double2 *) as->d,
-				                   (const double2 *) s->d, g->partial.p);
-			}
-			TE_TRY(two(&tmp, &tmp2));
+			Timed t(g, KC_REDUCE, x->n);
+			hipLaunchKernelGGL(k_bicg_omega, dim3(rb), dim3(256), 0, g->stream, n2, (const double2 *) as->d,
+			                   (const double2 *) s->d, g->partial.p);
 		}
+		if (n2 > 0 || g->nranks > 1) TE_TRY(two(&tmp, &tmp2));
 		const double   omega = tmp / tmp2;
 		const te_vec *dp = o ? mp : p, *ds = o ? ms : s;
 		double         rho_new = 0.0;
 		if (n2 > 0) {
-			{
-				Timed t(g, KC_VECOP, x->n);
-				hipLaunchKernelGGL(k_bicg_update, dim3(rb), dim3(256), 0, g->stream, n2, (double2 *) x->d, (double2 *) resid->d,
-				                   (const double2 *) dp->d, (const double2 *) ds->d, (const double2 *) ap->d,
-				                   (const double2 *) as->d, (const double2 *) rhat->d, alpha, omega, g->partial.p);
-			}
-			TE_TRY(two(&rho_new, &rsq));
+			Timed t(g, KC_VECOP, x->n);
+			hipLaunchKernelGGL(k_bicg_update, dim3(rb), dim3(256), 0, g->stream, n2, (double2 *) x->d, (double2 *) resid->d,
+			                   (const double2 *) dp->d, (const double2 *) ds->d, (const double2 *) ap->d,
+			                   (const double2 *) as->d, (const double2 *) rhat->d, alpha, omega, g->partial.p);
 		}
+		if (n2 > 0 || g->nranks > 1) TE_TRY(two(&rho_new, &rsq));
 		const double beta = rho_new * alpha / (rho * omega);
 		if (n2 > 0) {
 			Timed t(g, KC_VECOP, x->n);
@@ -1978,6 +2249,47 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 	if (iterations) *iterations = num_its;
 	if (rel_resid) *rel_resid = sqrt(rsq) / r0_norm;
 	return done(TE_OK);
+}
+
+// StarPatchOp<D>::apply (StarPatchOp.h:204-319; twins SevenPtPatchOperator.cpp:247-409, FivePtPatchOperator.h:172-261):
+// f = A_patch u, every face with a neighbour closed as homogeneous Dirichlet (ghost = -m) -- the operator the exact
+// patch solves invert (PatchSolvers/BiCGStabSolver.h:82-85 applies it). Same kernel as te_apply with patch-local face kinds.
+int te_patch_apply(te_gmg *g, int level, const te_vec *u, te_vec *f)
+{
+	int rc;
+	if ((rc = checkLevelVec(g, level, u, "te_patch_apply")) || (rc = checkLevelVec(g, level, f, "te_patch_apply"))) return rc;
+	if (u == f) return te::fail(TE_EINVAL, "te_patch_apply: in-place apply is not supported");
+	LevelHost &L  = *g->levels[level];
+	L.patch_local = true;
+	rc            = launchStencil<MODE_APPLY>(g, L, u->d, nullptr, f->d, 0.0);
+	L.patch_local = false;
+	return rc;
+}
+// Vector<D>::getLocalData(i) for a run of patches (PetscVector.h:87-98): what Init::initDirichlet, the writers and
+// the C++ adaptor's host mirror move -- never the whole vector for one patch.
+int te_vec_upload_patches(te_vec *v, int first_patch, int npatches, const double *host)
+{
+	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_upload_patches: null");
+	const size_t nc = v->g->levels[v->level]->nc;
+	if (first_patch < 0 || npatches < 0 || ((size_t) first_patch + npatches) * nc > v->n)
+		return te::fail(TE_EINVAL, "te_vec_upload_patches: patch range outside the vector");
+	if (npatches == 0) return TE_OK;
+	LevelHost &L = *v->g->levels[v->level];
+	if (L.xf_valid_for == v->d) L.xf_valid_for = nullptr;
+	HIPCHK(hipMemcpyAsync(v->d + (size_t) first_patch * nc, host, sizeof(double) * nc * npatches, hipMemcpyHostToDevice, v->g->stream));
+	HIPCHK(hipStreamSynchronize(v->g->stream));
+	return TE_OK;
+}
+int te_vec_download_patches(const te_vec *v, int first_patch, int npatches, double *host)
+{
+	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_download_patches: null");
+	const size_t nc = v->g->levels[v->level]->nc;
+	if (first_patch < 0 || npatches < 0 || ((size_t) first_patch + npatches) * nc > v->n)
+		return te::fail(TE_EINVAL, "te_vec_download_patches: patch range outside the vector");
+	if (npatches == 0) return TE_OK;
+	HIPCHK(hipMemcpyAsync(host, v->d + (size_t) first_patch * nc, sizeof(double) * nc * npatches, hipMemcpyDeviceToHost, v->g->stream));
+	HIPCHK(hipStreamSynchronize(v->g->stream));
+	return TE_OK;
 }
 
 int te_gmg_profile(te_gmg *g, int enable)

@@ -1,6 +1,7 @@
 // See mesh.hpp for the reference map. No HIP in this file: it is plain host C++ and is
 // exercised by the CPU test-suite through the C ABI (te_mesh_* / te_hier_* in capi.cpp).
 #include "mesh.hpp"
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -311,6 +312,21 @@ Hierarchy Hierarchy::build(const Tree &t, int n, bool neumann, int max_levels,
 			}
 			for (int p = 0; p < coarse.P_global; p++) {
 				if (!assigned[p]) throw std::runtime_error("te::Hierarchy: coarse patch without child");
+			}
+		}
+		// Agglomeration (the patches_per_proc idea of CycleFactory3d.cpp:104, without cutting the hierarchy short): a
+		// level with fewer than `agg` patches per rank, and every level below it, lives on rank 0. Those levels cost
+		// microseconds of compute but one latency-bound neighbour exchange per stencil operation when spread out; gathered,
+		// the cycle pays one block transfer down and one up (the inter-level blocks that exist anyway) and no exchange at
+		// all below. A global fact (patch counts, rank count, TE_AGGLOMERATE): the same on every rank.
+		if (nranks > 1) {
+			const char  *e   = getenv("TE_AGGLOMERATE");
+			const double agg = e ? atof(e) : 16.0;
+			bool         gathered = false;
+			for (size_t li = 1; li < h.levels.size(); li++) {
+				Level &lv = h.levels[li];
+				if (!gathered && lv.P_global < agg * nranks) gathered = true;
+				if (gathered) std::fill(lv.g_rank.begin(), lv.g_rank.end(), 0);
 			}
 		}
 		for (auto &lv : h.levels) {

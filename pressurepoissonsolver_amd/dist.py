@@ -79,7 +79,9 @@ def attach(gmg, dist):
 
     def cb(user, tag, send_ptr, recv_ptr, npeers, peers, soff, scnt, roff, rcnt, stream):
         try:
-            key = (tag, send_ptr, recv_ptr, npeers)
+            # the library issues the same exchange on two streams (overlapped on its communication stream, or in
+            # line on the solver stream): the stream is part of the key, an entry never serves another stream
+            key = (tag, send_ptr, recv_ptr, npeers, int(stream or 0))
             ent = cache.get(key)
             if ent is None:
                 ent = cache[key] = build(send_ptr, recv_ptr, npeers, peers, soff, scnt, roff, rcnt, stream)
@@ -107,6 +109,8 @@ def attach(gmg, dist):
 
     gmg._cb = capi.EXCHANGE_FN(cb)
     capi.check(capi.lib().te_gmg_set_exchange(gmg.h, gmg._cb, None))
+    # scalar reductions of te_bicgstab / te_gmg_verify_schedule (Vector.h:294,306,319 MPI_Allreduce)
+    gmg.set_allreduce(lambda vals, op: allreduce(dist, vals, op))
 
 
 def rccl_library():
@@ -190,18 +194,20 @@ class LocalFabric:
 
         gmg._cb = capi.EXCHANGE_FN(cb)
         capi.check(capi.lib().te_gmg_set_exchange(gmg.h, gmg._cb, None))
+        gmg.set_allreduce(self.allreduce(rank))
 
     def allreduce(self, rank):
-        """Deterministic sum over the virtual ranks (rank order), for solver.bicgstab."""
+        """Deterministic sum / max over the virtual ranks (rank order): red(values, op=0) -> list."""
         fab = self
         if not hasattr(fab, "_red"):
             fab._red = [None] * fab.n
 
-        def red(values):
+        def red(values, op=0):
             fab._red[rank] = list(values)
-            fab.barrier.wait()
-            out = [sum(fab._red[r][i] for r in range(fab.n)) for i in range(len(values))]
-            fab.barrier.wait()
+            fab.barrier.wait(timeout=fab.timeout)
+            f = max if op else sum
+            out = [f(fab._red[r][i] for r in range(fab.n)) for i in range(len(values))]
+            fab.barrier.wait(timeout=fab.timeout)
             return out
 
         return red
@@ -227,12 +233,16 @@ class LocalFabric:
         return out
 
 
-def allreduce_sum(dist, values):
-    """sum of a few host scalars over ranks (norms / dots: Vector.h:294,306,319)."""
+def allreduce(dist, values, op=0):
+    """sum (op 0) or max (op 1) of a few host scalars over ranks (norms / dots: Vector.h:294,306,319)."""
     if dist is None:
         return list(values)
     import torch
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor(list(values), dtype=torch.float64, device=dev)
-    dist.all_reduce(t)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM)
     return t.tolist()
+
+
+def allreduce_sum(dist, values):
+    return allreduce(dist, values, 0)

@@ -1,13 +1,22 @@
-"""Host mirror of BiCGStab<D>::solve (src/Thunderegg/BiCGStab.h:45-106) for multi-rank runs.
+"""BiCGStab<D>::solve (src/Thunderegg/BiCGStab.h:45-106) for multi-rank runs.
 
-Single-rank callers use the native te_bicgstab. Across ranks the five scalars of an iteration
-(Vector.h:294,319 MPI_Allreduce) are summed by `allreduce` (torch.distributed / LocalFabric);
-every vector operation is a native te_vec_* kernel.
+`bicgstab` is the native te_bicgstab: on a sharded hierarchy the scalars of an iteration are summed over the
+ranks (Vector.h:294,319 MPI_Allreduce) by the library's own RCCL communicator or by the registered all-reduce
+callback (dist.attach / LocalFabric.attach register one), 1 + 2 + 2 doubles per iteration, no Python in the loop.
+`bicgstab_host` is the statement-by-statement host mirror over te_vec_* calls (one reduction per scalar): the
+independent second statement the tests compare the native solver with.
 """
 import math
 
 
 def bicgstab(gmg, x, b, opts=None, max_it=1000, tol=1e-12, allreduce=None):
+    """Returns (iterations, final relative residual); `allreduce(values, op)` replaces the registered callback."""
+    if allreduce is not None:
+        gmg.set_allreduce(lambda vals, op: allreduce(vals) if op == 0 else allreduce(vals, op))
+    return gmg.bicgstab(x, b, opts, max_it=max_it, tol=tol)
+
+
+def bicgstab_host(gmg, x, b, opts=None, max_it=1000, tol=1e-12, allreduce=None):
     """Returns (iterations, final relative residual). `opts` = GMG cycle options used as the right
     preconditioner Mr (None: unpreconditioned). Statement order follows BiCGStab.h."""
     red = (lambda v: list(v)) if allreduce is None else allreduce

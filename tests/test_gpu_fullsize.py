@@ -1,6 +1,6 @@
-"""-m gpu: BASELINE.json's full sizes (C2: 256^3 = 512 patches of 32^3; C3: 512^3 = 4096 patches), where the
-CPU oracle is too slow to be the checker: size-independent properties of the operators, evaluated on the
-device through the C ABI.
+"""-m gpu: BASELINE.json's full sizes (C2: 256^3 = 512 patches of 32^3; C3: 512^3 = 4096 patches): size-independent
+properties of the operators, evaluated on the device through the C ABI. (The comparison with the CPU oracle at these
+sizes, on the default fused path, is tests/test_gpu_direct_parity.py.)
 
   linearity          A(a u + b v) = a A u + b A v                      (backward-error tolerance)
   symmetry           <A u, v> = <u, A v>   (uniform mesh, Dirichlet: the assembled operator is symmetric)

@@ -50,6 +50,9 @@ def test_sharded_ops_equal_single_rank(nranks, name, divides, n, dim, monkeypatc
     # exercise it (the 8-rank run keeps the default, i.e. covers the non-overlapped path too)
     if nranks != 8:
         monkeypatch.setenv("TE_OVERLAP_MIN", "0")
+    # coarse levels with few patches per rank are gathered on rank 0 by default (TE_AGGLOMERATE = 16 per rank); the
+    # 4-rank runs keep every level spread out, so both placements are compared with the single-rank result
+    monkeypatch.setenv("TE_AGGLOMERATE", "0" if nranks == 4 else "16")
     mesh = util.mesh(name, divides, dim)
     H1 = capi.Hierarchy(mesh, n)
     g1 = capi.GMG(H1)
@@ -95,6 +98,9 @@ def test_sharded_ops_equal_single_rank(nranks, name, divides, n, dim, monkeypatc
 
 @pytest.mark.parametrize("nranks", [2, 8])
 def test_sharded_bicgstab(nranks):
+    """te_bicgstab on a sharded hierarchy (scalars summed over the ranks through the registered all-reduce, all ranks
+    take the same branches) against the single-rank solve and against the statement-by-statement host mirror
+    solver.bicgstab_host (one reduction per scalar, the reference's call pattern BiCGStab.h:71-97)."""
     n = 8
     mesh = util.mesh("uniform", 2)
     H1 = capi.Hierarchy(mesh, n)
@@ -109,22 +115,85 @@ def test_sharded_bicgstab(nranks):
         idx = H.l2g(0)
         b = g.new_vector(0, f.reshape(-1, nc)[idx].ravel())
         x = g.new_vector(0)
-        its, rr = solver.bicgstab(g, x, b, g.default_opts(smoother=capi.SMOOTH_RBGS), allreduce=fab.allreduce(r))
-        return {"x": x.download(), "its": its, "rr": rr}
+        its, rr = solver.bicgstab(g, x, b, g.default_opts(smoother=capi.SMOOTH_RBGS))  # native, all-reduce of fab.attach
+        xh = g.new_vector(0)
+        itsh, rrh = solver.bicgstab_host(g, xh, b, g.default_opts(smoother=capi.SMOOTH_RBGS), allreduce=fab.allreduce(r))
+        return {"x": x.download(), "its": its, "rr": rr, "xh": xh.download(), "itsh": itsh, "rrh": rrh}
 
     got = shard_run(mesh, n, nranks, per_rank)
+    assert len(set(got["its"])) == 1 and len(set(got["rr"])) == 1  # every rank saw the same scalars
     assert all(abs(i - its1) <= 1 for i in got["its"]) and max(got["rr"]) <= 1e-12
     assert np.linalg.norm(got["x"] - want) <= 1e-9 * np.linalg.norm(want)
+    assert all(abs(i - j) <= 1 for i, j in zip(got["its"], got["itsh"])) and max(got["rrh"]) <= 1e-12
+    assert np.linalg.norm(got["x"] - got["xh"]) <= 1e-9 * np.linalg.norm(want)
 
 
-def test_two_processes_gloo():
-    """Real processes + torch.distributed (gloo staging through host) on the single GPU."""
+def test_schedule_check_catches_diverging_ranks():
+    """A rank that would issue a different exchange sequence (here: rank 1 is handed two pre-sweeps) is an error on
+    EVERY rank before anything is exchanged (te_gmg_verify_schedule, run by the first te_vcycle with new options)
+    instead of a hang in the middle of the cycle."""
+    n, nranks = 8, 2
+    mesh = util.mesh("uniform", 2)
+    fab = tedist.LocalFabric(nranks)
+    fab.timeout = 30.0
+    hs = [capi.Hierarchy(mesh, n, rank=r, nranks=nranks) for r in range(nranks)]
+    gs = [capi.GMG(h) for h in hs]
+    for r, g in enumerate(gs):
+        fab.attach(g, r)
+
+    def body(r):
+        g = gs[r]
+        f, u = g.new_vector(0), g.new_vector(0)
+        f.set(1.0)
+        good = g.default_opts(smoother=capi.SMOOTH_RBGS)
+        g.verify_schedule(good)  # matching options: passes
+        g.cycle(good, f, u)
+        bad = g.default_opts(smoother=capi.SMOOTH_RBGS, pre_sweeps=2 if r == 1 else 1)
+        try:
+            g.cycle(bad, f, u)
+        except capi.TeError as e:
+            return (e.code, str(e))
+        return (0, "")
+
+    out = fab.run(body)
+    assert all(code == capi.TE_ESTATE for code, _ in out), out
+    assert all("different exchange sequences" in msg for _, msg in out)
+
+
+def test_watchdog_ends_a_rank_whose_peer_never_answers():
+    """Two processes; rank 1 never calls the cycle. Rank 0's first exchange cannot complete: its watchdog thread must
+    end the process with status 86 within TE_EXCHANGE_TIMEOUT instead of hanging (the launcher then takes the job down)."""
+    import socket
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, TE_EXCHANGE_TIMEOUT="5", TE_NO_VERIFY="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.join(root, "tests", "mr_worker.py"), "--backend", "gloo",
+           "--hang-rank", "1"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "te_hip watchdog" in r.stderr and "MR_WORKER_OK" not in r.stdout, r.stderr[-3000:]
+    assert time.time() - t0 < 120
+
+
+@pytest.mark.parametrize("overlap_min", ["0", None], ids=["overlapped", "default"])
+def test_two_processes_gloo(overlap_min):
+    """Real processes + torch.distributed (gloo staging through host) on the single GPU: one attached callback
+    serves the level-0 face exchange on the communication stream (overlapped apply, TE_OVERLAP_MIN=0) and on the
+    solver stream (fused cycle) in the sequence apply, cycle, BiCGStab, apply; results equal the single-rank run."""
     import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = str(s.getsockname()[1])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.pop("TE_OVERLAP_MIN", None)
+    if overlap_min is not None:
+        env["TE_OVERLAP_MIN"] = overlap_min
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", port, os.path.join(root, "tests", "mr_worker.py"), "--backend", "gloo"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

@@ -105,22 +105,31 @@ def test_parent_links(name, dim, div):
                 assert np.allclose(2 * f["lengths"][p], c["lengths"][par])
 
 
+@pytest.mark.parametrize("agg", [0, 16])
 @pytest.mark.parametrize("nranks", [2, 4, 8])
-def test_morton_partition(nranks):
+def test_morton_partition(nranks, agg, monkeypatch):
+    """agg = patches per rank below which a level (and every coarser one) is gathered on rank 0
+    (TE_AGGLOMERATE, default 16; SURVEY 8(e), CycleFactory3d.cpp:104 semantics); 0 = never."""
+    monkeypatch.setenv("TE_AGGLOMERATE", str(agg))
     m = util.mesh("uniform", 3)  # 8^3 patches
     hs = [capi.Hierarchy(m, 4, rank=r, nranks=nranks) for r in range(nranks)]
+    gathered = False
     for lvl in range(hs[0].num_levels):
         t = hs[0].tables(lvl)
         P = len(t["id"])
         counts = np.bincount(t["rank"], minlength=nranks)
-        if P >= nranks:
+        gathered = gathered or (lvl > 0 and P < agg * nranks)
+        if gathered:
+            assert counts[0] == P  # the whole level on rank 0
+        elif P >= nranks:
             assert counts.max() - counts.min() <= 0, (lvl, counts)  # uniform tree: perfectly balanced
         owned = np.concatenate([h.l2g(lvl) for h in hs])
         assert sorted(owned) == list(range(P))  # every patch owned exactly once
         for r, h in enumerate(hs):
             assert np.all(t["rank"][h.l2g(lvl)] == r)
             assert np.array_equal(t["local"][h.l2g(lvl)], np.arange(len(h.l2g(lvl))))
-        if lvl + 1 < hs[0].num_levels:  # a coarse patch lives where its orthant-0 child lives
+        nxt = lvl + 1 < hs[0].num_levels and not (gathered or len(hs[0].tables(lvl + 1)["id"]) < agg * nranks)
+        if nxt:  # a coarse patch lives where its orthant-0 child lives (above the gathered levels)
             c = hs[0].tables(lvl + 1)
             for p in range(P):
                 if t["orth_on_parent"][p] <= 0:
