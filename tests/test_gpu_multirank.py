@@ -130,8 +130,8 @@ def test_sharded_bicgstab(nranks):
 
 def test_schedule_check_catches_diverging_ranks():
     """A rank that would issue a different exchange sequence (here: rank 1 is handed two pre-sweeps) is an error on
-    EVERY rank before anything is exchanged (te_gmg_verify_schedule, run by the first te_vcycle with new options)
-    instead of a hang in the middle of the cycle."""
+    EVERY rank before anything is exchanged (te_gmg_verify_schedule: a collective the host calls at setup, and
+    that the first te_vcycle with new options runs by itself) instead of a hang in the middle of the cycle."""
     n, nranks = 8, 2
     mesh = util.mesh("uniform", 2)
     fab = tedist.LocalFabric(nranks)
@@ -146,11 +146,11 @@ def test_schedule_check_catches_diverging_ranks():
         f, u = g.new_vector(0), g.new_vector(0)
         f.set(1.0)
         good = g.default_opts(smoother=capi.SMOOTH_RBGS)
-        g.verify_schedule(good)  # matching options: passes
-        g.cycle(good, f, u)
+        g.cycle(good, f, u)  # new options: checked by te_vcycle itself, passes
+        g.verify_schedule(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE, cycle_type=1))  # explicit: passes
         bad = g.default_opts(smoother=capi.SMOOTH_RBGS, pre_sweeps=2 if r == 1 else 1)
         try:
-            g.cycle(bad, f, u)
+            g.verify_schedule(bad)
         except capi.TeError as e:
             return (e.code, str(e))
         return (0, "")
