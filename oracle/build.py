@@ -3,6 +3,8 @@
   oracle/libte_oracle.so     g++: CPU restatement of the reference algorithm (te_oracle.cpp)
   oracle/_ref/libte_ref.so   g++ over /root/reference sources (Makefile.ref), only when that tree
                              is present (never on the GPU box, which uses the prebuilt file)
+  oracle/_ref/dropin_run     the reference's BiCGStab<3> + Vector<3> over the product's C++ adaptors, linked
+                             against libte_hip.so (tests/dropin_run.cpp), same condition
 """
 import os
 import subprocess
@@ -49,5 +51,37 @@ def build_ref(force=False):
     return LIB_REF
 
 
+def build_dropin(force=False):
+    """tests/dropin_run.cpp: the reference's own BiCGStab<3> (BiCGStab.h) and Vector<3> (Vector.cpp), compiled from where
+    they lie, over the product's C++ adaptors and linked against libte_hip.so -> oracle/_ref/dropin_run (git-ignored,
+    travels with the snapshot; run by tests/test_gpu_dropin.py on the GPU box). Only where the reference tree is."""
+    root = os.path.dirname(ORACLE_DIR)
+    out = os.path.join(ORACLE_DIR, "_ref", "dropin_run")
+    src = os.path.join(REF_ROOT, "src")
+    if not os.path.isdir(os.path.join(src, "Thunderegg")):
+        return out if os.path.exists(out) else None
+    hip = os.path.join(root, "pressurepoissonsolver_amd", "libte_hip.so")
+    adapt = os.path.join(root, "pressurepoissonsolver_amd", "thunderegg")
+    deps = [os.path.join(root, "tests", "dropin_run.cpp"), os.path.join(adapt, "HipGMG.h"), os.path.join(adapt, "HipInit.h"),
+            os.path.join(root, "include", "te_hip.h"), hip]
+    if not os.path.exists(hip):
+        return None
+    if not force and not _newer(out, deps):
+        return out
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    mpi = os.environ.get("MPI_PREFIX", "/opt/conda")
+    try:
+        # (libraries by path: -L<conda>/lib would put conda's older libstdc++ in front of the system's)
+        _run(["g++", "-std=c++11", "-O1", "-w", "-I" + src, "-I" + os.path.join(mpi, "include"),
+              "-I" + os.path.join(root, "include"), "-I" + adapt, deps[0], os.path.join(src, "Thunderegg", "Vector.cpp"),
+              hip, os.path.join(mpi, "lib", "libmpi.so"), "-Wl,-rpath,/usr/lib/x86_64-linux-gnu",
+              "-Wl,-rpath,$ORIGIN/../../pressurepoissonsolver_amd", "-Wl,-rpath,/opt/rocm/lib",
+              "-Wl,-rpath," + os.path.join(mpi, "lib"), "-Wl,-rpath-link,/opt/rocm/lib", "-o", out])
+    except subprocess.CalledProcessError as e:  # optional tooling
+        print("warning: drop-in program build failed:", e, file=sys.stderr)
+        return None
+    return out
+
+
 if __name__ == "__main__":
-    print(build_oracle("--force" in sys.argv), build_ref("--force" in sys.argv))
+    print(build_oracle("--force" in sys.argv), build_ref("--force" in sys.argv), build_dropin("--force" in sys.argv))

@@ -38,7 +38,7 @@ def build_hip(force=False):
     if not force and not _newer(LIB_HIP, deps):
         return LIB_HIP
     _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-          "-Wno-unused-result", "-x", "hip", srcs[0], "-x", "hip", srcs[1], "-x", "hip", srcs[2],
+          "-Wno-unused-result", "-Wl,-soname,libte_hip.so", "-x", "hip", srcs[0], "-x", "hip", srcs[1], "-x", "hip", srcs[2],
           "-o", LIB_HIP])
     return LIB_HIP
 

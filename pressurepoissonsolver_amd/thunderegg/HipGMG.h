@@ -22,6 +22,7 @@
 #include <Thunderegg/GMG/Smoother.h>
 #include <Thunderegg/Operators/Operator.h>
 #include <Thunderegg/Vector.h>
+#include <map>
 #include <memory>
 #include <te_hip.h>
 #include <vector>
@@ -48,36 +49,79 @@ struct Context {
 	Context &operator=(const Context &) = delete;
 };
 
-/// Host mirror that getLocalData() hands out: downloaded on construction, uploaded back on
-/// destruction when obtained through the non-const overload (the role PetscLDM plays for
-/// PetscVector, PetscVector.h:27-58). Slow path, used only by the drivers' Init / writers.
+/// Host side of getLocalData(): ONE mirror per vector, shared by all the views handed out, holding only the patches
+/// that are currently viewed. The first view of a patch downloads that patch (te_vec_download_patches: n^D doubles,
+/// not the vector); further views of the same patch alias the same host memory, as every VecGetArray of a
+/// PetscVector aliases the same storage (PetscVector.h:27-58), so concurrent views cannot lose each other's
+/// updates; when the last view of a patch goes away and any of them was writable the patch is uploaded back.
+struct HipMirror {
+	te_vec *v;
+	size_t  cells; // per patch
+	struct Slot {
+		std::vector<double> host;
+		int                 views = 0;
+		bool                dirty = false;
+	};
+	std::map<int, Slot> slots;
+	int                 failed = 0; // status of the last failed write-back (a destructor cannot throw)
+	HipMirror(te_vec *v_, size_t cells_) : v(v_), cells(cells_) {}
+	double *acquire(int patch, bool writable)
+	{
+		Slot &s = slots[patch];
+		if (s.views == 0) {
+			s.host.resize(cells);
+			check(te_vec_download_patches(v, patch, 1, s.host.data()));
+		}
+		s.views++;
+		s.dirty |= writable;
+		return s.host.data();
+	}
+	void release(int patch)
+	{
+		auto it = slots.find(patch);
+		if (it == slots.end() || --it->second.views > 0) return;
+		if (it->second.dirty) {
+			int rc = te_vec_upload_patches(v, patch, 1, it->second.host.data());
+			if (rc != TE_OK) failed = rc;
+		}
+		slots.erase(it);
+	}
+};
+/// The manager a LocalData carries: releases its patch when the last copy of the view is gone (the role PetscLDM
+/// plays for PetscVector).
 class HipLDM : public LocalDataManager
 {
+	std::shared_ptr<HipMirror> mirror;
+	int                        patch;
+
 	public:
-	te_vec             *v;
-	std::vector<double> host;
-	bool                writeback;
-	HipLDM(te_vec *v_, bool wb) : v(v_), host(te_vec_size(v_)), writeback(wb) { check(te_vec_download(v, host.data())); }
-	~HipLDM()
-	{
-		if (writeback) te_vec_upload(v, host.data());
-	}
+	double *data;
+	HipLDM(std::shared_ptr<HipMirror> m, int patch_, bool writable) : mirror(m), patch(patch_), data(m->acquire(patch_, writable)) {}
+	~HipLDM() { mirror->release(patch); }
 };
 
 template <size_t D> class HipVector : public Vector<D>
 {
 	public:
-	std::shared_ptr<Context> ctx;
-	te_vec                  *v = nullptr;
-	int                      level;
+	std::shared_ptr<Context>   ctx;
+	te_vec                    *v = nullptr;
+	int                        level;
+	std::shared_ptr<HipMirror> mirror;
 	HipVector(std::shared_ptr<Context> ctx_, int level_) : ctx(ctx_), level(level_)
 	{
 		check(te_vec_create(ctx->g, level, &v));
 		size_t cells = 1;
 		for (size_t i = 0; i < D; i++) cells *= ctx->n;
 		this->num_local_patches = (int) (te_vec_size(v) / cells);
+		mirror.reset(new HipMirror(v, cells));
 	}
-	~HipVector() { te_vec_destroy(v); }
+	~HipVector()
+	{
+		mirror->v = nullptr; // (no view can outlive the vector: LocalData is used inside patch loops)
+		te_vec_destroy(v);
+	}
+	/// status of the last failed write-back of a released view, TE_OK if none (a destructor cannot throw)
+	int writeBackStatus() const { return mirror->failed; }
 	static const te_vec *raw(std::shared_ptr<const Vector<D>> b)
 	{
 		auto p = std::dynamic_pointer_cast<const HipVector<D>>(b);
@@ -86,7 +130,8 @@ template <size_t D> class HipVector : public Vector<D>
 	}
 	LocalData<D> view(int patch, bool wb) const
 	{
-		std::shared_ptr<HipLDM> ldm(new HipLDM(v, wb));
+		if (patch < 0 || patch >= this->num_local_patches) throw 3;
+		std::shared_ptr<HipLDM> ldm(new HipLDM(mirror, patch, wb));
 		std::array<int, D>      lengths, strides;
 		int                     s = 1;
 		for (size_t i = 0; i < D; i++) {
@@ -94,7 +139,7 @@ template <size_t D> class HipVector : public Vector<D>
 			strides[i] = s;
 			s *= ctx->n;
 		}
-		return LocalData<D>(ldm->host.data() + (size_t) patch * s, strides, lengths, ldm);
+		return LocalData<D>(ldm->data, strides, lengths, ldm);
 	}
 	LocalData<D>       getLocalData(int p) override { return view(p, true); }
 	const LocalData<D> getLocalData(int p) const override { return view(p, false); }

@@ -20,4 +20,5 @@ def _built():
     build.build_hip()
     obuild.build_oracle()
     obuild.build_ref()
+    obuild.build_dropin()
     yield

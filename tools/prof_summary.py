@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Summarises the rocprofv3 runs of tools/profile_round.sh into small CSVs for profiles/ (each stamped with the
+commit it measured): kernel-trace stats, SQ counters (two passes of 8), FETCH_SIZE / WRITE_SIZE (separate passes;
+FETCH_SIZE doubled for 16-B/lane reads as MI355X_MICROARCH.md prescribes for gfx950).
+
+usage: prof_summary.py <run dir> <out prefix> <commit> <label>
+"""
+import collections
+import csv
+import glob
+import os
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    return name.replace("te::", "")
+
+
+def counters(d):
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            a = agg[short(r["Kernel_Name"])][r["Counter_Name"]]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    return agg
+
+
+def main():
+    run, out, commit, label = sys.argv[1:5]
+    head = f"# commit {commit}; {label}\n"
+    # 1. kernel stats
+    st = glob.glob(os.path.join(run, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        rows = list(csv.reader(open(st[0])))
+        with open(out + "_kernel_stats.csv", "w") as f:
+            f.write(head)
+            w = csv.writer(f)
+            w.writerow(rows[0])
+            for r in rows[1:]:
+                if float(r[4]) >= 0.05:
+                    r[0] = short(r[0])
+                    w.writerow(r)
+    # 2. SQ counters
+    sq = counters(os.path.join(run, "sq1"))
+    for k, v in counters(os.path.join(run, "sq2")).items():
+        sq[k].update(v)
+    if sq:
+        names = sorted({c for v in sq.values() for c in v})
+        with open(out + "_pmc_sq.csv", "w") as f:
+            f.write(head)
+            f.write("# per-launch means; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (MI355X_MICROARCH.md, PMC slots)\n")
+            w = csv.writer(f)
+            w.writerow(["kernel", "launches"] + names + ["wait_any_frac", "wait_inst_frac", "active_frac", "lds_conflict_frac"])
+            for k, v in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", [0, 1])[0]):
+                if not k.startswith("k_"):
+                    continue
+                m = {c: v[c][0] / max(v[c][1], 1) for c in v}
+                wc = m.get("SQ_WAVE_CYCLES", 0) or 1
+                lds = m.get("SQ_LDS_IDX_ACTIVE", 0) or 1
+                w.writerow([k, max(x[1] for x in v.values())] + [f"{m.get(c, 0):.0f}" for c in names]
+                           + [f"{m.get('SQ_WAIT_ANY', 0) / wc:.3f}", f"{m.get('SQ_WAIT_INST_ANY', 0) / wc:.3f}",
+                              f"{m.get('SQ_ACTIVE_INST_ANY', 0) / wc:.3f}", f"{m.get('SQ_LDS_BANK_CONFLICT', 0) / lds:.3f}"])
+    # 3. traffic
+    fe, wr = counters(os.path.join(run, "fetch")), counters(os.path.join(run, "write"))
+    if fe or wr:
+        with open(out + "_pmc_fetch_write.csv", "w") as f:
+            f.write(head)
+            f.write("# per-launch means in bytes: read = 2 x FETCH_SIZE KiB x 1024 (gfx950: wide reads are tallied at half), write = WRITE_SIZE KiB x 1024\n")
+            w = csv.writer(f)
+            w.writerow(["kernel", "launches", "read_bytes", "write_bytes", "total_bytes"])
+            for k in sorted(set(fe) | set(wr)):
+                if not k.startswith("k_"):
+                    continue
+                a, b = fe.get(k, {}).get("FETCH_SIZE", [0, 1]), wr.get(k, {}).get("WRITE_SIZE", [0, 1])
+                rb, wb = 2048.0 * a[0] / max(a[1], 1), 1024.0 * b[0] / max(b[1], 1)
+                w.writerow([k, max(a[1], b[1]), f"{rb:.0f}", f"{wb:.0f}", f"{rb + wb:.0f}"])
+
+
+if __name__ == "__main__":
+    main()
