@@ -163,6 +163,7 @@ struct LevelHost {
 		L.xf_out    = nullptr;
 		L.f6        = nullptr;
 		L.f6_out    = nullptr;
+		L.fcorr     = nullptr;
 		return L;
 	}
 	// compact x-face columns of the level's current iterate inside te_vcycle (ping-pong with the sweeps'
@@ -170,6 +171,11 @@ struct LevelHost {
 	DevBuf<double> cellvol;          // [P] product of the spacings (te_integrate)
 	std::vector<double> patch_vol;   // [P] product of the patch lengths (te_volume)
 	DevBuf<double> f6buf;            // [P][6][n^2]: the six face layers of an iterate that is never stored (opts.fuse = 3)
+	// [P][12][n^2]: ghost terms of this level's right-hand side that the finer level's pre-sweep exported instead of
+	// adding them in a fix-up pass (march3d.hpp FCorrSrc); f_has_corr: they belong to the current L.f (inside te_vcycle)
+	DevBuf<double> fcorr;
+	bool           f_has_corr = false;
+	DevBuf<double> rs6; // [P][6][(n/2)^2]: the 2x2 sums of the face layers, as the producer of the next level's fcorr
 	const double  *pack_f6 = nullptr; // set while that iterate is the one whose faces travel to other ranks
 	DevBuf<double> xfbuf[2];
 	int            xf_cur       = 0;
@@ -528,6 +534,11 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	if (D == 3 && ((rc = L->xfbuf[0].alloc((size_t) std::max(P, 1) * 2 * L->nf)) || (rc = L->xfbuf[1].alloc((size_t) std::max(P, 1) * 2 * L->nf))
 	               || (rc = L->f6buf.alloc((size_t) std::max(P, 1) * 6 * L->nf))))
 		return rc;
+	if (D == 3 && li > 0 && L->fuse2_ok && P > 0) { // a level that can read its right-hand side with FCORR
+		if ((rc = L->fcorr.alloc((size_t) P * 12 * L->nf))) return rc;
+		HIPCHK(hipMemset(L->fcorr.p, 0, sizeof(double) * L->fcorr.n));
+	}
+	if (D == 3 && L->fuse2_ok && P > 0 && (rc = L->rs6.alloc((size_t) P * 6 * L->nf / 4))) return rc;
 	if ((rc = L->cellvol.upload(cellvol))) return rc;
 	{
 		std::vector<int32_t> fkp(fk);
@@ -1179,14 +1190,16 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 // k_rbgs_zero_resid3d / k_restrict_fixup3d). out = S(0, f) with its x faces in xf_out, coarse = AvgRstr(f - A out).
 // store_u = false (opts.fuse = 3): the new iterate is left in L.f6buf as its six face layers only
 template <int N>
-int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out, bool store_u)
+int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out, bool store_u,
+                    double *fcorr_out, const double *fcorr_in)
 {
-	RestrictDst rd;
+	RestrictDst rd = RestrictDst();
 	rd.parent     = L.parent.p;
 	rd.orth       = L.orth.p;
 	rd.coarse     = coarse;
 	rd.remote     = L.upbuf.p;
 	rd.remote_off = L.up_off.p;
+	rd.rs6        = fcorr_out ? L.rs6.p : nullptr;
 	int rc;
 	if (L.P > 0) {
 		Timed      t(g, store_u ? KC_ZERO_RESID : KC_ZERO_RESID_FACES, (size_t) L.P * L.nc);
@@ -1197,7 +1210,15 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 			hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, true>), grid, blk, 0, g->stream, D, f, out, rd);
 		} else {
 			D.f6_out = L.f6buf.p;
-			hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false>), grid, blk, 0, g->stream, D, f, out, rd);
+			D.fcorr  = fcorr_in;
+			if (fcorr_out && fcorr_in)
+				hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false, true, true>), grid, blk, 0, g->stream, D, f, out, rd);
+			else if (fcorr_out)
+				hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false, true, false>), grid, blk, 0, g->stream, D, f, out, rd);
+			else if (fcorr_in)
+				hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false, false, true>), grid, blk, 0, g->stream, D, f, out, rd);
+			else
+				hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false, false, false>), grid, blk, 0, g->stream, D, f, out, rd);
 		}
 	}
 	// the new face layers of neighbours on other ranks (no-op on one rank)
@@ -1205,7 +1226,13 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	rc        = prepareGhosts<N>(g, L, out);
 	L.pack_f6 = nullptr;
 	if (rc) return rc;
-	if (L.P > 0) {
+	if (fcorr_out) { // the ghost terms were formed by the patches that own the face values: sort them into the coarse
+		// level's side array (a permutation copy of 6/128 of a vector instead of the fix-up pass)
+		if (L.Pc > 0) {
+			Timed t(g, KC_FIXUP, (size_t) L.P * 6 * L.nf / 4);
+			hipLaunchKernelGGL(k_fcorr_gather3d<N>, dim3(L.Pc * 12), dim3(256), 0, g->stream, L.dev(), L.child.p, L.rs6.p, fcorr_out);
+		}
+	} else if (L.P > 0) {
 		Timed    t(g, KC_FIXUP, (size_t) L.P * 6 * L.nf);
 		LevelDev D = L.dev();
 		if (store_u)
@@ -1225,7 +1252,8 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	return TE_OK;
 }
 // opts.fuse = 3, post-smoothing: out = S(v + P(prolong_from), f) with v = S(0, f) recomputed (its faces in L.f6buf)
-template <int N> int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from, double *xf_out)
+template <int N>
+int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from, double *xf_out, const double *fcorr_in)
 {
 	ProlongSrc ps;
 	ps.parent = L.parent.p;
@@ -1234,10 +1262,25 @@ template <int N> int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, d
 	auto launch = [&](LevelDev D) {
 		if (D.count == 0) return;
 		Timed t(g, KC_RESWEEP, (size_t) D.count * L.nc);
-		D.f6 = L.f6buf.p;
-		if constexpr (N >= 4)
-			hipLaunchKernelGGL(k_rbgs_resweep_prolong3d<N>, dim3(8 * ((D.count + 7) / 8)), dim3(Tile3<N>::TPB), 0, g->stream, D, f,
-			                   out, ps);
+		D.f6    = L.f6buf.p;
+		D.fcorr = fcorr_in;
+		if constexpr (N >= 4) {
+			const dim3  grid(8 * ((D.count + 7) / 8)), blk(Tile3<N>::TPB);
+			const char *ve = getenv("TE_RESWEEP_V"); // tuning variants (march3d.hpp), all bit-identical; default 3
+			const int   v  = ve ? atoi(ve) : 3;
+			if (fcorr_in) {
+				if (v == 0)
+					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 0, true>), grid, blk, 0, g->stream, D, f, out, ps);
+				else
+					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 3, true>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else if (v == 0) {
+				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 0, false>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else if (v == 7) {
+				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 7, false>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else {
+				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 3, false>), grid, blk, 0, g->stream, D, f, out, ps);
+			}
+		}
 	};
 	L.pack_f6 = L.f6buf.p; // neighbours on other ranks receive the face layers of v + P(coarse)
 	int rc    = withGhosts<N>(g, L, out /* unused: the faces come from pack_f6 */, launch, nullptr, xf_out, &ps);
@@ -1246,13 +1289,14 @@ template <int N> int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, d
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
-int resweepProlong(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from, double *xf_out)
+int resweepProlong(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from, double *xf_out,
+                   const double *fcorr_in)
 {
 	switch (L.n) {
-		case 4: return resweepProlongN<4>(g, L, f, out, prolong_from, xf_out);
-		case 8: return resweepProlongN<8>(g, L, f, out, prolong_from, xf_out);
-		case 16: return resweepProlongN<16>(g, L, f, out, prolong_from, xf_out);
-		default: return resweepProlongN<32>(g, L, f, out, prolong_from, xf_out);
+		case 4: return resweepProlongN<4>(g, L, f, out, prolong_from, xf_out, fcorr_in);
+		case 8: return resweepProlongN<8>(g, L, f, out, prolong_from, xf_out, fcorr_in);
+		case 16: return resweepProlongN<16>(g, L, f, out, prolong_from, xf_out, fcorr_in);
+		default: return resweepProlongN<32>(g, L, f, out, prolong_from, xf_out, fcorr_in);
 	}
 }
 // opts.fuse = 2 with the block-Jacobi smoother: after an exact patch solve from the zero iterate the residual
@@ -1263,7 +1307,7 @@ int resweepProlong(te_gmg *g, LevelHost &L, const double *f, double *out, const 
 // compact x faces or null; coarse: the coarse level's f with `coarse_n` entries.
 template <int N> int interfaceResidRestrictN(te_gmg *g, LevelHost &L, const double *u, const double *xf, double *coarse, size_t coarse_n)
 {
-	RestrictDst rd;
+	RestrictDst rd = RestrictDst();
 	rd.parent     = L.parent.p;
 	rd.orth       = L.orth.p;
 	rd.coarse     = coarse;
@@ -1300,13 +1344,14 @@ int interfaceResidRestrict(te_gmg *g, LevelHost &L, const double *u, const doubl
 		default: return interfaceResidRestrictN<32>(g, L, u, xf, coarse, coarse_n);
 	}
 }
-int zeroSweepResid(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out, bool store_u)
+int zeroSweepResid(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out, bool store_u,
+                   double *fcorr_out = nullptr, const double *fcorr_in = nullptr)
 {
 	switch (L.n) {
-		case 4: return zeroSweepResidN<4>(g, L, f, out, coarse, xf_out, store_u);
-		case 8: return zeroSweepResidN<8>(g, L, f, out, coarse, xf_out, store_u);
-		case 16: return zeroSweepResidN<16>(g, L, f, out, coarse, xf_out, store_u);
-		default: return zeroSweepResidN<32>(g, L, f, out, coarse, xf_out, store_u);
+		case 4: return zeroSweepResidN<4>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in);
+		case 8: return zeroSweepResidN<8>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in);
+		case 16: return zeroSweepResidN<16>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in);
+		default: return zeroSweepResidN<32>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in);
 	}
 }
 int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false,
@@ -1325,7 +1370,7 @@ int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double
 // on another rank write their block into upbuf; received blocks are placed by k_restrict_unpack3d.
 template <int N> int residRestrictN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse, const double *xf_in)
 {
-	RestrictDst rd;
+	RestrictDst rd = RestrictDst();
 	rd.parent     = L.parent.p;
 	rd.orth       = L.orth.p;
 	rd.coarse     = coarse;
@@ -1640,6 +1685,8 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	LevelHost &L        = *g->levels[l];
 	int        rc;
 	g->cur_level        = l;
+	const double *fcorr_in = (L.f_has_corr && L.fcorr.p) ? L.fcorr.p : nullptr; // ghost terms that still belong to f (see below)
+	L.f_has_corr           = false;
 	auto       materialise = [&]() -> int {
         if (!u_zero) return TE_OK;
         u_zero         = false;
@@ -1670,7 +1717,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 				double *xo = last ? nullptr : L.xfbuf[L.xf_cur ^ 1].p;
 				if (u_unstored) {
 					u_unstored = false;
-					if ((r = resweepProlong(g, L, f->d, L.t->d, c, xo))) return r;
+					if ((r = resweepProlong(g, L, f->d, L.t->d, c, xo, fcorr_in))) return r;
 				} else if ((r = launchRbgs(g, L, u->d, f->d, L.t->d, false, c, xfFor(L, u->d), xo))) {
 					return r;
 				}
@@ -1728,13 +1775,24 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	// pass over f (plus a pass over the face layers). All ranks take the same decision on a level or the ones
 	// that do not would wait for ghost faces nobody sends: it rests on facts every rank knows (dimension, options,
 	// global patch count) and on fuse2_ok, which the hierarchy builder sets identically on all ranks.
+	// (a level takes the fuse = 3 path when ...; the same predicate for the next level decides whether that level can
+	// read its right-hand side together with exported ghost terms, see below)
+	auto unstoredAt = [&](LevelHost &LL, bool has_coarser) {
+		return o->fuse >= 3 && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_RBGS && LL.fuse2_ok && has_coarser && o->cycle_type == 0
+		       && o->post_sweeps >= 1 && LL.prolong_fusable && LL.n >= 4 && !getenv("TE_NO_FUSE2") && !getenv("TE_NO_FUSE3");
+	};
 	if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_RBGS && L.fuse2_ok && !getenv("TE_NO_FUSE2")) {
 		u_zero = false;
 		// opts.fuse = 3: if exactly this sweep, the descent and a fused post-sweep follow, the iterate in between is
 		// never stored: the post-sweep kernel recomputes it from f (bit-identical to fuse = 2; a rank-local choice,
 		// the peers see the same exchanges)
-		u_unstored = o->fuse >= 3 && o->cycle_type == 0 && o->post_sweeps >= 1 && L.prolong_fusable && L.n >= 4 && !getenv("TE_NO_FUSE3");
-		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p, !u_unstored))) return rc;
+		u_unstored = unstoredAt(L, true);
+		// ... and if the next level takes the same path, its two kernels are the only readers of its right-hand side: the
+		// ghost terms of the restricted residual go to its side array instead of a fix-up pass (bit-identical; rank-local)
+		double *fcorr_out = (u_unstored && C.fcorr.p && unstoredAt(C, l + 2 < nl) && !getenv("TE_NO_FCORR")) ? C.fcorr.p : nullptr;
+		if (fcorr_in && !u_unstored) return te::fail(TE_ESTATE, "te_vcycle: exported ghost terms without a reader");
+		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p, !u_unstored, fcorr_out, fcorr_in))) return rc;
+		C.f_has_corr = fcorr_out != nullptr;
 		if (u_unstored) {
 			L.xf_valid_for = nullptr;
 		} else {
@@ -1749,6 +1807,8 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		if ((rc = smoothOnce(g, l, f, u, TE_SMOOTH_PATCH_SOLVE, o->omega, true))) return rc;
 		if ((rc = interfaceResidRestrict(g, L, u->d, xfFor(L, u->d), C.f->d, C.f->n))) return rc;
 		have_coarse_f = true;
+	} else if (fcorr_in) {
+		return te::fail(TE_ESTATE, "te_vcycle: exported ghost terms without a reader");
 	} else if ((rc = smooth(o->pre_sweeps, false))) {
 		return rc;
 	}

@@ -28,6 +28,7 @@ struct RestrictDst {
 	const int32_t *parent, *orth;
 	double        *coarse, *remote;
 	const int64_t *remote_off;
+	double        *rs6;   // [P][6][(N/2)^2]: 2x2 sums of the patches' face layers (march3d.hpp, k_rbgs_zero_resid3d EXPORT), or null
 };
 
 struct LevelDev {
@@ -50,6 +51,8 @@ struct LevelDev {
 	// a + N b with (a, b) the two other axes in order (the ghost-slot layout). f6 belongs to the input, f6_out is filled.
 	const double *f6;
 	double       *f6_out;
+	// ghost terms that still belong to this level's right-hand side (march3d.hpp FCorrSrc), or null
+	const double *fcorr;
 };
 
 // Blocks b, b+8, b+16, ... share an XCD (observed round-robin dispatch); give every XCD one

@@ -306,7 +306,7 @@ __global__ void k_pack_faces_prolong3d(const int32_t *__restrict__ faces, const 
 
 // Relax cell CB (0: even x, 1: odd x) of row k of the plane held in `cen` (LDS copy in tl):
 // v = (sum of off-diagonal neighbours / h^2 - f) / diag. Everything about the cell's position is static.
-template <int N, int K, int CB, bool ZERO_NBRS>
+template <int N, int K, int CB, bool ZERO_NBRS, bool STORE = true>
 __device__ __forceinline__ void relaxCell(double *tl, const double *idiag, int cz9, const int (&lds)[2], const int (&dix)[2][2],
                                           bool act, double rhx, double rhy, double rhz, double2 (&cen)[2],
                                           const double2 (&below)[2], const double2 (&above)[2], const double2 (&rhs)[2])
@@ -333,7 +333,7 @@ __device__ __forceinline__ void relaxCell(double *tl, const double *idiag, int c
 		cen[K].y = v;
 	else
 		cen[K].x = v;
-	if (act) tl[lds[K] + CB] = v;
+	if (STORE && act) tl[lds[K] + CB] = v; // (STORE = false: nobody reads this plane's LDS copy again)
 }
 
 // Patch-local red-black Gauss-Seidel sweep with neighbour ghosts frozen at the old iterate
@@ -606,6 +606,102 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	step(std::integral_constant<int, 0>{}, z1); // black update and store of the last plane (and, inside a patch, the red values above it)
 }
 
+// ---- ghost terms of the restricted residual without a pass of their own (opts.fuse = 3, two fused levels in a row) ---
+// k_restrict_fixup3d adds, for every face with a neighbour, -(1/h^2)/8 * (the four neighbour values behind a 2x2 block of
+// face cells) to the coarse cell behind the block. For x faces those coarse cells sit one per 64-byte sector: over a whole
+// level the fix-up reads and rewrites every sector of the coarse vector, 0.10 ms of a 1.09 ms cycle at 512^3. Instead, the
+// patch that OWNS the face values forms the finished terms (it holds the values in registers when its plane is final),
+// k_fcorr_gather3d sorts them into a compact side array of the coarse level, `fcorr` [coarse patch][12][N*N]:
+//   planes 0..3: x = 0, H-1, H, N-1 at (y + N z);  4..7: y = 0, H-1, H, N-1 at (x + N z);  8..11: z = ... at (x + N y)
+// (the octant faces of the eight children), pure stores, one writer per entry, and the kernels that read the coarse
+// right-hand side (k_rbgs_zero_resid3d / k_rbgs_resweep_prolong3d with FCORR) add them while loading:
+// f = ((f + x term) + y term) + z term -- the order in which k_restrict_fixup3d visits the faces (W,E,S,N,B,T), and the
+// same (w * g) / 8 summed in the same order, so the result is bit-identical to the fix-up pass. Entries of physical
+// faces are +0.
+template <int N> __device__ __forceinline__ int octPlane(int c) // 0, H-1, H, N-1 -> 0..3; other coordinates -> -1
+{
+	constexpr int H = N / 2;
+	return c == 0 ? 0 : (c == H - 1 ? 1 : (c == H ? 2 : (c == N - 1 ? 3 : -1)));
+}
+// what a reader of the coarse right-hand side adds to its two rows (k) of plane z
+template <int N> struct FCorrSrc {
+	const double *x[2]; // per cell of the pair: that cell's x plane at row 2Yp, or null
+	const double *y[2]; // per row k: that row's y plane at column 2X, or null
+	const double *zb;   // the patch's four z planes
+	__device__ __forceinline__ void init(const double *fcorr, int pid, int X, int Yp)
+	{
+		constexpr int NN = N * N;
+		const double *b  = fcorr + (size_t) pid * 12 * NN;
+#pragma unroll
+		for (int c = 0; c < 2; c++) {
+			const int j = octPlane<N>(2 * X + c);
+			x[c]        = j >= 0 ? b + (size_t) j * NN + 2 * Yp : nullptr;
+		}
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			const int j = octPlane<N>(2 * Yp + k);
+			y[k]        = j >= 0 ? b + (size_t) (4 + j) * NN + 2 * X : nullptr;
+		}
+		zb = b + (size_t) 8 * NN;
+	}
+	// issue the loads for plane z: cx[c] = {row 0, row 1} of cell c; cy[k] = {cell 0, cell 1} of row k; cz[k] likewise
+	__device__ __forceinline__ void load(int z, const int (&q)[2], double2 (&cx)[2], double2 (&cy)[2], double2 (&cz)[2]) const
+	{
+		constexpr int NP = N * N / 2;
+#pragma unroll
+		for (int c = 0; c < 2; c++) cx[c] = x[c] ? *reinterpret_cast<const double2 *>(x[c] + N * z) : double2{0.0, 0.0};
+#pragma unroll
+		for (int k = 0; k < 2; k++) cy[k] = y[k] ? *reinterpret_cast<const double2 *>(y[k] + N * z) : double2{0.0, 0.0};
+		const int jz = octPlane<N>(z);
+#pragma unroll
+		for (int k = 0; k < 2; k++) cz[k] = jz >= 0 ? reinterpret_cast<const double2 *>(zb)[(size_t) jz * NP + q[k]] : double2{0.0, 0.0};
+	}
+	static __device__ __forceinline__ void apply(double2 (&f)[2], const double2 (&cx)[2], const double2 (&cy)[2], const double2 (&cz)[2])
+	{
+#pragma clang fp contract(off)
+		f[0].x = ((f[0].x + cx[0].x) + cy[0].x) + cz[0].x;
+		f[0].y = ((f[0].y + cx[1].x) + cy[0].y) + cz[0].y;
+		f[1].x = ((f[1].x + cx[0].y) + cy[1].x) + cz[1].x;
+		f[1].y = ((f[1].y + cx[1].y) + cy[1].y) + cz[1].y;
+	}
+};
+// fcorr of the coarse level from the finished 2x2 sums the fine patches left in their own `rs6` [fine patch][6][H*H]
+// (k_rbgs_zero_resid3d EXPORT writes them next to its face layers: small stores into the patch's own region -- written
+// straight into six far-away coarse planes they stalled the kernel's in-order memory pipeline and doubled its time).
+// One workgroup per coarse patch and plane: entry (a, b) of plane j of axis ax belongs to child octant o; the term
+// comes from the patch across that child's face: rs6 of a local neighbour, or (neighbour on another rank) the sums of
+// k_restrict_fixup3d formed here from the ghost slot. Physical faces: +0. A pure permutation copy of finished values.
+template <int N>
+__global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_t *__restrict__ child, const double *__restrict__ rs6,
+                                                        double *__restrict__ fcorr)
+{
+	constexpr int NN = N * N, H = N / 2, HH = H * H;
+	const int     pc = blockIdx.x / 12, pl = blockIdx.x % 12, ax = pl >> 2, j = pl & 3;
+	const int     a0 = (ax == 0) ? 1 : 0, a1 = (ax == 2) ? 1 : 2; // the two other axes in order
+	const int     hi = j >> 1;                                    // which half of the coarse patch along ax
+	const int     s  = 2 * ax + (j & 1);                          // j = 0: low face of the low child, 1: its high face, 2: low face of the high child, 3: its high face
+	double       *d  = fcorr + ((size_t) pc * 12 + pl) * NN;
+	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+		const int a = i % N, b = i / N, oa = a >= H, ob = b >= H, ha = a - oa * H, hb = b - ob * H;
+		const int o = (hi << ax) | (oa << a0) | (ob << a1);
+		const int p = child[(size_t) pc * 8 + o];
+		double    v = 0.0;
+		if (p >= 0) {
+			const int kind = L.face_kind[(size_t) p * 6 + s], src = L.face_src[(size_t) p * 6 + s];
+			if (kind == FACE_LOCAL) {
+				v = rs6[((size_t) src * 6 + (s ^ 1)) * HH + ha + H * hb];
+			} else if (kind == FACE_GHOST) {
+				const double w = -L.rh2[(size_t) p * 3 + ax];
+#pragma unroll
+				for (int db = 0; db < 2; db++)
+#pragma unroll
+					for (int da = 0; da < 2; da++) v += (w * L.ghost[(size_t) src * NN + (2 * ha + da) + N * (2 * hb + db)]) / 8;
+			}
+		}
+		d[i] = v;
+	}
+}
+
 // ---- pre-smoothing sweep from a zero iterate + residual + restriction in one pass (opts.fuse = 2) --------------
 // Cycle.h:57-65 for the first sweep of a cycle: u = S(0, f); coarse f = AvgRstr(f - A u). The sweep of a patch
 // needs no neighbour data at all (every ghost of a zero iterate is zero), and the residual of every cell that
@@ -624,7 +720,10 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 // plane z-2 is still being read (residual) while the fastest waves already write plane z+1.
 // STORE_U = false (opts.fuse = 3): the new iterate is not stored at all, only its six face layers (L.f6_out): the
 // post-smoothing kernel k_rbgs_resweep_prolong3d recomputes it from f, everything else reads faces.
-template <int N, bool STORE_U>
+// EXPORT: the ghost terms of the restricted residual that this patch's face values contribute to its neighbours' coarse
+// cells go to rd.fcorr (see above) -- no k_restrict_fixup3d pass; FCORR: this level's own right-hand side carries such
+// terms in L.fcorr (it was produced that way by the finer level).
+template <int N, bool STORE_U, bool EXPORT = false, bool FCORR = false>
 __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L, const double *__restrict__ f,
                                                                      double *__restrict__ out, RestrictDst rd)
 {
@@ -659,6 +758,9 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 		idiag[tid] = 1.0 / (kf[0] * rhx + kf[1] * rhy + kf[2] * rhz);
 	}
 	for (int i = tid; i < 4 * T::LSZ; i += TPB) (&tile[0][0])[i] = 0.0; // halo ring stays zero: ghosts of a zero iterate
+	// EXPORT: the 2x2 sums of this patch's six face layers, [6][H*H] next to the patch's other face data
+	double *const rs = EXPORT ? rd.rs6 + (size_t) pid * 6 * (H * H) : nullptr;
+	double        eW = 0.0, eE = 0.0, eS = 0.0, eN = 0.0; // sums in progress (the z pair spans two steps)
 
 	const bool act = (T::NT == TPB) || tid < T::NT;
 	const int  X = act ? tid % H : 0, Yp = act ? tid / H : 0;
@@ -700,11 +802,18 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 	// new iterate: u3 = plane z-3, u2 = z-2, u1 = z-1, u0 = z (all start from zero); right-hand sides alongside
 	double2 u3[2], u2[2], u1[2], u0[2], f2[2], f1[2], f0[2], fn[2];
 	const double2 zero2 = double2{0.0, 0.0};
+	FCorrSrc<N>   fc;
+	double2       ccx[2], ccy[2], ccz[2]; // FCORR: the terms of the plane in fn
+	if (FCORR) fc.init(L.fcorr, pid, X, Yp);
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		u3[k] = u2[k] = u1[k] = u0[k] = zero2;
 		f2[k] = f1[k] = zero2;
 		f0[k] = fp2[q[k]];
+	}
+	if (FCORR) {
+		fc.load(0, q, ccx, ccy, ccz);
+		FCorrSrc<N>::apply(f0, ccx, ccy, ccz);
 	}
 	__syncthreads(); // idiag and the zeroed tiles
 
@@ -714,6 +823,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 		const int     zc   = (z + 1 < N) ? z + 1 : N - 1;
 #pragma unroll
 		for (int k = 0; k < 2; k++) fn[k] = fp2[zc * NP + q[k]];
+		if (FCORR) fc.load(zc, q, ccx, ccy, ccz);
 		double *tz = tile[bz];            // plane z
 		double *t1 = tile[(bz + 3) & 3];  // plane z-1
 		double *t2 = tile[(bz + 2) & 3];  // plane z-2
@@ -748,6 +858,39 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 					double *zo = fo + (zz == 0 ? 4 : 5) * NN + 2 * X;
 					*reinterpret_cast<double2 *>(zo + N * (2 * Yp))     = u1[0];
 					*reinterpret_cast<double2 *>(zo + N * (2 * Yp + 1)) = u1[1];
+				}
+			}
+			if (EXPORT && act) { // this plane's face values as ghost terms of the neighbours' restricted residuals
+				// (k_restrict_fixup3d's sum: (w g)/8 over the 2x2 block, first face coordinate fastest)
+				const int  zz = z - 1, zh = zz >> 1;
+				const bool second = zz & 1;
+				auto       pair = [&](double &e, double a, double b, double w) { // two cells of this plane join the block's sum
+                    double t = second ? e : 0.0;
+                    t += (w * a) / 8;
+                    t += (w * b) / 8;
+                    e = t;
+				};
+				constexpr int HH = H * H;
+				if (X == 0) { // x faces: block = rows (2Yp, 2Yp+1) x planes (zz, zz+1); entry (y, z)
+					pair(eW, u1[0].x, u1[1].x, -rhx);
+					if (second) rs[0 * HH + Yp + H * zh] = eW;
+				}
+				if (X == H - 1) {
+					pair(eE, u1[0].y, u1[1].y, -rhx);
+					if (second) rs[1 * HH + Yp + H * zh] = eE;
+				}
+				if (Yp == 0) { // y faces: block = cells (2X, 2X+1) x planes; entry (x, z)
+					pair(eS, u1[0].x, u1[0].y, -rhy);
+					if (second) rs[2 * HH + X + H * zh] = eS;
+				}
+				if (Yp == H - 1) {
+					pair(eN, u1[1].x, u1[1].y, -rhy);
+					if (second) rs[3 * HH + X + H * zh] = eN;
+				}
+				if (zz == 0 || zz == N - 1) { // z faces: the whole block is in this thread; entry (x, y)
+					double t = 0.0;
+					t += (-rhz * u1[0].x) / 8, t += (-rhz * u1[0].y) / 8, t += (-rhz * u1[1].x) / 8, t += (-rhz * u1[1].y) / 8;
+					rs[(zz == 0 ? 4 : 5) * HH + X + H * Yp] = t;
 				}
 			}
 		}
@@ -794,6 +937,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 			f1[k] = f0[k];
 			f0[k] = fn[k];
 		}
+		if (FCORR) FCorrSrc<N>::apply(f0, ccx, ccy, ccz);
 		bz = (bz + 1) & 3;
 	};
 #pragma unroll 1
@@ -928,10 +1072,16 @@ __global__ void k_pack_faces6_3d(const int32_t *__restrict__ faces, const double
 	}
 }
 
-template <int N>
+// V (tuning variants, all bit-identical): bit 0: the black values of the recomputed plane and of the sweep's plane z-1 are
+// not written back to LDS (nobody reads them: their x/y neighbours are red); bit 1: the top neighbour's plane is loaded on
+// the last steps only; bit 2: right-hand sides are requested five planes ahead instead of four (two steps before their
+// first use instead of one: a step is shorter than a loaded HBM round trip).
+// FCORR: this level's right-hand side carries ghost terms in L.fcorr (see FCorrSrc)
+template <int N, int V = 0, bool FCORR = false>
 __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelDev L, const double *__restrict__ f,
                                                                           double *__restrict__ out, ProlongSrc ps)
 {
+	constexpr bool LDS_ALL = !(V & 1), TG_ALWAYS = !(V & 2), DEEP = (V & 4) != 0;
 	using T           = Tile3<N>;
 	constexpr int TPB = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
 	constexpr int NN  = N * N, NNN = N * N * N;
@@ -1028,15 +1178,15 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 	auto fillBlack = [&](auto zpar, int z, double *tv, double2(&cen)[2], const double2(&below)[2], const double2(&above)[2],
 	                     const double2(&rhs)[2]) {
 		constexpr int ZP = decltype(zpar)::value;
-		relaxCell<N, 0, (1 + 0 + ZP) & 1, false>(tv, idiag, cz9of(z), lds, dix, act, rhx, rhy, rhz, cen, below, above, rhs);
-		relaxCell<N, 1, (1 + 1 + ZP) & 1, false>(tv, idiag, cz9of(z), lds, dix, act, rhx, rhy, rhz, cen, below, above, rhs);
+		relaxCell<N, 0, (1 + 0 + ZP) & 1, false, LDS_ALL>(tv, idiag, cz9of(z), lds, dix, act, rhx, rhy, rhz, cen, below, above, rhs);
+		relaxCell<N, 1, (1 + 1 + ZP) & 1, false, LDS_ALL>(tv, idiag, cz9of(z), lds, dix, act, rhx, rhy, rhz, cen, below, above, rhs);
 	};
 	using P0 = std::integral_constant<int, 0>;
 	using P1 = std::integral_constant<int, 1>;
 
 	// right-hand sides of planes z-1 .. z+3 (fn: z+4 in flight), recomputed planes r1 = v(z+1) (red entries are
 	// what is read), r2 = red(z+2) -> v(z+2), r3 = red(z+3); the sweep's planes as in k_rbgs3d
-	double2 fm[2], f0[2], f1[2], f2[2], f3[2], fn[2], r1[2], r2[2], r3[2];
+	double2 fm[2], f0[2], f1[2], f2[2], f3[2], f4[2], fn[2], r1[2], r2[2], r3[2];
 	double2 umm[2], um[2], uc[2], un[2], un2[2];
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
@@ -1045,7 +1195,19 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 		f1[k] = fp2[1 * NP + q[k]];
 		f2[k] = fp2[2 * NP + q[k]];
 		f3[k] = fp2[3 * NP + q[k]];
+		if (DEEP) f4[k] = fp2[(4 < N ? 4 : N - 1) * NP + q[k]];
 		umm[k] = zero2;
+	}
+	FCorrSrc<N> fc;
+	double2     ccx[2], ccy[2], ccz[2]; // FCORR: the terms of the plane in fn
+	if (FCORR) {
+		fc.init(L.fcorr, pid, X, Yp);
+		auto fix = [&](int z, double2(&fz)[2]) {
+			fc.load(z, q, ccx, ccy, ccz);
+			FCorrSrc<N>::apply(fz, ccx, ccy, ccz);
+		};
+		fix(0, f0), fix(1, f1), fix(2, f2), fix(3, f3);
+		if (DEEP) fix(4 < N ? 4 : N - 1, f4);
 	}
 	__syncthreads(); // idiag, zeroed tileV
 	{ // prologue: v(0), v(1)
@@ -1078,14 +1240,18 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 		constexpr int ZPAR = decltype(zpar)::value;
 		using ZQ          = std::integral_constant<int, 1 - ZPAR>;
 		// loads for the coming steps
-		const int zf = (z + 4 < N) ? z + 4 : N - 1, zc = (z + 1 < N) ? z + 1 : N - 1;
+		constexpr int AHEAD = DEEP ? 5 : 4;
+		const int     zf = (z + AHEAD < N) ? z + AHEAD : N - 1, zc = (z + 1 < N) ? z + 1 : N - 1;
 #pragma unroll
 		for (int k = 0; k < 2; k++) fn[k] = fp2[zf * NP + q[k]];
+		if (FCORR) fc.load(zf, q, ccx, ccy, ccz);
 		const double hvn = hs.s * (hs.p[zc * hs.stride] + shalo * chalo[NN * (zc >> 1)]);
 		const double c2  = (z + 2 < N) ? cown[NN * ((z + 2) >> 1) + cq] : stop * ctop[cq];
 		double2      tg[2];
+		if (TG_ALWAYS || z + 2 >= N) { // the top neighbour's plane (used on the last steps only)
 #pragma unroll
-		for (int k = 0; k < 2; k++) tg[k] = top.p[q[k]]; // the top neighbour's plane (used on the last steps only)
+			for (int k = 0; k < 2; k++) tg[k] = top.p[q[k]];
+		}
 		// before the barrier: red values two and three planes ahead, this plane of the iterate into LDS
 		double *tvz = tileV[z & 1];
 		if (z + 3 < N)
@@ -1120,8 +1286,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 		}
 		if (z > 0) {
 			const int cz9 = cz9of(z - 1);
-			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
-			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
+			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false, LDS_ALL>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
+			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false, LDS_ALL>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
 			if (act) {
 				op2[(z - 1) * NP + q[0]] = um[0];
 				op2[(z - 1) * NP + q[1]] = um[1];
@@ -1142,10 +1308,16 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 			f0[k]  = f1[k];
 			f1[k]  = f2[k];
 			f2[k]  = f3[k];
-			f3[k]  = fn[k];
+			if (DEEP) {
+				f3[k] = f4[k];
+				f4[k] = fn[k];
+			} else {
+				f3[k] = fn[k];
+			}
 			r1[k]  = r2[k];
 			r2[k]  = r3[k];
 		}
+		if (FCORR) FCorrSrc<N>::apply(DEEP ? f4 : f3, ccx, ccy, ccz);
 		hv = hvn;
 		bz = (bz == 2) ? 0 : bz + 1;
 	};

@@ -97,6 +97,45 @@ def test_sharded_ops_equal_single_rank(nranks, name, divides, n, dim, monkeypatc
 
 
 @pytest.mark.parametrize("nranks", [2, 8])
+def test_sharded_exported_ghost_terms(nranks, monkeypatch):
+    """Two fused levels in a row (4096 and 512 patches): the ghost terms of the restricted residual are exported by
+    the patches that own the face values and gathered into the coarse level's side array (k_fcorr_gather3d); across a
+    rank boundary they are formed from the ghost slots. Sharded == single rank == the fix-up pass (TE_NO_FCORR),
+    bit for bit."""
+    n = 4
+    mesh = util.mesh("uniform", 4)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    f = util.rand_vec(H1.cells(0), 5)
+    nc = n ** 3
+    want = {}
+    for nofc in (False, True):
+        if nofc:
+            monkeypatch.setenv("TE_NO_FCORR", "1")
+        else:
+            monkeypatch.delenv("TE_NO_FCORR", raising=False)
+        df, du = g1.new_vector(0, f), g1.new_vector(0)
+        g1.profile(True)
+        g1.profile_reset()
+        g1.cycle(g1.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+        rows = g1.profile_rows()
+        g1.profile(False)
+        want[nofc] = du.download()
+        assert rows["rbgs_zero_resid_restrict_faces"]["calls"] == 2 and rows["rbgs_resweep_prolong"]["calls"] == 2
+    assert np.array_equal(want[False], want[True])
+    monkeypatch.delenv("TE_NO_FCORR", raising=False)
+
+    def per_rank(r, H, g, fab):
+        idx = H.l2g(0)
+        df, du = g.new_vector(0, f.reshape(-1, nc)[idx].ravel()), g.new_vector(0)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+        return {"u": du.download()}
+
+    got = shard_run(mesh, n, nranks, per_rank)
+    assert np.array_equal(got["u"], want[False])
+
+
+@pytest.mark.parametrize("nranks", [2, 8])
 def test_sharded_bicgstab(nranks):
     """te_bicgstab on a sharded hierarchy (scalars summed over the ranks through the registered all-reduce, all ranks
     take the same branches) against the single-rank solve and against the statement-by-statement host mirror

@@ -123,6 +123,58 @@ template <int CH> __global__ __launch_bounds__(256) void triad_chunk_pipe(size_t
 	}
 }
 
+// patch walk with PL planes per step: loads of PL planes issued together one step ahead, stores of PL planes together
+template <int CH, int PL> __global__ __launch_bounds__(256) void triad_walk_multi(size_t nchunks, double *a, const double *b, const double *c)
+{
+	const size_t base = (size_t) blockIdx.x * CH * 512;
+	double2      x[2 * PL], y[2 * PL], xn[2 * PL], yn[2 * PL];
+#pragma unroll
+	for (int k = 0; k < 2 * PL; k++) {
+		size_t i = base + k * 256 + threadIdx.x;
+		x[k]     = ((const double2 *) b)[i];
+		y[k]     = ((const double2 *) c)[i];
+	}
+	for (int z = 0; z < CH; z += PL) {
+		const int zn = (z + PL < CH) ? z + PL : z;
+#pragma unroll
+		for (int k = 0; k < 2 * PL; k++) {
+			size_t i = base + zn * 512 + k * 256 + threadIdx.x;
+			xn[k]    = ((const double2 *) b)[i];
+			yn[k]    = ((const double2 *) c)[i];
+		}
+#pragma unroll
+		for (int k = 0; k < 2 * PL; k++) {
+			size_t i = base + z * 512 + k * 256 + threadIdx.x;
+			((double2 *) a)[i] = double2{x[k].x + 0.5 * y[k].x, x[k].y + 0.5 * y[k].y};
+			x[k] = xn[k];
+			y[k] = yn[k];
+		}
+	}
+}
+// read-one-write-one walk (the sweep kernels' mix), PL planes per step
+template <int CH, int PL> __global__ __launch_bounds__(256) void copy_walk_multi(size_t nchunks, double *a, const double *b)
+{
+	const size_t base = (size_t) blockIdx.x * CH * 512;
+	double2      x[2 * PL], xn[2 * PL];
+#pragma unroll
+	for (int k = 0; k < 2 * PL; k++) x[k] = ((const double2 *) b)[base + k * 256 + threadIdx.x];
+	for (int z = 0; z < CH; z += PL) {
+		const int zn = (z + PL < CH) ? z + PL : z;
+#pragma unroll
+		for (int k = 0; k < 2 * PL; k++) xn[k] = ((const double2 *) b)[base + zn * 512 + k * 256 + threadIdx.x];
+#pragma unroll
+		for (int k = 0; k < 2 * PL; k++) {
+			((double2 *) a)[base + z * 512 + k * 256 + threadIdx.x] = double2{x[k].x * 0.5, x[k].y * 0.5};
+			x[k] = xn[k];
+		}
+	}
+}
+__global__ __launch_bounds__(256) void copy_flat(size_t n2, double2 *a, const double2 *b)
+{
+	size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+	if (i < n2) { double2 x = b[i]; a[i] = double2{x.x * 0.5, x.y * 0.5}; }
+}
+
 int main(int argc, char **argv)
 {
 	size_t n = (size_t) 512 * 512 * 512;
@@ -192,5 +244,12 @@ int main(int argc, char **argv)
 	snprintf(nm, sizeof nm, "triad_chunk_pipe CH=%d", CH);                                                               \
 	timeit(nm, n * 24.0, [&] { hipLaunchKernelGGL(triad_chunk_pipe<CH>, dim3(n / (CH * 1024)), dim3(256), 0, 0, n / (CH * 1024), a, b, c); });
 	CHUNK(1) CHUNK(2) CHUNK(4) CHUNK(8) CHUNK(16) CHUNK(32)
+#define WALK(PL)                                                                                                          \
+	snprintf(nm, sizeof nm, "triad_walk_multi CH=32 PL=%d", PL);                                                          \
+	timeit(nm, n * 24.0, [&] { hipLaunchKernelGGL((triad_walk_multi<32, PL>), dim3(n / (32 * 1024)), dim3(256), 0, 0, n / (32 * 1024), a, b, c); }); \
+	snprintf(nm, sizeof nm, "copy_walk_multi CH=32 PL=%d", PL);                                                           \
+	timeit(nm, n * 16.0, [&] { hipLaunchKernelGGL((copy_walk_multi<32, PL>), dim3(n / (32 * 1024)), dim3(256), 0, 0, n / (32 * 1024), a, b); });
+	WALK(1) WALK(2) WALK(4)
+	timeit("copy_flat", n * 16.0, [&] { hipLaunchKernelGGL(copy_flat, dim3(n2 / 256), dim3(256), 0, 0, n2, (double2 *) a, (const double2 *) b); });
 	return 0;
 }

@@ -20,30 +20,55 @@ def short(name):
 
 
 def counters(d):
+    """{kernel: {counter: [sum, launches]}} from rocprofv3's CSV or rocpd (sqlite) output"""
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             a = agg[short(r["Kernel_Name"])][r["Counter_Name"]]
             a[0] += float(r["Counter_Value"])
             a[1] += 1
+    for f in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
+        import sqlite3
+        db = sqlite3.connect(f)
+        # one row per (dispatch, counter, dimension instance): sum the instances of a dispatch first
+        q = "select kernel_name, counter_name, dispatch_id, sum(value) from counters_collection group by 1, 2, 3"
+        for name, cn, _, val in db.execute(q):
+            a = agg[short(name)][cn]
+            a[0] += float(val)
+            a[1] += 1
     return agg
+
+
+def kernel_stats(d):
+    """rows (name, calls, total ns, average ns, percentage, min ns, max ns) from --stats CSV or the rocpd database"""
+    st = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        rows = list(csv.reader(open(st[0])))[1:]
+        return [(r[0], int(r[1]), float(r[2]), float(r[3]), float(r[4]), float(r[5]), float(r[6])) for r in rows]
+    out = []
+    for f in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):
+        import sqlite3
+        db = sqlite3.connect(f)
+        rows = list(db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name"))
+        tot = sum(r[2] for r in rows) or 1
+        out = [(r[0], r[1], float(r[2]), float(r[3]), 100.0 * r[2] / tot, float(r[4]), float(r[5])) for r in rows]
+        out.sort(key=lambda r: -r[2])
+    return out
 
 
 def main():
     run, out, commit, label = sys.argv[1:5]
     head = f"# commit {commit}; {label}\n"
     # 1. kernel stats
-    st = glob.glob(os.path.join(run, "stats", "**", "*kernel_stats.csv"), recursive=True)
-    if st:
-        rows = list(csv.reader(open(st[0])))
+    rows = kernel_stats(os.path.join(run, "stats"))
+    if rows:
         with open(out + "_kernel_stats.csv", "w") as f:
             f.write(head)
             w = csv.writer(f)
-            w.writerow(rows[0])
-            for r in rows[1:]:
-                if float(r[4]) >= 0.05:
-                    r[0] = short(r[0])
-                    w.writerow(r)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows:
+                if r[4] >= 0.05:
+                    w.writerow([short(r[0]), r[1], f"{r[2]:.0f}", f"{r[3]:.1f}", f"{r[4]:.2f}", f"{r[5]:.0f}", f"{r[6]:.0f}"])
     # 2. SQ counters
     sq = counters(os.path.join(run, "sq1"))
     for k, v in counters(os.path.join(run, "sq2")).items():
