@@ -5,18 +5,23 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one GMG V(1,1) cycle (GMG/Cycle.h:116-126 semantics: zero u, pre-smooth, residual,
-restrict, recurse, prolong-add, post-smooth; default options: te_cycle_opts.fuse = 2) over the whole 512^3 grid, 16^3 patches of 32^3
+restrict, recurse, prolong-add, post-smooth; default options: te_cycle_opts_default, fuse = 3) over the whole 512^3 grid, 16^3 patches of 32^3
 (apps/3d/steady -n 32 --mesh 4uni.bin --divide 1). Inputs are resident in HBM before the timed
 region. N > 1: one rank per GPU (torch.distributed, backend nccl == RCCL); the same 512^3
 problem is sharded by contiguous Morton ranges of patches (strong scaling).
 
 The JSON line carries `roofline` for the dominant kernel (HIP-event timed on the solver stream
 inside the timed region) and `cpu_baseline` (the CPU restatement of the reference algorithm,
-oracle/, timed on this host's cores on a bounded sample; rank 0, N = 1 only).
+oracle/, timed on this host's cores on the same workload, bounded to ~30 s; rank 0, N = 1 only).
+`roofline.traffic` (HBM bytes per launch from rocprofv3 PMC passes) is only reported when
+profiles/traffic.json was measured on exactly the kernel sources this run compiled (a hash of
+csrc/ travels with it); otherwise it is null.
 """
 import argparse
+import hashlib
 import json
 import os
+import platform
 import sys
 import time
 
@@ -77,41 +82,76 @@ def parse():
                                                  "--divide 2 or 3); --size is ignored")
     ap.add_argument("--divide", type=int, default=0, help="refineLeaves passes over --mesh (apps/3d/steady --divide)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=128, help="cells per axis of the CPU baseline sample")
+    ap.add_argument("--cpu-size", type=int, default=0, help="cells per axis of the CPU baseline (default: --size)")
     return ap.parse_args()
 
 
-def cpu_baseline(sample, smoother_id):
-    """CPU restatement of the reference V-cycle (reference smoother = block-Jacobi patch solves)
-    on `sample`^3 cells with all host cores; a few cycles, bounded to ~10-30 s."""
+def kernel_sources_sha():
+    """hash of the kernel sources this run compiled: profiles/traffic.json carries the same, so a PMC figure is
+    never quoted for kernels it was not measured on"""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "pressurepoissonsolver_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(size, dim, n):
+    """CPU restatement of the reference V-cycle (oracle/, pinned to the reference's golden vectors) timed on this
+    host beside the GPU number, on the SAME workload: `size`^dim uniform, V(1,1), both smoothers (the reference's
+    block-Jacobi patch solves and the patch-local RB-GS the GPU line uses), with all the cores this job may use
+    (the reference's `mpirun -np cores` analogue: OpenMP over patches) and with 1 thread (= one reference MPI rank;
+    on a 1/8-size sample, 2x smaller per axis, because one 512^3 cycle takes ~25 s on one core). ~30 s in total."""
     from oracle import oracle as orc
     from pressurepoissonsolver_amd import capi, problems
     ncpu = os.cpu_count() or 1
-    div = int(round(np.log2(sample // 32)))
-    m = capi.Mesh.uniform(3, div)
-    H = capi.Hierarchy(m, 32)
-    levels = orc.levels_from_hierarchy(H)
-    f = problems.random_rhs(H.tables(0)["id"], 32 ** 3)
-    o = orc.cycle_opts(smoother=0)
-    best = None
-    # 1 thread = what one reference MPI rank does (the reference is single-threaded per rank);
-    # then OpenMP over patches on up to 16 cores (the `mpirun -np cores` analogue). Report the faster.
-    for threads in sorted({1, min(ncpu, 16)}):
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = ncpu
+    # the GPU boxes of this pool grant 16 CPUs per GPU; TE_CPU_THREADS overrides
+    threads_all = int(os.environ.get("TE_CPU_THREADS", min(avail, 16)))
+
+    def run(sz, threads, smoother, budget):
+        m = capi.Mesh.uniform(dim, int(round(np.log2(sz // n))))
+        H = capi.Hierarchy(m, n)
+        levels = orc.levels_from_hierarchy(H)
+        f = problems.random_rhs(H.tables(0)["id"], n ** dim)
+        o = orc.cycle_opts(smoother=smoother)
         orc.set_threads(threads)
-        orc.cycle(levels, o, f)  # warm
-        t0, reps = time.time(), 0
-        while reps < 3 or (time.time() - t0 < 6.0 and reps < 50):
+        t0 = time.time()
+        orc.cycle(levels, o, f)  # warm (page faults of the level scratch)
+        warm = time.time() - t0
+        ts = []
+        while len(ts) < 2 or (sum(ts) + warm < budget and len(ts) < 20):
+            t0 = time.time()
             orc.cycle(levels, o, f)
-            reps += 1
-        dt = (time.time() - t0) / reps
-        if best is None or dt < best[0]:
-            best = (dt, threads, reps)
-    dt, threads, reps = best
-    return {"value": levels[0].size / dt, "unit": "lattice-site updates/s", "cores": threads, "kind": "port",
-            "sample": f"{sample}^3 uniform, {levels[0].P} patches of 32^3, V(1,1) with the reference's "
-                      f"block-Jacobi patch-solve smoother, {reps} cycles, {threads} OpenMP thread(s) "
-                      f"(host has {ncpu} logical CPUs; 1 and {min(ncpu, 16)} threads tried)",
-            "ms_per_step": dt * 1e3}
+            ts.append(time.time() - t0)
+        dt = float(np.median(ts))
+        return {"size": f"{sz}^{dim}", "threads": threads, "smoother": {0: "patch_solve", 2: "rbgs"}[smoother],
+                "ms_per_cycle": dt * 1e3, "updates_per_s": levels[0].size / dt, "cycles": len(ts)}
+
+    small = max(size // 2, 2 * n)
+    rows = [run(size, threads_all, 0, 8.0), run(size, threads_all, 2, 6.0), run(small, 1, 0, 6.0), run(small, 1, 2, 5.0)]
+    head = rows[0]
+    return {"value": head["updates_per_s"], "unit": "lattice-site updates/s", "cores": threads_all, "kind": "port",
+            "sample": f"{size}^{dim} uniform (the benchmarked workload), V(1,1), the reference's block-Jacobi patch-solve "
+                      f"smoother, median of {head['cycles']} cycles, {threads_all} OpenMP threads",
+            "ms_per_step": head["ms_per_cycle"], "cpu_model": cpu_model(), "nproc": ncpu, "cpus_available_to_job": avail,
+            "runs": rows,
+            "note": "CPU restatement of the reference algorithm (oracle/te_oracle.cpp), not the reference binary "
+                    "(PETSc/FFTW/Zoltan are absent); 1-thread rows = one reference MPI rank, on a 2x-per-axis smaller grid"}
 
 
 def main():
@@ -235,6 +275,19 @@ def main():
 
     ms_per_step = dt / a.steps * 1e3
     value = cells_global[0] / (dt / a.steps)
+    # median of per-cycle times: a second, untimed-by-the-contract pass with an event pair per cycle on
+    # the solver stream (`value` above stays the contract's K steps between two synchronisations)
+    g.profile(False)
+    ext = torch.cuda.ExternalStream(int(g.stream()))
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    barrier()
+    with torch.cuda.stream(ext):
+        for e0, e1 in evs:
+            e0.record()
+            g.cycle(opts, f, u)
+            e1.record()
+    barrier()
+    ms_median = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs]))
 
     # measured ceiling taken in the same run: a bare 2-read + 1-write fp64 stream over the
     # finest-level vectors, one 16-B element per thread (te_vec_scale_then_add_scaled: y = a y + b x)
@@ -266,14 +319,19 @@ def main():
         avg_ms = st["ms"] / st["calls"]
         bytes_per_launch = ALG_BYTES.get(name, 24.0) * st["cells"] / st["calls"]
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(f"{name}:{a.size}:{world}")
+                tj = json.load(open(tf))
+                if tj.get("kernel_sources_sha") == kernel_sources_sha():  # measured on exactly these kernels
+                    traffic = tj.get(f"{name}:{a.size}:{world}")
+                    traffic_src = tj.get("commit")
             except Exception:
                 traffic = None
         b_alg = vcycle_alg_bytes_per_finest_cell(cells_global)
+        # what the fused cycle's kernels must move at least: their own algorithmic bytes (warm-up table, every class)
+        fused_bytes = sum(ALG_BYTES.get(k, 0.0) * v["cells"] for k, v in rows_all.items()) / max(1, (a.warmup - 1) if a.warmup > 1 else 1)
         out = {
             "metric": "V-cycle lattice-site updates/sec, 512^3 3D Poisson" if (a.size == 512 and a.dim == 3 and not a.mesh) else
                       (f"V-cycle lattice-site updates/sec, {os.path.basename(a.mesh)} --divide {a.divide}, {a.dim}D Poisson" if a.mesh else
@@ -288,13 +346,20 @@ def main():
                        "levels": H.num_levels,
                        "smoother": a.smoother, "residual_reduction_per_cycle": reduction},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_measured_at_commit": traffic_src,
                          "avg_launch_ms": avg_ms, "launches": st["calls"],
                          "alg_bytes_per_site": ALG_BYTES.get(name, 24.0),
                          "measured_triad_GBs": triad_gbs, "frac_of_measured_triad": achieved / triad_gbs},
-            "vcycle_hbm": {"alg_bytes_per_finest_site": b_alg,
-                           "achieved_GBs": b_alg * cells_global[0] / (dt / a.steps) / 1e9,
-                           "frac_of_peak": b_alg * cells_global[0] / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world)},
+            # whole cycle: (i) against the bytes its fused kernels must move (a roofline fraction); (ii) SURVEY 8(d)'s
+            # UNFUSED definition (113 B per finest site) divided by the fused cycle's time -- a work-equivalent rate that
+            # can exceed the HBM peak because the fused cycle moves about a third of those bytes; not a roofline fraction
+            "vcycle_hbm": {"fused_alg_bytes_per_finest_site": fused_bytes / (H.sizes(0)[0] * n ** a.dim),
+                           "fused_achieved_GBs": fused_bytes / (dt / a.steps) / 1e9,
+                           "fused_frac_of_peak": fused_bytes / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+                           "unfused_definition_bytes_per_finest_site": b_alg,
+                           "unfused_definition_equivalent_GBs": b_alg * cells_global[0] / (dt / a.steps) / 1e9,
+                           "unfused_definition_equivalent_over_peak": b_alg * cells_global[0] / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world)},
+            "ms_per_step_median": ms_median,
             # per-kernel table from the warm-up steps (every class timed there; the timed region times only `kernel`)
             "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4),
                                    "GBs": (ALG_BYTES.get(k, 0) * v["cells"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
@@ -303,7 +368,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             from oracle import build as obuild
             obuild.build_oracle()
-            out["cpu_baseline"] = cpu_baseline(a.cpu_sample, sm)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_size or a.size, a.dim, n)
         print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()

@@ -3,7 +3,9 @@
 commit it measured): kernel-trace stats, SQ counters (two passes of 8), FETCH_SIZE / WRITE_SIZE (separate passes;
 FETCH_SIZE doubled for 16-B/lane reads as MI355X_MICROARCH.md prescribes for gfx950).
 
-usage: prof_summary.py <run dir> <out prefix> <commit> <label>
+usage: prof_summary.py <run dir> <out prefix> <commit> <label> [size world]
+With size and world it also rewrites profiles/traffic.json (bytes per launch per kernel class, what bench.py quotes as
+roofline.traffic) stamped with the commit and a hash of the kernel sources it was measured on.
 """
 import collections
 import csv
@@ -103,6 +105,31 @@ def main():
                 a, b = fe.get(k, {}).get("FETCH_SIZE", [0, 1]), wr.get(k, {}).get("WRITE_SIZE", [0, 1])
                 rb, wb = 2048.0 * a[0] / max(a[1], 1), 1024.0 * b[0] / max(b[1], 1)
                 w.writerow([k, max(a[1], b[1]), f"{rb:.0f}", f"{wb:.0f}", f"{rb + wb:.0f}"])
+        if len(sys.argv) > 6:
+            import json
+            sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from pmc_traffic import klass
+            import bench
+            size, world = sys.argv[5], sys.argv[6]
+            tot = collections.defaultdict(lambda: [0.0, 0.0, 0, 0])
+            for k in set(fe) | set(wr):
+                c = klass("te::" + k + "(")
+                if not c:
+                    continue
+                a, b = fe.get(k, {}).get("FETCH_SIZE", [0, 0]), wr.get(k, {}).get("WRITE_SIZE", [0, 0])
+                t = tot[c]
+                t[0] += 2048.0 * a[0]
+                t[1] += 1024.0 * b[0]
+                t[2] += a[1]
+                t[3] += b[1]
+            res = {"commit": commit, "kernel_sources_sha": bench.kernel_sources_sha(),
+                   "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py; bytes per launch = "
+                          "2 x FETCH_SIZE KiB x 1024 + WRITE_SIZE KiB x 1024 (gfx950: wide reads are tallied at half)"}
+            for c, t in sorted(tot.items()):
+                res[f"{c}:{size}:{world}"] = t[0] / max(t[2], 1) + t[1] / max(t[3], 1)
+            tf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+            json.dump(res, open(tf, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
