@@ -223,9 +223,8 @@ def main():
     sm = {"rbgs": capi.SMOOTH_RBGS, "jacobi": capi.SMOOTH_JACOBI, "patch_solve": capi.SMOOTH_PATCH_SOLVE}[a.smoother]
     opts = g.default_opts(smoother=sm)
 
-    t = H.tables(0)
-    ids = t["id"][H.l2g(0)]
-    f = g.new_vector(0, problems.random_rhs(ids, n ** a.dim))
+    f = g.new_vector(0)
+    g.init_problem(f, None, problem=capi.PROBLEM_RANDOM)  # U(-1,1) splitmix64(0x5EED + patch id), generated on the device
     u = g.new_vector(0)
     cells_global = [H.sizes(l)[1] * n ** a.dim for l in range(H.num_levels)]
 

@@ -206,6 +206,17 @@ int te_gmg_exchange_selftest(te_gmg *g, int n);
 int te_integrate(te_gmg *g, int level, const te_vec *v, double *out);
 int te_volume(te_gmg *g, int level, double *out);
 
+/* Init::initDirichlet / Init::initNeumann (apps/shared/Init.cpp:152-245, :57-151; 2D :246-361) for the drivers'
+ * canned problems, evaluated on the device straight into `f` and (may be NULL) `exact`: right-hand side and exact
+ * solution at the cell centres, physical Dirichlet data folded in as -2 g/h^2, Neumann data as +-g_n/h, in the
+ * reference's face order. TE_PROBLEM_TRIG / TE_PROBLEM_GAUSS are apps/3d/steady.cpp:221-292 (2D: apps/2d/steady.cpp:296-318);
+ * TE_PROBLEM_RANDOM is the timing input f ~ U(-1,1) from splitmix64(0x5EED + tree node id) (exact := 0). Arbitrary
+ * std::function problems go through Vector<D>::getLocalData (thunderegg/HipInit.h). */
+#define TE_PROBLEM_TRIG 0
+#define TE_PROBLEM_GAUSS 1
+#define TE_PROBLEM_RANDOM 2
+int te_init_problem(te_gmg *g, int level, int problem, int neumann, te_vec *f, te_vec *exact);
+
 /* kernel timing hooks for bench.py: HIP-event time of the last te_vcycle's dominant kernel */
 int te_gmg_profile(te_gmg *g, int enable);
 /* name[i] (<=63 chars), calls[i], total_ms[i] (HIP events on the solver stream), cells[i]

@@ -27,6 +27,7 @@ class TeLibraryMissing(ImportError):
 
 TE_OK, TE_EINVAL, TE_EHIP, TE_ESTATE, TE_EIO, TE_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
 SMOOTH_PATCH_SOLVE, SMOOTH_JACOBI, SMOOTH_RBGS = 0, 1, 2
+PROBLEM_TRIG, PROBLEM_GAUSS, PROBLEM_RANDOM = 0, 1, 2
 
 
 class CycleOpts(C.Structure):
@@ -113,6 +114,7 @@ SYMBOLS = {
     "te_gmg_profile_rows": (_I, [_P, _I, _P, _P, _P, _P]),
     "te_gmg_profile_reset": (_I, [_P]),
     "te_gmg_profile_select": (_I, [_P, C.c_char_p]),
+    "te_init_problem": (_I, [_P, _I, _I, _I, _P, _P]),
     "te_integrate": (_I, [_P, _I, _P, _P]),
     "te_volume": (_I, [_P, _I, _P]),
 }
@@ -403,6 +405,10 @@ class GMG:
         check(lib().te_bicgstab(self.h, C.byref(opts) if opts is not None else None, x.h, b.h, max_it, tol,
                                 C.byref(its), C.byref(rr)))
         return its.value, rr.value
+
+    def init_problem(self, f, exact=None, problem=0, neumann=False, level=0):
+        """Init::initDirichlet / initNeumann for the canned problems (0 trig, 1 gauss, 2 random rhs), on the device"""
+        check(lib().te_init_problem(self.h, level, problem, int(neumann), f.h, exact.h if exact is not None else None))
 
     def integrate(self, v, level=0):
         """Domain<D>::integrate (Domain.h:258-278), this rank's part"""

@@ -7,6 +7,7 @@
 #include "kernels2d.hpp"
 #include "patchsolve32.hpp"
 #include "patchsolve32_sym.hpp"
+#include "initkernels.hpp"
 #include <algorithm>
 #include <array>
 #include <atomic>
@@ -168,6 +169,8 @@ struct LevelHost {
 	}
 	// compact x-face columns of the level's current iterate inside te_vcycle (ping-pong with the sweeps'
 	// out-of-place output); xf_valid_for = the data pointer they describe, or null
+	DevBuf<double>  geom_starts, geom_h; // [P][3] lower corner and spacings (te_init_problem)
+	DevBuf<int32_t> node_ids;            // [P] tree node ids
 	DevBuf<double> cellvol;          // [P] product of the spacings (te_integrate)
 	std::vector<double> patch_vol;   // [P] product of the patch lengths (te_volume)
 	DevBuf<double> f6buf;            // [P][6][n^2]: the six face layers of an iterate that is never stored (opts.fuse = 3)
@@ -539,6 +542,19 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		HIPCHK(hipMemset(L->fcorr.p, 0, sizeof(double) * L->fcorr.n));
 	}
 	if (D == 3 && L->fuse2_ok && P > 0 && (rc = L->rs6.alloc((size_t) P * 6 * L->nf / 4))) return rc;
+	{
+		std::vector<double>  gs((size_t) P * 3, 0.0), gh((size_t) P * 3, 1.0);
+		std::vector<int32_t> ids(P);
+		for (int p = 0; p < P; p++) {
+			const int gp = lv.l2g[p];
+			ids[p]       = lv.g_id[gp];
+			for (int a = 0; a < D; a++) {
+				gs[(size_t) p * 3 + a] = lv.g_starts[(size_t) gp * D + a];
+				gh[(size_t) p * 3 + a] = lv.g_lengths[(size_t) gp * D + a] / n;
+			}
+		}
+		if ((rc = L->geom_starts.upload(gs)) || (rc = L->geom_h.upload(gh)) || (rc = L->node_ids.upload(ids))) return rc;
+	}
 	if ((rc = L->cellvol.upload(cellvol))) return rc;
 	{
 		std::vector<int32_t> fkp(fk);
@@ -2311,6 +2327,48 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 	return done(TE_OK);
 }
 
+// Init::initDirichlet / initNeumann for the drivers' canned problems, on the device (initkernels.hpp)
+int te_init_problem(te_gmg *g, int level, int problem, int neumann, te_vec *f, te_vec *exact)
+{
+	int rc;
+	if ((rc = checkLevelVec(g, level, f, "te_init_problem"))) return rc;
+	if (exact && (rc = checkLevelVec(g, level, exact, "te_init_problem"))) return rc;
+	if (exact == f) return te::fail(TE_EINVAL, "te_init_problem: f and exact must be different vectors");
+	LevelHost &L = *g->levels[level];
+	if (L.xf_valid_for == f->d || (exact && L.xf_valid_for == exact->d)) L.xf_valid_for = nullptr;
+	if (L.P == 0) return TE_OK;
+	InitGeom G;
+	G.dim = L.dim, G.n = L.n, G.P = L.P;
+	G.starts = L.geom_starts.p, G.h = L.geom_h.p, G.face_kind = L.face_kind.p, G.ids = L.node_ids.p;
+	const dim3 grid(gridFor(f->n, 256, 1 << 20)), blk(256);
+	double    *e = exact ? exact->d : nullptr;
+	Timed      t(g, KC_VECOP, f->n);
+#define TE_INIT(K, PROB)                                                                              \
+	if (neumann)                                                                                      \
+		hipLaunchKernelGGL((K<PROB, true>), grid, blk, 0, g->stream, G, f->d, e);                     \
+	else                                                                                              \
+		hipLaunchKernelGGL((K<PROB, false>), grid, blk, 0, g->stream, G, f->d, e);
+	if (problem == PROBLEM_RANDOM) {
+		hipLaunchKernelGGL(k_init_random, grid, blk, 0, g->stream, G, L.nc, (uint64_t) 0x5EED, f->d, e);
+	} else if (problem == PROBLEM_TRIG) {
+		if (L.dim == 3) {
+			TE_INIT(k_init3d, PROBLEM_TRIG)
+		} else {
+			TE_INIT(k_init2d, PROBLEM_TRIG)
+		}
+	} else if (problem == PROBLEM_GAUSS) {
+		if (L.dim == 3) {
+			TE_INIT(k_init3d, PROBLEM_GAUSS)
+		} else {
+			TE_INIT(k_init2d, PROBLEM_GAUSS)
+		}
+	} else {
+		return te::fail(TE_EINVAL, "te_init_problem: unknown problem");
+	}
+#undef TE_INIT
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
 // StarPatchOp<D>::apply (StarPatchOp.h:204-319; twins SevenPtPatchOperator.cpp:247-409, FivePtPatchOperator.h:172-261):
 // f = A_patch u, every face with a neighbour closed as homogeneous Dirichlet (ghost = -m) -- the operator the exact
 // patch solves invert (PatchSolvers/BiCGStabSolver.h:82-85 applies it). Same kernel as te_apply with patch-local face kinds.
