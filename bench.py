@@ -120,8 +120,18 @@ def cpu_baseline(size, dim, n):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = ncpu
-    # the GPU boxes of this pool grant 16 CPUs per GPU; TE_CPU_THREADS overrides
-    threads_all = int(os.environ.get("TE_CPU_THREADS", min(avail, 16)))
+    # cores this job may really use: the cgroup CPU quota when there is one (the GPU boxes of this pool grant a share
+    # of the host per GPU), else the affinity mask, capped at the physical cores (SMT siblings do not help a
+    # bandwidth-bound stencil); TE_CPU_THREADS overrides
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    phys = max(1, ncpu // 2)
+    threads_all = int(os.environ.get("TE_CPU_THREADS", min(avail, quota or avail, phys)))
 
     def run(sz, threads, smoother, budget):
         m = capi.Mesh.uniform(dim, int(round(np.log2(sz // n))))
@@ -148,7 +158,7 @@ def cpu_baseline(size, dim, n):
     return {"value": head["updates_per_s"], "unit": "lattice-site updates/s", "cores": threads_all, "kind": "port",
             "sample": f"{size}^{dim} uniform (the benchmarked workload), V(1,1), the reference's block-Jacobi patch-solve "
                       f"smoother, median of {head['cycles']} cycles, {threads_all} OpenMP threads",
-            "ms_per_step": head["ms_per_cycle"], "cpu_model": cpu_model(), "nproc": ncpu, "cpus_available_to_job": avail,
+            "ms_per_step": head["ms_per_cycle"], "cpu_model": cpu_model(), "nproc": ncpu, "cpus_available_to_job": avail, "cgroup_cpu_quota": quota,
             "runs": rows,
             "note": "CPU restatement of the reference algorithm (oracle/te_oracle.cpp), not the reference binary "
                     "(PETSc/FFTW/Zoltan are absent); 1-thread rows = one reference MPI rank, on a 2x-per-axis smaller grid"}

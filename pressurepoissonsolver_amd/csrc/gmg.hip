@@ -129,6 +129,7 @@ struct LevelHost {
 	// patch solve
 	DevBuf<int32_t> plan, zero_mode;
 	DevBuf<double>  mats, lam, corr; // corr: [P][6][n^2] interface terms of the patch right-hand sides
+	DevBuf<double>  matsT;           // 2D: the transform matrices transposed (k_patch_solve2d_lds)
 	DevBuf<double>  matsym;          // half matrices in MFMA fragment order (patchsolve32_sym.hpp), 32^3 patches
 	bool            sym_ok = false;  // every plan of the level has pure (DST-II/III or DCT-II/III) axes
 	DevBuf<int32_t> ps_list;         // otherwise: [patches with pure axes (n_pure) | the others]
@@ -179,6 +180,7 @@ struct LevelHost {
 	DevBuf<double> fcorr;
 	bool           f_has_corr = false;
 	DevBuf<double> rs6; // [P][6][(n/2)^2]: the 2x2 sums of the face layers, as the producer of the next level's fcorr
+	DevBuf<double> e4buf; // 2D: [P][4][n] edge layers of an iterate that is never stored (the 2D twin of f6buf)
 	const double  *pack_f6 = nullptr; // set while that iterate is the one whose faces travel to other ranks
 	DevBuf<double> xfbuf[2];
 	int            xf_cur       = 0;
@@ -641,6 +643,13 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 				if ((rc = L->ps_list.upload(lst))) return rc;
 			}
 		}
+		if (D == 2 && n <= 64) {
+			std::vector<double> mt(mats.size());
+			for (size_t m = 0; m < mats.size() / ((size_t) n * n); m++)
+				for (int i = 0; i < n; i++)
+					for (int j = 0; j < n; j++) mt[m * n * n + (size_t) j * n + i] = mats[m * n * n + (size_t) i * n + j];
+			if ((rc = L->matsT.upload(mt))) return rc;
+		}
 		if ((rc = L->corr.alloc((size_t) std::max(P, 1) * NS * L->nf))) return rc;
 		if ((rc = L->plan.upload(plan)) || (rc = L->mats.upload(mats)) || (rc = L->lam.upload(lam))
 		    || (rc = L->zero_mode.upload(zm)))
@@ -724,6 +733,10 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		if (D == 2 && L->lds2d && up.empty() && down.empty()) {
 			L->fuse2d          = true;
 			L->prolong_fusable = (L->nslots == 0 && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
+		}
+		if (D == 2 && L->fuse2d && L->prolong_fusable && !getenv("TE_NO_FUSE2")) { // the 3D fusions in 2D (kernels2d.hpp)
+			L->fuse2_ok = true;
+			if ((rc = L->e4buf.alloc((size_t) std::max(P, 1) * 4 * n))) return rc;
 		}
 		L->n_up    = (int) up.size();
 		L->n_down  = (int) down.size();
@@ -1065,11 +1078,45 @@ int residRestrict2d(te_gmg *g, LevelHost &L, const double *u, const double *f, d
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
-int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1)
+// *swapped: the result went to s1 (= L.t) instead of u: the caller exchanges the two vectors' buffers
+int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1, bool zero_guess, bool *swapped)
 {
-	int rc = prepareGhosts2d(g, L, u);
-	if (rc) return rc;
+	*swapped = false;
+	int          rc;
 	const size_t total = (size_t) L.P * L.nc;
+	if (L.n <= 64 && L.matsT.p && !getenv("TE_2D_SIMPLE")) { // one launch, the patch in LDS
+		if (!zero_guess && (rc = prepareGhosts2d(g, L, u))) return rc;
+		const size_t lds = sizeof(double) * 2 * L.nc;
+		Timed        t(g, KC_PS_MFMA, total);
+#define TE_PS2(Z, NC, T)                                                                                                     \
+	hipLaunchKernelGGL((k_patch_solve2d_lds<Z, NC, T>), dim3(L.P), dim3(T), lds, g->stream, L.dev2(), L.plan.p, L.mats.p, \
+	                   L.matsT.p, L.lam.p, L.zero_mode.p, f, u, s1)
+		const bool wide = L.n == 64 && L.P <= 128; // few patches: sixteen waves per patch
+		if (zero_guess) {
+			if (wide)
+				TE_PS2(true, 64, 1024);
+			else if (L.n == 64)
+				TE_PS2(true, 64, 256);
+			else
+				TE_PS2(true, 0, 256);
+		} else {
+			if (wide)
+				TE_PS2(false, 64, 1024);
+			else if (L.n == 64)
+				TE_PS2(false, 64, 256);
+			else
+				TE_PS2(false, 0, 256);
+		}
+#undef TE_PS2
+		HIPCHK(hipGetLastError());
+		*swapped = true;
+		return TE_OK;
+	}
+	if (zero_guess) {
+		Timed t(g, KC_VECOP, total);
+		HIPCHK(hipMemsetAsync(u, 0, sizeof(double) * total, g->stream));
+	}
+	if ((rc = prepareGhosts2d(g, L, u))) return rc;
 	const dim3   grid(gridFor(total, 256, 65536)), blk(256);
 	{
 		Timed t(g, KC_PATCH_RHS, total);
@@ -1117,6 +1164,46 @@ int prolong2d(te_gmg *g, LevelHost &L, const double *coarse, double *fine)
 	Timed t(g, KC_PROLONG, (size_t) L.P * L.nc);
 	hipLaunchKernelGGL(k_prolong2d, dim3(gridFor((size_t) L.P * L.nc, 256, 65536)), dim3(256), 0, g->stream, L.n, L.P, L.parent.p,
 	                   L.orth.p, coarse, L.upbuf.p, L.up_off.p, fine);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
+// opts.fuse = 2 / 3 in 2D (levels with L.fuse2_ok: patches in LDS, every parent and neighbour local): see kernels2d.hpp
+int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, bool store_u)
+{
+	if (L.P == 0) return TE_OK;
+	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
+	Prolong2D    dst{L.parent.p, L.orth.p, nullptr};
+	{
+		Timed t(g, store_u ? KC_ZERO_RESID : KC_ZERO_RESID_FACES, (size_t) L.P * L.nc);
+		if (store_u && L.n == 64)
+			hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<true, 64>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, coarse);
+		else if (store_u)
+			hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<true, 0>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, coarse);
+		else if (L.n == 64)
+			hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<false, 64>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, coarse);
+		else
+			hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<false, 0>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, coarse);
+	}
+	{
+		Timed t(g, KC_FIXUP, (size_t) L.P * 4 * L.nf);
+		hipLaunchKernelGGL(k_restrict_fixup2d, dim3(L.P), dim3(64), 0, g->stream, L.dev2(), out,
+		                   store_u ? (const double *) nullptr : (const double *) L.e4buf.p, dst, coarse);
+	}
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+int resweepProlong2d(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from)
+{
+	if (L.P == 0) return TE_OK;
+	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
+	Timed        t(g, KC_RESWEEP, (size_t) L.P * L.nc);
+	if (L.n == 64)
+		hipLaunchKernelGGL(k_rbgs_resweep_prolong2d_lds<64>, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
+		                   Prolong2D{L.parent.p, L.orth.p, prolong_from});
+	else
+		hipLaunchKernelGGL(k_rbgs_resweep_prolong2d_lds<0>, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
+		                   Prolong2D{L.parent.p, L.orth.p, prolong_from});
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
@@ -1308,6 +1395,7 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 int resweepProlong(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from, double *xf_out,
                    const double *fcorr_in)
 {
+	if (L.dim == 2) return resweepProlong2d(g, L, f, out, prolong_from);
 	switch (L.n) {
 		case 4: return resweepProlongN<4>(g, L, f, out, prolong_from, xf_out, fcorr_in);
 		case 8: return resweepProlongN<8>(g, L, f, out, prolong_from, xf_out, fcorr_in);
@@ -1363,6 +1451,7 @@ int interfaceResidRestrict(te_gmg *g, LevelHost &L, const double *u, const doubl
 int zeroSweepResid(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out, bool store_u,
                    double *fcorr_out = nullptr, const double *fcorr_in = nullptr)
 {
+	if (L.dim == 2) return zeroSweepResid2d(g, L, f, out, coarse, store_u);
 	switch (L.n) {
 		case 4: return zeroSweepResidN<4>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in);
 		case 8: return zeroSweepResidN<8>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in);
@@ -1553,11 +1642,18 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 	return TE_OK;
 }
 int patchSolve(te_gmg *g, LevelHost &L, const double *f, double *u, bool zero_guess = false,
-               const double *prolong_from = nullptr)
+               const double *prolong_from = nullptr, bool *swapped = nullptr)
 {
+	bool dummy;
+	if (!swapped) swapped = &dummy;
+	*swapped = false;
 	if (L.P == 0) return TE_OK;
 	double *s0 = L.r->d, *s1 = L.t->d;
-	if (L.dim == 2) return patchSolve2d(g, L, f, u, s0, s1);
+	if (L.dim == 2) {
+		int rc = patchSolve2d(g, L, f, u, s0, s1, zero_guess, swapped);
+		if (rc == TE_OK && *swapped && swapped == &dummy) return te::fail(TE_ESTATE, "patchSolve: 2D result left in scratch");
+		return rc;
+	}
 	switch (L.n) {
 		case 4: return patchSolveN<4>(g, L, f, u, s0, s1, zero_guess, prolong_from);
 		case 8: return patchSolveN<8>(g, L, f, u, s0, s1, zero_guess, prolong_from);
@@ -1650,7 +1746,12 @@ int smoothOnce(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, d
 	int        rc;
 	const bool xfok = (L.dim == 3 && g->in_cycle); // outside te_vcycle nobody keeps xf_valid_for honest
 	switch (smoother) {
-		case TE_SMOOTH_PATCH_SOLVE: return patchSolve(g, L, f->d, u->d, zero_guess); // keeps xf_valid_for itself
+		case TE_SMOOTH_PATCH_SOLVE: { // keeps xf_valid_for itself
+			bool swapped = false;
+			rc           = patchSolve(g, L, f->d, u->d, zero_guess, nullptr, &swapped);
+			if (rc == TE_OK && swapped) swapData(u, L.t.get()); // (2D: out of place)
+			return rc;
+		}
 		case TE_SMOOTH_JACOBI:
 			L.xf_valid_for = nullptr;
 			rc = launchStencil<MODE_JACOBI>(g, L, u->d, f->d, L.t->d, omega);
@@ -1744,7 +1845,8 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 				swapData(u, L.t.get());
 				continue;
 			}
-			if (u_zero && ((L.dim == 3 && (sm == TE_SMOOTH_RBGS || sm == TE_SMOOTH_PATCH_SOLVE)) || (L.lds2d && sm == TE_SMOOTH_RBGS))) {
+			if (u_zero && ((L.dim == 3 && (sm == TE_SMOOTH_RBGS || sm == TE_SMOOTH_PATCH_SOLVE)) || (L.lds2d && sm == TE_SMOOTH_RBGS)
+			               || (L.dim == 2 && sm == TE_SMOOTH_PATCH_SOLVE))) {
 				u_zero = false;
 				r      = smoothOnce(g, l, f, u, sm, o->omega, true);
 			} else {
@@ -1816,7 +1918,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 			swapData(u, L.t.get());
 		}
 		have_coarse_f = true;
-	} else if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_PATCH_SOLVE && L.fuse2_ok
+	} else if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_PATCH_SOLVE && L.fuse2_ok && L.dim == 3
 	           && !getenv("TE_NO_FUSE2")) {
 		// block Jacobi from the zero iterate: the residual lives on the face layers only (interfaceResidRestrictN)
 		u_zero = false;
@@ -2010,6 +2112,17 @@ int te_gmg_exchange_selftest(te_gmg *g, int n)
 	HIPCHK(hipStreamSynchronize(g->stream));
 	for (int i = 0; i < n; i++)
 		if (back[i] != h[i]) return te::fail(TE_ESTATE, "te_gmg_exchange_selftest: data mismatch");
+	if (g->rccl.comm) { // the scalar reduction of te_bicgstab / te_gmg_verify_schedule: ncclAllReduce on the solver stream
+		const double v[4] = {1.5, -2.25, 3.0, 0.125};
+		HIPCHK(hipMemcpyAsync(g->result.p, v, sizeof v, hipMemcpyHostToDevice, g->stream));
+		constexpr int ncclFloat64 = 8, ncclSum = 0;
+		int r2 = g->rccl.AllReduce(g->result.p, g->result.p, 4, ncclFloat64, ncclSum, g->rccl.comm, g->stream);
+		if (r2) return te::fail(TE_ESTATE, std::string("ncclAllReduce failed: ") + g->rccl.GetErrorString(r2));
+		HIPCHK(hipMemcpyAsync(g->result_host, g->result.p, sizeof v, hipMemcpyDeviceToHost, g->stream));
+		HIPCHK(hipStreamSynchronize(g->stream));
+		for (int i = 0; i < 4; i++)
+			if (g->result_host[i] != v[i] * g->nranks) return te::fail(TE_ESTATE, "te_gmg_exchange_selftest: all-reduce mismatch");
+	}
 	return TE_OK;
 }
 

@@ -264,6 +264,213 @@ __global__ __launch_bounds__(256) void k_resid_restrict2d_lds(Level2D L, const d
 	}
 }
 
+// ---- the 3D fusions in 2D (opts.fuse = 2 and 3; levels whose patches fit in LDS, all parents and neighbours local) ----
+// v = S(0, f): the zero-guess sweep of one patch entirely in LDS -- the arithmetic of k_rbgs2d_lds<ZERO> (the halo ring of
+// a zero iterate is zero). The tile must hold zeros on entry; on exit it holds v, ring still zero. The right-hand side
+// sits in registers (fr[k] = the x-pair number tid + 256 k of the patch, loaded once, 16 B per lane): the kernels that
+// sweep twice read f once, and no global load sits between two barriers.
+constexpr int F2D_MAX = 8; // pairs per thread: n <= 64 with 256 threads
+struct F2D { // (named scalars: an array of double2 indexed in an unrolled loop ended up in scratch memory)
+	double x0, y0, x1, y1, x2, y2, x3, y3, x4, y4, x5, y5, x6, y6, x7, y7;
+};
+#define TE_F2D_EACH(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+__device__ __forceinline__ void loadF2d(const double *fp, int nn, F2D &fr)
+{
+#define TE_LD(K)                                                                                          \
+	{                                                                                                     \
+		const int     i = threadIdx.x + K * 256;                                                          \
+		const double2 v = (i < nn / 2) ? reinterpret_cast<const double2 *>(fp)[i] : double2{0.0, 0.0};    \
+		fr.x##K = v.x, fr.y##K = v.y;                                                                     \
+	}
+	TE_F2D_EACH(TE_LD)
+#undef TE_LD
+}
+template <int COLOUR>
+__device__ __forceinline__ void halfSweep2d(double *tile, const double *idg, const F2D &fr, int n, double rhx, double rhy)
+{
+	const int lw = n + 2, nn = n * n;
+#define TE_RX(K)                                                                                          \
+	{                                                                                                     \
+		const int i = threadIdx.x + K * 256;                                                              \
+		if (i < nn / 2) {                                                                                 \
+			const int y = (2 * i) / n, odd = (y + COLOUR) & 1, x = (2 * i) % n + odd;                     \
+			double   *t0 = tile + (y + 1) * lw + x + 1;                                                   \
+			const int cx = (x == 0) ? 0 : (x == n - 1 ? 2 : 1), cy = (y == 0) ? 0 : (y == n - 1 ? 2 : 1); \
+			const double o = offdiag2d(t0[-1], t0[1], t0[-lw], t0[lw], rhx, rhy);                         \
+			double       fa = fr.x##K, fb = fr.y##K;                                                      \
+			asm volatile("" : "+v"(fa), "+v"(fb)); /* (a select of registers, not an indexed stack slot) */ \
+			*t0 = (o - (odd ? fb : fa)) / idg[cx + 3 * cy];                                               \
+		}                                                                                                 \
+	}
+	TE_F2D_EACH(TE_RX)
+#undef TE_RX
+	__syncthreads();
+}
+__device__ __forceinline__ void sweep2d(double *tile, const double *idg, const F2D &fr, int n, double rhx, double rhy)
+{
+	halfSweep2d<0>(tile, idg, fr, n, rhx, rhy);
+	halfSweep2d<1>(tile, idg, fr, n, rhx, rhy);
+}
+__device__ __forceinline__ void idiag2d(const Level2D &L, int p, double rhx, double rhy, double *idg)
+{
+	if (threadIdx.x < 9) {
+		const int    cx = threadIdx.x % 3, cy = threadIdx.x / 3;
+		const double kx = 2.0 + (cx == 0 ? kfold2d(L, p, 0) : 0.0) + (cx == 2 ? kfold2d(L, p, 1) : 0.0);
+		const double ky = 2.0 + (cy == 0 ? kfold2d(L, p, 2) : 0.0) + (cy == 2 ? kfold2d(L, p, 3) : 0.0);
+		idg[threadIdx.x] = kx * rhx + ky * rhy;
+	}
+}
+// Cycle.h:57-65 for the first sweep of a cycle in one pass over f (the 2D twin of k_rbgs_zero_resid3d): u = S(0, f),
+// coarse f = AvgRstr(f - A u) with a zero ghost on faces that have a neighbour (k_restrict_fixup2d adds that term from the
+// neighbours' edge layers afterwards). STORE_U: u is written (16 + 2 B per site); otherwise only its four edge layers
+// e4 [P][4][n] (opts.fuse = 3: k_rbgs_resweep_prolong2d_lds recomputes u from f): 8 + 2 B per site.
+// NC: the patch size as a compile-time constant (0: run-time L.n) -- every cell's (x, y) comes from an integer division by n,
+// dozens of instructions each at run time, shifts for NC = 64 (config C5)
+template <bool STORE_U, int NC>
+__global__ __launch_bounds__(256) void k_rbgs_zero_resid2d_lds(Level2D L, const double *__restrict__ f, double *__restrict__ out,
+                                                               double *__restrict__ e4, Prolong2D dst, double *__restrict__ coarse)
+{
+	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // (n+2) x (n+2), then 9 diagonals
+	const int     n = NC ? NC : L.n, lw = n + 2, nn = n * n, h = n / 2;
+	const int     p = blockIdx.x, tid = threadIdx.x;
+	const double *fp = f + (size_t) p * nn;
+	double       *idg = tile2d + lw * lw;
+	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
+	F2D fr;
+	loadF2d(fp, nn, fr);
+	idiag2d(L, p, rhx, rhy, idg);
+	for (int i = tid; i < lw * lw; i += blockDim.x) tile2d[i] = 0.0;
+	__syncthreads();
+	sweep2d(tile2d, idg, fr, n, rhx, rhy);
+	// the new iterate's edges (and the iterate itself), then the residual's ghost ring: physical faces -own / +own
+	// (StarPatchOp.h:39-65), faces with a neighbour 0
+	for (int i = tid; i < 4 * n; i += blockDim.x) {
+		const int    s = i / n, t = i % n;
+		const int    in = (s == 0) ? (t + 1) * lw + 1 : (s == 1) ? (t + 1) * lw + n : (s == 2) ? lw + t + 1 : n * lw + t + 1;
+		const int    ring = (s == 0) ? (t + 1) * lw : (s == 1) ? (t + 1) * lw + n + 1 : (s == 2) ? t + 1 : (n + 1) * lw + t + 1;
+		const double own = tile2d[in];
+		if (!STORE_U) e4[((size_t) p * 4 + s) * n + t] = own;
+		const int kind = L.face_kind[p * 4 + s];
+		tile2d[ring]   = kind == FACE_DIRICHLET ? -own : (kind == FACE_NEUMANN ? own : 0.0);
+	}
+	if (STORE_U)
+		for (int i = tid; i < nn / 2; i += blockDim.x) {
+			const int y = (2 * i) / n, x = (2 * i) % n;
+			reinterpret_cast<double2 *>(out + (size_t) p * nn)[i] = double2{tile2d[(y + 1) * lw + x + 1], tile2d[(y + 1) * lw + x + 2]};
+		}
+	__syncthreads();
+	const int pa = dst.parent[p], o = dst.orth[p];
+	double   *cp = coarse + (size_t) pa * nn + ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0);
+	for (int i = tid; i < h * h; i += blockDim.x) { // as k_resid_restrict2d_lds
+		const int hx = i % h, hy = i / h;
+		double    acc = 0.0;
+#pragma unroll
+		for (int dy = 0; dy < 2; dy++) {
+			const int     y = 2 * hy + dy, x = 2 * hx;
+			const double *t0 = tile2d + (y + 1) * lw + x + 1;
+			const double2 fv = *reinterpret_cast<const double2 *>(fp + x + n * y);
+			acc += (fv.x - lap2d(t0[-1], t0[0], t0[1], t0[-lw], t0[lw], rhx, rhy)) / 4;
+			acc += (fv.y - lap2d(t0[0], t0[1], t0[2], t0[1 - lw], t0[1 + lw], rhx, rhy)) / 4;
+		}
+		cp[hx + n * hy] = acc;
+	}
+}
+// the ghost terms the kernel above left out: for every face with a (local) neighbour, -(1/h^2)/4 * (the two neighbour
+// values behind a pair of face cells) is added to the coarse cell behind the pair; faces in the order W,E,S,N.
+// edges = e4 of the new iterate, or null: read them from u.
+__global__ __launch_bounds__(64) void k_restrict_fixup2d(Level2D L, const double *__restrict__ u, const double *__restrict__ e4,
+                                                         Prolong2D dst, double *__restrict__ coarse)
+{
+	const int n = L.n, nn = n * n, h = n / 2, p = blockIdx.x;
+	const int pa = dst.parent[p], o = dst.orth[p];
+	double   *cb = coarse + (size_t) pa * nn + ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0);
+	for (int s = 0; s < 4; s++) {
+		if (L.face_kind[p * 4 + s] == FACE_LOCAL) {
+			const int    src = L.face_src[p * 4 + s], ax = s >> 1;
+			const double w   = -L.rh2[p * 3 + ax];
+			for (int i = threadIdx.x; i < h; i += blockDim.x) {
+				double acc = 0.0;
+#pragma unroll
+				for (int d = 0; d < 2; d++) {
+					const int    t = 2 * i + d;
+					const double g = e4 ? e4[((size_t) src * 4 + (s ^ 1)) * n + t]
+					                    : u[(size_t) src * nn + (s == 0 ? n - 1 + n * t : (s == 1 ? n * t : (s == 2 ? t + n * (n - 1) : t)))];
+					acc += (w * g) / 4;
+				}
+				cb[ax == 0 ? ((s & 1) ? h - 1 : 0) + n * i : i + n * ((s & 1) ? h - 1 : 0)] += acc;
+			}
+		}
+		__syncthreads();
+	}
+}
+// opts.fuse = 3, post-smoothing: out = S(v + P(coarse), f) with v = S(0, f) recomputed in LDS (its neighbours' edges
+// come from e4): read f, 1/4 coarse, edges; write u -- 18.5 B per site instead of 26, and the pre-sweep kernel writes
+// no u at all. Same arithmetic as k_rbgs_zero_resid2d_lds followed by k_rbgs2d_lds<false, true>: bit-identical.
+template <int NC>
+__global__ __launch_bounds__(256) void k_rbgs_resweep_prolong2d_lds(Level2D L, const double *__restrict__ f, const double *__restrict__ e4,
+                                                                    double *__restrict__ out, Prolong2D ps)
+{
+	extern __shared__ __attribute__((aligned(16))) double tile2d[];
+	const int     n = NC ? NC : L.n, lw = n + 2, nn = n * n;
+	const int     p = blockIdx.x, tid = threadIdx.x;
+	const double *fp = f + (size_t) p * nn;
+	double       *idg = tile2d + lw * lw;
+	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
+	F2D fr;
+	double  cr[F2D_MAX]; // the coarse correction of each pair, requested before the recompute needs the memory pipeline
+	loadF2d(fp, nn, fr);
+#pragma unroll
+	for (int k = 0; k < F2D_MAX; k++) {
+		const int i = tid + k * 256;
+		cr[k]       = (i < nn / 2) ? coarseAt2d(ps, n, p, (2 * i) % n, (2 * i) / n) : 0.0;
+	}
+	// the halo ring of the sweep: the neighbours' facing values of v + P(coarse); physical faces folded -> 0
+	double hv[2] = {0.0, 0.0};
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const int i = tid + k * 256;
+		if (i < 4 * n) {
+			const int s = i / n, t = i % n;
+			if (L.face_kind[p * 4 + s] == FACE_LOCAL) {
+				const int src = L.face_src[p * 4 + s];
+				hv[k] = e4[((size_t) src * 4 + (s ^ 1)) * n + t];
+				hv[k] += coarseAt2d(ps, n, src, s == 0 ? n - 1 : (s == 1 ? 0 : t), s == 2 ? n - 1 : (s == 3 ? 0 : t));
+			}
+		}
+	}
+	idiag2d(L, p, rhx, rhy, idg);
+	for (int i = tid; i < lw * lw; i += blockDim.x) tile2d[i] = 0.0;
+	__syncthreads();
+	sweep2d(tile2d, idg, fr, n, rhx, rhy); // v
+#pragma unroll
+	for (int k = 0; k < F2D_MAX; k++) { // w = v + P(coarse), as k_rbgs2d_lds<false, true> forms it while loading
+		const int i = tid + k * 256;
+		if (i < nn / 2) {
+			const int y = (2 * i) / n, x = (2 * i) % n;
+			tile2d[(y + 1) * lw + x + 1] += cr[k];
+			tile2d[(y + 1) * lw + x + 2] += cr[k];
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < 2; k++) {
+		const int i = tid + k * 256;
+		if (i < 4 * n) {
+			const int s = i / n, t = i % n;
+			tile2d[(s == 0) ? (t + 1) * lw : (s == 1) ? (t + 1) * lw + n + 1 : (s == 2) ? t + 1 : (n + 1) * lw + t + 1] = hv[k];
+		}
+	}
+	__syncthreads();
+	sweep2d(tile2d, idg, fr, n, rhx, rhy);
+#pragma unroll
+	for (int k = 0; k < F2D_MAX; k++) {
+		const int i = tid + k * 256;
+		if (i < nn / 2) {
+			const int y = (2 * i) / n, x = (2 * i) % n;
+			reinterpret_cast<double2 *>(out + (size_t) p * nn)[i] = double2{tile2d[(y + 1) * lw + x + 1], tile2d[(y + 1) * lw + x + 2]};
+		}
+	}
+}
+
 // ghost slots of coarse/fine faces: 2*gamma - m, weights of BilinearInterpolator.cpp:76-115.
 // desc[8] = {patch, side, kind (2 = my neighbour is coarser, 3 = finer), half of the coarse face, nbr0, nbr1, -, -}
 __global__ void k_cf_ghost2d(int n, const int32_t *__restrict__ desc, const int32_t *__restrict__ slots,
@@ -431,6 +638,126 @@ __global__ __launch_bounds__(256) void k_dst_axis2d(int n, int P, const int32_t 
 		}
 		if (STAGE == 3) acc *= 4.0 / ((double) n * n);
 		out[idx] = acc;
+	}
+}
+
+// The same exact patch solve for patches that fit in LDS twice (n <= 64), ONE launch: right-hand side with the interface
+// terms, the four dense transform passes and the eigenvalue division on two LDS tiles, one workgroup per patch -- 16 B per
+// site instead of 24 + 4 x 16, and one kernel's latency instead of five on the coarsest level of a cycle (a single patch:
+// 78 us for five launches). Sums in the order of k_dst_axis2d. matsT: the same matrices transposed (x passes: lanes run
+// along the output index, so the matrix element must be contiguous across lanes). ZERO: the iterate is zero (no interface
+// term, u never read). Out of place: block Jacobi reads the neighbours' OLD face values, and another workgroup may be done
+// with its patch before this one starts.
+// TPB: threads per workgroup (256, or 1024 on levels with few patches: a single patch is a serial chain of four passes, and
+// sixteen waves shorten each of them four times)
+template <bool ZERO, int NC, int TPB = 256>
+__global__ __launch_bounds__(TPB) void k_patch_solve2d_lds(Level2D L, const int32_t *__restrict__ plan, const double *__restrict__ mats,
+                                                           const double *__restrict__ matsT, const double *__restrict__ lam,
+                                                           const int32_t *__restrict__ zero_mode, const double *__restrict__ f,
+                                                           const double *__restrict__ u, double *__restrict__ out)
+{
+	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // two tiles of n*n
+	const int     n = NC ? NC : L.n, nn = n * n;
+	const int     p = blockIdx.x, tid = threadIdx.x, pl = plan[p];
+	double       *A = tile2d, *B = tile2d + nn;
+	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
+	const double *fp = f + (size_t) p * nn, *up = u + (size_t) p * nn;
+	for (int c = tid; c < nn; c += TPB) { // k_patch_rhs2d
+		double v = fp[c];
+		if (!ZERO) {
+			const int    x = c % n, y = c / n, xy[2] = {x, y};
+			const double m = up[c];
+#pragma unroll
+			for (int ax = 0; ax < 2; ax++)
+#pragma unroll
+				for (int side = 0; side < 2; side++) {
+					if (xy[ax] != (side ? n - 1 : 0)) continue;
+					const int s = 2 * ax + side;
+					if (L.face_kind[p * 4 + s] < FACE_LOCAL) continue;
+					const double gh = ghost2d(L, u, p, s, xy[1 - ax], m, false);
+					v -= 2.0 * L.rh2[p * 3 + ax] * (0.5 * m + 0.5 * gh);
+				}
+		}
+		A[c] = v;
+	}
+	__syncthreads();
+	const double *lm = lam + (size_t) pl * 2 * n;
+	if (NC == 64) {
+		// lane l = one matrix row index, wave w: 16 outputs per thread whose sums advance together. Per j: ONE coalesced
+		// matrix load (the transposed matrix for both kinds of pass: lanes run along the OUTPUT index) and 16 LDS
+		// broadcast reads; sums in j order as k_dst_axis2d.
+		constexpr int WV = TPB / 64, KPT = 64 / WV; // waves, outputs per thread
+		const int     l = tid & 63, w = tid >> 6;
+#pragma unroll 1
+		for (int stage = 0; stage < 4; stage++) {
+			const int     ax = stage & 1;
+			const double *MT = matsT + ((size_t) pl * 4 + stage) * nn;
+			const double *in = (stage & 1) ? B : A;
+			double       *o  = (stage & 1) ? A : B;
+			double        acc[KPT];
+#pragma unroll
+			for (int k = 0; k < KPT; k++) acc[k] = 0.0;
+			// x pass: output (i = l, y = w + WV k) = sum_j M[l][j] in[y][j];  y pass: output (i = l, x = w + WV k) = sum_j M[l][j] in[j][x]
+			const int bs = ax ? 1 : 64, js = ax ? 64 : 1; // input element of output k at step j: in[(w + WV k) * bs + j * js]
+			// this lane's matrix column in chunks of eight, the next chunk requested while the current one is used (with one
+			// workgroup on the chip -- the coarsest level -- a load per step would cost a memory round trip per step)
+			double ma[8], mb[8];
+#pragma unroll
+			for (int jj = 0; jj < 8; jj++) ma[jj] = MT[jj * 64 + l];
+#pragma unroll 1
+			for (int jc = 0; jc < 64; jc += 8) {
+				const int jn = (jc + 8 < 64) ? jc + 8 : jc;
+#pragma unroll
+				for (int jj = 0; jj < 8; jj++) mb[jj] = MT[(jn + jj) * 64 + l];
+#pragma unroll
+				for (int jj = 0; jj < 8; jj++) {
+#pragma unroll
+					for (int k = 0; k < KPT; k++) acc[k] += ma[jj] * in[(w + WV * k) * bs + (jc + jj) * js];
+				}
+#pragma unroll
+				for (int jj = 0; jj < 8; jj++) ma[jj] = mb[jj];
+			}
+#pragma unroll
+			for (int k = 0; k < KPT; k++) {
+				const int c = ax ? l * 64 + (w + WV * k) : (w + WV * k) * 64 + l; // cell x + n y of the output
+				double    v = acc[k];
+				if (stage == 1) {
+					v /= -(lm[c % 64] * rhx + lm[64 + c / 64] * rhy);
+					if (zero_mode[pl] && c == 0) v = 0.0;
+				}
+				if (stage == 3)
+					out[(size_t) p * nn + c] = v * (4.0 / ((double) n * n));
+				else
+					o[c] = v;
+			}
+			__syncthreads();
+		}
+		return;
+	}
+#pragma unroll 1
+	for (int stage = 0; stage < 4; stage++) { // any n: the plain form
+		const int     ax = stage & 1, st = ax ? n : 1;
+		const double *M  = (ax ? mats : matsT) + ((size_t) pl * 4 + stage) * nn;
+		const double *in = (stage & 1) ? B : A;
+		double       *o  = (stage & 1) ? A : B;
+		for (int c = tid; c < nn; c += TPB) {
+			const int i = (c / st) % n, base = c - i * st;
+			double    acc = 0.0;
+			if (ax) {
+				for (int j = 0; j < n; j++) acc += M[(size_t) i * n + j] * in[base + j * st];
+			} else {
+				for (int j = 0; j < n; j++) acc += M[(size_t) j * n + i] * in[base + j];
+			}
+			if (stage == 1) {
+				acc /= -(lm[c % n] * rhx + lm[n + c / n] * rhy);
+				if (zero_mode[pl] && c == 0) acc = 0.0;
+			}
+			if (stage == 3)
+				out[(size_t) p * nn + c] = acc * (4.0 / ((double) n * n));
+			else
+				o[c] = acc;
+		}
+		__syncthreads();
 	}
 }
 } // namespace te

@@ -43,7 +43,7 @@ FULL = {
 FUSED_RBGS_3D = ("rbgs_zero_resid_restrict_faces", "rbgs_resweep_prolong", "restrict_fixup")
 FUSED_RBGS_REFINED = ("rbgs_zero_resid_restrict", "stencil_rbgs_prolong", "restrict_fixup")
 FUSED_PS_3D = ("patch_solve_mfma", "restrict_fixup")
-FUSED_2D = ("stencil_rbgs_zero", "resid_restrict", "stencil_rbgs_prolong")
+FUSED_2D = ("rbgs_zero_resid_restrict_faces", "rbgs_resweep_prolong", "restrict_fixup")
 
 
 @pytest.fixture(scope="module", params=list(FULL), ids=list(FULL))

@@ -197,6 +197,37 @@ def test_fused_presweep_residual_restrict(n, neumann, mesh, div):
             assert rel(outs[1], outs[0]) <= 1e-13
 
 
+@pytest.mark.parametrize("n,neumann,mesh,div", [(8, False, "uniform2d", 3), (16, True, "uniform2d", 3), (64, False, "uniform2d", 2)])
+def test_fused_presweep_residual_restrict_2d(n, neumann, mesh, div):
+    """The 2D twins of the fused kernels (k_rbgs_zero_resid2d_lds, k_restrict_fixup2d, k_rbgs_resweep_prolong2d_lds) on
+    uniform quadtree levels: fuse = 2 vs 1 to rounding (the ghost term of the residual is added separately), fuse = 3
+    (the iterate between the sweeps is recomputed in LDS, never stored) == fuse = 2 bit for bit, all against the oracle."""
+    m, H, levels = util.setup("uniform", n, div, neumann=neumann, dim=2)
+    g, L = capi.GMG(H), levels[0]
+    f = util.rand_vec(L.size, 55) / L.a["h"].min() ** 2
+    got = {}
+    for fuse in (1, 2, 3):
+        df, dc = g.new_vector(0, f), g.new_vector(0)
+        g.profile(True)
+        g.profile_reset()
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS, fuse=fuse), df, dc)
+        rows = g.profile_rows()
+        g.profile(False)
+        got[fuse] = dc.download()
+        assert ("rbgs_resweep_prolong" in rows) == (fuse == 3) and ("restrict_fixup" in rows) == (fuse >= 2)
+    assert not np.array_equal(got[1], got[2])
+    assert rel(got[2], got[1]) <= 1e-13
+    assert np.array_equal(got[3], got[2])
+    assert rel(got[3], orc.cycle(levels, orc.cycle_opts(smoother=2), f)) <= 1e-10
+    # W-cycle: the stored-iterate path (fuse = 2 kernels, explicit post-sweep on u + P e)
+    outs = []
+    for fuse in (1, 3):
+        df, dc = g.new_vector(0, f), g.new_vector(0)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS, fuse=fuse, cycle_type=1), df, dc)
+        outs.append(dc.download())
+    assert rel(outs[1], outs[0]) <= 1e-13
+
+
 def test_patch_solve_split_between_pure_and_mixed_axes(monkeypatch):
     """Neumann boundaries: patches that touch the boundary have a Dirichlet(interface)/Neumann axis (type-IV
     transforms, k_ps_fused), interior patches have pure DST axes (k_ps_sym); the level is split per patch.

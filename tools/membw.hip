@@ -169,6 +169,26 @@ template <int CH, int PL> __global__ __launch_bounds__(256) void copy_walk_multi
 		}
 	}
 }
+// long-lived workgroups, but at every step the grid covers ONE contiguous window: workgroup i's step z is plane z*G + i
+__global__ __launch_bounds__(256) void copy_walk_interleaved(size_t nplanes, double *a, const double *b)
+{
+	const size_t G = gridDim.x;
+	double2      x[2], xn[2];
+	size_t       pl = blockIdx.x;
+	if (pl >= nplanes) return;
+#pragma unroll
+	for (int k = 0; k < 2; k++) x[k] = ((const double2 *) b)[pl * 512 + k * 256 + threadIdx.x];
+	for (; pl < nplanes; pl += G) {
+		const size_t pn = (pl + G < nplanes) ? pl + G : pl;
+#pragma unroll
+		for (int k = 0; k < 2; k++) xn[k] = ((const double2 *) b)[pn * 512 + k * 256 + threadIdx.x];
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			((double2 *) a)[pl * 512 + k * 256 + threadIdx.x] = double2{x[k].x * 0.5, x[k].y * 0.5};
+			x[k] = xn[k];
+		}
+	}
+}
 __global__ __launch_bounds__(256) void copy_flat(size_t n2, double2 *a, const double2 *b)
 {
 	size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
@@ -250,6 +270,10 @@ int main(int argc, char **argv)
 	snprintf(nm, sizeof nm, "copy_walk_multi CH=32 PL=%d", PL);                                                           \
 	timeit(nm, n * 16.0, [&] { hipLaunchKernelGGL((copy_walk_multi<32, PL>), dim3(n / (32 * 1024)), dim3(256), 0, 0, n / (32 * 1024), a, b); });
 	WALK(1) WALK(2) WALK(4)
+	for (int G : {1024, 2048, 4096}) {
+		snprintf(nm, sizeof nm, "copy_walk_interleaved G=%d", G);
+		timeit(nm, n * 16.0, [&] { hipLaunchKernelGGL(copy_walk_interleaved, dim3(G), dim3(256), 0, 0, n / 1024, a, b); });
+	}
 	timeit("copy_flat", n * 16.0, [&] { hipLaunchKernelGGL(copy_flat, dim3(n2 / 256), dim3(256), 0, 0, n2, (double2 *) a, (const double2 *) b); });
 	return 0;
 }
