@@ -734,9 +734,16 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 			L->fuse2d          = true;
 			L->prolong_fusable = (L->nslots == 0 && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
 		}
-		if (D == 2 && L->fuse2d && L->prolong_fusable && !getenv("TE_NO_FUSE2")) { // the 3D fusions in 2D (kernels2d.hpp)
-			L->fuse2_ok = true;
-			if ((rc = L->e4buf.alloc((size_t) std::max(P, 1) * 4 * n))) return rc;
+		if (D == 2 && L->lds2d && !getenv("TE_NO_FUSE2")) { // the 3D fusions in 2D (kernels2d.hpp)
+			// a global fact, as in 3D (all ranks and every partition take the same arithmetic path): the level is uniformly
+			// refined everywhere -- no coarse/fine face, every patch a quadrant child
+			bool uniform = true;
+			for (int gp = 0; gp < lv.P_global && uniform; gp++) {
+				uniform = lv.g_orth_on_parent[gp] >= 0;
+				for (int s2 = 0; s2 < NS && uniform; s2++) uniform = lv.g_nbr_kind[(size_t) gp * NS + s2] <= NBR_NORMAL;
+			}
+			L->fuse2_ok = uniform;
+			if (uniform && (rc = L->e4buf.alloc((size_t) std::max(P, 1) * 4 * n))) return rc;
 		}
 		L->n_up    = (int) up.size();
 		L->n_down  = (int) down.size();
@@ -1171,24 +1178,44 @@ int prolong2d(te_gmg *g, LevelHost &L, const double *coarse, double *fine)
 // opts.fuse = 2 / 3 in 2D (levels with L.fuse2_ok: patches in LDS, every parent and neighbour local): see kernels2d.hpp
 int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, bool store_u)
 {
-	if (L.P == 0) return TE_OK;
 	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
 	Prolong2D    dst{L.parent.p, L.orth.p, nullptr};
-	{
+	int          rc;
+	if (L.P > 0) {
 		Timed t(g, store_u ? KC_ZERO_RESID : KC_ZERO_RESID_FACES, (size_t) L.P * L.nc);
+#define TE_ZR2(S, NC)                                                                                                             \
+	hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<S, NC>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, \
+	                   coarse, L.upbuf.p, L.up_off.p)
 		if (store_u && L.n == 64)
-			hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<true, 64>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, coarse);
+			TE_ZR2(true, 64);
 		else if (store_u)
-			hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<true, 0>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, coarse);
+			TE_ZR2(true, 0);
 		else if (L.n == 64)
-			hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<false, 64>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, coarse);
+			TE_ZR2(false, 64);
 		else
-			hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<false, 0>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, coarse);
+			TE_ZR2(false, 0);
+#undef TE_ZR2
 	}
-	{
+	if (L.nremote > 0) { // the new edge layers of neighbours on other ranks
+		{
+			Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
+			if (store_u)
+				hipLaunchKernelGGL(k_pack_faces2d, dim3(L.nremote), dim3(64), 0, g->stream, L.n, L.send_faces.p, out, L.sendbuf.p);
+			else
+				hipLaunchKernelGGL(k_pack_edges2d, dim3(L.nremote), dim3(64), 0, g->stream, L.n, L.send_faces.p, L.e4buf.p, L.sendbuf.p);
+		}
+		if ((rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p))) return rc;
+	}
+	if (L.P > 0) {
 		Timed t(g, KC_FIXUP, (size_t) L.P * 4 * L.nf);
 		hipLaunchKernelGGL(k_restrict_fixup2d, dim3(L.P), dim3(64), 0, g->stream, L.dev2(), out,
-		                   store_u ? (const double *) nullptr : (const double *) L.e4buf.p, dst, coarse);
+		                   store_u ? (const double *) nullptr : (const double *) L.e4buf.p, dst, coarse, L.upbuf.p, L.up_off.p);
+	}
+	// children whose parent lives on another rank: ship the finished blocks
+	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
+	if (L.n_down > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 4);
+		hipLaunchKernelGGL(k_restrict_unpack2d, dim3(L.n_down), dim3(256), 0, g->stream, L.n, L.down_desc.p, L.down_off.p, L.downbuf.p, coarse);
 	}
 	HIPCHK(hipGetLastError());
 	return TE_OK;

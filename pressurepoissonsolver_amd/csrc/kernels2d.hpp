@@ -326,9 +326,11 @@ __device__ __forceinline__ void idiag2d(const Level2D &L, int p, double rhx, dou
 // e4 [P][4][n] (opts.fuse = 3: k_rbgs_resweep_prolong2d_lds recomputes u from f): 8 + 2 B per site.
 // NC: the patch size as a compile-time constant (0: run-time L.n) -- every cell's (x, y) comes from an integer division by n,
 // dozens of instructions each at run time, shifts for NC = 64 (config C5)
+// A parent on another rank (dst.parent < -1): the restricted block goes to `remote` (h x h, shipped afterwards), as in 3D.
 template <bool STORE_U, int NC>
 __global__ __launch_bounds__(256) void k_rbgs_zero_resid2d_lds(Level2D L, const double *__restrict__ f, double *__restrict__ out,
-                                                               double *__restrict__ e4, Prolong2D dst, double *__restrict__ coarse)
+                                                               double *__restrict__ e4, Prolong2D dst, double *__restrict__ coarse,
+                                                               double *__restrict__ remote, const int64_t *__restrict__ remote_off)
 {
 	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // (n+2) x (n+2), then 9 diagonals
 	const int     n = NC ? NC : L.n, lw = n + 2, nn = n * n, h = n / 2;
@@ -360,7 +362,8 @@ __global__ __launch_bounds__(256) void k_rbgs_zero_resid2d_lds(Level2D L, const 
 		}
 	__syncthreads();
 	const int pa = dst.parent[p], o = dst.orth[p];
-	double   *cp = coarse + (size_t) pa * nn + ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0);
+	double   *cp = pa >= 0 ? coarse + (size_t) pa * nn + ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0) : remote + remote_off[-(pa + 2)];
+	const int cs = pa >= 0 ? n : h; // row stride of the destination
 	for (int i = tid; i < h * h; i += blockDim.x) { // as k_resid_restrict2d_lds
 		const int hx = i % h, hy = i / h;
 		double    acc = 0.0;
@@ -372,35 +375,65 @@ __global__ __launch_bounds__(256) void k_rbgs_zero_resid2d_lds(Level2D L, const 
 			acc += (fv.x - lap2d(t0[-1], t0[0], t0[1], t0[-lw], t0[lw], rhx, rhy)) / 4;
 			acc += (fv.y - lap2d(t0[0], t0[1], t0[2], t0[1 - lw], t0[1 + lw], rhx, rhy)) / 4;
 		}
-		cp[hx + n * hy] = acc;
+		cp[hx + cs * hy] = acc;
 	}
 }
 // the ghost terms the kernel above left out: for every face with a (local) neighbour, -(1/h^2)/4 * (the two neighbour
 // values behind a pair of face cells) is added to the coarse cell behind the pair; faces in the order W,E,S,N.
 // edges = e4 of the new iterate, or null: read them from u.
+// A neighbour on another rank: its edge arrived in a ghost slot. A parent on another rank: the block in `remote`.
 __global__ __launch_bounds__(64) void k_restrict_fixup2d(Level2D L, const double *__restrict__ u, const double *__restrict__ e4,
-                                                         Prolong2D dst, double *__restrict__ coarse)
+                                                         Prolong2D dst, double *__restrict__ coarse, double *__restrict__ remote,
+                                                         const int64_t *__restrict__ remote_off)
 {
 	const int n = L.n, nn = n * n, h = n / 2, p = blockIdx.x;
 	const int pa = dst.parent[p], o = dst.orth[p];
-	double   *cb = coarse + (size_t) pa * nn + ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0);
+	double   *cb = pa >= 0 ? coarse + (size_t) pa * nn + ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0) : remote + remote_off[-(pa + 2)];
+	const int cs = pa >= 0 ? n : h;
 	for (int s = 0; s < 4; s++) {
-		if (L.face_kind[p * 4 + s] == FACE_LOCAL) {
+		const int kind = L.face_kind[p * 4 + s];
+		if (kind >= FACE_LOCAL) {
 			const int    src = L.face_src[p * 4 + s], ax = s >> 1;
 			const double w   = -L.rh2[p * 3 + ax];
 			for (int i = threadIdx.x; i < h; i += blockDim.x) {
 				double acc = 0.0;
 #pragma unroll
 				for (int d = 0; d < 2; d++) {
-					const int    t = 2 * i + d;
-					const double g = e4 ? e4[((size_t) src * 4 + (s ^ 1)) * n + t]
-					                    : u[(size_t) src * nn + (s == 0 ? n - 1 + n * t : (s == 1 ? n * t : (s == 2 ? t + n * (n - 1) : t)))];
+					const int t = 2 * i + d;
+					double    g;
+					if (kind == FACE_GHOST)
+						g = L.ghost[(size_t) src * n + t];
+					else if (e4)
+						g = e4[((size_t) src * 4 + (s ^ 1)) * n + t];
+					else
+						g = u[(size_t) src * nn + (s == 0 ? n - 1 + n * t : (s == 1 ? n * t : (s == 2 ? t + n * (n - 1) : t)))];
 					acc += (w * g) / 4;
 				}
-				cb[ax == 0 ? ((s & 1) ? h - 1 : 0) + n * i : i + n * ((s & 1) ? h - 1 : 0)] += acc;
+				cb[ax == 0 ? ((s & 1) ? h - 1 : 0) + cs * i : i + cs * ((s & 1) ? h - 1 : 0)] += acc;
 			}
 		}
 		__syncthreads();
+	}
+}
+// the edge layers other ranks need, from e4 (the iterate itself was never stored)
+__global__ void k_pack_edges2d(int n, const int32_t *__restrict__ faces, const double *__restrict__ e4, double *__restrict__ sendbuf)
+{
+	const int p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
+	for (int i = threadIdx.x; i < n; i += blockDim.x) sendbuf[(size_t) blockIdx.x * n + i] = e4[((size_t) p * 4 + s) * n + i];
+}
+// restricted blocks that arrived from children on other ranks: into their quadrant of the coarse patch (as k_restrict_unpack3d)
+__global__ __launch_bounds__(256) void k_restrict_unpack2d(int n, const int32_t *__restrict__ desc, const int64_t *__restrict__ off,
+                                                           const double *__restrict__ buf, double *__restrict__ coarse)
+{
+	const int     nn = n * n, h = n / 2;
+	const int     pc = desc[2 * blockIdx.x], o = desc[2 * blockIdx.x + 1];
+	const double *b  = buf + off[blockIdx.x];
+	double       *cp = coarse + (size_t) pc * nn;
+	if (o < 0) {
+		for (int i = threadIdx.x; i < nn; i += blockDim.x) cp[i] = b[i];
+	} else {
+		const int bx = (o & 1) ? h : 0, by = (o & 2) ? h : 0;
+		for (int i = threadIdx.x; i < h * h; i += blockDim.x) cp[bx + i % h + n * (by + i / h)] = b[i];
 	}
 }
 // opts.fuse = 3, post-smoothing: out = S(v + P(coarse), f) with v = S(0, f) recomputed in LDS (its neighbours' edges
