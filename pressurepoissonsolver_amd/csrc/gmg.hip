@@ -48,13 +48,16 @@ enum KClass : int {
 	KC_DST, KC_VECOP, KC_REDUCE, KC_PACK, KC_EXCHANGE, KC_RBGS_ZERO, KC_RESID_RESTRICT, KC_PS_MFMA, KC_RBGS_PROLONG,
 	// launches on levels with few patches run other instantiations (z-slabs, split patches): classes of their own, so
 	// that a class above is one kernel symbol and its average duration is the one rocprofv3 --stats reports
-	KC_RBGS_SLABS, KC_STENCIL_SLABS, KC_PS_3PASS, KC_ZERO_RESID, KC_FIXUP, KC_RESWEEP, KC_ZERO_RESID_FACES, KC_COUNT
+	KC_RBGS_SLABS, KC_STENCIL_SLABS, KC_PS_3PASS, KC_ZERO_RESID, KC_FIXUP, KC_RESWEEP, KC_ZERO_RESID_FACES,
+	// the instantiations that read their right-hand side together with exported ghost terms (FCORR): other symbols again
+	KC_RESWEEP_FCORR, KC_ZERO_RESID_FACES_FCORR, KC_FCORR_GATHER, KC_COUNT
 };
 const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_jacobi", "stencil_rbgs",
                                     "cf_ghost", "restrict", "prolong_add", "patch_rhs", "dst_axis",
                                     "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict", "patch_solve_mfma", "stencil_rbgs_prolong",
                                     "stencil_rbgs_slabs", "stencil_slabs", "patch_solve_3pass", "rbgs_zero_resid_restrict",
-                                    "restrict_fixup", "rbgs_resweep_prolong", "rbgs_zero_resid_restrict_faces"};
+                                    "restrict_fixup", "rbgs_resweep_prolong", "rbgs_zero_resid_restrict_faces",
+                                    "rbgs_resweep_prolong_fcorr", "rbgs_zero_resid_restrict_faces_fcorr", "fcorr_gather"};
 
 template <typename T> struct DevBuf {
 	T     *p = nullptr;
@@ -1332,7 +1335,7 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	rd.rs6        = fcorr_out ? L.rs6.p : nullptr;
 	int rc;
 	if (L.P > 0) {
-		Timed      t(g, store_u ? KC_ZERO_RESID : KC_ZERO_RESID_FACES, (size_t) L.P * L.nc);
+		Timed      t(g, store_u ? KC_ZERO_RESID : (fcorr_in ? KC_ZERO_RESID_FACES_FCORR : KC_ZERO_RESID_FACES), (size_t) L.P * L.nc);
 		LevelDev   D = L.dev();
 		const dim3 grid(8 * ((L.P + 7) / 8)), blk(Tile3<N>::TPB);
 		if (store_u) {
@@ -1359,7 +1362,7 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	if (fcorr_out) { // the ghost terms were formed by the patches that own the face values: sort them into the coarse
 		// level's side array (a permutation copy of 6/128 of a vector instead of the fix-up pass)
 		if (L.Pc > 0) {
-			Timed t(g, KC_FIXUP, (size_t) L.P * 6 * L.nf / 4);
+			Timed t(g, KC_FCORR_GATHER, (size_t) L.P * 6 * L.nf / 4);
 			hipLaunchKernelGGL(k_fcorr_gather3d<N>, dim3(L.Pc * 12), dim3(256), 0, g->stream, L.dev(), L.child.p, L.rs6.p, fcorr_out);
 		}
 	} else if (L.P > 0) {
@@ -1391,7 +1394,7 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 	ps.coarse = prolong_from;
 	auto launch = [&](LevelDev D) {
 		if (D.count == 0) return;
-		Timed t(g, KC_RESWEEP, (size_t) D.count * L.nc);
+		Timed t(g, fcorr_in ? KC_RESWEEP_FCORR : KC_RESWEEP, (size_t) D.count * L.nc);
 		D.f6    = L.f6buf.p;
 		D.fcorr = fcorr_in;
 		if constexpr (N >= 4) {

@@ -121,7 +121,8 @@ def test_sharded_exported_ghost_terms(nranks, monkeypatch):
         rows = g1.profile_rows()
         g1.profile(False)
         want[nofc] = du.download()
-        assert rows["rbgs_zero_resid_restrict_faces"]["calls"] == 2 and rows["rbgs_resweep_prolong"]["calls"] == 2
+        assert rows["rbgs_zero_resid_restrict_faces"]["calls"] + rows.get("rbgs_zero_resid_restrict_faces_fcorr", {"calls": 0})["calls"] == 2
+        assert ("fcorr_gather" in rows) == (not nofc) and ("rbgs_resweep_prolong_fcorr" in rows) == (not nofc)
     assert np.array_equal(want[False], want[True])
     monkeypatch.delenv("TE_NO_FCORR", raising=False)
 
