@@ -928,6 +928,21 @@ template <int N> void packFaces(te_gmg *g, LevelHost &L, const double *u, const 
 	else
 		hipLaunchKernelGGL(k_pack_faces3d<N>, grid, blk, 0, g->stream, L.send_faces.p, u, L.sendbuf.p);
 }
+// ghost planes of the coarse/fine faces from the current iterate (u, or its face layers L.pack_f6 when it was never stored)
+template <int N> void cfGhosts(te_gmg *g, LevelHost &L, const double *u, const ProlongSrc *ps)
+{
+	Timed      t(g, KC_CFGHOST, (size_t) L.ncf * L.nf);
+	const dim3 grid(L.ncf), blk(N * N < 256 ? N * N : 256);
+	if (L.pack_f6) {
+		if (ps)
+			hipLaunchKernelGGL((k_cf_ghost6_3d<N, true>), grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, L.pack_f6, *ps, L.ghost.p);
+		else
+			hipLaunchKernelGGL((k_cf_ghost6_3d<N, false>), grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, L.pack_f6, ProlongSrc(), L.ghost.p);
+	} else if (ps)
+		hipLaunchKernelGGL(k_cf_ghost_prolong3d<N>, grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, u, *ps, L.ghost.p);
+	else
+		hipLaunchKernelGGL(k_cf_ghost3d<N>, grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, u, L.ghost.p);
+}
 template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u, const ProlongSrc *ps = nullptr)
 {
 	if (L.patch_local) return TE_OK; // the patch operator reads no neighbour
@@ -937,13 +952,7 @@ template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u, con
 		if (rc) return rc;
 	}
 	if (L.ncf == 0) return TE_OK;
-	Timed t(g, KC_CFGHOST, (size_t) L.ncf * L.nf);
-	if (ps)
-		hipLaunchKernelGGL(k_cf_ghost_prolong3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
-		                   L.cf_slots.p, u, *ps, L.ghost.p);
-	else
-		hipLaunchKernelGGL(k_cf_ghost3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
-		                   L.cf_slots.p, u, L.ghost.p);
+	cfGhosts<N>(g, L, u, ps);
 	return TE_OK;
 }
 // Run `launch(subset)` over all patches of the level with current ghosts. With off-rank neighbours the
@@ -975,15 +984,7 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 	HIPCHK(hipEventRecord(g->ev_recv, g->comm_stream));
 	launch(L.devPart(false)); // interior, concurrent with the exchange
 	HIPCHK(hipStreamWaitEvent(g->stream, g->ev_recv, 0));
-	if (L.ncf > 0) {
-		Timed t(g, KC_CFGHOST, (size_t) L.ncf * L.nf);
-		if (ps)
-			hipLaunchKernelGGL(k_cf_ghost_prolong3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
-			                   L.cf_slots.p, u, *ps, L.ghost.p);
-		else
-			hipLaunchKernelGGL(k_cf_ghost3d<N>, dim3(L.ncf), dim3(N * N < 256 ? N * N : 256), 0, g->stream, L.cf_desc.p,
-			                   L.cf_slots.p, u, L.ghost.p);
-	}
+	if (L.ncf > 0) cfGhosts<N>(g, L, u, ps);
 	launch(L.devPart(true)); // boundary
 	return TE_OK;
 }
@@ -1401,7 +1402,9 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 			const dim3  grid(8 * ((D.count + 7) / 8)), blk(Tile3<N>::TPB);
 			const char *ve = getenv("TE_RESWEEP_V"); // tuning variants (march3d.hpp), all bit-identical; default 3
 			const int   v  = ve ? atoi(ve) : 3;
-			if (fcorr_in) {
+			if (L.ncf > 0 || L.has_copy) { // refined level: copy-through patches / coarse-fine ghost slots
+				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 3, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else if (fcorr_in) {
 				if (v == 0)
 					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 0, true>), grid, blk, 0, g->stream, D, f, out, ps);
 				else
@@ -1927,7 +1930,8 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	// read its right-hand side together with exported ghost terms, see below)
 	auto unstoredAt = [&](LevelHost &LL, bool has_coarser) {
 		return o->fuse >= 3 && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_RBGS && LL.fuse2_ok && has_coarser && o->cycle_type == 0
-		       && o->post_sweeps >= 1 && LL.prolong_fusable && LL.n >= 4 && !getenv("TE_NO_FUSE2") && !getenv("TE_NO_FUSE3");
+		       && o->post_sweeps >= 1 && (LL.prolong_fusable || (LL.dim == 3 && LL.prolong_fusable_cf && !getenv("TE_NO_FUSE3_CF"))) && LL.n >= 4
+		       && !getenv("TE_NO_FUSE2") && !getenv("TE_NO_FUSE3");
 	};
 	if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_RBGS && L.fuse2_ok && !getenv("TE_NO_FUSE2")) {
 		u_zero = false;
@@ -1937,7 +1941,9 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		u_unstored = unstoredAt(L, true);
 		// ... and if the next level takes the same path, its two kernels are the only readers of its right-hand side: the
 		// ghost terms of the restricted residual go to its side array instead of a fix-up pass (bit-identical; rank-local)
-		double *fcorr_out = (u_unstored && C.fcorr.p && unstoredAt(C, l + 2 < nl) && !getenv("TE_NO_FCORR")) ? C.fcorr.p : nullptr;
+		double *fcorr_out = (u_unstored && L.prolong_fusable && C.fcorr.p && C.prolong_fusable && unstoredAt(C, l + 2 < nl) && !getenv("TE_NO_FCORR"))
+		                        ? C.fcorr.p
+		                        : nullptr; // (both levels uniformly refined)
 		if (fcorr_in && !u_unstored) return te::fail(TE_ESTATE, "te_vcycle: exported ghost terms without a reader");
 		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p, !u_unstored, fcorr_out, fcorr_in))) return rc;
 		C.f_has_corr = fcorr_out != nullptr;

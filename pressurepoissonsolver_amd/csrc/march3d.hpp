@@ -277,6 +277,56 @@ __global__ void k_cf_ghost_prolong3d(const int32_t *__restrict__ desc, const int
 	}
 }
 
+// k_cf_ghost3d / k_cf_ghost_prolong3d for an iterate that exists only as its six face layers (opts.fuse = 3 on a
+// refined level): every value the interface weights touch is a face-layer value. f6: [patch][side][a + N b].
+// PROLONG: the iterate is that + P(coarse), formed value by value as k_cf_ghost_prolong3d does.
+template <int N, bool PROLONG>
+__global__ void k_cf_ghost6_3d(const int32_t *__restrict__ desc, const int32_t *__restrict__ slots, const double *__restrict__ f6,
+                               ProlongSrc ps, double *__restrict__ ghost)
+{
+	constexpr int  NN = N * N;
+	const int32_t *d  = desc + (size_t) blockIdx.x * 8;
+	const int      p = d[0], s = d[1], kind = d[2], q = d[3];
+	const int      ax   = s >> 1;
+	const int      sa   = (ax == 0) ? N : 1;
+	const int      sb   = (ax == 2) ? N : NN;
+	const int      sn   = (ax == 0) ? 1 : (ax == 1 ? N : NN);
+	const int      mine = (s & 1) ? (N - 1) * sn : 0;
+	const int      oth  = (s & 1) ? 0 : (N - 1) * sn;
+	double        *g    = ghost + (size_t) slots[blockIdx.x] * NN;
+	// value at face cell (a, b) of `patch` on its side `side` (cell index base + a sa + b sb inside the patch)
+	auto U = [&](int patch, int side, int base, int a, int b) {
+		double v = f6[((size_t) patch * 6 + side) * NN + a + N * b];
+		if (PROLONG) v += coarseAtCell<N>(ps, patch, base + a * sa + b * sb);
+		return v;
+	};
+	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+		const int a = i % N, b = i / N;
+		double    m = U(p, s, mine, a, b);
+		double    gamma;
+		if (kind == 2) {
+			const int a0 = a & ~1, b0 = b & ~1;
+			double    sum = 0;
+			for (int bb = 0; bb < 2; bb++)
+				for (int aa = 0; aa < 2; aa++)
+					if (a0 + aa != a || b0 + bb != b) sum += U(p, s, mine, a0 + aa, b0 + bb);
+			const int ca = (a + ((q & 1) ? N : 0)) / 2, cb = (b + ((q & 2) ? N : 0)) / 2;
+			double    C  = d[4] >= 0 ? U(d[4], s ^ 1, oth, ca, cb) : ghost[(size_t) (-(d[4] + 2)) * NN + ca + N * cb];
+			gamma        = (11 * m - sum) / 12.0 + 4.0 * C / 12.0;
+		} else {
+			const int qa = (a >= N / 2), qb = (b >= N / 2);
+			const int nbq = d[4 + qa + 2 * qb];
+			const int fa = 2 * (a - qa * (N / 2)), fb = 2 * (b - qb * (N / 2));
+			double    sum = 0;
+			for (int bb = 0; bb < 2; bb++)
+				for (int aa = 0; aa < 2; aa++)
+					sum += 1.0 / 6.0 * (nbq >= 0 ? U(nbq, s ^ 1, oth, fa + aa, fb + bb) : ghost[(size_t) (-(nbq + 2)) * NN + (fa + aa) + N * (fb + bb)]);
+			gamma = 2.0 / 6.0 * m + sum;
+		}
+		g[i] = 2 * gamma - m;
+	}
+}
+
 // k_pack_faces3d for the iterate u + P(coarse u) that is never stored (see ProlongSrc): the face layers other
 // ranks need, with this rank's coarse correction added on the way out.
 template <int N>
@@ -989,6 +1039,8 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 					double    g;
 					if (kind == FACE_GHOST)
 						g = L.ghost[(size_t) src * NN + i];
+					else if (L.f6) // the iterate exists only as its face layers
+						g = L.f6[((size_t) src * 6 + (s ^ 1)) * NN + i];
 					else if (ax == 0 && L.xf) // compact x-face columns instead of a stride-N gather
 						g = L.xf[((size_t) src * 2 + ((s & 1) ^ 1)) * NN + i];
 					else
@@ -1077,7 +1129,9 @@ __global__ void k_pack_faces6_3d(const int32_t *__restrict__ faces, const double
 // the last steps only; bit 2: right-hand sides are requested five planes ahead instead of four (two steps before their
 // first use instead of one: a step is shorter than a loaded HBM round trip).
 // FCORR: this level's right-hand side carries ghost terms in L.fcorr (see FCorrSrc)
-template <int N, int V = 0, bool FCORR = false>
+// CFP: a refined level, as k_rbgs3d<..., CFP>: patches that copy through take their correction cell by cell from the
+// same-size coarse patch, coarse/fine ghost slots hold u + P e already (k_cf_ghost6_3d<N, true>)
+template <int N, int V = 0, bool FCORR = false, bool CFP = false>
 __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelDev L, const double *__restrict__ f,
                                                                           double *__restrict__ out, ProlongSrc ps)
 {
@@ -1135,22 +1189,62 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 		dix[0][0] = cx0 + 3 * cy0, dix[0][1] = cx1 + 3 * cy0, dix[1][0] = cx0 + 3 * cy1, dix[1][1] = cx1 + 3 * cy1;
 	}
 
-	// coarse-correction sources (as k_rbgs3d<N, false, true>)
-	const double *cown = coarseOctant<N>(ps, pid), *chalo = cown, *cbot = cown, *ctop = cown;
+	// coarse-correction sources (as k_rbgs3d<N, false, true, 1, CFP>)
+	static_assert(!CFP || !FCORR, "the exported ghost terms are for uniformly refined levels");
+	const bool    cpo  = CFP && ps.orth[pid] < 0; // this patch copies through: its correction is the same-size coarse patch
+	const double *yown = cpo ? ps.coarse + (size_t) ps.parent[pid] * NNN : nullptr;
+	const double *cown = cpo ? yown : coarseOctant<N>(ps, pid), *chalo = cown, *cbot = cown, *ctop = cown;
 	double        shalo = 0.0, sbot = 0.0, stop = 0.0;
 	const int     cq = X + N * Yp;
+	bool          cpb = false, cpt = false;
+	const double *ybot = nullptr, *ytop = nullptr;
+	int           hsh = 1; // z shift of the halo's coarse index (0 for a copy-through neighbour)
 	if (tid < 4 * N) {
 		const int side = tid / N, t = tid % N;
 		if (fk[side] == FACE_LOCAL) {
-			const double *cn = coarseOctant<N>(ps, fs[side]);
-			const int     cx = (side == 0) ? H - 1 : (side == 1 ? 0 : t / 2);
-			const int     cy = (side == 2) ? H - 1 : (side == 3 ? 0 : t / 2);
-			chalo = cn + cx + N * cy;
+			if (CFP && ps.orth[fs[side]] < 0) {
+				const int nbr = (side == 0) ? t * N + (N - 1) : (side == 1 ? t * N : (side == 2 ? (N - 1) * N + t : t));
+				chalo = ps.coarse + (size_t) ps.parent[fs[side]] * NNN + nbr;
+				hsh   = 0;
+			} else {
+				const double *cn = coarseOctant<N>(ps, fs[side]);
+				const int     cx = (side == 0) ? H - 1 : (side == 1 ? 0 : t / 2);
+				const int     cy = (side == 2) ? H - 1 : (side == 3 ? 0 : t / 2);
+				chalo = cn + cx + N * cy;
+			}
 			shalo = 1.0;
 		}
 	}
-	if (fk[4] == FACE_LOCAL) cbot = coarseOctant<N>(ps, fs[4]) + NN * (H - 1), sbot = 1.0;
-	if (fk[5] == FACE_LOCAL) ctop = coarseOctant<N>(ps, fs[5]), stop = 1.0;
+	if (fk[4] == FACE_LOCAL) {
+		if (CFP && ps.orth[fs[4]] < 0)
+			cpb = true, ybot = ps.coarse + (size_t) ps.parent[fs[4]] * NNN + NN * (N - 1);
+		else
+			cbot = coarseOctant<N>(ps, fs[4]) + NN * (H - 1);
+		sbot = 1.0;
+	}
+	if (fk[5] == FACE_LOCAL) {
+		if (CFP && ps.orth[fs[5]] < 0)
+			cpt = true, ytop = ps.coarse + (size_t) ps.parent[fs[5]] * NNN;
+		else
+			ctop = coarseOctant<N>(ps, fs[5]);
+		stop = 1.0;
+	}
+	// the correction of this thread's two cells of row k: plane z of the own patch / the bottom / top neighbour's facing plane
+	auto ownC = [&](int k, int z) {
+		if (CFP && cpo) return *reinterpret_cast<const double2 *>(yown + (size_t) z * NN + (2 * Yp + k) * N + 2 * X);
+		const double c = cown[NN * (z >> 1) + cq];
+		return double2{c, c};
+	};
+	auto botC = [&](int k) {
+		if (CFP && cpb) return *reinterpret_cast<const double2 *>(ybot + (2 * Yp + k) * N + 2 * X);
+		const double c = cbot[cq];
+		return double2{c, c};
+	};
+	auto topC = [&](int k) {
+		if (CFP && cpt) return *reinterpret_cast<const double2 *>(ytop + (2 * Yp + k) * N + 2 * X);
+		const double c = ctop[cq];
+		return double2{c, c};
+	};
 
 	const double2 zero2 = double2{0.0, 0.0};
 	auto cz9of = [](int z) { return (z == 0) ? 0 : (z == N - 1 ? 18 : 9); };
@@ -1223,12 +1317,21 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 		fillBlack(P1{}, 1, tileV[1], v1, v0, r2, f1);
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
-			const double  c0 = cown[cq], cb = sbot * cbot[cq]; // planes 0 and 1 share coarse plane 0
-			const double2 a  = bot.p[q[k]];
-			uc[k] = double2{v0[k].x + c0, v0[k].y + c0};
-			un[k] = double2{v1[k].x + c0, v1[k].y + c0};
-			um[k] = double2{bot.s * a.x, bot.s * a.y};
-			um[k].x += bot.s * cb, um[k].y += bot.s * cb;
+			if (!CFP) {
+				const double  c0 = cown[cq], cb = sbot * cbot[cq]; // planes 0 and 1 share coarse plane 0
+				const double2 a  = bot.p[q[k]];
+				uc[k] = double2{v0[k].x + c0, v0[k].y + c0};
+				un[k] = double2{v1[k].x + c0, v1[k].y + c0};
+				um[k] = double2{bot.s * a.x, bot.s * a.y};
+				um[k].x += bot.s * cb, um[k].y += bot.s * cb;
+			} else { // (the arithmetic of k_rbgs3d<..., CFP>'s first planes)
+				const double2 c0 = ownC(k, 0), c1 = ownC(k, 1), cb = botC(k);
+				const double2 a  = bot.p[q[k]];
+				uc[k] = double2{v0[k].x + c0.x, v0[k].y + c0.y};
+				un[k] = double2{v1[k].x + c1.x, v1[k].y + c1.y};
+				um[k] = double2{bot.s * a.x, bot.s * a.y};
+				um[k].x += bot.s * (sbot * cb.x), um[k].y += bot.s * (sbot * cb.y);
+			}
 			r1[k] = v1[k];
 		}
 		ldsBarrier(); // both red planes have been read: step 0 rewrites the first one
@@ -1239,14 +1342,23 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 	auto step = [&](auto zpar, int z) {
 		constexpr int ZPAR = decltype(zpar)::value;
 		using ZQ          = std::integral_constant<int, 1 - ZPAR>;
+		double2 c2v[2]; // CFP: the correction of plane z+2 (or of the top neighbour's plane), per row
 		// loads for the coming steps
 		constexpr int AHEAD = DEEP ? 5 : 4;
 		const int     zf = (z + AHEAD < N) ? z + AHEAD : N - 1, zc = (z + 1 < N) ? z + 1 : N - 1;
 #pragma unroll
 		for (int k = 0; k < 2; k++) fn[k] = fp2[zf * NP + q[k]];
 		if (FCORR) fc.load(zf, q, ccx, ccy, ccz);
-		const double hvn = hs.s * (hs.p[zc * hs.stride] + shalo * chalo[NN * (zc >> 1)]);
-		const double c2  = (z + 2 < N) ? cown[NN * ((z + 2) >> 1) + cq] : stop * ctop[cq];
+		const double hvn = hs.s * (hs.p[zc * hs.stride] + shalo * chalo[NN * (zc >> hsh)]);
+		const double c2  = CFP ? 0.0 : ((z + 2 < N) ? cown[NN * ((z + 2) >> 1) + cq] : stop * ctop[cq]);
+		if (CFP) {
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				const double2 c  = (z + 2 < N) ? ownC(k, z + 2) : topC(k);
+				const double  cs = (z + 2 < N) ? 1.0 : stop;
+				c2v[k]           = double2{cs * c.x, cs * c.y};
+			}
+		}
 		double2      tg[2];
 		if (TG_ALWAYS || z + 2 >= N) { // the top neighbour's plane (used on the last steps only)
 #pragma unroll
@@ -1273,10 +1385,12 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 		if (z + 2 < N) {
 			fillBlack(zpar, z + 2, tvz, r2, r1, r3, f2);
 #pragma unroll
-			for (int k = 0; k < 2; k++) un2[k] = double2{r2[k].x + c2, r2[k].y + c2};
+			for (int k = 0; k < 2; k++) un2[k] = CFP ? double2{r2[k].x + c2v[k].x, r2[k].y + c2v[k].y} : double2{r2[k].x + c2, r2[k].y + c2};
 		} else {
 #pragma unroll
-			for (int k = 0; k < 2; k++) un2[k] = double2{top.s * (tg[k].x + c2), top.s * (tg[k].y + c2)};
+			for (int k = 0; k < 2; k++)
+				un2[k] = CFP ? double2{top.s * (tg[k].x + c2v[k].x), top.s * (tg[k].y + c2v[k].y)}
+				             : double2{top.s * (tg[k].x + c2), top.s * (tg[k].y + c2)};
 		}
 		// the sweep itself (k_rbgs3d)
 		if (z < N) {

@@ -41,7 +41,7 @@ FULL = {
 }
 # kernel classes (te_gmg_profile_rows) that prove which path a default-option cycle took
 FUSED_RBGS_3D = ("rbgs_zero_resid_restrict_faces", "rbgs_resweep_prolong", "restrict_fixup")
-FUSED_RBGS_REFINED = ("rbgs_zero_resid_restrict", "stencil_rbgs_prolong", "restrict_fixup")
+FUSED_RBGS_REFINED = ("rbgs_zero_resid_restrict_faces", "rbgs_resweep_prolong", "restrict_fixup", "cf_ghost")
 FUSED_PS_3D = ("patch_solve_mfma", "restrict_fixup")
 FUSED_2D = ("rbgs_zero_resid_restrict_faces", "rbgs_resweep_prolong", "restrict_fixup")
 
