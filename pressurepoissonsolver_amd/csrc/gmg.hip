@@ -996,6 +996,7 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 	int zs = 1;
 	if (N >= 8) {
 		while (zs < 4 && (getenv("TE_ZS_FORCE") || (size_t) L.P * zs < 2048) && N / (zs * 2) >= 4) zs *= 2;
+		if (zs == 4 && N == 32 && L.P <= 64 && !getenv("TE_NO_ZS8")) zs = 8; // (see rbgsSlabs)
 	}
 	auto launch = [&](LevelDev D) {
 		if (D.count == 0) return;
@@ -1008,6 +1009,9 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 			case 2:
 				if constexpr (N >= 8)
 					hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
+				break;
+			case 8:
+				if constexpr (N >= 32) hipLaunchKernelGGL((k_stencil3d<N, MODE, 8>), grid(8), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
 				break;
 			default:
 				if constexpr (N >= 16)
@@ -1261,6 +1265,9 @@ template <int N> inline int rbgsSlabs(int count)
 {
 	int zs = 1;
 	while (zs < 4 && !getenv("TE_RBGS_NOSLAB") && (size_t) count * zs < 1024 && N / (zs * 2) >= 4) zs *= 2;
+	// very few patches (the coarsest levels of a cycle): a kernel is one patch's march, a dependent chain of plane steps of
+	// ~1-2 us each that nothing hides -- eight slabs of four planes (six steps) instead of four of eight (ten steps)
+	if (zs == 4 && N == 32 && count <= 64 && !getenv("TE_NO_ZS8")) zs = 8;
 	return zs;
 }
 template <int N, bool ZERO, bool PROLONG>
@@ -1268,7 +1275,9 @@ void launchRbgsKernel(te_gmg *g, const LevelDev &D, const double *u, const doubl
 {
 	const int  zs = rbgsSlabs<N>(D.count);
 	const dim3 grid(8 * ((D.count * zs + 7) / 8)), blk(Tile3<N>::TPB);
-	if (zs == 4) {
+	if (zs == 8) {
+		if constexpr (N >= 32) hipLaunchKernelGGL((k_rbgs3d<N, ZERO, PROLONG, 8>), grid, blk, 0, g->stream, D, u, f, out, ps);
+	} else if (zs == 4) {
 		if constexpr (N >= 16) hipLaunchKernelGGL((k_rbgs3d<N, ZERO, PROLONG, 4>), grid, blk, 0, g->stream, D, u, f, out, ps);
 	} else if (zs == 2) {
 		if constexpr (N >= 8) hipLaunchKernelGGL((k_rbgs3d<N, ZERO, PROLONG, 2>), grid, blk, 0, g->stream, D, u, f, out, ps);
