@@ -1409,21 +1409,34 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 		D.fcorr = fcorr_in;
 		if constexpr (N >= 4) {
 			const dim3  grid(8 * ((D.count + 7) / 8)), blk(Tile3<N>::TPB);
-			const char *ve = getenv("TE_RESWEEP_V"); // tuning variants (march3d.hpp), all bit-identical; default 3
-			const int   v  = ve ? atoi(ve) : 3;
+			const char *ve = getenv("TE_RESWEEP_V"); // tuning variants (march3d.hpp), all bit-identical; default 27
+			const int   v  = ve ? atoi(ve) : 27;
 			if (L.ncf > 0 || L.has_copy) { // refined level: copy-through patches / coarse-fine ghost slots
-				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 3, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
+				if (v == 3)
+					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 3, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
+				else
+					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 27, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (fcorr_in) {
 				if (v == 0)
 					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 0, true>), grid, blk, 0, g->stream, D, f, out, ps);
+				else if (ve && v == 27) // (measured: on a level whose vectors fit the Infinity Cache the non-temporal form is no faster)
+					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 27, true>), grid, blk, 0, g->stream, D, f, out, ps);
 				else
 					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 3, true>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 0) {
 				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 0, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 7) {
 				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 7, false>), grid, blk, 0, g->stream, D, f, out, ps);
-			} else {
+			} else if (v == 11) {
+				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 11, false>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else if (v == 19) {
+				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 19, false>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else if (v == 27) {
+				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 27, false>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else if (v == 3) {
 				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 3, false>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else {
+				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 27, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			}
 		}
 	};

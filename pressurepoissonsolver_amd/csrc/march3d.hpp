@@ -15,8 +15,30 @@
 #include "kernels3d.hpp"
 #include <type_traits>
 
+#ifndef TE_ZR_NT
+#define TE_ZR_NT 0 // (non-temporal loads of f in the pre-sweep cost more in the post-sweep, which finds less of f in the Infinity Cache)
+#endif
 namespace te
 {
+// streaming accesses that nothing re-reads before they leave the caches (a 1 GiB vector per pass): non-temporal
+template <bool NT> __device__ __forceinline__ double2 ldStream(const double2 *p)
+{
+	if (NT) {
+		double2 v;
+		v.x = __builtin_nontemporal_load(&p->x);
+		v.y = __builtin_nontemporal_load(&p->y);
+		return v;
+	}
+	return *p;
+}
+template <bool NT> __device__ __forceinline__ void stStream(double2 *p, double2 v)
+{
+	if (NT) {
+		__builtin_nontemporal_store(v.x, &p->x);
+		__builtin_nontemporal_store(v.y, &p->y);
+	} else
+		*p = v;
+}
 template <int N> struct Tile3 {
 	static constexpr int H   = N / 2;
 	static constexpr int NT  = H * H;               // threads that own cells
@@ -872,7 +894,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 		constexpr int ZPAR = decltype(zpar)::value;
 		const int     zc   = (z + 1 < N) ? z + 1 : N - 1;
 #pragma unroll
-		for (int k = 0; k < 2; k++) fn[k] = fp2[zc * NP + q[k]];
+		for (int k = 0; k < 2; k++) fn[k] = ldStream<TE_ZR_NT != 0>(fp2 + zc * NP + q[k]);
 		if (FCORR) fc.load(zc, q, ccx, ccy, ccz);
 		double *tz = tile[bz];            // plane z
 		double *t1 = tile[(bz + 3) & 3];  // plane z-1
@@ -1127,7 +1149,8 @@ __global__ void k_pack_faces6_3d(const int32_t *__restrict__ faces, const double
 // V (tuning variants, all bit-identical): bit 0: the black values of the recomputed plane and of the sweep's plane z-1 are
 // not written back to LDS (nobody reads them: their x/y neighbours are red); bit 1: the top neighbour's plane is loaded on
 // the last steps only; bit 2: right-hand sides are requested five planes ahead instead of four (two steps before their
-// first use instead of one: a step is shorter than a loaded HBM round trip).
+// first use instead of one: measured, no effect); bit 3 / bit 4: non-temporal loads of f / stores of u (a level's vectors
+// are not re-read before they have left the caches: +1.4 % at 512^3, +10 % at 256^3). Default 27.
 // FCORR: this level's right-hand side carries ghost terms in L.fcorr (see FCorrSrc)
 // CFP: a refined level, as k_rbgs3d<..., CFP>: patches that copy through take their correction cell by cell from the
 // same-size coarse patch, coarse/fine ghost slots hold u + P e already (k_cf_ghost6_3d<N, true>)
@@ -1135,7 +1158,7 @@ template <int N, int V = 0, bool FCORR = false, bool CFP = false>
 __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelDev L, const double *__restrict__ f,
                                                                           double *__restrict__ out, ProlongSrc ps)
 {
-	constexpr bool LDS_ALL = !(V & 1), TG_ALWAYS = !(V & 2), DEEP = (V & 4) != 0;
+	constexpr bool LDS_ALL = !(V & 1), TG_ALWAYS = !(V & 2), DEEP = (V & 4) != 0, NTL = (V & 8) != 0, NTS = (V & 16) != 0;
 	using T           = Tile3<N>;
 	constexpr int TPB = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
 	constexpr int NN  = N * N, NNN = N * N * N;
@@ -1347,7 +1370,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 		constexpr int AHEAD = DEEP ? 5 : 4;
 		const int     zf = (z + AHEAD < N) ? z + AHEAD : N - 1, zc = (z + 1 < N) ? z + 1 : N - 1;
 #pragma unroll
-		for (int k = 0; k < 2; k++) fn[k] = fp2[zf * NP + q[k]];
+		for (int k = 0; k < 2; k++) fn[k] = ldStream<NTL>(fp2 + zf * NP + q[k]);
 		if (FCORR) fc.load(zf, q, ccx, ccy, ccz);
 		const double hvn = hs.s * (hs.p[zc * hs.stride] + shalo * chalo[NN * (zc >> hsh)]);
 		const double c2  = CFP ? 0.0 : ((z + 2 < N) ? cown[NN * ((z + 2) >> 1) + cq] : stop * ctop[cq]);
@@ -1403,8 +1426,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false, LDS_ALL>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
 			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false, LDS_ALL>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
 			if (act) {
-				op2[(z - 1) * NP + q[0]] = um[0];
-				op2[(z - 1) * NP + q[1]] = um[1];
+				stStream<NTS>(op2 + (z - 1) * NP + q[0], um[0]);
+				stStream<NTS>(op2 + (z - 1) * NP + q[1], um[1]);
 				if (L.xf_out) {
 					double *xo = L.xf_out + (size_t) pid * 2 * NN + N * (z - 1) + 2 * Yp;
 					if (X == 0) *reinterpret_cast<double2 *>(xo) = double2{um[0].x, um[1].x};
