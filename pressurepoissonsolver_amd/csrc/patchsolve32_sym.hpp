@@ -34,6 +34,12 @@
 #pragma once
 #include "patchsolve32.hpp"
 
+#ifndef PSS_NTL
+#define PSS_NTL 1 // ... and non-temporal loads of the right-hand side (re-read one whole sweep later)
+#endif
+#ifndef PSS_NT
+#define PSS_NT 1 // non-temporal stores of the result (nothing re-reads a 1 GiB vector before it has left the caches)
+#endif
 namespace te
 {
 // fragment-ordered half matrices, per plan: [transform 6][parity 2][k-step 4][lane 64]
@@ -110,8 +116,13 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
 			const double *rl = base + (4 * k + q.g) * N, *rh = base + (N - 1 - 4 * k - q.g) * N;
+#if PSS_NTL
+			d.ll[k] = __builtin_nontemporal_load(rl + q.j), d.lh[k] = __builtin_nontemporal_load(rl + N - 1 - q.j);
+			d.hl[k] = __builtin_nontemporal_load(rh + q.j), d.hh[k] = __builtin_nontemporal_load(rh + N - 1 - q.j);
+#else
 			d.ll[k] = rl[q.j], d.lh[k] = rl[N - 1 - q.j];
 			d.hl[k] = rh[q.j], d.hh[k] = rh[N - 1 - q.j];
+#endif
 		}
 	};
 	// ring terms of plane z: lane l < 32 holds W[l] and S[l], l >= 32 holds E[l-32] and N[l-32]
@@ -396,8 +407,13 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 					const v4f64 yl = (py + qy) * scale, yh = (py - qy) * scale;
 #pragma unroll
 					for (int r = 0; r < 4; r++) {
+#if PSS_NT
+						__builtin_nontemporal_store(yl[r], &op[(g + 4 * r) * N + x]);
+						__builtin_nontemporal_store(yh[r], &op[(N - 1 - g - 4 * r) * N + x]);
+#else
 						op[(g + 4 * r) * N + x]         = yl[r];
 						op[(N - 1 - g - 4 * r) * N + x] = yh[r];
+#endif
 					}
 					if (xf_out && j == 0) { // the two x-face columns of the new iterate, compact (LevelDev.xf layout: [side][z][y])
 						double *xo = xf_out + ((size_t) pid * 2 + xc) * NN + N * z;
