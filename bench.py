@@ -52,9 +52,9 @@ ALG_BYTES = {
     # fuse = 3 (default): the iterate between the two sweeps exists only as its six face layers (6/32 of a vector)
     "rbgs_zero_resid_restrict_faces": 10.5,  # read f (8); write the face layers (1.5) and coarse f (1)
     "rbgs_resweep_prolong": 18.5,            # read f (8), coarse (1), neighbours' face layers (1.5); write u (8)
-    # the same two kernels on a level whose right-hand side carries exported ghost terms (12/32 of a vector: + 3)
-    "rbgs_zero_resid_restrict_faces_fcorr": 13.5,
-    "rbgs_resweep_prolong_fcorr": 21.5,
+    # the same two kernels on a level whose right-hand side carries exported x-face ghost terms (4/32 of a vector: + 1)
+    "rbgs_zero_resid_restrict_faces_fcorr": 11.5,
+    "rbgs_resweep_prolong_fcorr": 19.5,
     "fcorr_gather": 16.0,                    # per entry of the 2x2 face sums: read 8, write 8 (cells = entries)
     # levels with few patches run other instantiations, timed as classes of their own (one class = one kernel
     # symbol for the large levels); they only become "dominant" for small problems (--size 256):

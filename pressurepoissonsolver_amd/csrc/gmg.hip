@@ -178,7 +178,7 @@ struct LevelHost {
 	DevBuf<double> cellvol;          // [P] product of the spacings (te_integrate)
 	std::vector<double> patch_vol;   // [P] product of the patch lengths (te_volume)
 	DevBuf<double> f6buf;            // [P][6][n^2]: the six face layers of an iterate that is never stored (opts.fuse = 3)
-	// [P][12][n^2]: ghost terms of this level's right-hand side that the finer level's pre-sweep exported instead of
+	// [P][4][n^2]: the x-face ghost terms of this level's right-hand side that the finer level's pre-sweep exported instead of
 	// adding them in a fix-up pass (march3d.hpp FCorrSrc); f_has_corr: they belong to the current L.f (inside te_vcycle)
 	DevBuf<double> fcorr;
 	bool           f_has_corr = false;
@@ -543,7 +543,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	               || (rc = L->f6buf.alloc((size_t) std::max(P, 1) * 6 * L->nf))))
 		return rc;
 	if (D == 3 && li > 0 && L->fuse2_ok && P > 0) { // a level that can read its right-hand side with FCORR
-		if ((rc = L->fcorr.alloc((size_t) P * 12 * L->nf))) return rc;
+		if ((rc = L->fcorr.alloc((size_t) P * 4 * L->nf))) return rc;
 		HIPCHK(hipMemset(L->fcorr.p, 0, sizeof(double) * L->fcorr.n));
 	}
 	if (D == 3 && L->fuse2_ok && P > 0 && (rc = L->rs6.alloc((size_t) P * 6 * L->nf / 4))) return rc;
@@ -1342,7 +1342,10 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	rd.coarse     = coarse;
 	rd.remote     = L.upbuf.p;
 	rd.remote_off = L.up_off.p;
-	rd.rs6        = fcorr_out ? L.rs6.p : nullptr;
+	// the patches export their 2x2 face sums only on uniformly refined levels; a refined level's terms are formed by the
+	// gather kernel from the face layers
+	const bool export_rs6 = fcorr_out && L.prolong_fusable;
+	rd.rs6                = export_rs6 ? L.rs6.p : nullptr;
 	int rc;
 	if (L.P > 0) {
 		Timed      t(g, store_u ? KC_ZERO_RESID : (fcorr_in ? KC_ZERO_RESID_FACES_FCORR : KC_ZERO_RESID_FACES), (size_t) L.P * L.nc);
@@ -1354,9 +1357,9 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 		} else {
 			D.f6_out = L.f6buf.p;
 			D.fcorr  = fcorr_in;
-			if (fcorr_out && fcorr_in)
+			if (export_rs6 && fcorr_in)
 				hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false, true, true>), grid, blk, 0, g->stream, D, f, out, rd);
-			else if (fcorr_out)
+			else if (export_rs6)
 				hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false, true, false>), grid, blk, 0, g->stream, D, f, out, rd);
 			else if (fcorr_in)
 				hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false, false, true>), grid, blk, 0, g->stream, D, f, out, rd);
@@ -1373,7 +1376,8 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 		// level's side array (a permutation copy of 6/128 of a vector instead of the fix-up pass)
 		if (L.Pc > 0) {
 			Timed t(g, KC_FCORR_GATHER, (size_t) L.P * 6 * L.nf / 4);
-			hipLaunchKernelGGL(k_fcorr_gather3d<N>, dim3(L.Pc * 12), dim3(256), 0, g->stream, L.dev(), L.child.p, L.rs6.p, fcorr_out);
+			hipLaunchKernelGGL(k_fcorr_gather3d<N>, dim3(L.Pc * 12), dim3(256), 0, g->stream, L.dev(), L.child.p, L.copy.p,
+			                   export_rs6 ? (const double *) L.rs6.p : (const double *) nullptr, (const double *) L.f6buf.p, coarse, fcorr_out);
 		}
 	} else if (L.P > 0) {
 		Timed    t(g, KC_FIXUP, (size_t) L.P * 6 * L.nf);
@@ -1963,9 +1967,10 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		u_unstored = unstoredAt(L, true);
 		// ... and if the next level takes the same path, its two kernels are the only readers of its right-hand side: the
 		// ghost terms of the restricted residual go to its side array instead of a fix-up pass (bit-identical; rank-local)
-		double *fcorr_out = (u_unstored && L.prolong_fusable && C.fcorr.p && C.prolong_fusable && unstoredAt(C, l + 2 < nl) && !getenv("TE_NO_FCORR"))
+		double *fcorr_out = (u_unstored && L.dim == 3 && (L.prolong_fusable || !getenv("TE_NO_FCORR_CF")) && C.fcorr.p && C.prolong_fusable
+		                     && unstoredAt(C, l + 2 < nl) && !getenv("TE_NO_FCORR"))
 		                        ? C.fcorr.p
-		                        : nullptr; // (both levels uniformly refined)
+		                        : nullptr; // (the next level uniformly refined; this one may be refined: the gather forms the terms)
 		if (fcorr_in && !u_unstored) return te::fail(TE_ESTATE, "te_vcycle: exported ghost terms without a reader");
 		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p, !u_unstored, fcorr_out, fcorr_in))) return rc;
 		C.f_has_corr = fcorr_out != nullptr;

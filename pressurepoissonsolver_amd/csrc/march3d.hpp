@@ -683,11 +683,11 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 // face cells) to the coarse cell behind the block. For x faces those coarse cells sit one per 64-byte sector: over a whole
 // level the fix-up reads and rewrites every sector of the coarse vector, 0.10 ms of a 1.09 ms cycle at 512^3. Instead, the
 // patch that OWNS the face values forms the finished terms (it holds the values in registers when its plane is final),
-// k_fcorr_gather3d sorts them into a compact side array of the coarse level, `fcorr` [coarse patch][12][N*N]:
-//   planes 0..3: x = 0, H-1, H, N-1 at (y + N z);  4..7: y = 0, H-1, H, N-1 at (x + N z);  8..11: z = ... at (x + N y)
-// (the octant faces of the eight children), pure stores, one writer per entry, and the kernels that read the coarse
-// right-hand side (k_rbgs_zero_resid3d / k_rbgs_resweep_prolong3d with FCORR) add them while loading:
-// f = ((f + x term) + y term) + z term -- the order in which k_restrict_fixup3d visits the faces (W,E,S,N,B,T), and the
+// k_fcorr_gather3d adds the y and z terms to the coarse right-hand side in place (contiguous rows and planes) and sorts
+// the x terms into a compact side array of the coarse level, `fcorr` [coarse patch][4][N*N]: planes x = 0, H-1, H, N-1
+// (the x faces of the eight child octants) at (y + N z), pure stores, one writer per entry; the kernels that read the
+// coarse right-hand side (k_rbgs_zero_resid3d / k_rbgs_resweep_prolong3d with FCORR) add them while loading:
+// f = ((f + y term) + z term) + x term -- the order in which k_restrict_fixup3d visits the faces (S,N,B,T,W,E), and the
 // same (w * g) / 8 summed in the same order, so the result is bit-identical to the fix-up pass. Entries of physical
 // faces are +0.
 template <int N> __device__ __forceinline__ int octPlane(int c) // 0, H-1, H, N-1 -> 0..3; other coordinates -> -1
@@ -695,46 +695,50 @@ template <int N> __device__ __forceinline__ int octPlane(int c) // 0, H-1, H, N-
 	constexpr int H = N / 2;
 	return c == 0 ? 0 : (c == H - 1 ? 1 : (c == H ? 2 : (c == N - 1 ? 3 : -1)));
 }
-// what a reader of the coarse right-hand side adds to its two rows (k) of plane z
+// what a reader of the coarse right-hand side adds to its two rows (k) of plane z: the x terms (the y and z terms were added
+// in place by k_fcorr_gather3d). fcorr: [patch][4][N*N], plane j at (y + N z).
 template <int N> struct FCorrSrc {
-	const double *x[2]; // per cell of the pair: that cell's x plane at row 2Yp, or null
-	const double *y[2]; // per row k: that row's y plane at column 2X, or null
-	const double *zb;   // the patch's four z planes
+	// N >= 8: at most one of a thread's two cells lies on an octant face (one pointer, one pair of values); N = 4: both may
+	static constexpr int NX = (N >= 8) ? 1 : 2;
+	const double        *x[NX]; // that cell's x plane at row 2Yp, or null
+	int                  xc;    // N >= 8: which cell of the pair it is
 	__device__ __forceinline__ void init(const double *fcorr, int pid, int X, int Yp)
 	{
 		constexpr int NN = N * N;
-		const double *b  = fcorr + (size_t) pid * 12 * NN;
+		const double *b  = fcorr + (size_t) pid * 4 * NN;
+		if (NX == 1) {
+			const int j0 = octPlane<N>(2 * X), j1 = octPlane<N>(2 * X + 1), j = j0 >= 0 ? j0 : j1;
+			xc   = j0 >= 0 ? 0 : 1;
+			x[0] = j >= 0 ? b + (size_t) j * NN + 2 * Yp : nullptr;
+		} else {
+			xc = 0;
 #pragma unroll
-		for (int c = 0; c < 2; c++) {
-			const int j = octPlane<N>(2 * X + c);
-			x[c]        = j >= 0 ? b + (size_t) j * NN + 2 * Yp : nullptr;
+			for (int c = 0; c < NX; c++) {
+				const int j = octPlane<N>(2 * X + c);
+				x[c]        = j >= 0 ? b + (size_t) j * NN + 2 * Yp : nullptr;
+			}
 		}
-#pragma unroll
-		for (int k = 0; k < 2; k++) {
-			const int j = octPlane<N>(2 * Yp + k);
-			y[k]        = j >= 0 ? b + (size_t) (4 + j) * NN + 2 * X : nullptr;
-		}
-		zb = b + (size_t) 8 * NN;
 	}
-	// issue the loads for plane z: cx[c] = {row 0, row 1} of cell c; cy[k] = {cell 0, cell 1} of row k; cz[k] likewise
-	__device__ __forceinline__ void load(int z, const int (&q)[2], double2 (&cx)[2], double2 (&cy)[2], double2 (&cz)[2]) const
+	// issue the loads for plane z: cx[c] = {row 0, row 1} of that cell
+	__device__ __forceinline__ void load(int z, double2 (&cx)[NX]) const
 	{
-		constexpr int NP = N * N / 2;
 #pragma unroll
-		for (int c = 0; c < 2; c++) cx[c] = x[c] ? *reinterpret_cast<const double2 *>(x[c] + N * z) : double2{0.0, 0.0};
-#pragma unroll
-		for (int k = 0; k < 2; k++) cy[k] = y[k] ? *reinterpret_cast<const double2 *>(y[k] + N * z) : double2{0.0, 0.0};
-		const int jz = octPlane<N>(z);
-#pragma unroll
-		for (int k = 0; k < 2; k++) cz[k] = jz >= 0 ? reinterpret_cast<const double2 *>(zb)[(size_t) jz * NP + q[k]] : double2{0.0, 0.0};
+		for (int c = 0; c < NX; c++) cx[c] = x[c] ? *reinterpret_cast<const double2 *>(x[c] + N * z) : double2{0.0, 0.0};
 	}
-	static __device__ __forceinline__ void apply(double2 (&f)[2], const double2 (&cx)[2], const double2 (&cy)[2], const double2 (&cz)[2])
+	__device__ __forceinline__ void apply(double2 (&f)[2], const double2 (&cx)[NX]) const
 	{
 #pragma clang fp contract(off)
-		f[0].x = ((f[0].x + cx[0].x) + cy[0].x) + cz[0].x;
-		f[0].y = ((f[0].y + cx[1].x) + cy[0].y) + cz[0].y;
-		f[1].x = ((f[1].x + cx[0].y) + cy[1].x) + cz[1].x;
-		f[1].y = ((f[1].y + cx[1].y) + cy[1].y) + cz[1].y;
+		if (NX == 1) { // (the other cell takes + 0)
+			const double a0 = xc == 0 ? cx[0].x : 0.0, a1 = xc == 0 ? 0.0 : cx[0].x;
+			const double b0 = xc == 0 ? cx[0].y : 0.0, b1 = xc == 0 ? 0.0 : cx[0].y;
+			f[0].x = f[0].x + a0, f[0].y = f[0].y + a1;
+			f[1].x = f[1].x + b0, f[1].y = f[1].y + b1;
+		} else {
+			f[0].x = f[0].x + cx[0].x;
+			f[0].y = f[0].y + cx[NX - 1].x;
+			f[1].x = f[1].x + cx[0].y;
+			f[1].y = f[1].y + cx[NX - 1].y;
+		}
 	}
 };
 // fcorr of the coarse level from the finished 2x2 sums the fine patches left in their own `rs6` [fine patch][6][H*H]
@@ -743,34 +747,93 @@ template <int N> struct FCorrSrc {
 // One workgroup per coarse patch and plane: entry (a, b) of plane j of axis ax belongs to child octant o; the term
 // comes from the patch across that child's face: rs6 of a local neighbour, or (neighbour on another rank) the sums of
 // k_restrict_fixup3d formed here from the ghost slot. Physical faces: +0. A pure permutation copy of finished values.
+// rs6 == null (a refined fine level: copy-through patches, coarse/fine ghost slots): the sums are formed here from the
+// fine level's face layers f6; a coarse patch that is a copy of a fine patch takes w g cell by cell on its own two faces
+// of each axis, as the copy-through branch of k_restrict_fixup3d adds them.
 template <int N>
-__global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_t *__restrict__ child, const double *__restrict__ rs6,
-                                                        double *__restrict__ fcorr)
+__global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_t *__restrict__ child, const int32_t *__restrict__ copy,
+                                                        const double *__restrict__ rs6, const double *__restrict__ f6,
+                                                        double *__restrict__ coarse, double *__restrict__ fcorr)
 {
-	constexpr int NN = N * N, H = N / 2, HH = H * H;
-	const int     pc = blockIdx.x / 12, pl = blockIdx.x % 12, ax = pl >> 2, j = pl & 3;
-	const int     a0 = (ax == 0) ? 1 : 0, a1 = (ax == 2) ? 1 : 2; // the two other axes in order
-	const int     hi = j >> 1;                                    // which half of the coarse patch along ax
-	const int     s  = 2 * ax + (j & 1);                          // j = 0: low face of the low child, 1: its high face, 2: low face of the high child, 3: its high face
-	double       *d  = fcorr + ((size_t) pc * 12 + pl) * NN;
-	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
-		const int a = i % N, b = i / N, oa = a >= H, ob = b >= H, ha = a - oa * H, hb = b - ob * H;
-		const int o = (hi << ax) | (oa << a0) | (ob << a1);
-		const int p = child[(size_t) pc * 8 + o];
-		double    v = 0.0;
-		if (p >= 0) {
-			const int kind = L.face_kind[(size_t) p * 6 + s], src = L.face_src[(size_t) p * 6 + s];
-			if (kind == FACE_LOCAL) {
-				v = rs6[((size_t) src * 6 + (s ^ 1)) * HH + ha + H * hb];
-			} else if (kind == FACE_GHOST) {
-				const double w = -L.rh2[(size_t) p * 3 + ax];
-#pragma unroll
-				for (int db = 0; db < 2; db++)
-#pragma unroll
-					for (int da = 0; da < 2; da++) v += (w * L.ghost[(size_t) src * NN + (2 * ha + da) + N * (2 * hb + db)]) / 8;
-			}
+	constexpr int NN = N * N, NNN = N * N * N, H = N / 2, HH = H * H;
+	// one workgroup per plane; a thread's QN entries are independent chains of dependent loads (tables, then the value): all
+	// terms first, then the stores, so that the chains overlap
+	constexpr int QN = (NN + 255) / 256;
+	const int     pc = blockIdx.x / 12, blk = blockIdx.x % 12; // 0..3: the x planes; 4..7: the y planes; 8..11: the z planes
+	const bool    cp = copy && copy[pc];
+	// the term of entry (a, b) of plane j of axis ax of this coarse patch
+	auto term = [&](int ax, int j, int a, int b) -> double {
+		const int a0 = (ax == 0) ? 1 : 0, a1 = (ax == 2) ? 1 : 2; // the two other axes in order
+		if (cp) { // the coarse patch IS a fine patch that does not coarsen: its own two faces of the axis, cell by cell (w g)
+			if (j == 1 || j == 2) return 0.0;
+			const int p = child[(size_t) pc * 8], sp = 2 * ax + (j == 3);
+			if (p < 0) return 0.0;
+			const int kind = L.face_kind[(size_t) p * 6 + sp], src = L.face_src[(size_t) p * 6 + sp];
+			if (kind < FACE_LOCAL) return 0.0;
+			const double g = kind == FACE_GHOST ? L.ghost[(size_t) src * NN + a + N * b] : f6[((size_t) src * 6 + (sp ^ 1)) * NN + a + N * b];
+			return -L.rh2[(size_t) p * 3 + ax] * g;
 		}
-		d[i] = v;
+		const int s = 2 * ax + (j & 1), hi = j >> 1; // j = 0: low face of the low child, 1: its high face, 2, 3: the high child's
+		const int oa = a >= H, ob = b >= H, ha = a - oa * H, hb = b - ob * H;
+		const int p = child[(size_t) pc * 8 + ((hi << ax) | (oa << a0) | (ob << a1))];
+		if (p < 0) return 0.0;
+		const int kind = L.face_kind[(size_t) p * 6 + s], src = L.face_src[(size_t) p * 6 + s];
+		if (kind < FACE_LOCAL) return 0.0;
+		if (kind == FACE_LOCAL && rs6) return rs6[((size_t) src * 6 + (s ^ 1)) * HH + ha + H * hb];
+		// the sum of k_restrict_fixup3d over the 2x2 block, first face coordinate fastest
+		const double  w  = -L.rh2[(size_t) p * 3 + ax];
+		const double *gp = kind == FACE_GHOST ? L.ghost + (size_t) src * NN : f6 + ((size_t) src * 6 + (s ^ 1)) * NN;
+		double        v  = 0.0;
+#pragma unroll
+		for (int db = 0; db < 2; db++)
+#pragma unroll
+			for (int da = 0; da < 2; da++) v += (w * gp[(2 * ha + da) + N * (2 * hb + db)]) / 8;
+		return v;
+	};
+	constexpr int coord[4] = {0, H - 1, H, N - 1};
+	double       *cv       = coarse + (size_t) pc * NNN;
+	const int     j        = blk & 3;
+	double        v[QN], vy[QN], f[QN];
+	if (blk < 4) { // an x plane: into the side array
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k;
+			v[k]        = i < NN ? term(0, j, i % N, i / N) : 0.0;
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k;
+			if (i < NN) fcorr[((size_t) pc * 4 + j) * NN + i] = v[k];
+		}
+	} else if (blk < 8) { // a y plane: entry (x, z) -> cell (x, coord[j], z); the cells that also lie on a z plane are that plane's
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N;
+			v[k]        = (i < NN && octPlane<N>(b) < 0) ? term(1, j, a, b) : 0.0;
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N;
+			if (v[k] != 0.0) cv[a + N * coord[j] + NN * b] += v[k];
+		}
+	} else { // a z plane: entry (x, y) -> cell (x, y, coord[j]); a cell that lies on a y plane too takes its y term first
+#pragma clang fp contract(off)
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N, jy = octPlane<N>(b);
+			const bool in = i < NN;
+			f[k]          = in ? cv[a + N * b + NN * coord[j]] : 0.0;
+			vy[k]         = (in && jy >= 0) ? term(1, jy, a, coord[j]) : 0.0;
+			v[k]          = in ? term(2, j, a, b) : 0.0;
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N;
+			double    t = f[k];
+			if (vy[k] != 0.0) t = t + vy[k];
+			if (v[k] != 0.0) t = t + v[k];
+			if (vy[k] != 0.0 || v[k] != 0.0) cv[a + N * b + NN * coord[j]] = t;
+		}
 	}
 }
 
@@ -875,7 +938,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 	double2 u3[2], u2[2], u1[2], u0[2], f2[2], f1[2], f0[2], fn[2];
 	const double2 zero2 = double2{0.0, 0.0};
 	FCorrSrc<N>   fc;
-	double2       ccx[2], ccy[2], ccz[2]; // FCORR: the terms of the plane in fn
+	double2       ccx[FCorrSrc<N>::NX]; // FCORR: the x terms of the plane in fn
 	if (FCORR) fc.init(L.fcorr, pid, X, Yp);
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
@@ -884,8 +947,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 		f0[k] = fp2[q[k]];
 	}
 	if (FCORR) {
-		fc.load(0, q, ccx, ccy, ccz);
-		FCorrSrc<N>::apply(f0, ccx, ccy, ccz);
+		fc.load(0, ccx);
+		fc.apply(f0, ccx);
 	}
 	__syncthreads(); // idiag and the zeroed tiles
 
@@ -895,7 +958,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 		const int     zc   = (z + 1 < N) ? z + 1 : N - 1;
 #pragma unroll
 		for (int k = 0; k < 2; k++) fn[k] = ldStream<TE_ZR_NT != 0>(fp2 + zc * NP + q[k]);
-		if (FCORR) fc.load(zc, q, ccx, ccy, ccz);
+		if (FCORR) fc.load(zc, ccx);
 		double *tz = tile[bz];            // plane z
 		double *t1 = tile[(bz + 3) & 3];  // plane z-1
 		double *t2 = tile[(bz + 2) & 3];  // plane z-2
@@ -1009,7 +1072,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 			f1[k] = f0[k];
 			f0[k] = fn[k];
 		}
-		if (FCORR) FCorrSrc<N>::apply(f0, ccx, ccy, ccz);
+		if (FCORR) fc.apply(f0, ccx);
 		bz = (bz + 1) & 3;
 	};
 #pragma unroll 1
@@ -1049,7 +1112,8 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 	const int cs[3] = {c1, c2, c3};
 	if (o < 0) { // the patch copies through: every face cell's term goes to the same cell of the same-size coarse patch
 		double *cc = pa >= 0 ? rd.coarse + (size_t) pa * NNN : rd.remote + rd.remote_off[-(pa + 2)];
-		for (int s = 0; s < 6; s++) {
+		for (int so = 0; so < 6; so++) {
+			const int s = (so + 2) % 6; // faces in the order S, N, B, T, W, E (see FCorrSrc)
 			const int kind = L.face_kind[(size_t) p * 6 + s], src = L.face_src[(size_t) p * 6 + s];
 			if (kind >= FACE_LOCAL) {
 				const int    ax = s >> 1;
@@ -1075,7 +1139,8 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 		}
 		return;
 	}
-	for (int s = 0; s < 6; s++) {
+	for (int so = 0; so < 6; so++) {
+		const int s = (so + 2) % 6; // S, N, B, T, W, E
 		const int kind = L.face_kind[(size_t) p * 6 + s], src = L.face_src[(size_t) p * 6 + s];
 		if (kind >= FACE_LOCAL) {
 			const int    ax = s >> 1;
@@ -1316,12 +1381,12 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 		umm[k] = zero2;
 	}
 	FCorrSrc<N> fc;
-	double2     ccx[2], ccy[2], ccz[2]; // FCORR: the terms of the plane in fn
+	double2     ccx[FCorrSrc<N>::NX]; // FCORR: the x terms of the plane in fn
 	if (FCORR) {
 		fc.init(L.fcorr, pid, X, Yp);
 		auto fix = [&](int z, double2(&fz)[2]) {
-			fc.load(z, q, ccx, ccy, ccz);
-			FCorrSrc<N>::apply(fz, ccx, ccy, ccz);
+			fc.load(z, ccx);
+			fc.apply(fz, ccx);
 		};
 		fix(0, f0), fix(1, f1), fix(2, f2), fix(3, f3);
 		if (DEEP) fix(4 < N ? 4 : N - 1, f4);
@@ -1371,7 +1436,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 		const int     zf = (z + AHEAD < N) ? z + AHEAD : N - 1, zc = (z + 1 < N) ? z + 1 : N - 1;
 #pragma unroll
 		for (int k = 0; k < 2; k++) fn[k] = ldStream<NTL>(fp2 + zf * NP + q[k]);
-		if (FCORR) fc.load(zf, q, ccx, ccy, ccz);
+		if (FCORR) fc.load(zf, ccx);
 		const double hvn = hs.s * (hs.p[zc * hs.stride] + shalo * chalo[NN * (zc >> hsh)]);
 		const double c2  = CFP ? 0.0 : ((z + 2 < N) ? cown[NN * ((z + 2) >> 1) + cq] : stop * ctop[cq]);
 		if (CFP) {
@@ -1454,7 +1519,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 			r1[k]  = r2[k];
 			r2[k]  = r3[k];
 		}
-		if (FCORR) FCorrSrc<N>::apply(DEEP ? f4 : f3, ccx, ccy, ccz);
+		if (FCORR) fc.apply(DEEP ? f4 : f3, ccx);
 		hv = hvn;
 		bz = (bz == 2) ? 0 : bz + 1;
 	};
