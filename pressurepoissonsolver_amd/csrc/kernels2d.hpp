@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_rbgs2d(Level2D L, const double *__restr
 		const double  kx = 2.0 + (x == 0 ? kfold2d(L, p, 0) : 0.0) + (x == n - 1 ? kfold2d(L, p, 1) : 0.0);
 		const double  ky = 2.0 + (y == 0 ? kfold2d(L, p, 2) : 0.0) + (y == n - 1 ? kfold2d(L, p, 3) : 0.0);
 		const double  o  = offdiag2d(xl, xr, yl, yr, rhx, rhy);
-		out[idx]         = (o - f[idx]) / (kx * rhx + ky * rhy);
+		out[idx]         = (o - f[idx]) * (1.0 / (kx * rhx + ky * rhy)); // (reciprocal of the diagonal, as the 3D kernels and the LDS forms below)
 	}
 }
 
@@ -157,7 +157,7 @@ template <bool ZERO, bool PROLONG>
 __global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
                                                     double *__restrict__ out, Prolong2D ps)
 {
-	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // (n+2) x (n+2), then 9 inverse diagonals
+	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // (n+2) x (n+2), then the 9 reciprocals of the diagonal
 	const int     n = L.n, lw = n + 2, nn = n * n;
 	const int     p = blockIdx.x, tid = threadIdx.x;
 	const double *up = u + (size_t) p * nn;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__r
 		const int cx = tid % 3, cy = tid / 3;
 		const double kx = 2.0 + (cx == 0 ? kfold2d(L, p, 0) : 0.0) + (cx == 2 ? kfold2d(L, p, 1) : 0.0);
 		const double ky = 2.0 + (cy == 0 ? kfold2d(L, p, 2) : 0.0) + (cy == 2 ? kfold2d(L, p, 3) : 0.0);
-		idg[tid]        = kx * rhx + ky * rhy;
+		idg[tid]        = 1.0 / (kx * rhx + ky * rhy);
 	}
 	if (ZERO) {
 		for (int i = tid; i < lw * lw; i += blockDim.x) tile2d[i] = 0.0;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__r
 			double   *t0 = tile2d + (y + 1) * lw + x + 1;
 			const int cx = (x == 0) ? 0 : (x == n - 1 ? 2 : 1), cy = (y == 0) ? 0 : (y == n - 1 ? 2 : 1);
 			const double o = offdiag2d(t0[-1], t0[1], t0[-lw], t0[lw], rhx, rhy);
-			*t0            = (o - fp[x + n * y]) / idg[cx + 3 * cy];
+			*t0            = (o - fp[x + n * y]) * idg[cx + 3 * cy];
 		}
 		__syncthreads();
 	}
@@ -299,7 +299,7 @@ __device__ __forceinline__ void halfSweep2d(double *tile, const double *idg, con
 			const double o = offdiag2d(t0[-1], t0[1], t0[-lw], t0[lw], rhx, rhy);                         \
 			double       fa = fr.x##K, fb = fr.y##K;                                                      \
 			asm volatile("" : "+v"(fa), "+v"(fb)); /* (a select of registers, not an indexed stack slot) */ \
-			*t0 = (o - (odd ? fb : fa)) / idg[cx + 3 * cy];                                               \
+			*t0 = (o - (odd ? fb : fa)) * idg[cx + 3 * cy];                                               \
 		}                                                                                                 \
 	}
 	TE_F2D_EACH(TE_RX)
@@ -317,7 +317,7 @@ __device__ __forceinline__ void idiag2d(const Level2D &L, int p, double rhx, dou
 		const int    cx = threadIdx.x % 3, cy = threadIdx.x / 3;
 		const double kx = 2.0 + (cx == 0 ? kfold2d(L, p, 0) : 0.0) + (cx == 2 ? kfold2d(L, p, 1) : 0.0);
 		const double ky = 2.0 + (cy == 0 ? kfold2d(L, p, 2) : 0.0) + (cy == 2 ? kfold2d(L, p, 3) : 0.0);
-		idg[threadIdx.x] = kx * rhx + ky * rhy;
+		idg[threadIdx.x] = 1.0 / (kx * rhx + ky * rhy);
 	}
 }
 // Cycle.h:57-65 for the first sweep of a cycle in one pass over f (the 2D twin of k_rbgs_zero_resid3d): u = S(0, f),
