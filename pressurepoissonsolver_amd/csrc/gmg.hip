@@ -1099,6 +1099,32 @@ int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0
 	*swapped = false;
 	int          rc;
 	const size_t total = (size_t) L.P * L.nc;
+	if (L.n == 64 && L.matsT.p && !getenv("TE_2D_SIMPLE") && !getenv("TE_2D_NO_MFMA")) { // 64^2 patches: the four products on the matrix cores
+		if (!zero_guess && (rc = prepareGhosts2d(g, L, u))) return rc;
+		const size_t lds = sizeof(double) * 64 * PS2D_LD;
+		static bool  attr = false;
+		const bool   pf = L.P <= 256 && !getenv("TE_2D_NO_PF"); // few patches: a workgroup has its CU to itself anyway
+		auto         launch = [&](auto kern) -> int {
+            if (!attr) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+            hipLaunchKernelGGL(kern, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.matsT.p, L.lam.p, L.zero_mode.p, f, u, s1);
+            return TE_OK;
+		};
+		Timed t(g, KC_PS_MFMA, total);
+		if (!attr) { // all four once, so that the attribute is set whichever runs first
+			const void *ks[4] = {reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, false>),
+			                     reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, false>)};
+			for (const void *k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+			attr = true;
+		}
+		if (zero_guess)
+			rc = pf ? launch(k_patch_solve2d_mfma<true, true>) : launch(k_patch_solve2d_mfma<true, false>);
+		else
+			rc = pf ? launch(k_patch_solve2d_mfma<false, true>) : launch(k_patch_solve2d_mfma<false, false>);
+		if (rc) return rc;
+		HIPCHK(hipGetLastError());
+		*swapped = true;
+		return TE_OK;
+	}
 	if (L.n <= 64 && L.matsT.p && !getenv("TE_2D_SIMPLE")) { // one launch, the patch in LDS
 		if (!zero_guess && (rc = prepareGhosts2d(g, L, u))) return rc;
 		const size_t lds = sizeof(double) * 2 * L.nc;

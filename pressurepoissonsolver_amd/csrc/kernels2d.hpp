@@ -793,4 +793,137 @@ __global__ __launch_bounds__(TPB) void k_patch_solve2d_lds(Level2D L, const int3
 		__syncthreads();
 	}
 }
+
+// The exact 2D patch solve for 64^2 patches on the fp64 matrix cores: four 64x64x64 products (x forward, y forward +
+// eigenvalue division, x inverse, y inverse) as v_mfma_f64_16x16x4 tiles, D(16x16) += A(16x4) B(4x16) with lane
+// (j = l & 15, g = l >> 4) holding A[i = j][k = g], B[k = g][col = j], D[row = g + 4r][col = j]. Wave w owns the output rows
+// 16w .. 16w+15 of every stage (four 16x16 tiles, 16 k-steps each: 64 MFMAs per wave and stage); the data crosses between
+// stages through one LDS tile with padded rows (a row per lane: stride 65 doubles, conflict-free), the matrices come
+// transposed (matsT) so that sixteen lanes read 128 contiguous bytes. One workgroup per patch, out of place (block Jacobi
+// reads the neighbours' OLD values). Sums run in the MFMA's order, not k_dst_axis2d's: equal to rounding.
+typedef double v4f64_2d __attribute__((ext_vector_type(4)));
+constexpr int PS2D_LD = 65; // padded row length of the LDS tiles
+// PF: the matrix fragments of the next stage are fetched into registers a stage ahead (246 VGPRs, one workgroup per CU: for
+// levels of few patches, where the latency of the matrix loads is all there is); without it they are read where they are used
+// and two workgroups share a CU.
+template <bool ZERO, bool PF>
+__global__ __launch_bounds__(256) void k_patch_solve2d_mfma(Level2D L, const int32_t *__restrict__ plan, const double *__restrict__ matsT,
+                                                            const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
+                                                            const double *__restrict__ f, const double *__restrict__ u,
+                                                            double *__restrict__ out)
+{
+	constexpr int n = 64, nn = n * n, LD = PS2D_LD;
+	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // one tile of 64 x 65: stages 0 and 2 work on a wave's own rows in place
+	double       *A = tile2d, *B = tile2d;
+	const int     p = blockIdx.x, tid = threadIdx.x, pl = plan[p];
+	const int     w = tid >> 6, l = tid & 63, j = l & 15, g = l >> 4;
+	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
+	const double *fp = f + (size_t) p * nn, *up = u + (size_t) p * nn;
+	const double *MT = matsT + (size_t) pl * 4 * nn; // MT[stage][k * 64 + i] = M[stage][i][k]
+	const double *lm = lam + (size_t) pl * 2 * n;
+	double        mc[PF ? 64 : 1], mr[PF ? 16 : 1]; // matrix fragments of a B-side stage (4 column tiles x 16 k-steps) and of an A-side stage
+	auto          loadB = [&](int stage) {
+        if constexpr (PF) {
+#pragma unroll
+            for (int ks = 0; ks < 16; ks++)
+#pragma unroll
+                for (int ct = 0; ct < 4; ct++) mc[ks * 4 + ct] = MT[stage * nn + (4 * ks + g) * n + 16 * ct + j];
+        }
+	};
+	auto loadA = [&](int stage) {
+		if constexpr (PF) {
+#pragma unroll
+			for (int ks = 0; ks < 16; ks++) mr[ks] = MT[stage * nn + (4 * ks + g) * n + 16 * w + j];
+		}
+	};
+	auto fragB = [&](int stage, int ks, int ct) { return PF ? mc[ks * 4 + ct] : MT[stage * nn + (4 * ks + g) * n + 16 * ct + j]; };
+	auto fragA = [&](int stage, int ks) { return PF ? mr[ks] : MT[stage * nn + (4 * ks + g) * n + 16 * w + j]; };
+	loadB(0); // stage 0's matrix, in flight while the right-hand side is formed
+	for (int c = tid; c < nn; c += 256) { // k_patch_rhs2d into tile A [y][x]
+		const int x = c % n, y = c / n;
+		double    v = fp[c];
+		if (!ZERO) {
+			const int    xy[2] = {x, y};
+			const double m = up[c];
+#pragma unroll
+			for (int ax = 0; ax < 2; ax++)
+#pragma unroll
+				for (int side = 0; side < 2; side++) {
+					if (xy[ax] != (side ? n - 1 : 0)) continue;
+					const int s = 2 * ax + side;
+					if (L.face_kind[p * 4 + s] < FACE_LOCAL) continue;
+					const double gh = ghost2d(L, u, p, s, xy[1 - ax], m, false);
+					v -= 2.0 * L.rh2[p * 3 + ax] * (0.5 * m + 0.5 * gh);
+				}
+		}
+		A[y * LD + x] = v;
+	}
+	__syncthreads();
+	v4f64_2d d[4];
+	// ---- stage 0: Y1[y][kx] = sum_x X[y][x] Fx[kx][x]: A operand = X rows (LDS), B operand = Fx^T (registers)
+	loadA(1); // stage 1's matrix, in flight during stage 0
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++) d[ct] = v4f64_2d{0, 0, 0, 0};
+#pragma clang loop unroll_count(PF ? 16 : 4)
+	for (int ks = 0; ks < 16; ks++) {
+		const double a = A[(16 * w + j) * LD + 4 * ks + g];
+#pragma unroll
+		for (int ct = 0; ct < 4; ct++) d[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fragB(0, ks, ct), d[ct], 0, 0, 0);
+	}
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) B[(16 * w + g + 4 * r) * LD + 16 * ct + j] = d[ct][r];
+	loadB(2); // stage 2's matrix, in flight during stage 1
+	__syncthreads();
+	// ---- stage 1: Y2[ky][kx] = sum_y Fy[ky][y] Y1[y][kx], divided by the eigenvalues: A = Fy (registers), B = Y1 (LDS)
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++) d[ct] = v4f64_2d{0, 0, 0, 0};
+#pragma clang loop unroll_count(PF ? 16 : 4)
+	for (int ks = 0; ks < 16; ks++) {
+		const double a = fragA(1, ks);
+#pragma unroll
+		for (int ct = 0; ct < 4; ct++) d[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[(4 * ks + g) * LD + 16 * ct + j], d[ct], 0, 0, 0);
+	}
+	loadA(3);
+	__syncthreads(); // every wave has read all rows of Y1 before any overwrites its own
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int ky = 16 * w + g + 4 * r, kx = 16 * ct + j;
+			double    v  = d[ct][r] / -(lm[kx] * rhx + lm[n + ky] * rhy);
+			if (zero_mode[pl] && kx == 0 && ky == 0) v = 0.0;
+			A[ky * LD + kx] = v;
+		}
+	__syncthreads();
+	// ---- stage 2: Y3[ky][x] = sum_kx Y2[ky][kx] Gx[x][kx]: A = Y2 rows (LDS), B = Gx^T (registers)
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++) d[ct] = v4f64_2d{0, 0, 0, 0};
+#pragma clang loop unroll_count(PF ? 16 : 4)
+	for (int ks = 0; ks < 16; ks++) {
+		const double a = A[(16 * w + j) * LD + 4 * ks + g];
+#pragma unroll
+		for (int ct = 0; ct < 4; ct++) d[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fragB(2, ks, ct), d[ct], 0, 0, 0);
+	}
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) B[(16 * w + g + 4 * r) * LD + 16 * ct + j] = d[ct][r];
+	__syncthreads();
+	// ---- stage 3: U[y][x] = sum_ky Gy[y][ky] Y3[ky][x], scaled: A = Gy (registers), B = Y3 (LDS)
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++) d[ct] = v4f64_2d{0, 0, 0, 0};
+#pragma clang loop unroll_count(PF ? 16 : 4)
+	for (int ks = 0; ks < 16; ks++) {
+		const double a = fragA(3, ks);
+#pragma unroll
+		for (int ct = 0; ct < 4; ct++) d[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[(4 * ks + g) * LD + 16 * ct + j], d[ct], 0, 0, 0);
+	}
+	double *op = out + (size_t) p * nn;
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) op[(16 * w + g + 4 * r) * n + 16 * ct + j] = d[ct][r] * (4.0 / ((double) n * n));
+}
 } // namespace te
