@@ -285,32 +285,6 @@ __device__ __forceinline__ void loadF2d(const double *fp, int nn, F2D &fr)
 	TE_F2D_EACH(TE_LD)
 #undef TE_LD
 }
-template <int COLOUR>
-__device__ __forceinline__ void halfSweep2d(double *tile, const double *idg, const F2D &fr, int n, double rhx, double rhy)
-{
-	const int lw = n + 2, nn = n * n;
-#define TE_RX(K)                                                                                          \
-	{                                                                                                     \
-		const int i = threadIdx.x + K * 256;                                                              \
-		if (i < nn / 2) {                                                                                 \
-			const int y = (2 * i) / n, odd = (y + COLOUR) & 1, x = (2 * i) % n + odd;                     \
-			double   *t0 = tile + (y + 1) * lw + x + 1;                                                   \
-			const int cx = (x == 0) ? 0 : (x == n - 1 ? 2 : 1), cy = (y == 0) ? 0 : (y == n - 1 ? 2 : 1); \
-			const double o = offdiag2d(t0[-1], t0[1], t0[-lw], t0[lw], rhx, rhy);                         \
-			double       fa = fr.x##K, fb = fr.y##K;                                                      \
-			asm volatile("" : "+v"(fa), "+v"(fb)); /* (a select of registers, not an indexed stack slot) */ \
-			*t0 = (o - (odd ? fb : fa)) * idg[cx + 3 * cy];                                               \
-		}                                                                                                 \
-	}
-	TE_F2D_EACH(TE_RX)
-#undef TE_RX
-	__syncthreads();
-}
-__device__ __forceinline__ void sweep2d(double *tile, const double *idg, const F2D &fr, int n, double rhx, double rhy)
-{
-	halfSweep2d<0>(tile, idg, fr, n, rhx, rhy);
-	halfSweep2d<1>(tile, idg, fr, n, rhx, rhy);
-}
 __device__ __forceinline__ void idiag2d(const Level2D &L, int p, double rhx, double rhy, double *idg)
 {
 	if (threadIdx.x < 9) {
@@ -318,6 +292,163 @@ __device__ __forceinline__ void idiag2d(const Level2D &L, int p, double rhx, dou
 		const double kx = 2.0 + (cx == 0 ? kfold2d(L, p, 0) : 0.0) + (cx == 2 ? kfold2d(L, p, 1) : 0.0);
 		const double ky = 2.0 + (cy == 0 ? kfold2d(L, p, 2) : 0.0) + (cy == 2 ? kfold2d(L, p, 3) : 0.0);
 		idg[threadIdx.x] = 1.0 / (kx * rhx + ky * rhy);
+	}
+}
+// The tile of the fused kernels keeps the two colours apart: cell (x, y), x and y in -1 .. n (halo ring included), sits in
+// plane (x + y) & 1 at [(y + 1) * lwh + ((x + 1) >> 1)], lwh = n/2 + 1. A half sweep reads one plane and writes the other, and
+// the lanes of a row touch consecutive doubles (in the natural layout every access of a half sweep has stride 2: two-way
+// bank conflicts on each ds_read_b64). Same size as the natural tile: 2 (n + 2)(n/2 + 1) = (n + 2)^2.
+struct Tile2D {
+	double *t;
+	int     lwh, cs;
+	__device__ Tile2D(double *base, int n) : t(base), lwh(n / 2 + 1), cs((n + 2) * (n / 2 + 1)) {}
+	__device__ __forceinline__ double &at(int x, int y) const { return t[((x + y) & 1) * cs + (y + 1) * lwh + ((x + 1) >> 1)]; }
+};
+// Pair K of a thread (the x-pair number i = tid + 256 K of the patch): row y, pair column q (cells x = 2q, 2q + 1),
+// o = y & 1. Its red cell ((x + y) even) is x = 2q + o and sits at [y + 1][q + o] of plane 0, its black cell x = 2q + 1 - o
+// at [y + 1][q + 1 - o] of plane 1; a red cell's neighbours are [y + 1][q], [y + 1][q + 1], [y][q + o], [y + 2][q + o] of the black
+// plane, a black cell's the same with o -> 1 - o in the red plane.
+struct Pair2D {
+	int  y, q, o;
+	bool live;
+};
+__device__ __forceinline__ double fr_x(const F2D &fr, int K)
+{
+	switch (K) { // (K is a constant after unrolling)
+#define TE_FX(J) \
+	case J: return fr.x##J;
+		TE_F2D_EACH(TE_FX)
+#undef TE_FX
+	}
+	return 0.0;
+}
+__device__ __forceinline__ double fr_y(const F2D &fr, int K)
+{
+	switch (K) {
+#define TE_FY(J) \
+	case J: return fr.y##J;
+		TE_F2D_EACH(TE_FY)
+#undef TE_FY
+	}
+	return 0.0;
+}
+template <int NC> __device__ __forceinline__ Pair2D pairOf(int K, int n)
+{
+	const int i = threadIdx.x + K * 256, m = NC ? NC : n;
+	return Pair2D{(2 * i) / m, ((2 * i) % m) >> 1, ((2 * i) / m) & 1, i < m * m / 2};
+}
+// reciprocal diagonal of a cell: from the table in LDS, or -- NC = 64, where a thread's cells of one colour all have the same x
+// class and only its first and last pair can lie on the bottom / top row -- from two registers (mid[colour])
+template <int NC> __device__ __forceinline__ double idgOf(const double *idg, const double *mid, int K, int colour, int x, int y, int n)
+{
+	if (NC == 64 && K >= 1 && K <= 6) return mid[colour];
+	const int cx = (x == 0) ? 0 : (x == n - 1 ? 2 : 1), cy = (y == 0) ? 0 : (y == n - 1 ? 2 : 1);
+	return idg[cx + 3 * cy];
+}
+__device__ __forceinline__ double addRounded2d(double a, double b)
+{
+#pragma clang fp contract(off)
+	return a + b; // (never folded into the multiplication that produced a)
+}
+// v = S(0, f), the zero-guess sweep of one patch: red cells see zero neighbours only, (0 - f) / diag, and touch no LDS but to
+// store; black cells read the new red values, their ghosts (zero: the halo of a zero iterate, physical faces folded into the
+// diagonal) masked rather than read, so that the ring may already hold the next sweep's halo. ADDC: the black plane receives
+// v + c (the red cells of an iterate are never read by the sweep that follows it). rv / bv: the values of the thread's pairs.
+// The arithmetic of k_rbgs2d_lds<ZERO>: bit-identical.
+template <int NC, bool ADDC>
+__device__ __forceinline__ void zeroSweep2d(const Tile2D &T, const double *idg, const double *mid, const F2D &fr, const double *cr, int n,
+                                            double rhx, double rhy, double *rv, double *bv)
+{
+	double *R = T.t, *B = T.t + T.cs;
+#define TE_R1(K)                                                                                     \
+	{                                                                                                \
+		const Pair2D pr = pairOf<NC>(K, n);                                                          \
+		if (pr.live) {                                                                               \
+			double fa = fr.x##K, fb = fr.y##K;                                                       \
+			asm volatile("" : "+v"(fa), "+v"(fb));                                                   \
+			rv[K] = (0.0 - (pr.o ? fb : fa)) * idgOf<NC>(idg, mid, K, 0, 2 * pr.q + pr.o, pr.y, n);  \
+			R[(pr.y + 1) * T.lwh + pr.q + pr.o] = rv[K];                                             \
+		}                                                                                            \
+	}
+	TE_F2D_EACH(TE_R1)
+#undef TE_R1
+	ldsBarrier();
+#define TE_B1(K)                                                                                     \
+	{                                                                                                \
+		const Pair2D pr = pairOf<NC>(K, n);                                                          \
+		if (pr.live) {                                                                               \
+			const int     x = 2 * pr.q + 1 - pr.o, c = pr.q + 1 - pr.o;                              \
+			const double *r0 = R + (pr.y + 1) * T.lwh;                                               \
+			double        xl = r0[pr.q], xr = r0[pr.q + 1], yl = r0[c - T.lwh], yr = r0[c + T.lwh];  \
+			xl = (x == 0) ? 0.0 : xl, xr = (x == n - 1) ? 0.0 : xr;                                  \
+			yl = (pr.y == 0) ? 0.0 : yl, yr = (pr.y == n - 1) ? 0.0 : yr;                            \
+			double fa = fr.x##K, fb = fr.y##K;                                                       \
+			asm volatile("" : "+v"(fa), "+v"(fb));                                                   \
+			bv[K] = (offdiag2d(xl, xr, yl, yr, rhx, rhy) - (pr.o ? fa : fb)) * idgOf<NC>(idg, mid, K, 1, x, pr.y, n); \
+			B[(pr.y + 1) * T.lwh + c] = ADDC ? addRounded2d(bv[K], cr[K]) : bv[K];                   \
+		}                                                                                            \
+	}
+	TE_F2D_EACH(TE_B1)
+#undef TE_B1
+	ldsBarrier();
+}
+// one sweep over the tile (ring = the frozen halo), the new values of the thread's pairs to rv / bv; the black plane of the
+// result is not stored (nobody reads it: the caller writes the pairs to memory)
+template <int NC>
+__device__ __forceinline__ void lastSweep2d(const Tile2D &T, const double *idg, const double *mid, const F2D &fr, int n, double rhx, double rhy,
+                                            double *rv, double *bv)
+{
+	double *R = T.t, *B = T.t + T.cs;
+#define TE_R2(K)                                                                                     \
+	{                                                                                                \
+		const Pair2D pr = pairOf<NC>(K, n);                                                          \
+		if (pr.live) {                                                                               \
+			const int     c  = pr.q + pr.o;                                                          \
+			const double *b0 = B + (pr.y + 1) * T.lwh;                                               \
+			const double  o  = offdiag2d(b0[pr.q], b0[pr.q + 1], b0[c - T.lwh], b0[c + T.lwh], rhx, rhy); \
+			double        fa = fr.x##K, fb = fr.y##K;                                                \
+			asm volatile("" : "+v"(fa), "+v"(fb));                                                   \
+			rv[K] = (o - (pr.o ? fb : fa)) * idgOf<NC>(idg, mid, K, 0, 2 * pr.q + pr.o, pr.y, n);    \
+			R[(pr.y + 1) * T.lwh + c] = rv[K];                                                       \
+		}                                                                                            \
+	}
+	TE_F2D_EACH(TE_R2)
+#undef TE_R2
+	ldsBarrier();
+#define TE_B2(K)                                                                                     \
+	{                                                                                                \
+		const Pair2D pr = pairOf<NC>(K, n);                                                          \
+		if (pr.live) {                                                                               \
+			const int     c  = pr.q + 1 - pr.o;                                                      \
+			const double *r0 = R + (pr.y + 1) * T.lwh;                                               \
+			const double  o  = offdiag2d(r0[pr.q], r0[pr.q + 1], r0[c - T.lwh], r0[c + T.lwh], rhx, rhy); \
+			double        fa = fr.x##K, fb = fr.y##K;                                                \
+			asm volatile("" : "+v"(fa), "+v"(fb));                                                   \
+			bv[K] = (o - (pr.o ? fa : fb)) * idgOf<NC>(idg, mid, K, 1, 2 * pr.q + 1 - pr.o, pr.y, n); \
+		}                                                                                            \
+	}
+	TE_F2D_EACH(TE_B2)
+#undef TE_B2
+}
+// the pairs of a thread to memory, 16 B per lane
+template <int NC> __device__ __forceinline__ void storePairs2d(double *op, const double *rv, const double *bv, int n)
+{
+#pragma unroll
+	for (int K = 0; K < F2D_MAX; K++) {
+		const Pair2D pr = pairOf<NC>(K, n);
+		if (pr.live) reinterpret_cast<double2 *>(op)[threadIdx.x + K * 256] = pr.o ? double2{bv[K], rv[K]} : double2{rv[K], bv[K]};
+	}
+}
+// table of reciprocal diagonals to LDS, the thread's two mid-row values to registers (see idgOf); ends with a barrier
+template <int NC> __device__ __forceinline__ void idiagSetup2d(const Level2D &L, int p, double rhx, double rhy, double *idg, double *mid, int n)
+{
+	idiag2d(L, p, rhx, rhy, idg);
+	ldsBarrier();
+	if (NC == 64) {
+		const Pair2D pr = pairOf<NC>(1, n);
+		const int    xr = 2 * pr.q + pr.o, xb = 2 * pr.q + 1 - pr.o;
+		mid[0] = idg[((xr == 0) ? 0 : (xr == n - 1 ? 2 : 1)) + 3];
+		mid[1] = idg[((xb == 0) ? 0 : (xb == n - 1 ? 2 : 1)) + 3];
 	}
 }
 // Cycle.h:57-65 for the first sweep of a cycle in one pass over f (the 2D twin of k_rbgs_zero_resid3d): u = S(0, f),
@@ -332,50 +463,84 @@ __global__ __launch_bounds__(256) void k_rbgs_zero_resid2d_lds(Level2D L, const 
                                                                double *__restrict__ e4, Prolong2D dst, double *__restrict__ coarse,
                                                                double *__restrict__ remote, const int64_t *__restrict__ remote_off)
 {
-	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // (n+2) x (n+2), then 9 diagonals
-	const int     n = NC ? NC : L.n, lw = n + 2, nn = n * n, h = n / 2;
+	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // the colour-split tile (Tile2D), then 9 diagonals
+	const int     n = NC ? NC : L.n, nn = n * n, h = n / 2;
 	const int     p = blockIdx.x, tid = threadIdx.x;
 	const double *fp = f + (size_t) p * nn;
-	double       *idg = tile2d + lw * lw;
+	const Tile2D  T(tile2d, n);
+	double       *idg = tile2d + 2 * T.cs;
 	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
-	F2D fr;
+	F2D           fr;
+	double        rv[F2D_MAX], bv[F2D_MAX], mid[2];
 	loadF2d(fp, nn, fr);
-	idiag2d(L, p, rhx, rhy, idg);
-	for (int i = tid; i < lw * lw; i += blockDim.x) tile2d[i] = 0.0;
-	__syncthreads();
-	sweep2d(tile2d, idg, fr, n, rhx, rhy);
-	// the new iterate's edges (and the iterate itself), then the residual's ghost ring: physical faces -own / +own
-	// (StarPatchOp.h:39-65), faces with a neighbour 0
-	for (int i = tid; i < 4 * n; i += blockDim.x) {
-		const int    s = i / n, t = i % n;
-		const int    in = (s == 0) ? (t + 1) * lw + 1 : (s == 1) ? (t + 1) * lw + n : (s == 2) ? lw + t + 1 : n * lw + t + 1;
-		const int    ring = (s == 0) ? (t + 1) * lw : (s == 1) ? (t + 1) * lw + n + 1 : (s == 2) ? t + 1 : (n + 1) * lw + t + 1;
-		const double own = tile2d[in];
-		if (!STORE_U) e4[((size_t) p * 4 + s) * n + t] = own;
-		const int kind = L.face_kind[p * 4 + s];
-		tile2d[ring]   = kind == FACE_DIRICHLET ? -own : (kind == FACE_NEUMANN ? own : 0.0);
-	}
-	if (STORE_U)
-		for (int i = tid; i < nn / 2; i += blockDim.x) {
-			const int y = (2 * i) / n, x = (2 * i) % n;
-			reinterpret_cast<double2 *>(out + (size_t) p * nn)[i] = double2{tile2d[(y + 1) * lw + x + 1], tile2d[(y + 1) * lw + x + 2]};
+	idiagSetup2d<NC>(L, p, rhx, rhy, idg, mid, n);
+	zeroSweep2d<NC, false>(T, idg, mid, fr, nullptr, n, rhx, rhy, rv, bv);
+	// the new iterate, or only its four edge layers: from the registers that hold the pairs
+	if (STORE_U) {
+		storePairs2d<NC>(out + (size_t) p * nn, rv, bv, n);
+	} else {
+		double *e = e4 + (size_t) p * 4 * n;
+#pragma unroll
+		for (int K = 0; K < F2D_MAX; K++) {
+			const Pair2D pr = pairOf<NC>(K, n);
+			if (!pr.live) continue;
+			const double2 v = pr.o ? double2{bv[K], rv[K]} : double2{rv[K], bv[K]};
+			if (pr.q == 0) e[pr.y] = v.x;
+			if (pr.q == h - 1) e[n + pr.y] = v.y;
+			if (pr.y == 0) *reinterpret_cast<double2 *>(e + 2 * n + 2 * pr.q) = v;
+			if (pr.y == n - 1) *reinterpret_cast<double2 *>(e + 3 * n + 2 * pr.q) = v;
 		}
-	__syncthreads();
+	}
+	// residual and restriction; ghosts: physical faces -own / +own (StarPatchOp.h:39-65), faces with a neighbour 0
 	const int pa = dst.parent[p], o = dst.orth[p];
 	double   *cp = pa >= 0 ? coarse + (size_t) pa * nn + ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0) : remote + remote_off[-(pa + 2)];
 	const int cs = pa >= 0 ? n : h; // row stride of the destination
-	for (int i = tid; i < h * h; i += blockDim.x) { // as k_resid_restrict2d_lds
-		const int hx = i % h, hy = i / h;
-		double    acc = 0.0;
+	const int k0 = L.face_kind[p * 4], k1 = L.face_kind[p * 4 + 1], k2 = L.face_kind[p * 4 + 2], k3 = L.face_kind[p * 4 + 3];
+	auto      gh = [](int kind, double own) { return kind == FACE_DIRICHLET ? -own : (kind == FACE_NEUMANN ? own : 0.0); };
+	if (NC == 64) {
+		// a thread forms the residual of its own pairs (values and f in registers); rows y and y ^ 1 sit in the two halves of
+		// a wave: the even row's lanes fetch the odd row's two quarters and add them in AvgRstr's order
+		const double *R = T.t, *B = T.t + T.cs;
 #pragma unroll
-		for (int dy = 0; dy < 2; dy++) {
-			const int     y = 2 * hy + dy, x = 2 * hx;
-			const double *t0 = tile2d + (y + 1) * lw + x + 1;
-			const double2 fv = *reinterpret_cast<const double2 *>(fp + x + n * y);
-			acc += (fv.x - lap2d(t0[-1], t0[0], t0[1], t0[-lw], t0[lw], rhx, rhy)) / 4;
-			acc += (fv.y - lap2d(t0[0], t0[1], t0[2], t0[1 - lw], t0[1 + lw], rhx, rhy)) / 4;
+		for (int K = 0; K < F2D_MAX; K++) {
+			const Pair2D  pr = pairOf<NC>(K, n);
+			const int     y = pr.y, q = pr.q, ro = (y + 1) * T.lwh;
+			// cell x = 2q has colour o (its plane A), cell 2q + 1 the other (plane Bp)
+			const double *A = pr.o ? B : R, *Bp = pr.o ? R : B;
+			const double  c0 = pr.o ? bv[K] : rv[K], c1 = pr.o ? rv[K] : bv[K];
+			// (x - 1, y) has colour of cell x + 1: plane Bp at column (2q) >> 1 = q; (x + 2, y) has cell x's colour: plane A at q + 1
+			double xl = Bp[ro + q], xr = A[ro + q + 1];
+			// (x, y -+ 1): the other colour than cell x: plane Bp at (2q + 1) >> 1 = q; (x + 1, y -+ 1): plane A at (2q + 2) >> 1 = q + 1
+			double d0 = Bp[ro - T.lwh + q], u0 = Bp[ro + T.lwh + q], d1 = A[ro - T.lwh + q + 1], u1 = A[ro + T.lwh + q + 1];
+			xl = (q == 0) ? gh(k0, c0) : xl, xr = (q == h - 1) ? gh(k1, c1) : xr;
+			if (y == 0) d0 = gh(k2, c0), d1 = gh(k2, c1);
+			if (y == n - 1) u0 = gh(k3, c0), u1 = gh(k3, c1);
+			const double ra = (fr_x(fr, K) - lap2d(xl, c0, c1, d0, u0, rhx, rhy)) / 4;
+			const double rb = (fr_y(fr, K) - lap2d(c0, c1, xr, d1, u1, rhx, rhy)) / 4;
+			const double pa_ = __shfl_xor(ra, 32), pb_ = __shfl_xor(rb, 32);
+			if (!pr.o) {
+				double acc = 0.0; // AvgRstr.h:95-102 order: x then y, each /(1 << D)
+				acc += ra, acc += rb, acc += pa_, acc += pb_;
+				cp[q + cs * (y >> 1)] = acc;
+			}
 		}
-		cp[hx + cs * hy] = acc;
+	} else {
+		for (int i = tid; i < h * h; i += blockDim.x) { // as k_resid_restrict2d_lds
+			const int hx = i % h, hy = i / h;
+			double    acc = 0.0;
+#pragma unroll
+			for (int dy = 0; dy < 2; dy++) {
+				const int     y = 2 * hy + dy, x = 2 * hx;
+				const double2 fv = *reinterpret_cast<const double2 *>(fp + x + n * y);
+				const double  c0 = T.at(x, y), c1 = T.at(x + 1, y);
+				const double  xl = x > 0 ? T.at(x - 1, y) : gh(k0, c0), xr = x + 2 < n ? T.at(x + 2, y) : gh(k1, c1);
+				const double  d0 = y > 0 ? T.at(x, y - 1) : gh(k2, c0), d1 = y > 0 ? T.at(x + 1, y - 1) : gh(k2, c1);
+				const double  u0 = y + 1 < n ? T.at(x, y + 1) : gh(k3, c0), u1 = y + 1 < n ? T.at(x + 1, y + 1) : gh(k3, c1);
+				acc += (fv.x - lap2d(xl, c0, c1, d0, u0, rhx, rhy)) / 4;
+				acc += (fv.y - lap2d(c0, c1, xr, d1, u1, rhx, rhy)) / 4;
+			}
+			cp[hx + cs * hy] = acc;
+		}
 	}
 }
 // the ghost terms the kernel above left out: for every face with a (local) neighbour, -(1/h^2)/4 * (the two neighbour
@@ -444,64 +609,41 @@ __global__ __launch_bounds__(256) void k_rbgs_resweep_prolong2d_lds(Level2D L, c
                                                                     double *__restrict__ out, Prolong2D ps)
 {
 	extern __shared__ __attribute__((aligned(16))) double tile2d[];
-	const int     n = NC ? NC : L.n, lw = n + 2, nn = n * n;
+	const int     n = NC ? NC : L.n, nn = n * n;
 	const int     p = blockIdx.x, tid = threadIdx.x;
 	const double *fp = f + (size_t) p * nn;
-	double       *idg = tile2d + lw * lw;
+	const Tile2D  T(tile2d, n);
+	double       *idg = tile2d + 2 * T.cs;
 	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
-	F2D fr;
-	double  cr[F2D_MAX]; // the coarse correction of each pair, requested before the recompute needs the memory pipeline
+	F2D           fr;
+	double        cr[F2D_MAX]; // the coarse correction of each pair, requested before the recompute needs the memory pipeline
+	double        rv[F2D_MAX], bv[F2D_MAX], mid[2];
 	loadF2d(fp, nn, fr);
 #pragma unroll
 	for (int k = 0; k < F2D_MAX; k++) {
 		const int i = tid + k * 256;
 		cr[k]       = (i < nn / 2) ? coarseAt2d(ps, n, p, (2 * i) % n, (2 * i) / n) : 0.0;
 	}
-	// the halo ring of the sweep: the neighbours' facing values of v + P(coarse); physical faces folded -> 0
-	double hv[2] = {0.0, 0.0};
+	// the halo ring of the second sweep: the neighbours' facing values of v + P(coarse); physical faces folded -> 0. It goes
+	// into the tile right away: the zero-guess sweep masks its ghosts instead of reading them.
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		const int i = tid + k * 256;
 		if (i < 4 * n) {
 			const int s = i / n, t = i % n;
+			double    hv = 0.0;
 			if (L.face_kind[p * 4 + s] == FACE_LOCAL) {
 				const int src = L.face_src[p * 4 + s];
-				hv[k] = e4[((size_t) src * 4 + (s ^ 1)) * n + t];
-				hv[k] += coarseAt2d(ps, n, src, s == 0 ? n - 1 : (s == 1 ? 0 : t), s == 2 ? n - 1 : (s == 3 ? 0 : t));
+				hv = e4[((size_t) src * 4 + (s ^ 1)) * n + t];
+				hv += coarseAt2d(ps, n, src, s == 0 ? n - 1 : (s == 1 ? 0 : t), s == 2 ? n - 1 : (s == 3 ? 0 : t));
 			}
+			T.at(s == 0 ? -1 : (s == 1 ? n : t), s == 2 ? -1 : (s == 3 ? n : t)) = hv;
 		}
 	}
-	idiag2d(L, p, rhx, rhy, idg);
-	for (int i = tid; i < lw * lw; i += blockDim.x) tile2d[i] = 0.0;
-	__syncthreads();
-	sweep2d(tile2d, idg, fr, n, rhx, rhy); // v
-#pragma unroll
-	for (int k = 0; k < F2D_MAX; k++) { // w = v + P(coarse), as k_rbgs2d_lds<false, true> forms it while loading
-		const int i = tid + k * 256;
-		if (i < nn / 2) {
-			const int y = (2 * i) / n, x = (2 * i) % n;
-			tile2d[(y + 1) * lw + x + 1] += cr[k];
-			tile2d[(y + 1) * lw + x + 2] += cr[k];
-		}
-	}
-#pragma unroll
-	for (int k = 0; k < 2; k++) {
-		const int i = tid + k * 256;
-		if (i < 4 * n) {
-			const int s = i / n, t = i % n;
-			tile2d[(s == 0) ? (t + 1) * lw : (s == 1) ? (t + 1) * lw + n + 1 : (s == 2) ? t + 1 : (n + 1) * lw + t + 1] = hv[k];
-		}
-	}
-	__syncthreads();
-	sweep2d(tile2d, idg, fr, n, rhx, rhy);
-#pragma unroll
-	for (int k = 0; k < F2D_MAX; k++) {
-		const int i = tid + k * 256;
-		if (i < nn / 2) {
-			const int y = (2 * i) / n, x = (2 * i) % n;
-			reinterpret_cast<double2 *>(out + (size_t) p * nn)[i] = double2{tile2d[(y + 1) * lw + x + 1], tile2d[(y + 1) * lw + x + 2]};
-		}
-	}
+	idiagSetup2d<NC>(L, p, rhx, rhy, idg, mid, n);
+	zeroSweep2d<NC, true>(T, idg, mid, fr, cr, n, rhx, rhy, rv, bv); // the black plane now holds v + P(coarse)
+	lastSweep2d<NC>(T, idg, mid, fr, n, rhx, rhy, rv, bv);
+	storePairs2d<NC>(out + (size_t) p * nn, rv, bv, n);
 }
 
 // ghost slots of coarse/fine faces: 2*gamma - m, weights of BilinearInterpolator.cpp:76-115.
