@@ -25,7 +25,8 @@ CASES = [("2uni.bin", 8, 0, False), ("2refine.bin", 8, 0, False), ("3uni.bin", 4
          ("uniform", 32, 1, True), ("2refine.bin", 32, 0, False),  # 32^3: the matrix-core patch solve, every transform type
          # 2D twins (configs C1: one 256^2 patch; C5-style: 64^2 patches; refined quadtree; Neumann)
          ("2d2uni.bin", 8, 0, False), ("2d2ref.bin", 8, 0, False), ("2d2ref.bin", 16, 1, False), ("2d2ref.bin", 8, 0, True),
-         ("uniform2d", 256, 0, False), ("uniform2d", 64, 2, False)]
+         ("uniform2d", 256, 0, False), ("uniform2d", 64, 2, False),
+         ("uniform2d", 64, 2, True)]  # 64^2 Neumann: every transform type and the null mode through k_patch_solve2d_mfma
 
 
 @pytest.fixture(scope="module", params=CASES, ids=lambda c: f"{c[0]}-n{c[1]}-d{c[2]}{'-neumann' if c[3] else ''}")
@@ -197,7 +198,8 @@ def test_fused_presweep_residual_restrict(n, neumann, mesh, div):
             assert rel(outs[1], outs[0]) <= 1e-13
 
 
-@pytest.mark.parametrize("n,neumann,mesh,div", [(8, False, "uniform2d", 3), (16, True, "uniform2d", 3), (64, False, "uniform2d", 2)])
+@pytest.mark.parametrize("n,neumann,mesh,div", [(8, False, "uniform2d", 3), (16, True, "uniform2d", 3), (64, False, "uniform2d", 2),
+                                                  (12, True, "uniform2d", 2), (32, False, "uniform2d", 2), (64, True, "uniform2d", 2)])
 def test_fused_presweep_residual_restrict_2d(n, neumann, mesh, div):
     """The 2D twins of the fused kernels (k_rbgs_zero_resid2d_lds, k_restrict_fixup2d, k_rbgs_resweep_prolong2d_lds) on
     uniform quadtree levels: fuse = 2 vs 1 to rounding (the ghost term of the residual is added separately), fuse = 3
