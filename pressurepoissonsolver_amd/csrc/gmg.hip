@@ -1063,12 +1063,18 @@ int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, doub
 		const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
 		Prolong2D    ps{L.parent.p, L.orth.p, prolong_from};
 		Timed        t(g, zero_guess ? KC_RBGS_ZERO : (prolong_from ? KC_RBGS_PROLONG : KC_RBGS), (size_t) L.P * L.nc);
+#define TE_RB2(Z, PR)                                                                                                          \
+	if (L.n == 64)                                                                                                             \
+		hipLaunchKernelGGL((k_rbgs2d_lds<Z, PR, 64>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);          \
+	else                                                                                                                       \
+		hipLaunchKernelGGL((k_rbgs2d_lds<Z, PR, 0>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps)
 		if (zero_guess)
-			hipLaunchKernelGGL((k_rbgs2d_lds<true, false>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);
+			TE_RB2(true, false);
 		else if (prolong_from)
-			hipLaunchKernelGGL((k_rbgs2d_lds<false, true>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);
+			TE_RB2(false, true);
 		else
-			hipLaunchKernelGGL((k_rbgs2d_lds<false, false>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);
+			TE_RB2(false, false);
+#undef TE_RB2
 		HIPCHK(hipGetLastError());
 		return TE_OK;
 	}

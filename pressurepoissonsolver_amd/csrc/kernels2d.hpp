@@ -148,69 +148,6 @@ __device__ __forceinline__ double coarseAt2d(const Prolong2D &ps, int n, int p, 
 	return ps.coarse[(size_t) ps.parent[p] * n * n + (x + ((o & 1) ? n : 0)) / 2 + n * ((y + ((o & 2) ? n : 0)) / 2)];
 }
 
-// The same sweep in ONE pass for patches that fit in LDS (n <= 64: (n+2)^2 doubles = 34 KiB): one workgroup
-// per patch loads u and its frozen halo ring once, relaxes red then black in LDS, and stores the result:
-// 24 B per site instead of two passes over u, f and out. Bit-identical to k_rbgs2d<0> + k_rbgs2d<1>.
-// ZERO: the iterate is zero (first sweep of a cycle): u and its ghosts are never read (16 B per site).
-// PROLONG: the iterate is u + P(coarse) (see Prolong2D), formed while loading (26 B per site).
-template <bool ZERO, bool PROLONG>
-__global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
-                                                    double *__restrict__ out, Prolong2D ps)
-{
-	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // (n+2) x (n+2), then the 9 reciprocals of the diagonal
-	const int     n = L.n, lw = n + 2, nn = n * n;
-	const int     p = blockIdx.x, tid = threadIdx.x;
-	const double *up = u + (size_t) p * nn;
-	const double *fp = f + (size_t) p * nn;
-	double       *idg = tile2d + lw * lw;
-	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
-	if (tid < 9) {
-		const int cx = tid % 3, cy = tid / 3;
-		const double kx = 2.0 + (cx == 0 ? kfold2d(L, p, 0) : 0.0) + (cx == 2 ? kfold2d(L, p, 1) : 0.0);
-		const double ky = 2.0 + (cy == 0 ? kfold2d(L, p, 2) : 0.0) + (cy == 2 ? kfold2d(L, p, 3) : 0.0);
-		idg[tid]        = 1.0 / (kx * rhx + ky * rhy);
-	}
-	if (ZERO) {
-		for (int i = tid; i < lw * lw; i += blockDim.x) tile2d[i] = 0.0;
-	} else {
-		for (int i = tid; i < nn / 2; i += blockDim.x) { // interior, 16 B per lane
-			const int y = (2 * i) / n, x = (2 * i) % n;
-			double2   v = reinterpret_cast<const double2 *>(up)[i];
-			if (PROLONG) {
-				const double c = coarseAt2d(ps, n, p, x, y); // x even: both cells of the pair share the coarse cell
-				v.x += c, v.y += c;
-			}
-			tile2d[(y + 1) * lw + x + 1] = v.x;
-			tile2d[(y + 1) * lw + x + 2] = v.y;
-		}
-		for (int i = tid; i < 4 * n; i += blockDim.x) { // halo ring: frozen ghosts (physical faces folded -> 0)
-			const int s = i / n, t = i % n;
-			double    g = ghost2d(L, u, p, s, t, 0.0, true);
-			if (PROLONG && L.face_kind[p * 4 + s] == FACE_LOCAL) { // the neighbour's facing cell carries its own correction
-				const int src = L.face_src[p * 4 + s];
-				g += coarseAt2d(ps, n, src, s == 0 ? n - 1 : (s == 1 ? 0 : t), s == 2 ? n - 1 : (s == 3 ? 0 : t));
-			}
-			const int idx = (s == 0) ? (t + 1) * lw : (s == 1) ? (t + 1) * lw + n + 1 : (s == 2) ? t + 1 : (n + 1) * lw + t + 1;
-			tile2d[idx]   = g;
-		}
-	}
-	__syncthreads();
-	for (int colour = 0; colour < 2; colour++) {
-		for (int i = tid; i < nn / 2; i += blockDim.x) { // the cell of this colour in every x-pair
-			const int y = (2 * i) / n, x = (2 * i) % n + ((y + colour) & 1);
-			double   *t0 = tile2d + (y + 1) * lw + x + 1;
-			const int cx = (x == 0) ? 0 : (x == n - 1 ? 2 : 1), cy = (y == 0) ? 0 : (y == n - 1 ? 2 : 1);
-			const double o = offdiag2d(t0[-1], t0[1], t0[-lw], t0[lw], rhx, rhy);
-			*t0            = (o - fp[x + n * y]) * idg[cx + 3 * cy];
-		}
-		__syncthreads();
-	}
-	for (int i = tid; i < nn / 2; i += blockDim.x) {
-		const int y = (2 * i) / n, x = (2 * i) % n;
-		reinterpret_cast<double2 *>(out + (size_t) p * nn)[i] = double2{tile2d[(y + 1) * lw + x + 1], tile2d[(y + 1) * lw + x + 2]};
-	}
-}
-
 // Fused residual + restriction for patches that fit in LDS (Cycle.h:59-65 in one pass): one workgroup per
 // fine patch loads u and its ghost ring, each thread forms the four residuals of a coarse cell and adds
 // them in AvgRstr's order (restrictCell2d): bit-identical to k_stencil2d<MODE_RESID> + k_restrict2d,
@@ -451,6 +388,56 @@ template <int NC> __device__ __forceinline__ void idiagSetup2d(const Level2D &L,
 		mid[1] = idg[((xb == 0) ? 0 : (xb == n - 1 ? 2 : 1)) + 3];
 	}
 }
+// The sweep k_rbgs2d<0> + k_rbgs2d<1> in ONE pass for patches that fit in LDS (n <= 64: (n+2)^2 doubles = 34 KiB): one
+// workgroup per patch loads u and its frozen halo ring once, relaxes red then black on the colour-split tile and stores the
+// result from registers: 24 B per site instead of two passes over u, f and out. Bit-identical to the two-pass form.
+// Only the black cells of the old iterate go to LDS (the red half sweep reads black neighbours and overwrites red cells).
+// ZERO: the iterate is zero (first sweep of a cycle): u and its ghosts are never read (16 B per site).
+// PROLONG: the iterate is u + P(coarse) (see Prolong2D), formed while loading (26 B per site).
+template <bool ZERO, bool PROLONG, int NC>
+__global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
+                                                    double *__restrict__ out, Prolong2D ps)
+{
+	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // Tile2D, then the 9 reciprocals of the diagonal
+	const int     n = NC ? NC : L.n, nn = n * n;
+	const int     p = blockIdx.x, tid = threadIdx.x;
+	const double *up = u + (size_t) p * nn;
+	const Tile2D  T(tile2d, n);
+	double       *idg = tile2d + 2 * T.cs;
+	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
+	F2D           fr;
+	double        rv[F2D_MAX], bv[F2D_MAX], mid[2];
+	loadF2d(f + (size_t) p * nn, nn, fr);
+	if (!ZERO) {
+#pragma unroll
+		for (int K = 0; K < F2D_MAX; K++) {
+			const Pair2D pr = pairOf<NC>(K, n);
+			if (!pr.live) continue;
+			double2 v = reinterpret_cast<const double2 *>(up)[tid + K * 256];
+			if (PROLONG) {
+				const double c = coarseAt2d(ps, n, p, 2 * pr.q, pr.y); // both cells of the pair share the coarse cell
+				v.x += c, v.y += c;
+			}
+			T.t[T.cs + (pr.y + 1) * T.lwh + pr.q + 1 - pr.o] = pr.o ? v.x : v.y; // the black cell: x = 2q + 1 - o
+		}
+		for (int i = tid; i < 4 * n; i += blockDim.x) { // halo ring: frozen ghosts (physical faces folded -> 0)
+			const int s = i / n, t = i % n;
+			double    g = ghost2d(L, u, p, s, t, 0.0, true);
+			if (PROLONG && L.face_kind[p * 4 + s] == FACE_LOCAL) { // the neighbour's facing cell carries its own correction
+				const int src = L.face_src[p * 4 + s];
+				g += coarseAt2d(ps, n, src, s == 0 ? n - 1 : (s == 1 ? 0 : t), s == 2 ? n - 1 : (s == 3 ? 0 : t));
+			}
+			T.at(s == 0 ? -1 : (s == 1 ? n : t), s == 2 ? -1 : (s == 3 ? n : t)) = g;
+		}
+	}
+	idiagSetup2d<NC>(L, p, rhx, rhy, idg, mid, n);
+	if (ZERO)
+		zeroSweep2d<NC, false>(T, idg, mid, fr, nullptr, n, rhx, rhy, rv, bv);
+	else
+		lastSweep2d<NC>(T, idg, mid, fr, n, rhx, rhy, rv, bv);
+	storePairs2d<NC>(out + (size_t) p * nn, rv, bv, n);
+}
+
 // Cycle.h:57-65 for the first sweep of a cycle in one pass over f (the 2D twin of k_rbgs_zero_resid3d): u = S(0, f),
 // coarse f = AvgRstr(f - A u) with a zero ghost on faces that have a neighbour (k_restrict_fixup2d adds that term from the
 // neighbours' edge layers afterwards). STORE_U: u is written (16 + 2 B per site); otherwise only its four edge layers
