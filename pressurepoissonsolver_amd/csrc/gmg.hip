@@ -1053,6 +1053,13 @@ template <int MODE> int launchStencil2d(te_gmg *g, LevelHost &L, const double *u
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
+// 64^2 patches: 512 threads per workgroup (four x-pairs per thread instead of eight: half the registers, twice the waves per
+// CU at the same four resident patches)
+static int tpb2d()
+{
+	static const int v = getenv("TE_2D_TPB") ? atoi(getenv("TE_2D_TPB")) : 512;
+	return v == 256 ? 256 : 512;
+}
 // zero_guess: levels with L.lds2d; prolong_from: levels with L.fuse2d && L.prolong_fusable (the caller checks)
 int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false,
                  const double *prolong_from = nullptr)
@@ -1064,7 +1071,9 @@ int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, doub
 		Prolong2D    ps{L.parent.p, L.orth.p, prolong_from};
 		Timed        t(g, zero_guess ? KC_RBGS_ZERO : (prolong_from ? KC_RBGS_PROLONG : KC_RBGS), (size_t) L.P * L.nc);
 #define TE_RB2(Z, PR)                                                                                                          \
-	if (L.n == 64)                                                                                                             \
+	if (L.n == 64 && tpb2d() == 512)                                                                                           \
+		hipLaunchKernelGGL((k_rbgs2d_lds<Z, PR, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), u, f, out, ps);     \
+	else if (L.n == 64)                                                                                                        \
 		hipLaunchKernelGGL((k_rbgs2d_lds<Z, PR, 64>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);          \
 	else                                                                                                                       \
 		hipLaunchKernelGGL((k_rbgs2d_lds<Z, PR, 0>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps)
@@ -1226,7 +1235,14 @@ int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, doub
 #define TE_ZR2(S, NC)                                                                                                             \
 	hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<S, NC>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, \
 	                   coarse, L.upbuf.p, L.up_off.p)
-		if (store_u && L.n == 64)
+		if (L.n == 64 && tpb2d() == 512) {
+			if (store_u)
+				hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<true, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst,
+				                   coarse, L.upbuf.p, L.up_off.p);
+			else
+				hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<false, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst,
+				                   coarse, L.upbuf.p, L.up_off.p);
+		} else if (store_u && L.n == 64)
 			TE_ZR2(true, 64);
 		else if (store_u)
 			TE_ZR2(true, 0);
@@ -1265,7 +1281,10 @@ int resweepProlong2d(te_gmg *g, LevelHost &L, const double *f, double *out, cons
 	if (L.P == 0) return TE_OK;
 	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
 	Timed        t(g, KC_RESWEEP, (size_t) L.P * L.nc);
-	if (L.n == 64)
+	if (L.n == 64 && tpb2d() == 512)
+		hipLaunchKernelGGL((k_rbgs_resweep_prolong2d_lds<64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
+		                   Prolong2D{L.parent.p, L.orth.p, prolong_from});
+	else if (L.n == 64)
 		hipLaunchKernelGGL(k_rbgs_resweep_prolong2d_lds<64>, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
 		                   Prolong2D{L.parent.p, L.orth.p, prolong_from});
 	else

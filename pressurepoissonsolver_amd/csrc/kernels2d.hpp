@@ -211,11 +211,11 @@ struct F2D { // (named scalars: an array of double2 indexed in an unrolled loop 
 	double x0, y0, x1, y1, x2, y2, x3, y3, x4, y4, x5, y5, x6, y6, x7, y7;
 };
 #define TE_F2D_EACH(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
-__device__ __forceinline__ void loadF2d(const double *fp, int nn, F2D &fr)
+template <int TPB> __device__ __forceinline__ void loadF2d(const double *fp, int nn, F2D &fr)
 {
 #define TE_LD(K)                                                                                          \
 	{                                                                                                     \
-		const int     i = threadIdx.x + K * 256;                                                          \
+		const int     i = threadIdx.x + K * TPB;                                                          \
 		const double2 v = (i < nn / 2) ? reinterpret_cast<const double2 *>(fp)[i] : double2{0.0, 0.0};    \
 		fr.x##K = v.x, fr.y##K = v.y;                                                                     \
 	}
@@ -269,16 +269,16 @@ __device__ __forceinline__ double fr_y(const F2D &fr, int K)
 	}
 	return 0.0;
 }
-template <int NC> __device__ __forceinline__ Pair2D pairOf(int K, int n)
+template <int NC, int TPB> __device__ __forceinline__ Pair2D pairOf(int K, int n)
 {
-	const int i = threadIdx.x + K * 256, m = NC ? NC : n;
+	const int i = threadIdx.x + K * TPB, m = NC ? NC : n;
 	return Pair2D{(2 * i) / m, ((2 * i) % m) >> 1, ((2 * i) / m) & 1, i < m * m / 2};
 }
 // reciprocal diagonal of a cell: from the table in LDS, or -- NC = 64, where a thread's cells of one colour all have the same x
 // class and only its first and last pair can lie on the bottom / top row -- from two registers (mid[colour])
-template <int NC> __device__ __forceinline__ double idgOf(const double *idg, const double *mid, int K, int colour, int x, int y, int n)
+template <int NC, int TPB> __device__ __forceinline__ double idgOf(const double *idg, const double *mid, int K, int colour, int x, int y, int n)
 {
-	if (NC == 64 && K >= 1 && K <= 6) return mid[colour];
+	if (NC == 64 && K >= 1 && K <= NC * NC / 2 / TPB - 2) return mid[colour];
 	const int cx = (x == 0) ? 0 : (x == n - 1 ? 2 : 1), cy = (y == 0) ? 0 : (y == n - 1 ? 2 : 1);
 	return idg[cx + 3 * cy];
 }
@@ -292,18 +292,18 @@ __device__ __forceinline__ double addRounded2d(double a, double b)
 // diagonal) masked rather than read, so that the ring may already hold the next sweep's halo. ADDC: the black plane receives
 // v + c (the red cells of an iterate are never read by the sweep that follows it). rv / bv: the values of the thread's pairs.
 // The arithmetic of k_rbgs2d_lds<ZERO>: bit-identical.
-template <int NC, bool ADDC>
+template <int NC, int TPB, bool ADDC>
 __device__ __forceinline__ void zeroSweep2d(const Tile2D &T, const double *idg, const double *mid, const F2D &fr, const double *cr, int n,
                                             double rhx, double rhy, double *rv, double *bv)
 {
 	double *R = T.t, *B = T.t + T.cs;
 #define TE_R1(K)                                                                                     \
 	{                                                                                                \
-		const Pair2D pr = pairOf<NC>(K, n);                                                          \
+		const Pair2D pr = pairOf<NC, TPB>(K, n);                                                          \
 		if (pr.live) {                                                                               \
 			double fa = fr.x##K, fb = fr.y##K;                                                       \
 			asm volatile("" : "+v"(fa), "+v"(fb));                                                   \
-			rv[K] = (0.0 - (pr.o ? fb : fa)) * idgOf<NC>(idg, mid, K, 0, 2 * pr.q + pr.o, pr.y, n);  \
+			rv[K] = (0.0 - (pr.o ? fb : fa)) * idgOf<NC, TPB>(idg, mid, K, 0, 2 * pr.q + pr.o, pr.y, n);  \
 			R[(pr.y + 1) * T.lwh + pr.q + pr.o] = rv[K];                                             \
 		}                                                                                            \
 	}
@@ -312,7 +312,7 @@ __device__ __forceinline__ void zeroSweep2d(const Tile2D &T, const double *idg, 
 	ldsBarrier();
 #define TE_B1(K)                                                                                     \
 	{                                                                                                \
-		const Pair2D pr = pairOf<NC>(K, n);                                                          \
+		const Pair2D pr = pairOf<NC, TPB>(K, n);                                                          \
 		if (pr.live) {                                                                               \
 			const int     x = 2 * pr.q + 1 - pr.o, c = pr.q + 1 - pr.o;                              \
 			const double *r0 = R + (pr.y + 1) * T.lwh;                                               \
@@ -321,7 +321,7 @@ __device__ __forceinline__ void zeroSweep2d(const Tile2D &T, const double *idg, 
 			yl = (pr.y == 0) ? 0.0 : yl, yr = (pr.y == n - 1) ? 0.0 : yr;                            \
 			double fa = fr.x##K, fb = fr.y##K;                                                       \
 			asm volatile("" : "+v"(fa), "+v"(fb));                                                   \
-			bv[K] = (offdiag2d(xl, xr, yl, yr, rhx, rhy) - (pr.o ? fa : fb)) * idgOf<NC>(idg, mid, K, 1, x, pr.y, n); \
+			bv[K] = (offdiag2d(xl, xr, yl, yr, rhx, rhy) - (pr.o ? fa : fb)) * idgOf<NC, TPB>(idg, mid, K, 1, x, pr.y, n); \
 			B[(pr.y + 1) * T.lwh + c] = ADDC ? addRounded2d(bv[K], cr[K]) : bv[K];                   \
 		}                                                                                            \
 	}
@@ -331,21 +331,21 @@ __device__ __forceinline__ void zeroSweep2d(const Tile2D &T, const double *idg, 
 }
 // one sweep over the tile (ring = the frozen halo), the new values of the thread's pairs to rv / bv; the black plane of the
 // result is not stored (nobody reads it: the caller writes the pairs to memory)
-template <int NC>
+template <int NC, int TPB>
 __device__ __forceinline__ void lastSweep2d(const Tile2D &T, const double *idg, const double *mid, const F2D &fr, int n, double rhx, double rhy,
                                             double *rv, double *bv)
 {
 	double *R = T.t, *B = T.t + T.cs;
 #define TE_R2(K)                                                                                     \
 	{                                                                                                \
-		const Pair2D pr = pairOf<NC>(K, n);                                                          \
+		const Pair2D pr = pairOf<NC, TPB>(K, n);                                                          \
 		if (pr.live) {                                                                               \
 			const int     c  = pr.q + pr.o;                                                          \
 			const double *b0 = B + (pr.y + 1) * T.lwh;                                               \
 			const double  o  = offdiag2d(b0[pr.q], b0[pr.q + 1], b0[c - T.lwh], b0[c + T.lwh], rhx, rhy); \
 			double        fa = fr.x##K, fb = fr.y##K;                                                \
 			asm volatile("" : "+v"(fa), "+v"(fb));                                                   \
-			rv[K] = (o - (pr.o ? fb : fa)) * idgOf<NC>(idg, mid, K, 0, 2 * pr.q + pr.o, pr.y, n);    \
+			rv[K] = (o - (pr.o ? fb : fa)) * idgOf<NC, TPB>(idg, mid, K, 0, 2 * pr.q + pr.o, pr.y, n);    \
 			R[(pr.y + 1) * T.lwh + c] = rv[K];                                                       \
 		}                                                                                            \
 	}
@@ -354,35 +354,35 @@ __device__ __forceinline__ void lastSweep2d(const Tile2D &T, const double *idg, 
 	ldsBarrier();
 #define TE_B2(K)                                                                                     \
 	{                                                                                                \
-		const Pair2D pr = pairOf<NC>(K, n);                                                          \
+		const Pair2D pr = pairOf<NC, TPB>(K, n);                                                          \
 		if (pr.live) {                                                                               \
 			const int     c  = pr.q + 1 - pr.o;                                                      \
 			const double *r0 = R + (pr.y + 1) * T.lwh;                                               \
 			const double  o  = offdiag2d(r0[pr.q], r0[pr.q + 1], r0[c - T.lwh], r0[c + T.lwh], rhx, rhy); \
 			double        fa = fr.x##K, fb = fr.y##K;                                                \
 			asm volatile("" : "+v"(fa), "+v"(fb));                                                   \
-			bv[K] = (o - (pr.o ? fa : fb)) * idgOf<NC>(idg, mid, K, 1, 2 * pr.q + 1 - pr.o, pr.y, n); \
+			bv[K] = (o - (pr.o ? fa : fb)) * idgOf<NC, TPB>(idg, mid, K, 1, 2 * pr.q + 1 - pr.o, pr.y, n); \
 		}                                                                                            \
 	}
 	TE_F2D_EACH(TE_B2)
 #undef TE_B2
 }
 // the pairs of a thread to memory, 16 B per lane
-template <int NC> __device__ __forceinline__ void storePairs2d(double *op, const double *rv, const double *bv, int n)
+template <int NC, int TPB> __device__ __forceinline__ void storePairs2d(double *op, const double *rv, const double *bv, int n)
 {
 #pragma unroll
 	for (int K = 0; K < F2D_MAX; K++) {
-		const Pair2D pr = pairOf<NC>(K, n);
-		if (pr.live) reinterpret_cast<double2 *>(op)[threadIdx.x + K * 256] = pr.o ? double2{bv[K], rv[K]} : double2{rv[K], bv[K]};
+		const Pair2D pr = pairOf<NC, TPB>(K, n);
+		if (pr.live) reinterpret_cast<double2 *>(op)[threadIdx.x + K * TPB] = pr.o ? double2{bv[K], rv[K]} : double2{rv[K], bv[K]};
 	}
 }
 // table of reciprocal diagonals to LDS, the thread's two mid-row values to registers (see idgOf); ends with a barrier
-template <int NC> __device__ __forceinline__ void idiagSetup2d(const Level2D &L, int p, double rhx, double rhy, double *idg, double *mid, int n)
+template <int NC, int TPB> __device__ __forceinline__ void idiagSetup2d(const Level2D &L, int p, double rhx, double rhy, double *idg, double *mid, int n)
 {
 	idiag2d(L, p, rhx, rhy, idg);
 	ldsBarrier();
 	if (NC == 64) {
-		const Pair2D pr = pairOf<NC>(1, n);
+		const Pair2D pr = pairOf<NC, TPB>(1, n);
 		const int    xr = 2 * pr.q + pr.o, xb = 2 * pr.q + 1 - pr.o;
 		mid[0] = idg[((xr == 0) ? 0 : (xr == n - 1 ? 2 : 1)) + 3];
 		mid[1] = idg[((xb == 0) ? 0 : (xb == n - 1 ? 2 : 1)) + 3];
@@ -394,8 +394,8 @@ template <int NC> __device__ __forceinline__ void idiagSetup2d(const Level2D &L,
 // Only the black cells of the old iterate go to LDS (the red half sweep reads black neighbours and overwrites red cells).
 // ZERO: the iterate is zero (first sweep of a cycle): u and its ghosts are never read (16 B per site).
 // PROLONG: the iterate is u + P(coarse) (see Prolong2D), formed while loading (26 B per site).
-template <bool ZERO, bool PROLONG, int NC>
-__global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
+template <bool ZERO, bool PROLONG, int NC, int TPB = 256>
+__global__ __launch_bounds__(TPB) void k_rbgs2d_lds(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
                                                     double *__restrict__ out, Prolong2D ps)
 {
 	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // Tile2D, then the 9 reciprocals of the diagonal
@@ -407,13 +407,13 @@ __global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__r
 	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
 	F2D           fr;
 	double        rv[F2D_MAX], bv[F2D_MAX], mid[2];
-	loadF2d(f + (size_t) p * nn, nn, fr);
+	loadF2d<TPB>(f + (size_t) p * nn, nn, fr);
 	if (!ZERO) {
 #pragma unroll
 		for (int K = 0; K < F2D_MAX; K++) {
-			const Pair2D pr = pairOf<NC>(K, n);
+			const Pair2D pr = pairOf<NC, TPB>(K, n);
 			if (!pr.live) continue;
-			double2 v = reinterpret_cast<const double2 *>(up)[tid + K * 256];
+			double2 v = reinterpret_cast<const double2 *>(up)[tid + K * TPB];
 			if (PROLONG) {
 				const double c = coarseAt2d(ps, n, p, 2 * pr.q, pr.y); // both cells of the pair share the coarse cell
 				v.x += c, v.y += c;
@@ -430,12 +430,12 @@ __global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__r
 			T.at(s == 0 ? -1 : (s == 1 ? n : t), s == 2 ? -1 : (s == 3 ? n : t)) = g;
 		}
 	}
-	idiagSetup2d<NC>(L, p, rhx, rhy, idg, mid, n);
+	idiagSetup2d<NC, TPB>(L, p, rhx, rhy, idg, mid, n);
 	if (ZERO)
-		zeroSweep2d<NC, false>(T, idg, mid, fr, nullptr, n, rhx, rhy, rv, bv);
+		zeroSweep2d<NC, TPB, false>(T, idg, mid, fr, nullptr, n, rhx, rhy, rv, bv);
 	else
-		lastSweep2d<NC>(T, idg, mid, fr, n, rhx, rhy, rv, bv);
-	storePairs2d<NC>(out + (size_t) p * nn, rv, bv, n);
+		lastSweep2d<NC, TPB>(T, idg, mid, fr, n, rhx, rhy, rv, bv);
+	storePairs2d<NC, TPB>(out + (size_t) p * nn, rv, bv, n);
 }
 
 // Cycle.h:57-65 for the first sweep of a cycle in one pass over f (the 2D twin of k_rbgs_zero_resid3d): u = S(0, f),
@@ -445,8 +445,8 @@ __global__ __launch_bounds__(256) void k_rbgs2d_lds(Level2D L, const double *__r
 // NC: the patch size as a compile-time constant (0: run-time L.n) -- every cell's (x, y) comes from an integer division by n,
 // dozens of instructions each at run time, shifts for NC = 64 (config C5)
 // A parent on another rank (dst.parent < -1): the restricted block goes to `remote` (h x h, shipped afterwards), as in 3D.
-template <bool STORE_U, int NC>
-__global__ __launch_bounds__(256) void k_rbgs_zero_resid2d_lds(Level2D L, const double *__restrict__ f, double *__restrict__ out,
+template <bool STORE_U, int NC, int TPB = 256>
+__global__ __launch_bounds__(TPB) void k_rbgs_zero_resid2d_lds(Level2D L, const double *__restrict__ f, double *__restrict__ out,
                                                                double *__restrict__ e4, Prolong2D dst, double *__restrict__ coarse,
                                                                double *__restrict__ remote, const int64_t *__restrict__ remote_off)
 {
@@ -459,17 +459,17 @@ __global__ __launch_bounds__(256) void k_rbgs_zero_resid2d_lds(Level2D L, const 
 	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
 	F2D           fr;
 	double        rv[F2D_MAX], bv[F2D_MAX], mid[2];
-	loadF2d(fp, nn, fr);
-	idiagSetup2d<NC>(L, p, rhx, rhy, idg, mid, n);
-	zeroSweep2d<NC, false>(T, idg, mid, fr, nullptr, n, rhx, rhy, rv, bv);
+	loadF2d<TPB>(fp, nn, fr);
+	idiagSetup2d<NC, TPB>(L, p, rhx, rhy, idg, mid, n);
+	zeroSweep2d<NC, TPB, false>(T, idg, mid, fr, nullptr, n, rhx, rhy, rv, bv);
 	// the new iterate, or only its four edge layers: from the registers that hold the pairs
 	if (STORE_U) {
-		storePairs2d<NC>(out + (size_t) p * nn, rv, bv, n);
+		storePairs2d<NC, TPB>(out + (size_t) p * nn, rv, bv, n);
 	} else {
 		double *e = e4 + (size_t) p * 4 * n;
 #pragma unroll
 		for (int K = 0; K < F2D_MAX; K++) {
-			const Pair2D pr = pairOf<NC>(K, n);
+			const Pair2D pr = pairOf<NC, TPB>(K, n);
 			if (!pr.live) continue;
 			const double2 v = pr.o ? double2{bv[K], rv[K]} : double2{rv[K], bv[K]};
 			if (pr.q == 0) e[pr.y] = v.x;
@@ -490,7 +490,8 @@ __global__ __launch_bounds__(256) void k_rbgs_zero_resid2d_lds(Level2D L, const 
 		const double *R = T.t, *B = T.t + T.cs;
 #pragma unroll
 		for (int K = 0; K < F2D_MAX; K++) {
-			const Pair2D  pr = pairOf<NC>(K, n);
+			const Pair2D  pr = pairOf<NC, TPB>(K, n);
+			if (!pr.live) continue; // (the same for the whole workgroup)
 			const int     y = pr.y, q = pr.q, ro = (y + 1) * T.lwh;
 			// cell x = 2q has colour o (its plane A), cell 2q + 1 the other (plane Bp)
 			const double *A = pr.o ? B : R, *Bp = pr.o ? R : B;
@@ -591,8 +592,8 @@ __global__ __launch_bounds__(256) void k_restrict_unpack2d(int n, const int32_t 
 // opts.fuse = 3, post-smoothing: out = S(v + P(coarse), f) with v = S(0, f) recomputed in LDS (its neighbours' edges
 // come from e4): read f, 1/4 coarse, edges; write u -- 18.5 B per site instead of 26, and the pre-sweep kernel writes
 // no u at all. Same arithmetic as k_rbgs_zero_resid2d_lds followed by k_rbgs2d_lds<false, true>: bit-identical.
-template <int NC>
-__global__ __launch_bounds__(256) void k_rbgs_resweep_prolong2d_lds(Level2D L, const double *__restrict__ f, const double *__restrict__ e4,
+template <int NC, int TPB = 256>
+__global__ __launch_bounds__(TPB) void k_rbgs_resweep_prolong2d_lds(Level2D L, const double *__restrict__ f, const double *__restrict__ e4,
                                                                     double *__restrict__ out, Prolong2D ps)
 {
 	extern __shared__ __attribute__((aligned(16))) double tile2d[];
@@ -605,17 +606,17 @@ __global__ __launch_bounds__(256) void k_rbgs_resweep_prolong2d_lds(Level2D L, c
 	F2D           fr;
 	double        cr[F2D_MAX]; // the coarse correction of each pair, requested before the recompute needs the memory pipeline
 	double        rv[F2D_MAX], bv[F2D_MAX], mid[2];
-	loadF2d(fp, nn, fr);
+	loadF2d<TPB>(fp, nn, fr);
 #pragma unroll
 	for (int k = 0; k < F2D_MAX; k++) {
-		const int i = tid + k * 256;
+		const int i = tid + k * TPB;
 		cr[k]       = (i < nn / 2) ? coarseAt2d(ps, n, p, (2 * i) % n, (2 * i) / n) : 0.0;
 	}
 	// the halo ring of the second sweep: the neighbours' facing values of v + P(coarse); physical faces folded -> 0. It goes
 	// into the tile right away: the zero-guess sweep masks its ghosts instead of reading them.
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
-		const int i = tid + k * 256;
+		const int i = tid + k * TPB;
 		if (i < 4 * n) {
 			const int s = i / n, t = i % n;
 			double    hv = 0.0;
@@ -627,10 +628,10 @@ __global__ __launch_bounds__(256) void k_rbgs_resweep_prolong2d_lds(Level2D L, c
 			T.at(s == 0 ? -1 : (s == 1 ? n : t), s == 2 ? -1 : (s == 3 ? n : t)) = hv;
 		}
 	}
-	idiagSetup2d<NC>(L, p, rhx, rhy, idg, mid, n);
-	zeroSweep2d<NC, true>(T, idg, mid, fr, cr, n, rhx, rhy, rv, bv); // the black plane now holds v + P(coarse)
-	lastSweep2d<NC>(T, idg, mid, fr, n, rhx, rhy, rv, bv);
-	storePairs2d<NC>(out + (size_t) p * nn, rv, bv, n);
+	idiagSetup2d<NC, TPB>(L, p, rhx, rhy, idg, mid, n);
+	zeroSweep2d<NC, TPB, true>(T, idg, mid, fr, cr, n, rhx, rhy, rv, bv); // the black plane now holds v + P(coarse)
+	lastSweep2d<NC, TPB>(T, idg, mid, fr, n, rhx, rhy, rv, bv);
+	storePairs2d<NC, TPB>(out + (size_t) p * nn, rv, bv, n);
 }
 
 // ghost slots of coarse/fine faces: 2*gamma - m, weights of BilinearInterpolator.cpp:76-115.
