@@ -1264,7 +1264,7 @@ int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, doub
 	}
 	if (L.P > 0) {
 		Timed t(g, KC_FIXUP, (size_t) L.P * 4 * L.nf);
-		hipLaunchKernelGGL(k_restrict_fixup2d, dim3(L.P), dim3(64), 0, g->stream, L.dev2(), out,
+		hipLaunchKernelGGL(k_restrict_fixup2d, dim3(L.P), dim3(128), 0, g->stream, L.dev2(), out,
 		                   store_u ? (const double *) nullptr : (const double *) L.e4buf.p, dst, coarse, L.upbuf.p, L.up_off.p);
 	}
 	// children whose parent lives on another rank: ship the finished blocks

@@ -535,36 +535,49 @@ __global__ __launch_bounds__(TPB) void k_rbgs_zero_resid2d_lds(Level2D L, const 
 // values behind a pair of face cells) is added to the coarse cell behind the pair; faces in the order W,E,S,N.
 // edges = e4 of the new iterate, or null: read them from u.
 // A neighbour on another rank: its edge arrived in a ghost slot. A parent on another rank: the block in `remote`.
-__global__ __launch_bounds__(64) void k_restrict_fixup2d(Level2D L, const double *__restrict__ u, const double *__restrict__ e4,
-                                                         Prolong2D dst, double *__restrict__ coarse, double *__restrict__ remote,
-                                                         const int64_t *__restrict__ remote_off)
+__global__ __launch_bounds__(128) void k_restrict_fixup2d(Level2D L, const double *__restrict__ u, const double *__restrict__ e4,
+                                                          Prolong2D dst, double *__restrict__ coarse, double *__restrict__ remote,
+                                                          const int64_t *__restrict__ remote_off)
 {
 	const int n = L.n, nn = n * n, h = n / 2, p = blockIdx.x;
 	const int pa = dst.parent[p], o = dst.orth[p];
 	double   *cb = pa >= 0 ? coarse + (size_t) pa * nn + ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0) : remote + remote_off[-(pa + 2)];
 	const int cs = pa >= 0 ? n : h;
+	// the sum of face s for the coarse cell number i along it
+	auto term = [&](int s, int kind, int i) {
+		const int    src = L.face_src[p * 4 + s], ax = s >> 1;
+		const double w   = -L.rh2[p * 3 + ax];
+		double       acc = 0.0;
+#pragma unroll
+		for (int d = 0; d < 2; d++) {
+			const int t = 2 * i + d;
+			double    g;
+			if (kind == FACE_GHOST)
+				g = L.ghost[(size_t) src * n + t];
+			else if (e4)
+				g = e4[((size_t) src * 4 + (s ^ 1)) * n + t];
+			else
+				g = u[(size_t) src * nn + (s == 0 ? n - 1 + n * t : (s == 1 ? n * t : (s == 2 ? t + n * (n - 1) : t)))];
+			acc += (w * g) / 4;
+		}
+		return acc;
+	};
+	auto cell = [&](int s, int i) { return (s >> 1) == 0 ? ((s & 1) ? h - 1 : 0) + cs * i : i + cs * ((s & 1) ? h - 1 : 0); };
+	if (h >= 2 && h <= 32) {
+		// one 32-lane group per face, all four sums in flight at once; W and E touch different cells, S and N too: two rounds of
+		// additions (a corner cell takes its W/E term, then its S/N term -- the order of the face-by-face loop below)
+		const int  s = threadIdx.x >> 5, i = threadIdx.x & 31, kind = L.face_kind[p * 4 + s];
+		const bool act = i < h && kind >= FACE_LOCAL;
+		const double acc = act ? term(s, kind, i) : 0.0;
+		if (act && s < 2) cb[cell(s, i)] += acc;
+		__syncthreads();
+		if (act && s >= 2) cb[cell(s, i)] += acc;
+		return;
+	}
 	for (int s = 0; s < 4; s++) {
 		const int kind = L.face_kind[p * 4 + s];
-		if (kind >= FACE_LOCAL) {
-			const int    src = L.face_src[p * 4 + s], ax = s >> 1;
-			const double w   = -L.rh2[p * 3 + ax];
-			for (int i = threadIdx.x; i < h; i += blockDim.x) {
-				double acc = 0.0;
-#pragma unroll
-				for (int d = 0; d < 2; d++) {
-					const int t = 2 * i + d;
-					double    g;
-					if (kind == FACE_GHOST)
-						g = L.ghost[(size_t) src * n + t];
-					else if (e4)
-						g = e4[((size_t) src * 4 + (s ^ 1)) * n + t];
-					else
-						g = u[(size_t) src * nn + (s == 0 ? n - 1 + n * t : (s == 1 ? n * t : (s == 2 ? t + n * (n - 1) : t)))];
-					acc += (w * g) / 4;
-				}
-				cb[ax == 0 ? ((s & 1) ? h - 1 : 0) + cs * i : i + cs * ((s & 1) ? h - 1 : 0)] += acc;
-			}
-		}
+		if (kind >= FACE_LOCAL)
+			for (int i = threadIdx.x; i < h; i += blockDim.x) cb[cell(s, i)] += term(s, kind, i);
 		__syncthreads();
 	}
 }
