@@ -183,6 +183,7 @@ struct LevelHost {
 	DevBuf<double> fcorr;
 	bool           f_has_corr = false;
 	DevBuf<double> rs6; // [P][6][(n/2)^2]: the 2x2 sums of the face layers, as the producer of the next level's fcorr
+	DevBuf<int32_t> gtab; // 3D: [Pc][48] block starts in rs6 for k_fcorr_gather3d (built at its first launch)
 	DevBuf<double> e4buf; // 2D: [P][4][n] edge layers of an iterate that is never stored (the 2D twin of f6buf)
 	const double  *pack_f6 = nullptr; // set while that iterate is the one whose faces travel to other ranks
 	DevBuf<double> xfbuf[2];
@@ -1426,9 +1427,16 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	if (fcorr_out) { // the ghost terms were formed by the patches that own the face values: sort them into the coarse
 		// level's side array (a permutation copy of 6/128 of a vector instead of the fix-up pass)
 		if (L.Pc > 0) {
+			const bool use_gtab = export_rs6 && !getenv("TE_NO_GTAB");
+			if (use_gtab && !L.gtab.p && (size_t) L.P * 6 * (N / 2) * (N / 2) < ((size_t) 1 << 31)) { // once per level
+				int rc2 = L.gtab.alloc((size_t) L.Pc * 48);
+				if (rc2) return rc2;
+				hipLaunchKernelGGL(k_gather_table3d<N>, dim3(L.Pc), dim3(64), 0, g->stream, L.dev(), L.child.p, L.copy.p, L.gtab.p);
+			}
 			Timed t(g, KC_FCORR_GATHER, (size_t) L.P * 6 * L.nf / 4);
 			hipLaunchKernelGGL(k_fcorr_gather3d<N>, dim3(L.Pc * 12), dim3(256), 0, g->stream, L.dev(), L.child.p, L.copy.p,
-			                   export_rs6 ? (const double *) L.rs6.p : (const double *) nullptr, (const double *) L.f6buf.p, coarse, fcorr_out);
+			                   export_rs6 ? (const double *) L.rs6.p : (const double *) nullptr, (const double *) L.f6buf.p, coarse, fcorr_out,
+			                   use_gtab ? (const int32_t *) L.gtab.p : (const int32_t *) nullptr);
 		}
 	} else if (L.P > 0) {
 		Timed    t(g, KC_FIXUP, (size_t) L.P * 6 * L.nf);

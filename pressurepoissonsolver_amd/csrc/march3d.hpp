@@ -750,10 +750,38 @@ template <int N> struct FCorrSrc {
 // rs6 == null (a refined fine level: copy-through patches, coarse/fine ghost slots): the sums are formed here from the
 // fine level's face layers f6; a coarse patch that is a copy of a fine patch takes w g cell by cell on its own two faces
 // of each axis, as the copy-through branch of k_restrict_fixup3d adds them.
+// gtab [coarse patch][axis][plane j][quadrant oa + 2 ob] (built once per level by k_gather_table3d): where in rs6 the 16x16
+// block of finished terms of that quarter plane starts; -1: the terms are zero (physical face, no such child); -2: take the
+// general path (neighbour on another rank, copy-through patch). One cached table read instead of the dependent chain
+// child -> face kind / source -> value (the kernel is all latency: 90 % of its wave cycles wait).
+template <int N>
+__global__ void k_gather_table3d(LevelDev L, const int32_t *__restrict__ child, const int32_t *__restrict__ copy, int32_t *__restrict__ gtab)
+{
+	constexpr int HH = (N / 2) * (N / 2);
+	const int     pc = blockIdx.x, e = threadIdx.x;
+	if (e >= 48) return;
+	const int ax = e / 16, j = (e / 4) % 4, oa = e & 1, ob = (e >> 1) & 1;
+	int32_t   v;
+	if (copy && copy[pc]) {
+		v = -2;
+	} else {
+		const int a0 = (ax == 0) ? 1 : 0, a1 = (ax == 2) ? 1 : 2;
+		const int s = 2 * ax + (j & 1), hi = j >> 1;
+		const int p = child[(size_t) pc * 8 + ((hi << ax) | (oa << a0) | (ob << a1))];
+		if (p < 0) {
+			v = -1;
+		} else {
+			const int kind = L.face_kind[(size_t) p * 6 + s], src = L.face_src[(size_t) p * 6 + s];
+			v              = kind < FACE_LOCAL ? -1 : (kind == FACE_LOCAL ? (int32_t) (((size_t) src * 6 + (s ^ 1)) * HH) : -2);
+		}
+	}
+	gtab[(size_t) pc * 48 + e] = v;
+}
 template <int N>
 __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_t *__restrict__ child, const int32_t *__restrict__ copy,
                                                         const double *__restrict__ rs6, const double *__restrict__ f6,
-                                                        double *__restrict__ coarse, double *__restrict__ fcorr)
+                                                        double *__restrict__ coarse, double *__restrict__ fcorr,
+                                                        const int32_t *__restrict__ gtab)
 {
 	constexpr int NN = N * N, NNN = N * N * N, H = N / 2, HH = H * H;
 	// one workgroup per plane; a thread's QN entries are independent chains of dependent loads (tables, then the value): all
@@ -763,6 +791,12 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 	const bool    cp = copy && copy[pc];
 	// the term of entry (a, b) of plane j of axis ax of this coarse patch
 	auto term = [&](int ax, int j, int a, int b) -> double {
+		if (rs6 && gtab) { // (a uniformly refined fine level: the finished sums of the neighbours)
+			const int oa = a >= H, ob = b >= H;
+			const int t  = gtab[(size_t) pc * 48 + ax * 16 + j * 4 + oa + 2 * ob];
+			if (t >= 0) return rs6[(size_t) t + (a - oa * H) + H * (b - ob * H)];
+			if (t == -1) return 0.0;
+		}
 		const int a0 = (ax == 0) ? 1 : 0, a1 = (ax == 2) ? 1 : 2; // the two other axes in order
 		if (cp) { // the coarse patch IS a fine patch that does not coarsen: its own two faces of the axis, cell by cell (w g)
 			if (j == 1 || j == 2) return 0.0;
