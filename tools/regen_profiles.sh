@@ -1,0 +1,14 @@
+#!/bin/bash
+# (run through gpurun) every judged file of a round at one commit: tools/regen_profiles.sh <commit>
+# rocprofv3 passes (profile_round.sh), traffic.json from them, then the bench lines of the five configurations
+set -o pipefail
+cd $GRAFT_REPO_ROOT
+C=$1
+bash tools/profile_round.sh r02f $C > gpurun_out/r02f_profile.log 2>&1 || { tail -5 gpurun_out/r02f_profile.log; exit 1; }
+tail -3 gpurun_out/r02f_profile.log
+python3 tools/prof_summary.py gpurun_out/r02f gpurun_out/r02f/summary $C "bench.py --steps 20 --warmup 5" 512 1 > /dev/null && cp profiles/traffic.json gpurun_out/r02f_traffic.json
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/r02f_bench_512.json 2> gpurun_out/r02f_bench_512.err && echo bench512 ok &&
+python3 bench.py --steps 20 --warmup 5 --smoother patch_solve --no-cpu-baseline > gpurun_out/r02f_bench_512_ps.json 2>> gpurun_out/r02f_bench_512.err && echo ps ok &&
+python3 bench.py --steps 20 --warmup 5 --size 256 --no-cpu-baseline > gpurun_out/r02f_bench_256.json 2>> gpurun_out/r02f_bench_512.err && echo 256 ok &&
+python3 bench.py --steps 20 --warmup 5 --dim 2 --size 4096 --patch 64 --no-cpu-baseline > gpurun_out/r02f_bench_2d.json 2>> gpurun_out/r02f_bench_512.err && echo 2d ok &&
+python3 bench.py --steps 20 --warmup 5 --mesh tests/golden/2refine.bin --divide 3 --no-cpu-baseline > gpurun_out/r02f_bench_c4.json 2>> gpurun_out/r02f_bench_512.err && echo c4 ok
