@@ -2,6 +2,7 @@
 // BiCGStab. Host C++ + HIP for gfx950 only. There is no CPU fallback anywhere in this file:
 // if HIP cannot give us a device, te_gmg_create fails with TE_EHIP.
 #include "capi_common.hpp"
+#include <hip/hip_ext.h>
 #include "kernels3d.hpp"
 #include "march3d.hpp"
 #include "kernels2d.hpp"
@@ -205,6 +206,7 @@ struct LevelHost {
 struct EventPair {
 	hipEvent_t a, b;
 	int        kc;
+	bool       valid; // both events recorded in this use
 };
 } // namespace
 
@@ -276,7 +278,11 @@ namespace
 struct Timed {
 	te_gmg *g;
 	int     idx = -1;
-	Timed(te_gmg *g_, int kc, size_t ncells = 0) : g(g_)
+	bool    ext, first = true;
+	// ext: the launches of this scope go through launchT, which hands the events to the dispatch itself (hipExtLaunchKernelGGL:
+	// time stamps of the kernel's own start and end, as rocprofv3 sees it) -- an event recorded on the stream before and after a
+	// launch costs a barrier packet each, several microseconds around a kernel of tens
+	Timed(te_gmg *g_, int kc, size_t ncells = 0, bool ext_ = false) : g(g_), ext(ext_)
 	{
 		if (!g->profiling || (g->prof_only >= 0 && g->prof_only != kc)) return;
 		g->cells[kc] += (int64_t) ncells;
@@ -285,22 +291,38 @@ struct Timed {
 			if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
 			g->ev_pool.push_back(e);
 		}
-		idx                  = (int) g->ev_used++;
-		g->ev_pool[idx].kc   = kc;
-		(void) hipEventRecord(g->ev_pool[idx].a, g->stream);
+		idx                   = (int) g->ev_used++;
+		g->ev_pool[idx].kc    = kc;
+		g->ev_pool[idx].valid = false;
+		if (!ext) (void) hipEventRecord(g->ev_pool[idx].a, g->stream);
 	}
 	~Timed()
 	{
-		if (idx >= 0) (void) hipEventRecord(g->ev_pool[idx].b, g->stream);
+		if (idx >= 0 && !ext) {
+			(void) hipEventRecord(g->ev_pool[idx].b, g->stream);
+			g->ev_pool[idx].valid = true;
+		}
 	}
 };
+// a kernel launch inside an ext scope: the first one carries the start event, every one the stop event (the last record counts)
+template <typename K, typename... A> void launchT(Timed &t, K kern, dim3 grid, dim3 blk, size_t shm, hipStream_t s, A... args)
+{
+	if (t.idx >= 0 && t.ext) {
+		EventPair &e = t.g->ev_pool[t.idx];
+		hipExtLaunchKernelGGL(kern, grid, blk, shm, s, t.first ? e.a : (hipEvent_t) nullptr, e.b, 0, args...);
+		t.first = false;
+		e.valid = true;
+	} else {
+		hipLaunchKernelGGL(kern, grid, blk, shm, s, args...);
+	}
+}
 void drainEvents(te_gmg *g)
 {
 	if (g->ev_used == 0) return;
 	(void) hipStreamSynchronize(g->stream);
 	for (size_t i = 0; i < g->ev_used; i++) {
 		float ms = 0;
-		if (hipEventElapsedTime(&ms, g->ev_pool[i].a, g->ev_pool[i].b) == hipSuccess) {
+		if (g->ev_pool[i].valid && hipEventElapsedTime(&ms, g->ev_pool[i].a, g->ev_pool[i].b) == hipSuccess) {
 			g->calls[g->ev_pool[i].kc]++;
 			g->total_ms[g->ev_pool[i].kc] += ms;
 		}
@@ -1070,14 +1092,14 @@ int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, doub
 	if (L.n <= 64 && !getenv("TE_2D_SIMPLE")) { // the patch and its halo ring fit in LDS: one pass
 		const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
 		Prolong2D    ps{L.parent.p, L.orth.p, prolong_from};
-		Timed        t(g, zero_guess ? KC_RBGS_ZERO : (prolong_from ? KC_RBGS_PROLONG : KC_RBGS), (size_t) L.P * L.nc);
+		Timed        t(g, zero_guess ? KC_RBGS_ZERO : (prolong_from ? KC_RBGS_PROLONG : KC_RBGS), (size_t) L.P * L.nc, true);
 #define TE_RB2(Z, PR)                                                                                                          \
 	if (L.n == 64 && tpb2d() == 512)                                                                                           \
-		hipLaunchKernelGGL((k_rbgs2d_lds<Z, PR, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), u, f, out, ps);     \
+		launchT(t, (k_rbgs2d_lds<Z, PR, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), u, f, out, ps);     \
 	else if (L.n == 64)                                                                                                        \
-		hipLaunchKernelGGL((k_rbgs2d_lds<Z, PR, 64>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);          \
+		launchT(t, (k_rbgs2d_lds<Z, PR, 64>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);          \
 	else                                                                                                                       \
-		hipLaunchKernelGGL((k_rbgs2d_lds<Z, PR, 0>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps)
+		launchT(t, (k_rbgs2d_lds<Z, PR, 0>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps)
 		if (zero_guess)
 			TE_RB2(true, false);
 		else if (prolong_from)
@@ -1120,12 +1142,11 @@ int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0
 		const size_t lds = sizeof(double) * 64 * PS2D_LD;
 		static bool  attr = false;
 		const bool   pf = L.P <= 256 && !getenv("TE_2D_NO_PF"); // few patches: a workgroup has its CU to itself anyway
+		Timed        t(g, KC_PS_MFMA, total, true);
 		auto         launch = [&](auto kern) -> int {
-            if (!attr) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-            hipLaunchKernelGGL(kern, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.matsT.p, L.lam.p, L.zero_mode.p, f, u, s1);
+            launchT(t, kern, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.matsT.p, L.lam.p, L.zero_mode.p, f, u, s1);
             return TE_OK;
 		};
-		Timed t(g, KC_PS_MFMA, total);
 		if (!attr) { // all four once, so that the attribute is set whichever runs first
 			const void *ks[4] = {reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, false>),
 			                     reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, false>)};
@@ -1232,16 +1253,16 @@ int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, doub
 	Prolong2D    dst{L.parent.p, L.orth.p, nullptr};
 	int          rc;
 	if (L.P > 0) {
-		Timed t(g, store_u ? KC_ZERO_RESID : KC_ZERO_RESID_FACES, (size_t) L.P * L.nc);
+		Timed t(g, store_u ? KC_ZERO_RESID : KC_ZERO_RESID_FACES, (size_t) L.P * L.nc, true);
 #define TE_ZR2(S, NC)                                                                                                             \
-	hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<S, NC>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, \
+	launchT(t, (k_rbgs_zero_resid2d_lds<S, NC>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, \
 	                   coarse, L.upbuf.p, L.up_off.p)
 		if (L.n == 64 && tpb2d() == 512) {
 			if (store_u)
-				hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<true, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst,
+				launchT(t, (k_rbgs_zero_resid2d_lds<true, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst,
 				                   coarse, L.upbuf.p, L.up_off.p);
 			else
-				hipLaunchKernelGGL((k_rbgs_zero_resid2d_lds<false, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst,
+				launchT(t, (k_rbgs_zero_resid2d_lds<false, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst,
 				                   coarse, L.upbuf.p, L.up_off.p);
 		} else if (store_u && L.n == 64)
 			TE_ZR2(true, 64);
@@ -1281,15 +1302,15 @@ int resweepProlong2d(te_gmg *g, LevelHost &L, const double *f, double *out, cons
 {
 	if (L.P == 0) return TE_OK;
 	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
-	Timed        t(g, KC_RESWEEP, (size_t) L.P * L.nc);
+	Timed        t(g, KC_RESWEEP, (size_t) L.P * L.nc, true);
 	if (L.n == 64 && tpb2d() == 512)
-		hipLaunchKernelGGL((k_rbgs_resweep_prolong2d_lds<64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
+		launchT(t, (k_rbgs_resweep_prolong2d_lds<64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
 		                   Prolong2D{L.parent.p, L.orth.p, prolong_from});
 	else if (L.n == 64)
-		hipLaunchKernelGGL(k_rbgs_resweep_prolong2d_lds<64>, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
+		launchT(t, k_rbgs_resweep_prolong2d_lds<64>, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
 		                   Prolong2D{L.parent.p, L.orth.p, prolong_from});
 	else
-		hipLaunchKernelGGL(k_rbgs_resweep_prolong2d_lds<0>, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
+		launchT(t, k_rbgs_resweep_prolong2d_lds<0>, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
 		                   Prolong2D{L.parent.p, L.orth.p, prolong_from});
 	HIPCHK(hipGetLastError());
 	return TE_OK;
@@ -1400,23 +1421,23 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	rd.rs6                = export_rs6 ? L.rs6.p : nullptr;
 	int rc;
 	if (L.P > 0) {
-		Timed      t(g, store_u ? KC_ZERO_RESID : (fcorr_in ? KC_ZERO_RESID_FACES_FCORR : KC_ZERO_RESID_FACES), (size_t) L.P * L.nc);
+		Timed      t(g, store_u ? KC_ZERO_RESID : (fcorr_in ? KC_ZERO_RESID_FACES_FCORR : KC_ZERO_RESID_FACES), (size_t) L.P * L.nc, true);
 		LevelDev   D = L.dev();
 		const dim3 grid(8 * ((L.P + 7) / 8)), blk(Tile3<N>::TPB);
 		if (store_u) {
 			D.xf_out = xf_out;
-			hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, true>), grid, blk, 0, g->stream, D, f, out, rd);
+			launchT(t, (k_rbgs_zero_resid3d<N, true>), grid, blk, 0, g->stream, D, f, out, rd);
 		} else {
 			D.f6_out = L.f6buf.p;
 			D.fcorr  = fcorr_in;
 			if (export_rs6 && fcorr_in)
-				hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false, true, true>), grid, blk, 0, g->stream, D, f, out, rd);
+				launchT(t, (k_rbgs_zero_resid3d<N, false, true, true>), grid, blk, 0, g->stream, D, f, out, rd);
 			else if (export_rs6)
-				hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false, true, false>), grid, blk, 0, g->stream, D, f, out, rd);
+				launchT(t, (k_rbgs_zero_resid3d<N, false, true, false>), grid, blk, 0, g->stream, D, f, out, rd);
 			else if (fcorr_in)
-				hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false, false, true>), grid, blk, 0, g->stream, D, f, out, rd);
+				launchT(t, (k_rbgs_zero_resid3d<N, false, false, true>), grid, blk, 0, g->stream, D, f, out, rd);
 			else
-				hipLaunchKernelGGL((k_rbgs_zero_resid3d<N, false, false, false>), grid, blk, 0, g->stream, D, f, out, rd);
+				launchT(t, (k_rbgs_zero_resid3d<N, false, false, false>), grid, blk, 0, g->stream, D, f, out, rd);
 		}
 	}
 	// the new face layers of neighbours on other ranks (no-op on one rank)
@@ -1467,7 +1488,7 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 	ps.coarse = prolong_from;
 	auto launch = [&](LevelDev D) {
 		if (D.count == 0) return;
-		Timed t(g, fcorr_in ? KC_RESWEEP_FCORR : KC_RESWEEP, (size_t) D.count * L.nc);
+		Timed t(g, fcorr_in ? KC_RESWEEP_FCORR : KC_RESWEEP, (size_t) D.count * L.nc, true);
 		D.f6    = L.f6buf.p;
 		D.fcorr = fcorr_in;
 		if constexpr (N >= 4) {
@@ -1476,30 +1497,30 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 			const int   v  = ve ? atoi(ve) : 27;
 			if (L.ncf > 0 || L.has_copy) { // refined level: copy-through patches / coarse-fine ghost slots
 				if (v == 3)
-					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 3, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
+					launchT(t, (k_rbgs_resweep_prolong3d<N, 3, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
 				else
-					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 27, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
+					launchT(t, (k_rbgs_resweep_prolong3d<N, 27, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (fcorr_in) {
 				if (v == 0)
-					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 0, true>), grid, blk, 0, g->stream, D, f, out, ps);
+					launchT(t, (k_rbgs_resweep_prolong3d<N, 0, true>), grid, blk, 0, g->stream, D, f, out, ps);
 				else if (ve && v == 27) // (measured: on a level whose vectors fit the Infinity Cache the non-temporal form is no faster)
-					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 27, true>), grid, blk, 0, g->stream, D, f, out, ps);
+					launchT(t, (k_rbgs_resweep_prolong3d<N, 27, true>), grid, blk, 0, g->stream, D, f, out, ps);
 				else
-					hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 3, true>), grid, blk, 0, g->stream, D, f, out, ps);
+					launchT(t, (k_rbgs_resweep_prolong3d<N, 3, true>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 0) {
-				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 0, false>), grid, blk, 0, g->stream, D, f, out, ps);
+				launchT(t, (k_rbgs_resweep_prolong3d<N, 0, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 7) {
-				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 7, false>), grid, blk, 0, g->stream, D, f, out, ps);
+				launchT(t, (k_rbgs_resweep_prolong3d<N, 7, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 11) {
-				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 11, false>), grid, blk, 0, g->stream, D, f, out, ps);
+				launchT(t, (k_rbgs_resweep_prolong3d<N, 11, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 19) {
-				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 19, false>), grid, blk, 0, g->stream, D, f, out, ps);
+				launchT(t, (k_rbgs_resweep_prolong3d<N, 19, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 27) {
-				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 27, false>), grid, blk, 0, g->stream, D, f, out, ps);
+				launchT(t, (k_rbgs_resweep_prolong3d<N, 27, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 3) {
-				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 3, false>), grid, blk, 0, g->stream, D, f, out, ps);
+				launchT(t, (k_rbgs_resweep_prolong3d<N, 3, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else {
-				hipLaunchKernelGGL((k_rbgs_resweep_prolong3d<N, 27, false>), grid, blk, 0, g->stream, D, f, out, ps);
+				launchT(t, (k_rbgs_resweep_prolong3d<N, 27, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			}
 		}
 	};
@@ -1679,7 +1700,7 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 				                           hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS_BYTES));
 				lds_ok = true;
 			}
-			Timed         t(g, KC_PS_MFMA, total);
+			Timed         t(g, KC_PS_MFMA, total, true);
 			const dim3    b512(512);
 			const double *cp = zero_guess ? (const double *) nullptr : (const double *) L.corr.p;
 			// pure axes: half-size transforms, one resident workgroup per CU walks over the patches (k_ps_sym);
@@ -1692,20 +1713,20 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 				const dim3 gs(std::min(n_sym, ncu));
 				double    *xo = (g->in_cycle && n_mix == 0 && !g->no_xf_export) ? L.xfbuf[L.xf_cur ^ 1].p : nullptr; // (k_ps_fused does not export)
 				if (zero_guess)
-					hipLaunchKernelGGL(k_ps_sym<false>, gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
+					launchT(t, k_ps_sym<false>, gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
 					                   L.zero_mode.p, L.rh2.p, f, cp, u, xo, lst_sym);
 				else
-					hipLaunchKernelGGL(k_ps_sym<true>, gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
+					launchT(t, k_ps_sym<true>, gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
 					                   L.zero_mode.p, L.rh2.p, f, cp, u, xo, lst_sym);
 				if (xo) xfProduced(L, u);
 			}
 			if (n_mix > 0) {
 				const dim3 gf(8 * ((n_mix + 7) / 8));
 				if (zero_guess)
-					hipLaunchKernelGGL(k_ps_fused<false>, gf, b512, PSF_LDS_BYTES, g->stream, n_mix, L.plan.p, L.mats.p, L.lam.p,
+					launchT(t, k_ps_fused<false>, gf, b512, PSF_LDS_BYTES, g->stream, n_mix, L.plan.p, L.mats.p, L.lam.p,
 					                   L.zero_mode.p, L.rh2.p, f, cp, u, lst_mix);
 				else
-					hipLaunchKernelGGL(k_ps_fused<true>, gf, b512, PSF_LDS_BYTES, g->stream, n_mix, L.plan.p, L.mats.p, L.lam.p,
+					launchT(t, k_ps_fused<true>, gf, b512, PSF_LDS_BYTES, g->stream, n_mix, L.plan.p, L.mats.p, L.lam.p,
 					                   L.zero_mode.p, L.rh2.p, f, cp, u, lst_mix);
 			}
 			HIPCHK(hipGetLastError());
