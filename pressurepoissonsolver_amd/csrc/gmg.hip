@@ -758,7 +758,9 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		L->prolong_fusable_cf = (D == 3 && up.empty() && down.empty() && !getenv("TE_NO_CFP"));
 		if (D == 2 && L->lds2d && up.empty() && down.empty()) {
 			L->fuse2d          = true;
-			L->prolong_fusable = (L->nslots == 0 && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
+			// (faces on other ranks are fine: their values of u + P e arrive in ghost slots, packProlongFaces2d)
+			L->prolong_fusable = ((getenv("TE_2D_NO_MR_FUSE") ? L->nslots == 0 : L->ncf == 0)
+			                      && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
 		}
 		if (D == 2 && L->lds2d && !getenv("TE_NO_FUSE2")) { // the 3D fusions in 2D (kernels2d.hpp)
 			// a global fact, as in 3D (all ranks and every partition take the same arithmetic path): the level is uniformly
@@ -1083,12 +1085,25 @@ static int tpb2d()
 	static const int v = getenv("TE_2D_TPB") ? atoi(getenv("TE_2D_TPB")) : 512;
 	return v == 256 ? 256 : 512;
 }
+// faces of u + P(coarse) for the neighbours on other ranks (u: the stored iterate, or e4: only its edge layers exist), and
+// their values into this rank's ghost slots
+int packProlongFaces2d(te_gmg *g, LevelHost &L, const double *u, const double *e4, const Prolong2D &ps)
+{
+	if (L.nremote == 0 || L.patch_local) return TE_OK;
+	{
+		Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
+		hipLaunchKernelGGL(k_pack_faces_prolong2d, dim3(L.nremote), dim3(64), 0, g->stream, L.n, L.send_faces.p, u, e4, ps, L.sendbuf.p);
+	}
+	return doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p);
+}
 // zero_guess: levels with L.lds2d; prolong_from: levels with L.fuse2d && L.prolong_fusable (the caller checks)
 int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false,
                  const double *prolong_from = nullptr)
 {
 	int rc;
-	if (!zero_guess && !prolong_from && (rc = prepareGhosts2d(g, L, u))) return rc; // (prolong_from: no ghost slots)
+	if (!zero_guess && !prolong_from && (rc = prepareGhosts2d(g, L, u))) return rc;
+	if (prolong_from && (rc = packProlongFaces2d(g, L, u, nullptr, Prolong2D{L.parent.p, L.orth.p, prolong_from}))) return rc;
+	if (L.P == 0) return TE_OK;
 	if (L.n <= 64 && !getenv("TE_2D_SIMPLE")) { // the patch and its halo ring fit in LDS: one pass
 		const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
 		Prolong2D    ps{L.parent.p, L.orth.p, prolong_from};
@@ -1300,6 +1315,8 @@ int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, doub
 }
 int resweepProlong2d(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from)
 {
+	int rc = packProlongFaces2d(g, L, nullptr, L.e4buf.p, Prolong2D{L.parent.p, L.orth.p, prolong_from});
+	if (rc) return rc;
 	if (L.P == 0) return TE_OK;
 	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
 	Timed        t(g, KC_RESWEEP, (size_t) L.P * L.nc, true);

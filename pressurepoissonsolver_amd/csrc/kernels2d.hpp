@@ -633,10 +633,13 @@ __global__ __launch_bounds__(TPB) void k_rbgs_resweep_prolong2d_lds(Level2D L, c
 		if (i < 4 * n) {
 			const int s = i / n, t = i % n;
 			double    hv = 0.0;
-			if (L.face_kind[p * 4 + s] == FACE_LOCAL) {
+			const int kind = L.face_kind[p * 4 + s];
+			if (kind == FACE_LOCAL) {
 				const int src = L.face_src[p * 4 + s];
 				hv = e4[((size_t) src * 4 + (s ^ 1)) * n + t];
 				hv += coarseAt2d(ps, n, src, s == 0 ? n - 1 : (s == 1 ? 0 : t), s == 2 ? n - 1 : (s == 3 ? 0 : t));
+			} else if (kind == FACE_GHOST) { // the neighbour's rank sent the same sum (k_pack_faces_prolong2d)
+				hv = L.ghost[(size_t) L.face_src[p * 4 + s] * n + t];
 			}
 			T.at(s == 0 ? -1 : (s == 1 ? n : t), s == 2 ? -1 : (s == 3 ? n : t)) = hv;
 		}
@@ -686,6 +689,20 @@ __global__ void k_pack_faces2d(int n, const int32_t *__restrict__ faces, const d
 	const double *up = u + (size_t) p * n * n + ((s & 1) ? (n - 1) * sn : 0);
 	double       *o  = sendbuf + (size_t) blockIdx.x * n;
 	for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = up[i * sa];
+}
+
+// the facing values of u + P(coarse) -- u stored, or (e4 != null) only its edge layers -- for neighbours on other ranks: the
+// sums a local neighbour would form itself (k_rbgs2d_lds<false, true>, k_rbgs_resweep_prolong2d_lds), same operands, same order
+__global__ void k_pack_faces_prolong2d(int n, const int32_t *__restrict__ faces, const double *__restrict__ u, const double *__restrict__ e4,
+                                       Prolong2D ps, double *__restrict__ sendbuf)
+{
+	const int p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
+	for (int i = threadIdx.x; i < n; i += blockDim.x) {
+		const int x = s == 0 ? 0 : (s == 1 ? n - 1 : i), y = s == 2 ? 0 : (s == 3 ? n - 1 : i);
+		double    v = e4 ? e4[((size_t) p * 4 + s) * n + i] : u[(size_t) p * n * n + x + n * y];
+		v += coarseAt2d(ps, n, p, x, y);
+		sendbuf[(size_t) blockIdx.x * n + i] = v;
+	}
 }
 
 __device__ __forceinline__ double restrictCell2d(const double *fp, int n, int hx, int hy)

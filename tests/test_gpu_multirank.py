@@ -136,6 +136,46 @@ def test_sharded_exported_ghost_terms(nranks, monkeypatch):
     assert np.array_equal(got["u"], want[False])
 
 
+@pytest.mark.parametrize("nranks,n", [(2, 64), (4, 64), (4, 16)])
+def test_sharded_2d_recomputing_post_sweep(nranks, n, monkeypatch):
+    """2D uniform levels cut by rank boundaries take the fuse = 3 path too: the neighbour's rank sends the facing values of
+    v + P(coarse) (k_pack_faces_prolong2d: the sum a local neighbour's value would get) and k_rbgs_resweep_prolong2d_lds reads
+    them from ghost slots. Sharded == single rank bit for bit, for the stored-iterate path (fuse = 2) as well."""
+    monkeypatch.setenv("TE_AGGLOMERATE", "0")  # every level stays spread out: rank boundaries on all of them
+    mesh = util.mesh("uniform", 3, 2)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    f = util.rand_vec(H1.cells(0), 9)
+    nc = n * n
+    want = {}
+    for fuse in (2, 3):
+        df, du = g1.new_vector(0, f), g1.new_vector(0)
+        g1.cycle(g1.default_opts(smoother=capi.SMOOTH_RBGS, fuse=fuse), df, du)
+        want[fuse] = du.download()
+    assert np.array_equal(want[2], want[3])
+
+    def per_rank(r, H, g, fab):
+        idx = H.l2g(0)
+        out = {}
+        for fuse in (2, 3):
+            df, du = g.new_vector(0, f.reshape(-1, nc)[idx].ravel()), g.new_vector(0)
+            g.profile(True)
+            g.profile_reset()
+            g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS, fuse=fuse), df, du)
+            rows = g.profile_rows()
+            g.profile(False)
+            out[f"u{fuse}"] = du.download()
+            out[f"resweep{fuse}"] = rows.get("rbgs_resweep_prolong", {"calls": 0})["calls"]
+            out[f"fused_prolong{fuse}"] = rows.get("stencil_rbgs_prolong", {"calls": 0})["calls"]
+        return out
+
+    got = shard_run(mesh, n, nranks, per_rank, dim=2)
+    assert np.array_equal(got["u3"], want[3]) and np.array_equal(got["u2"], want[2])
+    # level 0 (64 patches) and level 1 (16) are cut by rank boundaries on every rank that owns patches of them
+    assert all(c >= 2 for c in got["resweep3"]), got["resweep3"]
+    assert all(c >= 2 for c in got["fused_prolong2"]), got["fused_prolong2"]
+
+
 @pytest.mark.parametrize("nranks", [2, 8])
 def test_sharded_bicgstab(nranks):
     """te_bicgstab on a sharded hierarchy (scalars summed over the ranks through the registered all-reduce, all ranks
