@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Copies what tools/regen_profiles.sh left under gpurun_out/ into profiles/ under the round's names, each bench line
+stamped with the commit it measured.   usage: install_profiles.py <round tag, e.g. r02> <commit>"""
+import json
+import shutil
+import sys
+
+tag, commit = sys.argv[1:3]
+names = {"r02f_bench_512.json": "bench_512_n1.json", "r02f_bench_512_ps.json": "bench_512_n1_patch_solve.json",
+         "r02f_bench_256.json": "bench_256_n1.json", "r02f_bench_2d.json": "bench_2d_4096_n1.json",
+         "r02f_bench_c4.json": "bench_c4_2refine_div3_n1.json"}
+for src, dst in names.items():
+    d = json.loads(open("gpurun_out/" + src).read().strip().splitlines()[-1])
+    d = {"measured_at_commit": commit, **d}
+    json.dump(d, open(f"profiles/{tag}_{dst}", "w"), indent=1)
+    r = d.get("roofline", {})
+    print(dst, round(d["ms_per_step"], 4), d.get("ms_per_step_median") and round(d["ms_per_step_median"], 4), round(d["value"] / 1e9, 1),
+          r.get("kernel"), round(r.get("frac", 0), 3), r.get("traffic"))
+for src, dst in {"summary_kernel_stats.csv": "kernel_stats_512_rbgs.csv", "summary_pmc_sq.csv": "pmc_sq_512_rbgs.csv",
+                 "summary_pmc_fetch_write.csv": "pmc_fetch_write_512_rbgs.csv"}.items():
+    shutil.copy("gpurun_out/r02f/" + src, f"profiles/{tag}_{dst}")
+shutil.copy("gpurun_out/r02f_traffic.json", "profiles/traffic.json")
