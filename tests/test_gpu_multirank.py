@@ -142,6 +142,7 @@ def test_sharded_2d_recomputing_post_sweep(nranks, n, monkeypatch):
     v + P(coarse) (k_pack_faces_prolong2d: the sum a local neighbour's value would get) and k_rbgs_resweep_prolong2d_lds reads
     them from ghost slots. Sharded == single rank bit for bit, for the stored-iterate path (fuse = 2) as well."""
     monkeypatch.setenv("TE_AGGLOMERATE", "0")  # every level stays spread out: rank boundaries on all of them
+    monkeypatch.delenv("TE_2D_NO_MR_FUSE", raising=False)
     mesh = util.mesh("uniform", 3, 2)
     H1 = capi.Hierarchy(mesh, n)
     g1 = capi.GMG(H1)
