@@ -79,7 +79,7 @@ def test_default_cycle_against_oracle_at_full_size(full, smoother):
     elif full["dim"] == 3:
         need = FUSED_PS_3D
     else:
-        need = FUSED_2D if smoother == capi.SMOOTH_RBGS else ()
+        need = FUSED_2D if smoother == capi.SMOOTH_RBGS else ("patch_solve_mfma",)  # (64^2 patches: k_patch_solve2d_mfma)
     for k in need:
         assert k in rows and rows[k]["calls"] >= 1, (k, sorted(rows))
     if full["mesh"] == "uniform" and full["dim"] == 3 and smoother == capi.SMOOTH_RBGS:
@@ -96,6 +96,35 @@ def test_default_cycle_against_oracle_at_full_size(full, smoother):
     # RB-GS ~0.18 (3D)
     r = f - orc.apply(levels[0], got)
     assert np.linalg.norm(r) <= (0.2 if smoother == capi.SMOOTH_PATCH_SOLVE else 0.35) * np.linalg.norm(f)
+
+
+OTHER_SHAPES = {  # cycles other than bench.py's V(1,1), at C2's full size (256^3, 512 patches): options for both sides
+    "w-cycle-rbgs": dict(smoother=capi.SMOOTH_RBGS, cycle_type=1),
+    "v22-rbgs": dict(smoother=capi.SMOOTH_RBGS, pre_sweeps=2, post_sweeps=2),
+    "v11-jacobi": dict(smoother=capi.SMOOTH_JACOBI, omega=0.8),
+    "w-cycle-patch-solve": dict(smoother=capi.SMOOTH_PATCH_SOLVE, cycle_type=1),
+    "v11-rbgs-relaxed-coarse": dict(smoother=capi.SMOOTH_RBGS, exact_coarse=0, coarse_sweeps=3),
+}
+
+
+@pytest.mark.parametrize("shape", list(OTHER_SHAPES))
+@pytest.mark.parametrize("neumann", [False, True], ids=["dirichlet", "neumann"])
+def test_other_cycle_shapes_against_oracle_at_c2_size(shape, neumann):
+    """W-cycles (WCycle.h:45-68), V(2,2), weighted Jacobi and a relaxed coarsest level on 256^3 with default fusion, Dirichlet
+    and Neumann physical boundaries (the Neumann patch solve splits the level between k_ps_sym and k_ps_fused)."""
+    kw = OTHER_SHAPES[shape]
+    m, H, levels = util.setup("uniform", 32, 3, neumann=neumann)
+    assert levels[0].P == 512
+    orc.set_threads(min(os.cpu_count() or 1, 16))
+    g = capi.GMG(H)
+    f = problems.random_rhs(H.tables(0)["id"], 32 ** 3)
+    if neumann:
+        f -= f.mean()  # (uniform cells: a compatible right-hand side)
+    df, du = g.new_vector(0, f), g.new_vector(0)
+    g.cycle(g.default_opts(**kw), df, du)
+    names = dict(pre_sweeps="pre", post_sweeps="post", coarse_sweeps="coarse")
+    want = orc.cycle(levels, orc.cycle_opts(**{names.get(k, k): v for k, v in kw.items()}), f)
+    assert rel(du.download(), want) <= 1e-10
 
 
 @pytest.mark.parametrize("smoother", [capi.SMOOTH_RBGS, capi.SMOOTH_PATCH_SOLVE], ids=["rbgs", "patch_solve"])
