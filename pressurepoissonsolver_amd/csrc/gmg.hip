@@ -233,6 +233,8 @@ struct te_gmg {
 	void                                   *allreduce_user = nullptr;
 	// schedule check (te_gmg_verify_schedule): exchanges are recorded instead of performed
 	bool recording = false;
+	bool ps2d_attr = false, ps_lds_ok = false; // dynamic-LDS attributes of the patch-solve kernels set on this solver's device
+	int  ncu = 0;
 	struct ExRec {
 		int     tag, level, peer;
 		int64_t send_cnt, recv_cnt;
@@ -1155,7 +1157,7 @@ int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0
 	if (L.n == 64 && L.matsT.p && !getenv("TE_2D_SIMPLE") && !getenv("TE_2D_NO_MFMA")) { // 64^2 patches: the four products on the matrix cores
 		if (!zero_guess && (rc = prepareGhosts2d(g, L, u))) return rc;
 		const size_t lds = sizeof(double) * 64 * PS2D_LD;
-		static bool  attr = false;
+		bool        &attr = g->ps2d_attr;
 		const bool   pf = L.P <= 256 && !getenv("TE_2D_NO_PF"); // few patches: a workgroup has its CU to itself anyway
 		Timed        t(g, KC_PS_MFMA, total, true);
 		auto         launch = [&](auto kern) -> int {
@@ -1701,8 +1703,8 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 				hipLaunchKernelGGL((k_face_corr3d<N, false>), dim3(L.P * 6), b256, 0, g->stream, D, u, L.corr.p, ps);
 		}
 		if (one_pass) { // the whole solve in one pass over HBM (k_ps_fused)
-			static bool lds_ok = false;
-			static int  ncu    = 0;
+			bool &lds_ok = g->ps_lds_ok;
+			int  &ncu    = g->ncu;
 			if (!lds_ok) {
 				int dev = 0;
 				HIPCHK(hipGetDevice(&dev));
