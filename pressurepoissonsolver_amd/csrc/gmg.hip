@@ -232,6 +232,7 @@ struct te_gmg {
 	te_allreduce_fn                         allreduce      = nullptr;
 	void                                   *allreduce_user = nullptr;
 	// schedule check (te_gmg_verify_schedule): exchanges are recorded instead of performed
+	te_vec *bicg_work[8] = {nullptr}; // te_bicgstab's work vectors (level 0), allocated at its first call
 	bool recording = false;
 	bool ps2d_attr = false, ps_lds_ok = false; // dynamic-LDS attributes of the patch-solve kernels set on this solver's device
 	int  ncu = 0;
@@ -2170,6 +2171,8 @@ void te_gmg_destroy(te_gmg *g)
 		for (te_vec *v : {L->u.get(), L->f.get(), L->r.get(), L->t.get()})
 			if (v && v->d) (void) hipFree(v->d);
 	}
+	for (te_vec *v : g->bicg_work)
+		if (v) te_vec_destroy(v);
 	for (auto &e : g->ev_pool) {
 		(void) hipEventDestroy(e.a);
 		(void) hipEventDestroy(e.b);
@@ -2514,14 +2517,12 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 	if ((rc = checkLevelVec(g, 0, x, "te_bicgstab")) || (rc = checkLevelVec(g, 0, b, "te_bicgstab"))) return rc;
 	if (g->nranks > 1 && !g->rccl.comm && !g->allreduce)
 		return te::fail(TE_ESTATE, "te_bicgstab on a sharded hierarchy needs te_gmg_use_rccl or te_gmg_set_allreduce");
-	te_vec *w[8] = {nullptr};
-	auto    done = [&](int code) {
-        for (auto q : w)
-            if (q) te_vec_destroy(q);
-        return code;
-	};
-	for (auto &p : w)
-		if ((rc = newVec(g, 0, &p))) return done(rc);
+	// the eight work vectors stay with the solver (a driver solves again and again: allocating and freeing 8 GiB at 512^3
+	// cost 2.5 ms per solve); released in te_gmg_destroy
+	te_vec **w   = g->bicg_work;
+	auto    done = [&](int code) { return code; };
+	for (int i = 0; i < 8; i++)
+		if (!w[i] && (rc = newVec(g, 0, &w[i]))) return rc;
 	te_vec *resid = w[0], *ms = w[1], *mp = w[2], *rhat = w[3], *p = w[4], *ap = w[5], *as = w[6], *s = w[7];
 	double r0sq, rsq, rho, tmp, tmp2;
 #define TE_TRY(x)                \
