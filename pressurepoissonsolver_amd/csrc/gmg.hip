@@ -187,6 +187,9 @@ struct LevelHost {
 	DevBuf<int32_t> gtab; // 3D: [Pc][48] block starts in rs6 for k_fcorr_gather3d (built at its first launch)
 	DevBuf<double> e4buf; // 2D: [P][4][n] edge layers of an iterate that is never stored (the 2D twin of f6buf)
 	const double  *pack_f6 = nullptr; // set while that iterate is the one whose faces travel to other ranks
+	// reference smoother, opts.fuse = 3: the zero-guess pre-sweep is asked to store only the face layers of its result (ps_faces_req,
+	// set by the cycle); ps_faces: it did -- f6buf holds them, the level's u is undefined until the post-sweep rewrites it
+	bool ps_faces_req = false, ps_faces = false;
 	DevBuf<double> xfbuf[2];
 	int            xf_cur       = 0;
 	const double  *xf_valid_for = nullptr;
@@ -1577,7 +1580,10 @@ template <int N> int interfaceResidRestrictN(te_gmg *g, LevelHost &L, const doub
 	rd.remote     = L.upbuf.p;
 	rd.remote_off = L.up_off.p;
 	int rc;
-	if ((rc = prepareGhosts<N>(g, L, u))) return rc;
+	L.pack_f6 = L.ps_faces ? L.f6buf.p : nullptr; // (the iterate exists only as its face layers)
+	rc        = prepareGhosts<N>(g, L, u);
+	L.pack_f6 = nullptr;
+	if (rc) return rc;
 	{
 		Timed t(g, KC_VECOP, coarse_n);
 		HIPCHK(hipMemsetAsync(coarse, 0, sizeof(double) * coarse_n, g->stream));
@@ -1586,7 +1592,8 @@ template <int N> int interfaceResidRestrictN(te_gmg *g, LevelHost &L, const doub
 	if (L.P > 0) {
 		Timed    t(g, KC_FIXUP, (size_t) L.P * 6 * L.nf);
 		LevelDev D = L.dev();
-		D.xf       = xf;
+		D.xf       = L.ps_faces ? nullptr : xf;
+		D.f6       = L.ps_faces ? L.f6buf.p : nullptr;
 		hipLaunchKernelGGL((k_restrict_fixup3d<N, true>), dim3(L.P), dim3(256), 0, g->stream, D, u, rd);
 	}
 	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
@@ -1675,6 +1682,8 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 {
 	const size_t total = (size_t) L.P * L.nc;
 	int          rc;
+	const bool   faces_req = L.ps_faces_req && zero_guess; // (a request holds for the very next sweep only)
+	L.ps_faces_req         = false;
 	if (N == 32 && !getenv("TE_PS_SLOW")) {
 		// matrix-core path (patchsolve32.hpp): interface terms on the face layers only, then x,y forward
 		// per plane; z forward + eigenvalue divide + z inverse; x,y inverse. A zero initial guess has no
@@ -1694,10 +1703,15 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 			ps.parent = L.parent.p;
 			ps.orth   = L.orth.p;
 			ps.coarse = prolong_from;
-			if ((rc = prepareGhosts<N>(g, L, u, prolong_from ? &ps : nullptr))) return rc;
+			L.pack_f6 = L.ps_faces ? L.f6buf.p : nullptr;
+			rc        = prepareGhosts<N>(g, L, u, prolong_from ? &ps : nullptr);
+			L.pack_f6 = nullptr;
+			if (rc) return rc;
 			Timed    t(g, KC_PATCH_RHS, (size_t) L.P * 6 * L.nf);
 			LevelDev D = L.dev();
-			D.xf       = xf_in;
+			D.xf       = L.ps_faces ? nullptr : xf_in;
+			D.f6       = L.ps_faces ? L.f6buf.p : nullptr;
+			L.ps_faces = false; // (this sweep rewrites the whole iterate)
 			if (prolong_from)
 				hipLaunchKernelGGL((k_face_corr3d<N, true>), dim3(L.P * 6), b256, 0, g->stream, D, u, L.corr.p, ps);
 			else
@@ -1718,6 +1732,8 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 				                           hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS_BYTES));
 				HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_sym<true>),
 				                           hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS_BYTES));
+				HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_sym<false, true>),
+				                           hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS_BYTES));
 				lds_ok = true;
 			}
 			Timed         t(g, KC_PS_MFMA, total, true);
@@ -1732,12 +1748,18 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 			if (n_sym > 0) {
 				const dim3 gs(std::min(n_sym, ncu));
 				double    *xo = (g->in_cycle && n_mix == 0 && !g->no_xf_export) ? L.xfbuf[L.xf_cur ^ 1].p : nullptr; // (k_ps_fused does not export)
-				if (zero_guess)
-					launchT(t, k_ps_sym<false>, gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
-					                   L.zero_mode.p, L.rh2.p, f, cp, u, xo, lst_sym);
+				const bool faces = faces_req && n_mix == 0 && L.f6buf.p;
+				if (faces) { // only the face layers of the result: see k_ps_sym<CORR, FACES>
+					launchT(t, (k_ps_sym<false, true>), gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
+					        L.zero_mode.p, L.rh2.p, f, cp, u, (double *) nullptr, lst_sym, L.f6buf.p);
+					L.ps_faces = true;
+					xo         = nullptr;
+				} else if (zero_guess)
+					launchT(t, (k_ps_sym<false, false>), gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
+					        L.zero_mode.p, L.rh2.p, f, cp, u, xo, lst_sym, (double *) nullptr);
 				else
-					launchT(t, k_ps_sym<true>, gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
-					                   L.zero_mode.p, L.rh2.p, f, cp, u, xo, lst_sym);
+					launchT(t, (k_ps_sym<true, false>), gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
+					        L.zero_mode.p, L.rh2.p, f, cp, u, xo, lst_sym, (double *) nullptr);
 				if (xo) xfProduced(L, u);
 			}
 			if (n_mix > 0) {
@@ -2085,6 +2107,11 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	           && !getenv("TE_NO_FUSE2")) {
 		// block Jacobi from the zero iterate: the residual lives on the face layers only (interfaceResidRestrictN)
 		u_zero = false;
+		// opts.fuse = 3: ... and so does everything the post-sweep reads of this iterate (its interface terms, k_face_corr3d
+		// on u + P e): the pre-sweep stores the six face layers of its result and nothing else (bit-identical; rank-local)
+		L.ps_faces_req = o->fuse >= 3 && o->cycle_type == 0 && o->post_sweeps >= 1 && L.n == 32 && L.P >= 256 && L.prolong_fusable
+		                 && (L.sym_ok || L.n_pure == L.P) && L.f6buf.p && !getenv("TE_PS_SLOW") && !getenv("TE_PS_MODE")
+		                 && !getenv("TE_NO_PS_FACES");
 		if ((rc = smoothOnce(g, l, f, u, TE_SMOOTH_PATCH_SOLVE, o->omega, true))) return rc;
 		if ((rc = interfaceResidRestrict(g, L, u->d, xfFor(L, u->d), C.f->d, C.f->n))) return rc;
 		have_coarse_f = true;
@@ -2499,11 +2526,11 @@ int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u)
 		g->verified_opts.insert(optsKey(o));
 	}
 	if (!o->fuse && (rc = te_vec_set(u, 0.0))) return rc; // Cycle.h:118
-	for (auto &L : g->levels) L->xf_valid_for = nullptr;
+	for (auto &L : g->levels) L->xf_valid_for = nullptr, L->ps_faces = L->ps_faces_req = false;
 	g->in_cycle = getenv("TE_NO_XF") == nullptr;
 	rc          = visit(g, o, 0, f, u, o->fuse != 0);
 	g->in_cycle = false;
-	for (auto &L : g->levels) L->xf_valid_for = nullptr;
+	for (auto &L : g->levels) L->xf_valid_for = nullptr, L->ps_faces = L->ps_faces_req = false;
 	return rc;
 }
 

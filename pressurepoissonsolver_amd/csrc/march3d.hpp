@@ -1165,7 +1165,9 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 						g = L.xf[((size_t) src * 2 + ((s & 1) ^ 1)) * NN + i];
 					else
 						g = u[(size_t) src * NNN + oth + cell];
-					if (OWN) g += (ax == 0 && L.xf) ? L.xf[((size_t) p * 2 + (s & 1)) * NN + i] : u[(size_t) p * NNN + mine + cell];
+					if (OWN)
+						g += L.f6 ? L.f6[((size_t) p * 6 + s) * NN + i]
+						          : ((ax == 0 && L.xf) ? L.xf[((size_t) p * 2 + (s & 1)) * NN + i] : u[(size_t) p * NNN + mine + cell]);
 					cc[mine + cell] += w * g;
 				}
 			}
@@ -1199,7 +1201,9 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 						else
 							g = u[(size_t) src * NNN + oth + a * sa + b * sb];
 						if (OWN) {
-							if (ax == 0 && L.xf)
+							if (L.f6)
+								g += L.f6[((size_t) p * 6 + s) * NN + a + N * b];
+							else if (ax == 0 && L.xf)
 								g += L.xf[((size_t) p * 2 + (s & 1)) * NN + a + N * b];
 							else
 								g += u[(size_t) p * NNN + ((s & 1) ? (N - 1) * sn : 0) + a * sa + b * sb];

@@ -50,7 +50,10 @@ __global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *_
 			const int a = i % N, b = i / N;
 			const int cell = a * sa + b * sb;
 			double    m, gh;
-			if (ax == 0 && L.xf) { // x faces from the compact columns the producer of u exported (LevelDev.xf): no strided reads
+			if (L.f6) { // the old iterate exists only as its six face layers (k_ps_sym<false, FACES>)
+				m  = L.f6[((size_t) p * 6 + s) * NN + i];
+				gh = (kind == FACE_LOCAL) ? L.f6[((size_t) src * 6 + (s ^ 1)) * NN + i] : L.ghost[(size_t) src * NN + i];
+			} else if (ax == 0 && L.xf) { // x faces from the compact columns the producer of u exported (LevelDev.xf): no strided reads
 				m  = L.xf[((size_t) p * 2 + (s & 1)) * NN + i];
 				gh = (kind == FACE_LOCAL) ? L.xf[((size_t) src * 2 + ((s & 1) ^ 1)) * NN + i] : L.ghost[(size_t) src * NN + i];
 			} else {

@@ -81,12 +81,17 @@ struct PssPlane {
 
 // list (may be null): the kernel works on patches list[0..P) instead of 0..P (levels where only some patches
 // have pure axes; the others take k_ps_fused).
-template <bool CORR>
+// FACES (opts.fuse = 3, the zero-guess pre-sweep of a V-cycle): only the six face layers of the result are stored, into
+// f6_out [patch][6][N*N] (the layout of the RB-GS face layers: W,E at (y + N z), S,N at (x + N z), B,T at (x + N y)) -- the
+// residual of a block-Jacobi sweep from zero lives on the faces (interfaceResidRestrict) and the post-sweep overwrites the
+// iterate, reading the old one only through its interface terms (k_face_corr3d): 8 + 1.5 B per site instead of 16.
+template <bool CORR, bool FACES = false>
 __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict__ plan, const double *__restrict__ frag,
                                                 const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
                                                 const double *__restrict__ rh2, const double *__restrict__ in,
                                                 const double *__restrict__ corr, double *__restrict__ out,
-                                                double *__restrict__ xf_out, const int32_t *__restrict__ list)
+                                                double *__restrict__ xf_out, const int32_t *__restrict__ list,
+                                                double *__restrict__ f6_out = nullptr)
 {
 	constexpr int N = 32, NN = N * N;
 	extern __shared__ __attribute__((aligned(16))) double xbuf[];
@@ -405,6 +410,21 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 					}
 					const int   x  = xc ? N - 1 - j : j;
 					const v4f64 yl = (py + qy) * scale, yh = (py - qy) * scale;
+					if (FACES) {
+						double *fb = f6_out + (size_t) pid * 6 * NN;
+						if (z == 0 || z == N - 1) { // a z face: the whole plane
+							double *zp = fb + (z ? 5 : 4) * NN;
+#pragma unroll
+							for (int r = 0; r < 4; r++) zp[(g + 4 * r) * N + x] = yl[r], zp[(N - 1 - g - 4 * r) * N + x] = yh[r];
+						}
+						if (g == 0) fb[2 * NN + x + N * z] = yl[0], fb[3 * NN + x + N * z] = yh[0]; // rows y = 0 and y = N - 1
+						if (j == 0) { // columns x = 0 (xc = 0) and x = N - 1
+							double *xo = fb + xc * NN + N * z;
+#pragma unroll
+							for (int r = 0; r < 4; r++) xo[g + 4 * r] = yl[r], xo[N - 1 - g - 4 * r] = yh[r];
+						}
+						continue;
+					}
 #pragma unroll
 					for (int r = 0; r < 4; r++) {
 #if PSS_NT

@@ -177,6 +177,31 @@ def test_sharded_2d_recomputing_post_sweep(nranks, n, monkeypatch):
     assert all(c >= 2 for c in got["fused_prolong2"]), got["fused_prolong2"]
 
 
+def test_sharded_reference_smoother_face_layers(monkeypatch):
+    """The reference smoother's pre-sweep that stores face layers only (k_ps_sym<false, FACES>), cut by a rank boundary: the
+    neighbour's rank receives the layers packed from the face buffer. 512 patches of 32^3 on 2 ranks == single rank."""
+    monkeypatch.setenv("TE_AGGLOMERATE", "16")
+    n = 32
+    mesh = util.mesh("uniform", 3)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    f = util.rand_vec(H1.cells(0), 11)
+    nc = n ** 3
+    df, du = g1.new_vector(0, f), g1.new_vector(0)
+    g1.cycle(g1.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, du)
+    want = du.download()
+    del df, du
+
+    def per_rank(r, H, g, fab):
+        idx = H.l2g(0)
+        df, du = g.new_vector(0, f.reshape(-1, nc)[idx].ravel()), g.new_vector(0)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, du)
+        return {"u": du.download()}
+
+    got = shard_run(mesh, n, 2, per_rank)
+    assert np.array_equal(got["u"], want)
+
+
 @pytest.mark.parametrize("nranks", [2, 8])
 def test_sharded_bicgstab(nranks):
     """te_bicgstab on a sharded hierarchy (scalars summed over the ranks through the registered all-reduce, all ranks

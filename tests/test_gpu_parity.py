@@ -254,6 +254,31 @@ def test_patch_solve_split_between_pure_and_mixed_axes(monkeypatch):
     assert (diff == 0).sum() >= 56 and (diff > 0).sum() <= 8
 
 
+def test_reference_smoother_pre_sweep_stores_face_layers_only(monkeypatch):
+    """opts.fuse = 3 with the reference smoother: the zero-guess pre-sweep of a level that takes the single-pass solve stores
+    the six face layers of its result and nothing else (k_ps_sym<false, FACES>) -- its residual lives on the faces and the
+    post-sweep overwrites the iterate, reading the old one through its interface terms only. Bit-identical to the stored
+    iterate (TE_NO_PS_FACES, fuse = 2) and equal to the oracle; 512 patches of 32^3, V(1,1) and V(1,2)."""
+    m, H, levels = util.setup("uniform", 32, 3)
+    g, L = capi.GMG(H), levels[0]
+    f = util.rand_vec(L.size, 77) / L.a["h"].min() ** 2
+    for kw in (dict(), dict(post_sweeps=2)):
+        got = {}
+        for name, env, fuse in (("faces", None, 3), ("stored", "1", 3), ("fuse2", None, 2)):
+            if env:
+                monkeypatch.setenv("TE_NO_PS_FACES", env)
+            else:
+                monkeypatch.delenv("TE_NO_PS_FACES", raising=False)
+            df, du = g.new_vector(0, f), g.new_vector(0)
+            du.set(3.0)
+            g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE, fuse=fuse, **kw), df, du)
+            got[name] = du.download()
+        assert np.array_equal(got["faces"], got["stored"]) and np.array_equal(got["faces"], got["fuse2"])
+        names = dict(post_sweeps="post")
+        want = orc.cycle(levels, orc.cycle_opts(smoother=capi.SMOOTH_PATCH_SOLVE, **{names[k]: v for k, v in kw.items()}), f)
+        assert rel(got["faces"], want) <= 1e-10
+
+
 def test_blas1(case):
     g, L = case["g"], case["levels"][0]
     a, b, c = (util.rand_vec(L.size, s) for s in (60, 61, 62))
