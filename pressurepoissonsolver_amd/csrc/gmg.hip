@@ -8,6 +8,7 @@
 #include "kernels2d.hpp"
 #include "patchsolve32.hpp"
 #include "patchsolve32_sym.hpp"
+#include "patchsolve16.hpp"
 #include "initkernels.hpp"
 #include <algorithm>
 #include <array>
@@ -1684,8 +1685,8 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 	int          rc;
 	const bool   faces_req = L.ps_faces_req && zero_guess; // (a request holds for the very next sweep only)
 	L.ps_faces_req         = false;
-	if (N == 32 && !getenv("TE_PS_SLOW")) {
-		// matrix-core path (patchsolve32.hpp): interface terms on the face layers only, then x,y forward
+	if ((N == 32 || N == 16) && !getenv("TE_PS_SLOW")) {
+		// matrix-core path (patchsolve32.hpp; 16^3 patches: patchsolve16.hpp): interface terms on the face layers only, then x,y forward
 		// per plane; z forward + eigenvalue divide + z inverse; x,y inverse. A zero initial guess has no
 		// interface term (gamma = 0) and u is overwritten without being read.
 		// few patches: the three-pass kernels, each patch spread over `seg` workgroups (one patch per CU would
@@ -1716,6 +1717,17 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 				hipLaunchKernelGGL((k_face_corr3d<N, true>), dim3(L.P * 6), b256, 0, g->stream, D, u, L.corr.p, ps);
 			else
 				hipLaunchKernelGGL((k_face_corr3d<N, false>), dim3(L.P * 6), b256, 0, g->stream, D, u, L.corr.p, ps);
+		}
+		if constexpr (N == 16) { // the whole solve of a 16^3 patch in one launch, the patch in LDS (k_ps16)
+			Timed t(g, KC_PS_MFMA, total, true);
+			if (zero_guess)
+				launchT(t, k_ps16<false>, dim3(L.P), b256, 0, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p, L.zero_mode.p, L.rh2.p, f,
+				        (const double *) nullptr, u);
+			else
+				launchT(t, k_ps16<true>, dim3(L.P), b256, 0, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p, L.zero_mode.p, L.rh2.p, f,
+				        (const double *) L.corr.p, u);
+			HIPCHK(hipGetLastError());
+			return TE_OK;
 		}
 		if (one_pass) { // the whole solve in one pass over HBM (k_ps_fused)
 			bool &lds_ok = g->ps_lds_ok;
@@ -2063,7 +2075,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         if (o->fuse && next_sweeps > 0
             && (L.prolong_fusable || L.prolong_fusable_cf)
             && (o->smoother == TE_SMOOTH_RBGS
-                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.dim == 3 && L.n == 32 && !getenv("TE_PS_SLOW")))) {
+                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.dim == 3 && (L.n == 32 || L.n == 16) && !getenv("TE_PS_SLOW")))) {
             pending_prolong = C.u->d;
             return TE_OK;
         }
