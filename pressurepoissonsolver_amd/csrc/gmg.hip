@@ -1685,7 +1685,7 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 	int          rc;
 	const bool   faces_req = L.ps_faces_req && zero_guess; // (a request holds for the very next sweep only)
 	L.ps_faces_req         = false;
-	if ((N == 32 || N == 16) && !getenv("TE_PS_SLOW")) {
+	if (!getenv("TE_PS_SLOW")) { // (3D patches are 4, 8, 16 or 32 cells wide)
 		// matrix-core path (patchsolve32.hpp; 16^3 patches: patchsolve16.hpp): interface terms on the face layers only, then x,y forward
 		// per plane; z forward + eigenvalue divide + z inverse; x,y inverse. A zero initial guess has no
 		// interface term (gamma = 0) and u is overwritten without being read.
@@ -1717,6 +1717,17 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 				hipLaunchKernelGGL((k_face_corr3d<N, true>), dim3(L.P * 6), b256, 0, g->stream, D, u, L.corr.p, ps);
 			else
 				hipLaunchKernelGGL((k_face_corr3d<N, false>), dim3(L.P * 6), b256, 0, g->stream, D, u, L.corr.p, ps);
+		}
+		if constexpr (N <= 8) { // 4^3 / 8^3 patches: one launch as well (vector units: k_ps_small)
+			Timed t(g, KC_DST, total, true);
+			if (zero_guess)
+				launchT(t, (k_ps_small<N, false>), dim3(L.P), b256, 0, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p, L.zero_mode.p, L.rh2.p, f,
+				        (const double *) nullptr, u);
+			else
+				launchT(t, (k_ps_small<N, true>), dim3(L.P), b256, 0, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p, L.zero_mode.p, L.rh2.p, f,
+				        (const double *) L.corr.p, u);
+			HIPCHK(hipGetLastError());
+			return TE_OK;
 		}
 		if constexpr (N == 16) { // the whole solve of a 16^3 patch in one launch, the patch in LDS (k_ps16)
 			Timed t(g, KC_PS_MFMA, total, true);
@@ -2075,7 +2086,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         if (o->fuse && next_sweeps > 0
             && (L.prolong_fusable || L.prolong_fusable_cf)
             && (o->smoother == TE_SMOOTH_RBGS
-                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.dim == 3 && (L.n == 32 || L.n == 16) && !getenv("TE_PS_SLOW")))) {
+                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.dim == 3 && !getenv("TE_PS_SLOW")))) {
             pending_prolong = C.u->d;
             return TE_OK;
         }

@@ -110,4 +110,61 @@ __global__ __launch_bounds__(256) void k_ps16(int P, const int32_t *__restrict__
 		for (int r = 0; r < 4; r++) op[z * NN + (g + 4 * r) * N + j] = d6[r] * scale;
 	}
 }
+
+// 4^3 and 8^3 patches (the reference's test meshes): the whole solve in one launch as well, one workgroup per patch, the six
+// one-axis transforms of k_dst_axis3d back to back on two LDS copies of the patch (same sums in the same order), interface
+// terms subtracted while loading (k_face_corr3d) -- one launch and 16 B/site instead of seven and 112.
+template <int N, bool CORR>
+__global__ __launch_bounds__(256) void k_ps_small(int P, const int32_t *__restrict__ plan, const double *__restrict__ mats,
+                                                  const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
+                                                  const double *__restrict__ rh2, const double *__restrict__ in,
+                                                  const double *__restrict__ corr, double *__restrict__ out)
+{
+	static_assert(N <= 8, "two copies of the patch and six matrices in static LDS");
+	constexpr int NN = N * N, NNN = N * N * N;
+	__shared__ double buf[2][NNN], Ms[6 * NN];
+	const int pid = blockIdx.x;
+	if (pid >= P) return;
+	const int pl = plan[pid];
+	for (int i = threadIdx.x; i < 6 * NN; i += 256) Ms[i] = mats[(size_t) pl * 6 * NN + i];
+	const double *cr = CORR ? corr + (size_t) pid * 6 * NN : nullptr;
+	for (int c = threadIdx.x; c < NNN; c += 256) {
+		const int x = c % N, y = (c / N) % N, z = c / NN;
+		double    v = in[(size_t) pid * NNN + c];
+		if (CORR) { // W/E, S/N, B/T (StarPatchOp.h:185-203)
+			if (x == 0) v -= cr[0 * NN + y + N * z];
+			if (x == N - 1) v -= cr[1 * NN + y + N * z];
+			if (y == 0) v -= cr[2 * NN + x + N * z];
+			if (y == N - 1) v -= cr[3 * NN + x + N * z];
+			if (z == 0) v -= cr[4 * NN + x + N * y];
+			if (z == N - 1) v -= cr[5 * NN + x + N * y];
+		}
+		buf[0][c] = v;
+	}
+	__syncthreads();
+	const double *lm = lam + (size_t) pl * 3 * N;
+	const double *rh = rh2 + (size_t) pid * 3;
+#pragma unroll
+	for (int stage = 0; stage < 6; stage++) {
+		const int     ax = stage % 3, st = (ax == 0) ? 1 : (ax == 1 ? N : NN);
+		const double *src = buf[stage & 1], *M = Ms + stage * NN;
+		double       *dst = buf[(stage & 1) ^ 1];
+		for (int c = threadIdx.x; c < NNN; c += 256) {
+			const int i = (c / st) % N, base = c - i * st;
+			double    acc = 0.0;
+#pragma unroll
+			for (int j = 0; j < N; j++) acc += M[i * N + j] * src[base + j * st];
+			if (stage == 2) {
+				const int x = c % N, y = (c / N) % N, z = c / NN;
+				acc /= -(lm[x] * rh[0] + lm[N + y] * rh[1] + lm[2 * N + z] * rh[2]);
+				if (zero_mode[pl] && c == 0) acc = 0.0;
+			}
+			if (stage == 5)
+				out[(size_t) pid * NNN + c] = acc * (8.0 / ((double) N * N * N));
+			else
+				dst[c] = acc;
+		}
+		__syncthreads();
+	}
+}
 } // namespace te
