@@ -1222,11 +1222,17 @@ int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0
 		Timed t(g, KC_PATCH_RHS, total);
 		hipLaunchKernelGGL(k_patch_rhs2d, grid, blk, 0, g->stream, L.dev2(), u, f, s0);
 	}
+	const bool mfma2d = L.n % 16 == 0 && !getenv("TE_2D_SIMPLE"); // large patches: the passes on the matrix cores
+	const dim3 gridm(((size_t) L.P * (L.n / 16) * (L.n / 16) + 3) / 4);
 #define TE_DST2(STAGE, IN, OUT)                                                                                          \
 	{                                                                                                                    \
 		Timed t(g, KC_DST, total);                                                                                       \
-		hipLaunchKernelGGL(k_dst_axis2d<STAGE>, grid, blk, 0, g->stream, L.n, L.P, L.plan.p, L.mats.p, L.lam.p,          \
-		                   L.zero_mode.p, L.rh2.p, IN, OUT);                                                             \
+		if (mfma2d)                                                                                                      \
+			hipLaunchKernelGGL(k_dst_axis2d_mfma<STAGE>, gridm, blk, 0, g->stream, L.n, L.P, L.plan.p, L.mats.p, L.lam.p, \
+			                   L.zero_mode.p, L.rh2.p, IN, OUT);                                                         \
+		else                                                                                                             \
+			hipLaunchKernelGGL(k_dst_axis2d<STAGE>, grid, blk, 0, g->stream, L.n, L.P, L.plan.p, L.mats.p, L.lam.p,      \
+			                   L.zero_mode.p, L.rh2.p, IN, OUT);                                                         \
 	}
 	TE_DST2(0, s0, s1)
 	TE_DST2(1, s1, s0)

@@ -834,6 +834,51 @@ __global__ __launch_bounds__(256) void k_dst_axis2d(int n, int P, const int32_t 
 	}
 }
 
+// The same pass on the fp64 matrix cores for patches too large for LDS (n a multiple of 16; config C1: one 256^2 patch): a wave
+// per 16x16 tile of the output, K = n in steps of four, both operands straight from global memory (the patch and the matrix
+// stay in L2). x passes: Out = In M^T, y passes: Out = M In. Sums in the MFMA's order: equal to k_dst_axis2d to rounding.
+template <int STAGE>
+__global__ __launch_bounds__(256) void k_dst_axis2d_mfma(int n, int P, const int32_t *__restrict__ plan,
+                                                         const double *__restrict__ mats, const double *__restrict__ lam,
+                                                         const int32_t *__restrict__ zero_mode, const double *__restrict__ rh2,
+                                                         const double *__restrict__ in, double *__restrict__ out)
+{
+	constexpr int AX = STAGE % 2;
+	const int     nn = n * n, tn = n / 16, tp = tn * tn;
+	const int     t  = blockIdx.x * 4 + (threadIdx.x >> 6);
+	if (t >= P * tp) return;
+	const int     p = t / tp, tr = (t % tp) / tn, tc = (t % tp) % tn; // tile row / column of the output
+	const int     l = threadIdx.x & 63, j = l & 15, g = l >> 4;
+	const int     pl = plan[p];
+	const double *M  = mats + ((size_t) pl * 4 + STAGE) * nn;
+	const double *ip = in + (size_t) p * nn;
+	// AX = 0: A[i = row y][k] = In[y][k], B[k][col i] = M[i][k];   AX = 1: A[i = row][k] = M[row][k], B[k][col x] = In[k][x]
+	const double *ap = AX == 0 ? ip + (size_t) (16 * tr + j) * n + g : M + (size_t) (16 * tr + j) * n + g;
+	const double *bp = AX == 0 ? M + (size_t) (16 * tc + j) * n + g : ip + (size_t) g * n + 16 * tc + j;
+	const size_t  bstep = AX == 0 ? 4 : (size_t) 4 * n;
+	typedef double v4 __attribute__((ext_vector_type(4)));
+	v4 d = v4{0, 0, 0, 0};
+	for (int k0 = 0; k0 < n / 4; k0 += 4) { // (n is a multiple of 16) four steps' operands in flight together
+		double a[4], b[4];
+#pragma unroll
+		for (int q = 0; q < 4; q++) a[q] = ap[4 * (k0 + q)], b[q] = bp[(k0 + q) * bstep];
+#pragma unroll
+		for (int q = 0; q < 4; q++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], d, 0, 0, 0);
+	}
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+		const int row = 16 * tr + g + 4 * r, col = 16 * tc + j;
+		double    v   = d[r];
+		if (STAGE == 1) {
+			const double *lm = lam + (size_t) pl * 2 * n;
+			v /= -(lm[col] * rh2[p * 3] + lm[n + row] * rh2[p * 3 + 1]);
+			if (zero_mode[pl] && row == 0 && col == 0) v = 0.0;
+		}
+		if (STAGE == 3) v *= 4.0 / ((double) n * n);
+		out[(size_t) p * nn + (size_t) row * n + col] = v;
+	}
+}
+
 // The same exact patch solve for patches that fit in LDS twice (n <= 64), ONE launch: right-hand side with the interface
 // terms, the four dense transform passes and the eigenvalue division on two LDS tiles, one workgroup per patch -- 16 B per
 // site instead of 24 + 4 x 16, and one kernel's latency instead of five on the coarsest level of a cycle (a single patch:
