@@ -38,6 +38,7 @@ FULL = {
     "C3-512^3": dict(mesh="uniform", n=32, div=4, dim=3, patches=4096),
     "C4-2refine-div2": dict(mesh="2refine.bin", n=32, div=2, dim=3, patches=960),
     "C5-4096^2": dict(mesh="uniform", n=64, div=6, dim=2, patches=4096),
+    "256^3-in-16^3": dict(mesh="uniform", n=16, div=4, dim=3, patches=4096),  # the 16^3 kernels (k_ps16) at depth
 }
 # kernel classes (te_gmg_profile_rows) that prove which path a default-option cycle took
 FUSED_RBGS_3D = ("rbgs_zero_resid_restrict_faces", "rbgs_resweep_prolong", "restrict_fixup")
