@@ -8,18 +8,19 @@ from pressurepoissonsolver_amd import capi, problems, dist as tedist
 nr = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 sm = {"rbgs": capi.SMOOTH_RBGS, "patch_solve": capi.SMOOTH_PATCH_SOLVE}[sys.argv[3] if len(sys.argv) > 3 else "rbgs"]
-n = 32
+dim = int(sys.argv[4]) if len(sys.argv) > 4 else 3  # mr_profile.py 8 4096 rbgs 2 = config C5 on 8 ranks
+n = 32 if dim == 3 else 64
 div = int(round(np.log2(size // n)))
 fab = tedist.LocalFabric(nr)
 out = {}
 
 def body(rank):
-    mesh = capi.Mesh.uniform(3, div)
+    mesh = capi.Mesh.uniform(dim, div)
     H = capi.Hierarchy(mesh, n, rank=rank, nranks=nr)
     g = capi.GMG(H)
     fab.attach(g, rank)
     ids = H.tables(0)["id"][H.l2g(0)]
-    f = g.new_vector(0, problems.random_rhs(ids, n ** 3))
+    f = g.new_vector(0, problems.random_rhs(ids, n ** dim))
     u = g.new_vector(0)
     o = g.default_opts(smoother=sm)
     for _ in range(2):
