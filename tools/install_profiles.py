@@ -19,4 +19,6 @@ for src, dst in names.items():
 for src, dst in {"summary_kernel_stats.csv": "kernel_stats_512_rbgs.csv", "summary_pmc_sq.csv": "pmc_sq_512_rbgs.csv",
                  "summary_pmc_fetch_write.csv": "pmc_fetch_write_512_rbgs.csv"}.items():
     shutil.copy("gpurun_out/r02f/" + src, f"profiles/{tag}_{dst}")
+for v, dst in {"ps": "kernel_stats_512_patch_solve.csv", "2d": "kernel_stats_2d_4096.csv"}.items():
+    shutil.copy(f"gpurun_out/r02f_{v}/summary_kernel_stats.csv", f"profiles/{tag}_{dst}")
 shutil.copy("gpurun_out/r02f_traffic.json", "profiles/traffic.json")
