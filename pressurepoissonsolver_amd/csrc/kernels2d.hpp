@@ -466,16 +466,12 @@ __global__ __launch_bounds__(TPB) void k_rbgs_zero_resid2d_lds(Level2D L, const 
 	if (STORE_U) {
 		storePairs2d<NC, TPB>(out + (size_t) p * nn, rv, bv, n);
 	} else {
+		// (from the tile, which is complete and no longer written: one thread per edge value, 512 contiguous bytes per side --
+		// from the registers that hold the pairs the W and E columns were 64 single 8-byte stores each)
 		double *e = e4 + (size_t) p * 4 * n;
-#pragma unroll
-		for (int K = 0; K < F2D_MAX; K++) {
-			const Pair2D pr = pairOf<NC, TPB>(K, n);
-			if (!pr.live) continue;
-			const double2 v = pr.o ? double2{bv[K], rv[K]} : double2{rv[K], bv[K]};
-			if (pr.q == 0) e[pr.y] = v.x;
-			if (pr.q == h - 1) e[n + pr.y] = v.y;
-			if (pr.y == 0) *reinterpret_cast<double2 *>(e + 2 * n + 2 * pr.q) = v;
-			if (pr.y == n - 1) *reinterpret_cast<double2 *>(e + 3 * n + 2 * pr.q) = v;
+		for (int i = tid; i < 4 * n; i += TPB) {
+			const int s = i / n, t = i % n;
+			e[i]        = T.at(s == 0 ? 0 : (s == 1 ? n - 1 : t), s == 2 ? 0 : (s == 3 ? n - 1 : t));
 		}
 	}
 	// residual and restriction; ghosts: physical faces -own / +own (StarPatchOp.h:39-65), faces with a neighbour 0
