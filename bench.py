@@ -168,6 +168,35 @@ def cpu_baseline(size, dim, n):
                     "(PETSc/FFTW/Zoltan are absent); 1-thread rows = one reference MPI rank, on a 2x-per-axis smaller grid"}
 
 
+def self_launch(ngpus, json_out):
+    """`python bench.py --gpus N` with no launcher environment (the reference's drivers are self-contained under
+    mpirun, apps/3d/steady.cpp:74-78): start one rank per GPU through torch.distributed.run as a CHILD process -- never an
+    exec, and before anything in this process has initialised the GPU -- pass rank 0's single JSON line through and return
+    the launcher's exit status (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("+ " + " ".join(cmd), file=sys.stderr, flush=True)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # (stderr is inherited)
+    lines = [ln for ln in p.stdout.splitlines() if ln.lstrip().startswith("{")]
+    for ln in p.stdout.splitlines():
+        if ln not in lines and ln.strip():
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], file=json_out, flush=True)
+    if p.returncode == 0 and not lines:
+        print("bench.py: the ranks exited without a JSON line", file=sys.stderr)
+        return 1
+    return p.returncode
+
+
 def main():
     a = parse()
     # stdout carries exactly one JSON line: everything else that libraries print there (e.g. Gloo's connection
@@ -178,9 +207,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: this process has not touched the GPU (torch is not imported yet); it starts
+        # the N ranks as children and relays rank 0's JSON line and the launcher's exit status
+        raise SystemExit(self_launch(a.gpus, json_out))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {a.gpus} was started with WORLD_SIZE={world}: one rank per GPU")
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
