@@ -25,6 +25,7 @@ extern "C" {
 #define TE_ESTATE -3   /* call not valid in the object's current state */
 #define TE_EIO -4      /* mesh file unreadable */
 #define TE_EUNSUPPORTED -5
+#define TE_ENOMEM -6    /* host allocation failed */
 
 typedef struct te_mesh te_mesh; /* octree / quadtree              (OctTree.h:34 Tree<D>) */
 typedef struct te_hier te_hier; /* host level tables, one rank    (ThundereggDomGen.h:95-222 + Domain.h) */
@@ -163,6 +164,15 @@ int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u);
  * TE_ESTATE when several ranks exist and neither is set. */
 int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, int max_it,
                 double tol, int *iterations, double *rel_resid);
+/* te_bicgstab allocates its eight level-0 work vectors at its first call and keeps them for the next solve (a driver
+ * solves again and again; 8 x the size of x: 8 GiB at 512^3). They are freed by te_gmg_destroy -- or by this call, for a
+ * caller that has finished solving and wants the memory back (the next te_bicgstab allocates them again). */
+int te_gmg_release_workspace(te_gmg *g);
+
+/* The TE_* switches are read from the environment once, in te_gmg_create. This call sets (value) or
+ * clears (NULL) one of them for this solver afterwards -- how the tests pin one implementation against another. TE_ESTATE
+ * for the few that shape the level tables and are therefore fixed at creation; TE_EINVAL for an unknown name. */
+int te_gmg_set_option(te_gmg *g, const char *name, const char *value);
 
 /* ------------------------------------------------------------ multi-rank ghost exchange */
 /* The library never talks to the network itself. When a level has off-rank neighbours, it
@@ -199,6 +209,11 @@ int te_gmg_set_allreduce(te_gmg *g, te_allreduce_fn fn, void *user);
 int te_gmg_verify_schedule(te_gmg *g, const te_cycle_opts *o);
 /* moves n doubles through the active exchange back-end with this rank as its own peer (diagnostic) */
 int te_gmg_exchange_selftest(te_gmg *g, int n);
+/* diagnostic for the watchdog: `seconds` of exchanges enqueued without a host synchronisation (the host runs ahead of the
+ * GPU; each exchange completes in milliseconds). Returns the number issued (> 0), or a TE_E* code; a watchdog that aged
+ * its deadline from the first exchange instead of the oldest OUTSTANDING one would end the process with status 86 here
+ * once `seconds` exceeds TE_EXCHANGE_TIMEOUT. With one rank the watchdog runs only when TE_EXCHANGE_TIMEOUT is set. */
+int te_gmg_watchdog_selftest(te_gmg *g, double seconds);
 
 /* Domain<D>::integrate (Domain.h:258-278) and Domain<D>::volume (:237-251), this rank's part (the host adds the
  * ranks as it does for norms): sum over local patches of (sum of the patch's cells) * (cell volume), resp. of the

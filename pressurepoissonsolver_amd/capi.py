@@ -25,7 +25,7 @@ class TeLibraryMissing(ImportError):
     pass
 
 
-TE_OK, TE_EINVAL, TE_EHIP, TE_ESTATE, TE_EIO, TE_EUNSUPPORTED = 0, -1, -2, -3, -4, -5
+TE_OK, TE_EINVAL, TE_EHIP, TE_ESTATE, TE_EIO, TE_EUNSUPPORTED, TE_ENOMEM = 0, -1, -2, -3, -4, -5, -6
 SMOOTH_PATCH_SOLVE, SMOOTH_JACOBI, SMOOTH_RBGS = 0, 1, 2
 PROBLEM_TRIG, PROBLEM_GAUSS, PROBLEM_RANDOM = 0, 1, 2
 
@@ -104,12 +104,15 @@ SYMBOLS = {
     "te_prolong_add": (_I, [_P, _I, _P, _P]),
     "te_vcycle": (_I, [_P, C.POINTER(CycleOpts), _P, _P]),
     "te_bicgstab": (_I, [_P, C.POINTER(CycleOpts), _P, _P, _I, _D, C.POINTER(_I), _PD]),
+    "te_gmg_release_workspace": (_I, [_P]),
+    "te_gmg_set_option": (_I, [_P, C.c_char_p, C.c_char_p]),
     "te_gmg_set_exchange": (_I, [_P, EXCHANGE_FN, _P]),
     "te_rccl_unique_id": (_I, [C.c_char_p, C.c_char_p]),
     "te_gmg_use_rccl": (_I, [_P, C.c_char_p, C.c_char_p, _I, _I]),
     "te_gmg_set_allreduce": (_I, [_P, ALLREDUCE_FN, _P]),
     "te_gmg_verify_schedule": (_I, [_P, C.POINTER(CycleOpts)]),
     "te_gmg_exchange_selftest": (_I, [_P, _I]),
+    "te_gmg_watchdog_selftest": (_I, [_P, _D]),
     "te_gmg_profile": (_I, [_P, _I]),
     "te_gmg_profile_rows": (_I, [_P, _I, _P, _P, _P, _P]),
     "te_gmg_profile_reset": (_I, [_P]),
@@ -377,6 +380,14 @@ class GMG:
     def residual(self, u, f, r, level=0): check(lib().te_residual(self.h, level, u.h, f.h, r.h))
     def patch_apply(self, u, f, level=0): check(lib().te_patch_apply(self.h, level, u.h, f.h))
     def verify_schedule(self, opts): check(lib().te_gmg_verify_schedule(self.h, C.byref(opts)))
+
+    def set_option(self, name, value="1"):
+        """one TE_* switch of this solver (they are read from the environment once, at creation); None clears it"""
+        check(lib().te_gmg_set_option(self.h, name.encode(), None if value is None else str(value).encode()))
+
+    def release_workspace(self):
+        """hand te_bicgstab's work vectors back (8 x a level-0 vector)"""
+        check(lib().te_gmg_release_workspace(self.h))
 
     def set_allreduce(self, fn):
         """fn(list of floats, op) -> list of floats (op 0 sum, 1 max), the same on every rank"""

@@ -3,6 +3,7 @@
 // if HIP cannot give us a device, te_gmg_create fails with TE_EHIP.
 #include "capi_common.hpp"
 #include <hip/hip_ext.h>
+#include <rccl/rccl.h> // enum values and ncclUniqueId only: the library itself is dlopen'ed (te_gmg_use_rccl)
 #include "kernels3d.hpp"
 #include "march3d.hpp"
 #include "kernels2d.hpp"
@@ -60,6 +61,38 @@ const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_j
                                     "stencil_rbgs_slabs", "stencil_slabs", "patch_solve_3pass", "rbgs_zero_resid_restrict",
                                     "restrict_fixup", "rbgs_resweep_prolong", "rbgs_zero_resid_restrict_faces",
                                     "rbgs_resweep_prolong_fcorr", "rbgs_zero_resid_restrict_faces_fcorr", "fcorr_gather"};
+
+// Every TE_* switch of this library. They are read from the environment ONCE, in te_gmg_create;
+// te_gmg_set_option changes one afterwards (the tests pin one implementation against another that way). Nothing on a
+// launch path looks at the environment.
+enum Opt : int {
+	O_2D_SIMPLE, O_2D_NO_MFMA, O_2D_NO_PF, O_2D_NO_MR_FUSE, O_2D_TPB, O_NO_FUSE2, O_NO_FUSE3, O_NO_FUSE3_CF, O_NO_CFP, O_NO_XF,
+	O_NO_FCORR, O_NO_FCORR_CF, O_NO_GTAB, O_NO_OVERLAP, O_OVERLAP_MIN, O_NO_PS_FACES, O_PS_MODE, O_PS_SLOW, O_RBGS_NOSLAB,
+	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_COUNT
+};
+const char *optName[O_COUNT] = {"TE_2D_SIMPLE", "TE_2D_NO_MFMA", "TE_2D_NO_PF", "TE_2D_NO_MR_FUSE", "TE_2D_TPB", "TE_NO_FUSE2", "TE_NO_FUSE3",
+                                "TE_NO_FUSE3_CF", "TE_NO_CFP", "TE_NO_XF", "TE_NO_FCORR", "TE_NO_FCORR_CF", "TE_NO_GTAB", "TE_NO_OVERLAP",
+                                "TE_OVERLAP_MIN", "TE_NO_PS_FACES", "TE_PS_MODE", "TE_PS_SLOW", "TE_RBGS_NOSLAB", "TE_ZS_FORCE", "TE_NO_ZS8",
+                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH"};
+// options that shape the level tables te_gmg_create builds: fixed for the solver's lifetime
+inline bool optStructural(int o) { return o == O_2D_SIMPLE || o == O_NO_CFP || o == O_2D_NO_MR_FUSE || o == O_NO_OVERLAP || o == O_EXCHANGE_TIMEOUT; }
+struct Cfg {
+	bool        on[O_COUNT] = {};
+	std::string val[O_COUNT];
+	void        set(int o, const char *v)
+	{
+		on[o]  = v != nullptr;
+		val[o] = v ? v : "";
+	}
+	void fromEnv()
+	{
+		for (int o = 0; o < O_COUNT; o++) set(o, getenv(optName[o]));
+	}
+	bool        has(int o) const { return on[o]; }
+	const char *str(int o) const { return on[o] ? val[o].c_str() : nullptr; }
+	int         num(int o, int dflt) const { return on[o] ? atoi(val[o].c_str()) : dflt; }
+	double      real(int o, double dflt) const { return on[o] ? atof(val[o].c_str()) : dflt; }
+};
 
 template <typename T> struct DevBuf {
 	T     *p = nullptr;
@@ -215,6 +248,7 @@ struct EventPair {
 } // namespace
 
 struct te_gmg {
+	Cfg                                     cfg; // the TE_* switches, read once in te_gmg_create
 	int                                     device = 0;
 	hipStream_t                             stream = nullptr;
 	// ghost exchanges run on their own stream so that interior patches compute underneath them
@@ -247,17 +281,24 @@ struct te_gmg {
 	std::vector<ExRec>         record;
 	int                        cur_level = 0;
 	std::set<uint64_t>         verified_opts;
-	// watchdog: an exchange that has not completed TE_EXCHANGE_TIMEOUT seconds after it was issued ends the process
+	// watchdog: an exchange that has not completed TE_EXCHANGE_TIMEOUT seconds after it was issued ends the process.
+	// Outstanding exchanges sit in a ring in issue order, each with its own event and issue time: the deadline always
+	// belongs to the OLDEST one that has not completed (a host that runs ahead of the GPU keeps the newest event
+	// incomplete at every poll; that must not age the deadline of exchanges that did complete).
 	struct Watchdog {
-		std::thread                           th;
-		std::mutex                            mu;
-		std::atomic<bool>                     stop{false};
-		bool                                  pending = false;
-		std::chrono::steady_clock::time_point since;
-		hipEvent_t                            ev = nullptr;
-		bool                                  ev_recorded = false;
-		double                                timeout_s = 300.0;
-		int                                   tag = 0, level = 0;
+		static constexpr int RING = 64;
+		struct Slot {
+			hipEvent_t                            ev = nullptr;
+			bool                                  recorded = false; // false: still inside the (possibly blocking) host call
+			std::chrono::steady_clock::time_point since;
+			int                                   tag = 0, level = 0;
+		};
+		std::thread       th;
+		std::mutex        mu;
+		std::atomic<bool> stop{false};
+		Slot              slot[RING];
+		uint64_t          head = 0, tail = 0; // [head, tail) outstanding
+		double            timeout_s = 300.0;
 	} wd;
 	// optional: RCCL point-to-point called straight from this library (no host callback per exchange)
 	struct Rccl {
@@ -551,10 +592,10 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		}
 	}
 	L->nslots = nslots;
-	L->lds2d  = (D == 2 && n <= 64 && n % 2 == 0 && !getenv("TE_2D_SIMPLE"));
+	L->lds2d  = (D == 2 && n <= 64 && n % 2 == 0 && !g->cfg.has(O_2D_SIMPLE));
 	// see LevelHost::fuse2_ok: a global fact only. (Refined levels qualify: patches that copy through and
 	// coarse/fine faces -- whose ghost slots carry the interpolated value -- are handled by both kernels.)
-	L->fuse2_ok = (D == 3 && li + 1 < (int) H.levels.size() && lv.P_global >= 256 && !getenv("TE_NO_FUSE2"));
+	L->fuse2_ok = (D == 3 && li + 1 < (int) H.levels.size() && lv.P_global >= 256); // (TE_NO_FUSE2 is looked at where the path is chosen)
 	L->ncf    = (int) cfs.size();
 	int rc;
 	{
@@ -762,14 +803,14 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		L->prolong_fusable = (D == 3 && L->ncf == 0 && up.empty() && down.empty()
 		                      && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
 		L->has_copy           = std::any_of(orth.begin(), orth.end(), [](int32_t o) { return o < 0; });
-		L->prolong_fusable_cf = (D == 3 && up.empty() && down.empty() && !getenv("TE_NO_CFP"));
+		L->prolong_fusable_cf = (D == 3 && up.empty() && down.empty() && !g->cfg.has(O_NO_CFP));
 		if (D == 2 && L->lds2d && up.empty() && down.empty()) {
 			L->fuse2d          = true;
 			// (faces on other ranks are fine: their values of u + P e arrive in ghost slots, packProlongFaces2d)
-			L->prolong_fusable = ((getenv("TE_2D_NO_MR_FUSE") ? L->nslots == 0 : L->ncf == 0)
+			L->prolong_fusable = ((g->cfg.has(O_2D_NO_MR_FUSE) ? L->nslots == 0 : L->ncf == 0)
 			                      && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
 		}
-		if (D == 2 && L->lds2d && !getenv("TE_NO_FUSE2")) { // the 3D fusions in 2D (kernels2d.hpp)
+		if (D == 2 && L->lds2d) { // the 3D fusions in 2D (kernels2d.hpp)
 			// a global fact, as in 3D (all ranks and every partition take the same arithmetic path): the level is uniformly
 			// refined everywhere -- no coarse/fine face, every patch a quadrant child
 			bool uniform = true;
@@ -824,23 +865,29 @@ inline bool sameShape(const te_vec *a, const te_vec *b) { return a && b && a->g 
 // waiting for ever, with no error. Every exchange arms a deadline and records an event behind itself on its
 // stream; a thread polls the event and ends the PROCESS (exit status 86, message on stderr) when the deadline
 // passes first -- the launcher (torchrun, mpirun) then takes the job down instead of hanging the node.
+void watchdogRetire(te_gmg::Watchdog &w) // (mutex held) drop completed exchanges from the front
+{
+	while (w.head < w.tail) {
+		auto &sl = w.slot[w.head % te_gmg::Watchdog::RING];
+		if (!sl.recorded || hipEventQuery(sl.ev) != hipSuccess) break;
+		w.head++;
+	}
+}
 void watchdogLoop(te_gmg *g)
 {
 	auto &w = g->wd;
 	while (!w.stop.load()) {
 		std::this_thread::sleep_for(std::chrono::milliseconds(50));
 		std::lock_guard<std::mutex> lk(w.mu);
-		if (!w.pending) continue;
-		if (w.ev_recorded && hipEventQuery(w.ev) == hipSuccess) {
-			w.pending = false;
-			continue;
-		}
-		const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - w.since).count();
+		watchdogRetire(w);
+		if (w.head == w.tail) continue;
+		const auto  &sl     = w.slot[w.head % te_gmg::Watchdog::RING];
+		const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - sl.since).count();
 		if (waited > w.timeout_s) {
 			fprintf(stderr,
 			        "te_hip watchdog: rank %d: exchange (tag %d, level %d) has not completed after %.0f s -- a peer is "
 			        "missing or issued a different exchange sequence; ending the process\n",
-			        g->rank, w.tag, w.level, waited);
+			        g->rank, sl.tag, sl.level, waited);
 			fflush(stderr);
 			_exit(86);
 		}
@@ -849,43 +896,55 @@ void watchdogLoop(te_gmg *g)
 void watchdogStart(te_gmg *g)
 {
 	auto &w = g->wd;
-	if (w.th.joinable() || g->nranks < 2) return;
-	if (const char *t = getenv("TE_EXCHANGE_TIMEOUT")) w.timeout_s = atof(t);
+	if (w.th.joinable() || (g->nranks < 2 && !g->cfg.has(O_EXCHANGE_TIMEOUT))) return; // (one rank: only when asked for, te_gmg_watchdog_selftest)
+	w.timeout_s = g->cfg.real(O_EXCHANGE_TIMEOUT, w.timeout_s);
 	if (w.timeout_s <= 0) return; // TE_EXCHANGE_TIMEOUT=0 disables it
-	if (hipEventCreateWithFlags(&w.ev, hipEventDisableTiming) != hipSuccess) return;
+	for (auto &sl : w.slot)
+		if (hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) return;
 	w.th = std::thread(watchdogLoop, g);
 }
 void watchdogStop(te_gmg *g)
 {
 	auto &w = g->wd;
-	if (!w.th.joinable()) return;
-	w.stop.store(true);
-	w.th.join();
-	if (w.ev) (void) hipEventDestroy(w.ev);
-	w.ev = nullptr;
+	if (w.th.joinable()) {
+		w.stop.store(true);
+		w.th.join();
+	}
+	for (auto &sl : w.slot) {
+		if (sl.ev) (void) hipEventDestroy(sl.ev);
+		sl.ev = nullptr;
+	}
 }
-struct WatchdogArm { // around the issue of one exchange: deadline from the first exchange still outstanding
+struct WatchdogArm { // around the issue of one exchange: takes a ring slot (issue time now), records its event behind the exchange
 	te_gmg     *g;
 	hipStream_t stream;
+	int64_t     idx = -1;
 	WatchdogArm(te_gmg *g_, hipStream_t st, int tag) : g(g_), stream(st)
 	{
 		auto &w = g->wd;
 		if (!w.th.joinable()) return;
 		std::lock_guard<std::mutex> lk(w.mu);
-		if (!w.pending) {
-			w.pending = true;
-			w.since   = std::chrono::steady_clock::now();
+		watchdogRetire(w);
+		if (w.tail - w.head == te_gmg::Watchdog::RING) {
+			// ring full (the host is more than RING exchanges ahead of the GPU): the newest slot is reused -- it keeps its
+			// issue time, which is the older one; a deadline can only fire later than strictly necessary, never earlier
+			idx = (int64_t) (w.tail - 1);
+		} else {
+			idx          = (int64_t) w.tail++;
+			auto &sl     = w.slot[idx % te_gmg::Watchdog::RING];
+			sl.since     = std::chrono::steady_clock::now();
+			sl.tag       = tag;
+			sl.level     = g->cur_level;
 		}
-		w.ev_recorded = false; // a blocking host callback is covered too: no event yet, only the deadline
-		w.tag         = tag;
-		w.level       = g->cur_level;
+		w.slot[idx % te_gmg::Watchdog::RING].recorded = false; // a blocking host callback is covered too: no event yet, only the deadline
 	}
 	~WatchdogArm()
 	{
 		auto &w = g->wd;
-		if (!w.th.joinable()) return;
+		if (idx < 0) return;
 		std::lock_guard<std::mutex> lk(w.mu);
-		w.ev_recorded = (hipEventRecord(w.ev, stream) == hipSuccess);
+		auto &sl    = w.slot[idx % te_gmg::Watchdog::RING];
+		sl.recorded = (hipEventRecord(sl.ev, stream) == hipSuccess);
 	}
 };
 
@@ -904,8 +963,7 @@ int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double 
 		// one RCCL group per exchange, enqueued on the solver stream behind the pack kernel: every
 		// send/recv of the exchange progresses together over the direct xGMI links, no host round trip
 		std::unique_ptr<Timed> t(timed ? new Timed(g, KC_EXCHANGE, 0) : nullptr);
-		constexpr int ncclFloat64 = 8; // rccl.h:467
-		int           rc         = g->rccl.GroupStart();
+		int rc = g->rccl.GroupStart();
 		for (size_t i = 0; i < pl.peers.size() && rc == 0; i++) {
 			if (pl.recv_cnt[i] > 0)
 				rc = g->rccl.Recv(recv + pl.recv_off[i], (size_t) pl.recv_cnt[i], ncclFloat64, pl.peers[i], g->rccl.comm, stream);
@@ -929,8 +987,7 @@ int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double 
 int finishReduce(te_gmg *g, int n, int op, bool global)
 {
 	if (global && g->nranks > 1 && g->rccl.comm) {
-		constexpr int ncclFloat64 = 8, ncclSum = 0, ncclMax = 2;
-		WatchdogArm   arm(g, g->stream, 100 + op);
+		WatchdogArm arm(g, g->stream, 100 + op);
 		int rc = g->rccl.AllReduce(g->result.p, g->result.p, (size_t) n, ncclFloat64, op ? ncclMax : ncclSum, g->rccl.comm, g->stream);
 		if (rc) return te::fail(TE_ESTATE, std::string("ncclAllReduce failed: ") + g->rccl.GetErrorString(rc));
 	}
@@ -1001,8 +1058,8 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 	};
 	// (levels with few local patches: nothing worth hiding under the exchange, and the second stream and its two
 	// events only add host calls and latency)
-	const char *omin = getenv("TE_OVERLAP_MIN"); // tests set 0 so that their small levels take the overlapped path
-	if (L.patch_local || g->recording || L.nremote == 0 || !g->overlap || L.n_int == 0 || L.P < (omin ? atoi(omin) : 128)) {
+	// (TE_OVERLAP_MIN: tests set 0 so that their small levels take the overlapped path)
+	if (L.patch_local || g->recording || L.nremote == 0 || !g->overlap || L.n_int == 0 || L.P < g->cfg.num(O_OVERLAP_MIN, 128)) {
 		int rc = prepareGhosts<N>(g, L, u, ps);
 		if (rc) return rc;
 		launch(L.dev());
@@ -1027,8 +1084,8 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 	// enough workgroups to fill 256 CUs a few times over: split patches into z-slabs when few
 	int zs = 1;
 	if (N >= 8) {
-		while (zs < 4 && (getenv("TE_ZS_FORCE") || (size_t) L.P * zs < 2048) && N / (zs * 2) >= 4) zs *= 2;
-		if (zs == 4 && N == 32 && L.P <= 64 && !getenv("TE_NO_ZS8")) zs = 8; // (see rbgsSlabs)
+		while (zs < 4 && (g->cfg.has(O_ZS_FORCE) || (size_t) L.P * zs < 2048) && N / (zs * 2) >= 4) zs *= 2;
+		if (zs == 4 && N == 32 && L.P <= 64 && !g->cfg.has(O_NO_ZS8)) zs = 8; // (see rbgsSlabs)
 	}
 	auto launch = [&](LevelDev D) {
 		if (D.count == 0) return;
@@ -1087,11 +1144,7 @@ template <int MODE> int launchStencil2d(te_gmg *g, LevelHost &L, const double *u
 }
 // 64^2 patches: 512 threads per workgroup (four x-pairs per thread instead of eight: half the registers, twice the waves per
 // CU at the same four resident patches)
-static int tpb2d()
-{
-	static const int v = getenv("TE_2D_TPB") ? atoi(getenv("TE_2D_TPB")) : 512;
-	return v == 256 ? 256 : 512;
-}
+static int tpb2d(const te_gmg *g) { return g->cfg.num(O_2D_TPB, 512) == 256 ? 256 : 512; }
 // faces of u + P(coarse) for the neighbours on other ranks (u: the stored iterate, or e4: only its edge layers exist), and
 // their values into this rank's ghost slots
 int packProlongFaces2d(te_gmg *g, LevelHost &L, const double *u, const double *e4, const Prolong2D &ps)
@@ -1111,12 +1164,12 @@ int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, doub
 	if (!zero_guess && !prolong_from && (rc = prepareGhosts2d(g, L, u))) return rc;
 	if (prolong_from && (rc = packProlongFaces2d(g, L, u, nullptr, Prolong2D{L.parent.p, L.orth.p, prolong_from}))) return rc;
 	if (L.P == 0) return TE_OK;
-	if (L.n <= 64 && !getenv("TE_2D_SIMPLE")) { // the patch and its halo ring fit in LDS: one pass
+	if (L.n <= 64 && !g->cfg.has(O_2D_SIMPLE)) { // the patch and its halo ring fit in LDS: one pass
 		const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
 		Prolong2D    ps{L.parent.p, L.orth.p, prolong_from};
 		Timed        t(g, zero_guess ? KC_RBGS_ZERO : (prolong_from ? KC_RBGS_PROLONG : KC_RBGS), (size_t) L.P * L.nc, true);
 #define TE_RB2(Z, PR)                                                                                                          \
-	if (L.n == 64 && tpb2d() == 512)                                                                                           \
+	if (L.n == 64 && tpb2d(g) == 512)                                                                                           \
 		launchT(t, (k_rbgs2d_lds<Z, PR, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), u, f, out, ps);     \
 	else if (L.n == 64)                                                                                                        \
 		launchT(t, (k_rbgs2d_lds<Z, PR, 64>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);          \
@@ -1159,11 +1212,11 @@ int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0
 	*swapped = false;
 	int          rc;
 	const size_t total = (size_t) L.P * L.nc;
-	if (L.n == 64 && L.matsT.p && !getenv("TE_2D_SIMPLE") && !getenv("TE_2D_NO_MFMA")) { // 64^2 patches: the four products on the matrix cores
+	if (L.n == 64 && L.matsT.p && !g->cfg.has(O_2D_SIMPLE) && !g->cfg.has(O_2D_NO_MFMA)) { // 64^2 patches: the four products on the matrix cores
 		if (!zero_guess && (rc = prepareGhosts2d(g, L, u))) return rc;
 		const size_t lds = sizeof(double) * 64 * PS2D_LD;
 		bool        &attr = g->ps2d_attr;
-		const bool   pf = L.P <= 256 && !getenv("TE_2D_NO_PF"); // few patches: a workgroup has its CU to itself anyway
+		const bool   pf = L.P <= 256 && !g->cfg.has(O_2D_NO_PF); // few patches: a workgroup has its CU to itself anyway
 		Timed        t(g, KC_PS_MFMA, total, true);
 		auto         launch = [&](auto kern) -> int {
             launchT(t, kern, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.matsT.p, L.lam.p, L.zero_mode.p, f, u, s1);
@@ -1184,7 +1237,7 @@ int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0
 		*swapped = true;
 		return TE_OK;
 	}
-	if (L.n <= 64 && L.matsT.p && !getenv("TE_2D_SIMPLE")) { // one launch, the patch in LDS
+	if (L.n <= 64 && L.matsT.p && !g->cfg.has(O_2D_SIMPLE)) { // one launch, the patch in LDS
 		if (!zero_guess && (rc = prepareGhosts2d(g, L, u))) return rc;
 		const size_t lds = sizeof(double) * 2 * L.nc;
 		Timed        t(g, KC_PS_MFMA, total);
@@ -1222,7 +1275,7 @@ int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0
 		Timed t(g, KC_PATCH_RHS, total);
 		hipLaunchKernelGGL(k_patch_rhs2d, grid, blk, 0, g->stream, L.dev2(), u, f, s0);
 	}
-	const bool mfma2d = L.n % 16 == 0 && !getenv("TE_2D_SIMPLE"); // large patches: the passes on the matrix cores
+	const bool mfma2d = L.n % 16 == 0 && !g->cfg.has(O_2D_SIMPLE); // large patches: the passes on the matrix cores
 	const dim3 gridm(((size_t) L.P * (L.n / 16) * (L.n / 16) + 3) / 4);
 #define TE_DST2(STAGE, IN, OUT)                                                                                          \
 	{                                                                                                                    \
@@ -1285,7 +1338,7 @@ int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, doub
 #define TE_ZR2(S, NC)                                                                                                             \
 	launchT(t, (k_rbgs_zero_resid2d_lds<S, NC>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, \
 	                   coarse, L.upbuf.p, L.up_off.p)
-		if (L.n == 64 && tpb2d() == 512) {
+		if (L.n == 64 && tpb2d(g) == 512) {
 			if (store_u)
 				launchT(t, (k_rbgs_zero_resid2d_lds<true, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst,
 				                   coarse, L.upbuf.p, L.up_off.p);
@@ -1333,7 +1386,7 @@ int resweepProlong2d(te_gmg *g, LevelHost &L, const double *f, double *out, cons
 	if (L.P == 0) return TE_OK;
 	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
 	Timed        t(g, KC_RESWEEP, (size_t) L.P * L.nc, true);
-	if (L.n == 64 && tpb2d() == 512)
+	if (L.n == 64 && tpb2d(g) == 512)
 		launchT(t, (k_rbgs_resweep_prolong2d_lds<64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
 		                   Prolong2D{L.parent.p, L.orth.p, prolong_from});
 	else if (L.n == 64)
@@ -1364,19 +1417,19 @@ template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, 
 	}
 }
 // z-slabs per patch for the RB-GS kernels: enough workgroups to occupy 256 CUs x 4 when the level has few patches
-template <int N> inline int rbgsSlabs(int count)
+template <int N> inline int rbgsSlabs(const te_gmg *g, int count)
 {
 	int zs = 1;
-	while (zs < 4 && !getenv("TE_RBGS_NOSLAB") && (size_t) count * zs < 1024 && N / (zs * 2) >= 4) zs *= 2;
+	while (zs < 4 && !g->cfg.has(O_RBGS_NOSLAB) && (size_t) count * zs < 1024 && N / (zs * 2) >= 4) zs *= 2;
 	// very few patches (the coarsest levels of a cycle): a kernel is one patch's march, a dependent chain of plane steps of
 	// ~1-2 us each that nothing hides -- eight slabs of four planes (six steps) instead of four of eight (ten steps)
-	if (zs == 4 && N == 32 && count <= 64 && !getenv("TE_NO_ZS8")) zs = 8;
+	if (zs == 4 && N == 32 && count <= 64 && !g->cfg.has(O_NO_ZS8)) zs = 8;
 	return zs;
 }
 template <int N, bool ZERO, bool PROLONG>
 void launchRbgsKernel(te_gmg *g, const LevelDev &D, const double *u, const double *f, double *out, const ProlongSrc &ps)
 {
-	const int  zs = rbgsSlabs<N>(D.count);
+	const int  zs = rbgsSlabs<N>(g, D.count);
 	const dim3 grid(8 * ((D.count * zs + 7) / 8)), blk(Tile3<N>::TPB);
 	if (zs == 8) {
 		if constexpr (N >= 32) hipLaunchKernelGGL((k_rbgs3d<N, ZERO, PROLONG, 8>), grid, blk, 0, g->stream, D, u, f, out, ps);
@@ -1405,7 +1458,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 				                   D, u, f, out, ps);
 				return;
 			}
-			Timed t(g, rbgsSlabs<N>(D.count) > 1 ? KC_RBGS_SLABS : KC_RBGS_PROLONG, (size_t) D.count * L.nc);
+			Timed t(g, rbgsSlabs<N>(g, D.count) > 1 ? KC_RBGS_SLABS : KC_RBGS_PROLONG, (size_t) D.count * L.nc);
 			launchRbgsKernel<N, false, true>(g, D, u, f, out, ps);
 		};
 		// neighbours on other ranks receive this rank's face layers of u + P(coarse) (exchange under the interior)
@@ -1415,7 +1468,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 		return TE_OK;
 	}
 	if (zero_guess) { // a zero iterate has zero ghosts everywhere: nothing to exchange or build
-		Timed    t(g, rbgsSlabs<N>(L.P) > 1 ? KC_RBGS_SLABS : KC_RBGS_ZERO, (size_t) L.P * L.nc);
+		Timed    t(g, rbgsSlabs<N>(g, L.P) > 1 ? KC_RBGS_SLABS : KC_RBGS_ZERO, (size_t) L.P * L.nc);
 		LevelDev D = L.dev();
 		D.xf_out   = xf_out;
 		launchRbgsKernel<N, true, false>(g, D, u, f, out, ProlongSrc());
@@ -1424,7 +1477,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 	}
 	auto launch = [&](LevelDev D) {
 		if (D.count == 0) return;
-		Timed t(g, rbgsSlabs<N>(D.count) > 1 ? KC_RBGS_SLABS : KC_RBGS, (size_t) D.count * L.nc);
+		Timed t(g, rbgsSlabs<N>(g, D.count) > 1 ? KC_RBGS_SLABS : KC_RBGS, (size_t) D.count * L.nc);
 		launchRbgsKernel<N, false, false>(g, D, u, f, out, ProlongSrc());
 	};
 	int rc = withGhosts<N>(g, L, u, launch, xf_in, xf_out);
@@ -1478,7 +1531,7 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	if (fcorr_out) { // the ghost terms were formed by the patches that own the face values: sort them into the coarse
 		// level's side array (a permutation copy of 6/128 of a vector instead of the fix-up pass)
 		if (L.Pc > 0) {
-			const bool use_gtab = export_rs6 && !getenv("TE_NO_GTAB");
+			const bool use_gtab = export_rs6 && !g->cfg.has(O_NO_GTAB);
 			if (use_gtab && !L.gtab.p && (size_t) L.P * 6 * (N / 2) * (N / 2) < ((size_t) 1 << 31)) { // once per level
 				int rc2 = L.gtab.alloc((size_t) L.Pc * 48);
 				if (rc2) return rc2;
@@ -1523,7 +1576,7 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 		D.fcorr = fcorr_in;
 		if constexpr (N >= 4) {
 			const dim3  grid(8 * ((D.count + 7) / 8)), blk(Tile3<N>::TPB);
-			const char *ve = getenv("TE_RESWEEP_V"); // tuning variants (march3d.hpp), all bit-identical; default 27
+			const char *ve = g->cfg.str(O_RESWEEP_V); // tuning variants (march3d.hpp), all bit-identical; default 27
 			const int   v  = ve ? atoi(ve) : 27;
 			if (L.ncf > 0 || L.has_copy) { // refined level: copy-through patches / coarse-fine ghost slots
 				if (v == 3)
@@ -1691,14 +1744,14 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 	int          rc;
 	const bool   faces_req = L.ps_faces_req && zero_guess; // (a request holds for the very next sweep only)
 	L.ps_faces_req         = false;
-	if (!getenv("TE_PS_SLOW")) { // (3D patches are 4, 8, 16 or 32 cells wide)
+	if (!g->cfg.has(O_PS_SLOW)) { // (3D patches are 4, 8, 16 or 32 cells wide)
 		// matrix-core path (patchsolve32.hpp; 16^3 patches: patchsolve16.hpp): interface terms on the face layers only, then x,y forward
 		// per plane; z forward + eigenvalue divide + z inverse; x,y inverse. A zero initial guess has no
 		// interface term (gamma = 0) and u is overwritten without being read.
 		// few patches: the three-pass kernels, each patch spread over `seg` workgroups (one patch per CU would
 		// leave most of the chip idle and a single solve takes ~80 us); otherwise the single-pass kernel
 		// (TE_PS_MODE = 1pass | 1pass-dense | 3pass pins the choice; 3pass also pins one workgroup per patch: tests)
-		const char *mode     = getenv("TE_PS_MODE");
+		const char *mode     = g->cfg.str(O_PS_MODE);
 		const bool  one_pass = mode ? !strncmp(mode, "1pass", 5) : L.P >= 256;
 		const int   seg      = (one_pass || mode) ? 1 : (L.P >= 128 ? 2 : (L.P >= 64 ? 4 : 8));
 		const dim3 gp(L.P, seg), b256(256);
@@ -2092,7 +2145,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         if (o->fuse && next_sweeps > 0
             && (L.prolong_fusable || L.prolong_fusable_cf)
             && (o->smoother == TE_SMOOTH_RBGS
-                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.dim == 3 && !getenv("TE_PS_SLOW")))) {
+                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.dim == 3 && !g->cfg.has(O_PS_SLOW)))) {
             pending_prolong = C.u->d;
             return TE_OK;
         }
@@ -2107,10 +2160,10 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	// read its right-hand side together with exported ghost terms, see below)
 	auto unstoredAt = [&](LevelHost &LL, bool has_coarser) {
 		return o->fuse >= 3 && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_RBGS && LL.fuse2_ok && has_coarser && o->cycle_type == 0
-		       && o->post_sweeps >= 1 && (LL.prolong_fusable || (LL.dim == 3 && LL.prolong_fusable_cf && !getenv("TE_NO_FUSE3_CF"))) && LL.n >= 4
-		       && !getenv("TE_NO_FUSE2") && !getenv("TE_NO_FUSE3");
+		       && o->post_sweeps >= 1 && (LL.prolong_fusable || (LL.dim == 3 && LL.prolong_fusable_cf && !g->cfg.has(O_NO_FUSE3_CF))) && LL.n >= 4
+		       && !g->cfg.has(O_NO_FUSE2) && !g->cfg.has(O_NO_FUSE3);
 	};
-	if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_RBGS && L.fuse2_ok && !getenv("TE_NO_FUSE2")) {
+	if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_RBGS && L.fuse2_ok && !g->cfg.has(O_NO_FUSE2)) {
 		u_zero = false;
 		// opts.fuse = 3: if exactly this sweep, the descent and a fused post-sweep follow, the iterate in between is
 		// never stored: the post-sweep kernel recomputes it from f (bit-identical to fuse = 2; a rank-local choice,
@@ -2118,8 +2171,8 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		u_unstored = unstoredAt(L, true);
 		// ... and if the next level takes the same path, its two kernels are the only readers of its right-hand side: the
 		// ghost terms of the restricted residual go to its side array instead of a fix-up pass (bit-identical; rank-local)
-		double *fcorr_out = (u_unstored && L.dim == 3 && (L.prolong_fusable || !getenv("TE_NO_FCORR_CF")) && C.fcorr.p && C.prolong_fusable
-		                     && unstoredAt(C, l + 2 < nl) && !getenv("TE_NO_FCORR"))
+		double *fcorr_out = (u_unstored && L.dim == 3 && (L.prolong_fusable || !g->cfg.has(O_NO_FCORR_CF)) && C.fcorr.p && C.prolong_fusable
+		                     && unstoredAt(C, l + 2 < nl) && !g->cfg.has(O_NO_FCORR))
 		                        ? C.fcorr.p
 		                        : nullptr; // (the next level uniformly refined; this one may be refined: the gather forms the terms)
 		if (fcorr_in && !u_unstored) return te::fail(TE_ESTATE, "te_vcycle: exported ghost terms without a reader");
@@ -2133,14 +2186,14 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		}
 		have_coarse_f = true;
 	} else if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_PATCH_SOLVE && L.fuse2_ok && L.dim == 3
-	           && !getenv("TE_NO_FUSE2")) {
+	           && !g->cfg.has(O_NO_FUSE2)) {
 		// block Jacobi from the zero iterate: the residual lives on the face layers only (interfaceResidRestrictN)
 		u_zero = false;
 		// opts.fuse = 3: ... and so does everything the post-sweep reads of this iterate (its interface terms, k_face_corr3d
 		// on u + P e): the pre-sweep stores the six face layers of its result and nothing else (bit-identical; rank-local)
 		L.ps_faces_req = o->fuse >= 3 && o->cycle_type == 0 && o->post_sweeps >= 1 && L.n == 32 && L.P >= 256 && L.prolong_fusable
-		                 && (L.sym_ok || L.n_pure == L.P) && L.f6buf.p && !getenv("TE_PS_SLOW") && !getenv("TE_PS_MODE")
-		                 && !getenv("TE_NO_PS_FACES");
+		                 && (L.sym_ok || L.n_pure == L.P) && L.f6buf.p && !g->cfg.has(O_PS_SLOW) && !g->cfg.has(O_PS_MODE)
+		                 && !g->cfg.has(O_NO_PS_FACES);
 		if ((rc = smoothOnce(g, l, f, u, TE_SMOOTH_PATCH_SOLVE, o->omega, true))) return rc;
 		if ((rc = interfaceResidRestrict(g, L, u->d, xfFor(L, u->d), C.f->d, C.f->n))) return rc;
 		have_coarse_f = true;
@@ -2160,6 +2213,21 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 }
 } // namespace
 
+// Nothing may unwind into a C caller (ctypes, the reference's C++ built with other flags): every int-returning entry
+// point below runs inside this barrier. std::bad_alloc and friends come from the std::vector / std::map set-up code.
+template <class F> static int guarded(F body) noexcept
+{
+	try {
+		return body();
+	} catch (const std::bad_alloc &) {
+		return te::fail(TE_ENOMEM, "out of host memory");
+	} catch (const std::exception &e) {
+		return te::fail(TE_ESTATE, std::string("unexpected exception: ") + e.what());
+	} catch (...) {
+		return te::fail(TE_ESTATE, "unexpected exception");
+	}
+}
+
 extern "C" {
 void te_cycle_opts_default(te_cycle_opts *o)
 {
@@ -2174,6 +2242,7 @@ void te_cycle_opts_default(te_cycle_opts *o)
 
 int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 {
+	return guarded([&]() -> int {
 	if (!h || !out) return te::fail(TE_EINVAL, "te_gmg_create: null argument");
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -2193,7 +2262,8 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 	HIPCHK(hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking));
 	HIPCHK(hipEventCreateWithFlags(&g->ev_pack, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&g->ev_recv, hipEventDisableTiming));
-	g->overlap = getenv("TE_NO_OVERLAP") == nullptr;
+	g->cfg.fromEnv();
+	g->overlap = !g->cfg.has(O_NO_OVERLAP);
 	int rc;
 	for (int li = 0; li < (int) h->h.levels.size(); li++)
 		if ((rc = buildLevel(g.get(), h->h, li))) return rc;
@@ -2216,6 +2286,7 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 	HIPCHK(hipStreamSynchronize(g->stream));
 	*out = g.release();
 	return TE_OK;
+	});
 }
 void te_gmg_destroy(te_gmg *g)
 {
@@ -2241,16 +2312,19 @@ void te_gmg_destroy(te_gmg *g)
 	(void) hipStreamDestroy(g->stream);
 	delete g;
 }
-int   te_gmg_num_levels(const te_gmg *g) { return g ? (int) g->levels.size() : TE_EINVAL; }
+int   te_gmg_num_levels(const te_gmg *g) { return guarded([&]() -> int { return g ? (int) g->levels.size() : TE_EINVAL; }); }
 int   te_gmg_sync(te_gmg *g)
 {
+	return guarded([&]() -> int {
 	if (!g) return te::fail(TE_EINVAL, "te_gmg_sync: null");
 	HIPCHK(hipStreamSynchronize(g->stream));
 	return TE_OK;
+	});
 }
 void *te_gmg_stream(te_gmg *g) { return g ? (void *) g->stream : nullptr; }
 int   te_gmg_set_exchange(te_gmg *g, te_exchange_fn fn, void *user)
 {
+	return guarded([&]() -> int {
 	if (!g) return te::fail(TE_EINVAL, "te_gmg_set_exchange: null");
 	if (fn && g->rccl.comm) { // an explicit callback replaces the native RCCL back-end
 		(void) g->rccl.CommDestroy(g->rccl.comm);
@@ -2260,18 +2334,22 @@ int   te_gmg_set_exchange(te_gmg *g, te_exchange_fn fn, void *user)
 	g->exchange_user = user;
 	if (fn) watchdogStart(g);
 	return TE_OK;
+	});
 }
 int te_gmg_set_allreduce(te_gmg *g, te_allreduce_fn fn, void *user)
 {
+	return guarded([&]() -> int {
 	if (!g) return te::fail(TE_EINVAL, "te_gmg_set_allreduce: null");
 	g->allreduce      = fn;
 	g->allreduce_user = user;
 	return TE_OK;
+	});
 }
 
 static void *rcclSym(void *lib, const char *name) { return dlsym(lib, name); }
 int te_rccl_unique_id(const char *libpath, char *id128)
 {
+	return guarded([&]() -> int {
 	if (!libpath || !id128) return te::fail(TE_EINVAL, "te_rccl_unique_id: null argument");
 	void *lib = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
 	if (!lib) return te::fail(TE_EIO, std::string("te_rccl_unique_id: dlopen failed: ") + dlerror());
@@ -2280,18 +2358,19 @@ int te_rccl_unique_id(const char *libpath, char *id128)
 	int rc = get(id128);
 	if (rc) return te::fail(TE_ESTATE, "ncclGetUniqueId failed");
 	return TE_OK;
+	});
 }
 int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank, int nranks)
 {
+	return guarded([&]() -> int {
 	if (!g || !libpath || !id128) return te::fail(TE_EINVAL, "te_gmg_use_rccl: null argument");
 	HIPCHK(hipSetDevice(g->device));
 	void *lib = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
 	if (!lib) return te::fail(TE_EIO, std::string("te_gmg_use_rccl: dlopen failed: ") + dlerror());
-	struct Id {
-		char b[128];
-	} id;
-	memcpy(id.b, id128, 128);
-	auto init = (int (*)(void **, int, Id, int)) rcclSym(lib, "ncclCommInitRank");
+	static_assert(sizeof(ncclUniqueId) == 128, "te_rccl_unique_id hands out 128 bytes");
+	ncclUniqueId id;
+	memcpy(&id, id128, 128);
+	auto init = (int (*)(void **, int, ncclUniqueId, int)) rcclSym(lib, "ncclCommInitRank");
 	te_gmg::Rccl r;
 	r.lib            = lib;
 	r.GroupStart     = (int (*)()) rcclSym(lib, "ncclGroupStart");
@@ -2303,18 +2382,21 @@ int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank,
 	r.GetErrorString = (const char *(*) (int) ) rcclSym(lib, "ncclGetErrorString");
 	if (!init || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.CommDestroy || !r.GetErrorString || !r.AllReduce)
 		return te::fail(TE_EIO, "te_gmg_use_rccl: RCCL symbols missing in " + std::string(libpath));
+	if (nranks > 1 && (rank != g->rank || nranks != g->nranks)) // (before the communicator exists: nothing to leak)
+		return te::fail(TE_EINVAL, "te_gmg_use_rccl: rank / nranks differ from the hierarchy's");
 	int rc = init(&r.comm, nranks, id, rank);
 	if (rc) return te::fail(TE_ESTATE, std::string("ncclCommInitRank failed: ") + r.GetErrorString(rc));
-	if (nranks > 1 && (rank != g->rank || nranks != g->nranks))
-		return te::fail(TE_EINVAL, "te_gmg_use_rccl: rank / nranks differ from the hierarchy's");
+	if (g->rccl.comm && g->rccl.CommDestroy) (void) g->rccl.CommDestroy(g->rccl.comm); // a second call replaces the first communicator
 	g->rccl = r;
 	watchdogStart(g);
 	return TE_OK;
+	});
 }
 // moves n doubles from a scratch send buffer to a scratch receive buffer of level 0 through the same
 // code path as a real exchange, with this rank as its own peer; returns TE_OK iff the data arrived intact
 int te_gmg_exchange_selftest(te_gmg *g, int n)
 {
+	return guarded([&]() -> int {
 	if (!g || n < 1) return te::fail(TE_EINVAL, "te_gmg_exchange_selftest: bad argument");
 	LevelHost &L = *g->levels[0];
 	if ((size_t) 2 * n > L.r->n) return te::fail(TE_EINVAL, "te_gmg_exchange_selftest: n too large");
@@ -2336,7 +2418,6 @@ int te_gmg_exchange_selftest(te_gmg *g, int n)
 	if (g->rccl.comm) { // the scalar reduction of te_bicgstab / te_gmg_verify_schedule: ncclAllReduce on the solver stream
 		const double v[4] = {1.5, -2.25, 3.0, 0.125};
 		HIPCHK(hipMemcpyAsync(g->result.p, v, sizeof v, hipMemcpyHostToDevice, g->stream));
-		constexpr int ncclFloat64 = 8, ncclSum = 0;
 		int r2 = g->rccl.AllReduce(g->result.p, g->result.p, 4, ncclFloat64, ncclSum, g->rccl.comm, g->stream);
 		if (r2) return te::fail(TE_ESTATE, std::string("ncclAllReduce failed: ") + g->rccl.GetErrorString(r2));
 		HIPCHK(hipMemcpyAsync(g->result_host, g->result.p, sizeof v, hipMemcpyDeviceToHost, g->stream));
@@ -2345,14 +2426,17 @@ int te_gmg_exchange_selftest(te_gmg *g, int n)
 			if (g->result_host[i] != v[i] * g->nranks) return te::fail(TE_ESTATE, "te_gmg_exchange_selftest: all-reduce mismatch");
 	}
 	return TE_OK;
+	});
 }
 
 int te_vec_create(te_gmg *g, int level, te_vec **out)
 {
+	return guarded([&]() -> int {
 	if (!g || !out || level < 0 || level >= (int) g->levels.size())
 		return te::fail(TE_EINVAL, "te_vec_create: bad argument");
 	HIPCHK(hipSetDevice(g->device));
 	return newVec(g, level, out);
+	});
 }
 void te_vec_destroy(te_vec *v)
 {
@@ -2364,42 +2448,52 @@ void te_vec_destroy(te_vec *v)
 size_t te_vec_size(const te_vec *v) { return v ? v->n : 0; }
 int    te_vec_upload(te_vec *v, const double *host)
 {
+	return guarded([&]() -> int {
 	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_upload: null");
 	HIPCHK(hipMemcpyAsync(v->d, host, sizeof(double) * v->n, hipMemcpyHostToDevice, v->g->stream));
 	HIPCHK(hipStreamSynchronize(v->g->stream));
 	return TE_OK;
+	});
 }
 int te_vec_download(const te_vec *v, double *host)
 {
+	return guarded([&]() -> int {
 	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_download: null");
 	HIPCHK(hipMemcpyAsync(host, v->d, sizeof(double) * v->n, hipMemcpyDeviceToHost, v->g->stream));
 	HIPCHK(hipStreamSynchronize(v->g->stream));
 	return TE_OK;
+	});
 }
 void *te_vec_device_ptr(te_vec *v) { return v ? v->d : nullptr; }
 
-int te_vec_set(te_vec *v, double a) { return vecop<VOP_SET>(v, nullptr, nullptr, a, 0, 0); }
-int te_vec_scale(te_vec *v, double a) { return vecop<VOP_SCALE>(v, nullptr, nullptr, a, 0, 0); }
-int te_vec_shift(te_vec *v, double d) { return vecop<VOP_SHIFT>(v, nullptr, nullptr, d, 0, 0); }
-int te_vec_copy(te_vec *v, const te_vec *b) { return vecop<VOP_COPY>(v, b, nullptr, 0, 0, 0); }
-int te_vec_add(te_vec *v, const te_vec *b) { return vecop<VOP_ADD>(v, b, nullptr, 0, 0, 0); }
-int te_vec_add_scaled(te_vec *v, double a, const te_vec *b) { return vecop<VOP_ADD_SCALED>(v, b, nullptr, a, 0, 0); }
+int te_vec_set(te_vec *v, double a) { return guarded([&]() -> int { return vecop<VOP_SET>(v, nullptr, nullptr, a, 0, 0); }); }
+int te_vec_scale(te_vec *v, double a) { return guarded([&]() -> int { return vecop<VOP_SCALE>(v, nullptr, nullptr, a, 0, 0); }); }
+int te_vec_shift(te_vec *v, double d) { return guarded([&]() -> int { return vecop<VOP_SHIFT>(v, nullptr, nullptr, d, 0, 0); }); }
+int te_vec_copy(te_vec *v, const te_vec *b) { return guarded([&]() -> int { return vecop<VOP_COPY>(v, b, nullptr, 0, 0, 0); }); }
+int te_vec_add(te_vec *v, const te_vec *b) { return guarded([&]() -> int { return vecop<VOP_ADD>(v, b, nullptr, 0, 0, 0); }); }
+int te_vec_add_scaled(te_vec *v, double a, const te_vec *b) { return guarded([&]() -> int { return vecop<VOP_ADD_SCALED>(v, b, nullptr, a, 0, 0); }); }
 int te_vec_add_scaled2(te_vec *v, double alpha, const te_vec *a, double beta, const te_vec *b)
 {
+	return guarded([&]() -> int {
 	return vecop<VOP_ADD_SCALED2>(v, a, b, alpha, beta, 0);
+	});
 }
-int te_vec_scale_then_add(te_vec *v, double a, const te_vec *b) { return vecop<VOP_SCALE_THEN_ADD>(v, b, nullptr, a, 0, 0); }
+int te_vec_scale_then_add(te_vec *v, double a, const te_vec *b) { return guarded([&]() -> int { return vecop<VOP_SCALE_THEN_ADD>(v, b, nullptr, a, 0, 0); }); }
 int te_vec_scale_then_add_scaled(te_vec *v, double a, double be, const te_vec *b)
 {
+	return guarded([&]() -> int {
 	return vecop<VOP_SCALE_THEN_ADD_SCALED>(v, b, nullptr, a, be, 0);
+	});
 }
 int te_vec_scale_then_add_scaled2(te_vec *v, double a, double be, const te_vec *b, double ga, const te_vec *c)
 {
+	return guarded([&]() -> int {
 	return vecop<VOP_SCALE_THEN_ADD_SCALED2>(v, b, c, a, be, ga);
+	});
 }
-int te_vec_two_norm_sq(const te_vec *v, double *out) { return reduce<RED_SUMSQ>(v, nullptr, out); }
-int te_vec_inf_norm(const te_vec *v, double *out) { return reduce<RED_MAXABS>(v, nullptr, out); }
-int te_vec_dot(const te_vec *v, const te_vec *b, double *out) { return reduce<RED_DOT>(v, b, out); }
+int te_vec_two_norm_sq(const te_vec *v, double *out) { return guarded([&]() -> int { return reduce<RED_SUMSQ>(v, nullptr, out); }); }
+int te_vec_inf_norm(const te_vec *v, double *out) { return guarded([&]() -> int { return reduce<RED_MAXABS>(v, nullptr, out); }); }
+int te_vec_dot(const te_vec *v, const te_vec *b, double *out) { return guarded([&]() -> int { return reduce<RED_DOT>(v, b, out); }); }
 
 static int checkLevelVec(te_gmg *g, int level, const te_vec *v, const char *who)
 {
@@ -2409,43 +2503,53 @@ static int checkLevelVec(te_gmg *g, int level, const te_vec *v, const char *who)
 }
 int te_apply(te_gmg *g, int level, const te_vec *u, te_vec *f)
 {
+	return guarded([&]() -> int {
 	int rc;
 	if ((rc = checkLevelVec(g, level, u, "te_apply")) || (rc = checkLevelVec(g, level, f, "te_apply"))) return rc;
 	if (u == f) return te::fail(TE_EINVAL, "te_apply: in-place apply is not supported");
 	return launchStencil<MODE_APPLY>(g, *g->levels[level], u->d, nullptr, f->d, 0.0);
+	});
 }
 int te_residual(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *r)
 {
+	return guarded([&]() -> int {
 	int rc;
 	if ((rc = checkLevelVec(g, level, u, "te_residual")) || (rc = checkLevelVec(g, level, f, "te_residual"))
 	    || (rc = checkLevelVec(g, level, r, "te_residual")))
 		return rc;
 	if (u == r) return te::fail(TE_EINVAL, "te_residual: r must not alias u");
 	return launchStencil<MODE_RESID>(g, *g->levels[level], u->d, f->d, r->d, 0.0);
+	});
 }
 int te_smooth(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega, int sweeps)
 {
+	return guarded([&]() -> int {
 	int rc;
 	if ((rc = checkLevelVec(g, level, u, "te_smooth")) || (rc = checkLevelVec(g, level, f, "te_smooth"))) return rc;
 	for (int i = 0; i < sweeps; i++)
 		if ((rc = smoothOnce(g, level, f, u, smoother, omega))) return rc;
 	return TE_OK;
+	});
 }
 int te_restrict(te_gmg *g, int fine_level, const te_vec *fine, te_vec *coarse)
 {
+	return guarded([&]() -> int {
 	int rc;
 	if ((rc = checkLevelVec(g, fine_level, fine, "te_restrict"))
 	    || (rc = checkLevelVec(g, fine_level + 1, coarse, "te_restrict")))
 		return rc;
 	return doRestrict(g, fine_level, fine->d, coarse->d);
+	});
 }
 int te_prolong_add(te_gmg *g, int fine_level, const te_vec *coarse, te_vec *fine)
 {
+	return guarded([&]() -> int {
 	int rc;
 	if ((rc = checkLevelVec(g, fine_level, fine, "te_prolong_add"))
 	    || (rc = checkLevelVec(g, fine_level + 1, coarse, "te_prolong_add")))
 		return rc;
 	return doProlong(g, fine_level, coarse->d, fine->d);
+	});
 }
 
 // Dry run of one te_vcycle with `o` on zero vectors in which every exchange is recorded instead of performed; the
@@ -2476,7 +2580,7 @@ static int verifySchedule(te_gmg *g, const te_cycle_opts *o)
 	g->recording    = true;
 	g->record.clear();
 	for (auto &L : g->levels) L->xf_valid_for = nullptr;
-	g->in_cycle = getenv("TE_NO_XF") == nullptr;
+	g->in_cycle = !g->cfg.has(O_NO_XF);
 	rc          = visit(g, o, 0, f, u, o->fuse != 0);
 	g->in_cycle = false;
 	for (auto &L : g->levels) L->xf_valid_for = nullptr;
@@ -2485,13 +2589,20 @@ static int verifySchedule(te_gmg *g, const te_cycle_opts *o)
 	(void) hipStreamSynchronize(g->stream);
 	te_vec_destroy(f);
 	te_vec_destroy(u);
-	if (rc) return rc;
-	// [dir 0 = sent by row to column, 1 = expected by column from row][row][col][count, doubles, hash lo, hash hi]
-	std::vector<double>   m((size_t) 2 * R * R * 4, 0.0);
+	// The reductions below are collective: a rank whose dry run failed still takes part (its peers would otherwise wait
+	// in them until the watchdog fires) and reports the failure through one more summed word, so that all ranks fail together.
+	int               local_rc  = rc;
+	const std::string local_msg = rc ? std::string(te_last_error()) : std::string();
+	// [dir 0 = sent by row to column, 1 = expected by column from row][row][col][count, doubles, hash lo, hash hi] + [failed ranks, 0, 0, 0]
+	std::vector<double>   m((size_t) 2 * R * R * 4 + 4, 0.0);
 	std::vector<uint64_t> hs((size_t) R, 0), hr((size_t) R, 0);
 	auto at = [&](int dir, int from, int to, int k) -> double & { return m[(((size_t) dir * R + from) * R + to) * 4 + k]; };
 	for (auto &e : g->record) {
-		if (e.peer < 0 || e.peer >= R) return te::fail(TE_ESTATE, "te_gmg_verify_schedule: peer out of range");
+		if (local_rc) break;
+		if (e.peer < 0 || e.peer >= R) {
+			local_rc = te::fail(TE_ESTATE, "te_gmg_verify_schedule: peer out of range");
+			break;
+		}
 		if (e.send_cnt > 0) {
 			at(0, g->rank, e.peer, 0) += 1;
 			at(0, g->rank, e.peer, 1) += (double) e.send_cnt;
@@ -2508,12 +2619,16 @@ static int verifySchedule(te_gmg *g, const te_cycle_opts *o)
 		at(1, q, g->rank, 2) = (double) (hr[q] & 0xFFFFFF), at(1, q, g->rank, 3) = (double) ((hr[q] >> 24) & 0xFFFFFF);
 	}
 	g->record.clear();
+	m[m.size() - 4] = local_rc ? 1.0 : 0.0;
 	// sum over ranks, four doubles at a time through the same path as the solver's scalar reductions
 	for (size_t i = 0; i < m.size(); i += 4) {
 		HIPCHK(hipMemcpyAsync(g->result.p, &m[i], 4 * sizeof(double), hipMemcpyHostToDevice, g->stream));
 		if ((rc = finishReduce(g, 4, 0, true))) return rc;
 		for (int k = 0; k < 4; k++) m[i + k] = g->result_host[k];
 	}
+	if (local_rc) return te::fail(local_rc, local_msg.empty() ? std::string(te_last_error()) : local_msg);
+	if (m[m.size() - 4] > 0.0)
+		return te::fail(TE_ESTATE, "te_gmg_verify_schedule: the dry run of the cycle failed on " + std::to_string((int) m[m.size() - 4]) + " other rank(s)");
 	for (int r = 0; r < R; r++)
 		for (int q = 0; q < R; q++)
 			for (int k = 0; k < 4; k++)
@@ -2537,30 +2652,34 @@ static uint64_t optsKey(const te_cycle_opts *o)
 }
 int te_gmg_verify_schedule(te_gmg *g, const te_cycle_opts *o)
 {
+	return guarded([&]() -> int {
 	if (!g || !o) return te::fail(TE_EINVAL, "te_gmg_verify_schedule: null argument");
 	int rc = verifySchedule(g, o);
 	if (rc == TE_OK) g->verified_opts.insert(optsKey(o));
 	return rc;
+	});
 }
 int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u)
 {
+	return guarded([&]() -> int {
 	int rc;
 	if (!o) return te::fail(TE_EINVAL, "te_vcycle: null options");
 	if ((rc = checkLevelVec(g, 0, f, "te_vcycle")) || (rc = checkLevelVec(g, 0, u, "te_vcycle"))) return rc;
 	// several ranks: the first cycle with a new set of options checks that all ranks will issue matching exchange
 	// sequences (a mismatch would otherwise be a silent hang inside RCCL); TE_NO_VERIFY skips it
 	if (g->nranks > 1 && !g->recording && (g->rccl.comm || g->allreduce) && !g->verified_opts.count(optsKey(o))
-	    && !getenv("TE_NO_VERIFY")) {
+	    && !g->cfg.has(O_NO_VERIFY)) {
 		if ((rc = verifySchedule(g, o))) return rc;
 		g->verified_opts.insert(optsKey(o));
 	}
 	if (!o->fuse && (rc = te_vec_set(u, 0.0))) return rc; // Cycle.h:118
 	for (auto &L : g->levels) L->xf_valid_for = nullptr, L->ps_faces = L->ps_faces_req = false;
-	g->in_cycle = getenv("TE_NO_XF") == nullptr;
+	g->in_cycle = !g->cfg.has(O_NO_XF);
 	rc          = visit(g, o, 0, f, u, o->fuse != 0);
 	g->in_cycle = false;
 	for (auto &L : g->levels) L->xf_valid_for = nullptr, L->ps_faces = L->ps_faces_req = false;
 	return rc;
+	});
 }
 
 // BiCGStab.h:45-106, statement for statement, on device vectors. Several ranks: every scalar is summed over the
@@ -2569,6 +2688,7 @@ int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u)
 int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, int max_it, double tol,
                 int *iterations, double *rel_resid)
 {
+	return guarded([&]() -> int {
 	int rc;
 	if ((rc = checkLevelVec(g, 0, x, "te_bicgstab")) || (rc = checkLevelVec(g, 0, b, "te_bicgstab"))) return rc;
 	if (g->nranks > 1 && !g->rccl.comm && !g->allreduce)
@@ -2657,11 +2777,13 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 	if (iterations) *iterations = num_its;
 	if (rel_resid) *rel_resid = sqrt(rsq) / r0_norm;
 	return done(TE_OK);
+	});
 }
 
 // Init::initDirichlet / initNeumann for the drivers' canned problems, on the device (initkernels.hpp)
 int te_init_problem(te_gmg *g, int level, int problem, int neumann, te_vec *f, te_vec *exact)
 {
+	return guarded([&]() -> int {
 	int rc;
 	if ((rc = checkLevelVec(g, level, f, "te_init_problem"))) return rc;
 	if (exact && (rc = checkLevelVec(g, level, exact, "te_init_problem"))) return rc;
@@ -2700,12 +2822,14 @@ int te_init_problem(te_gmg *g, int level, int problem, int neumann, te_vec *f, t
 #undef TE_INIT
 	HIPCHK(hipGetLastError());
 	return TE_OK;
+	});
 }
 // StarPatchOp<D>::apply (StarPatchOp.h:204-319; twins SevenPtPatchOperator.cpp:247-409, FivePtPatchOperator.h:172-261):
 // f = A_patch u, every face with a neighbour closed as homogeneous Dirichlet (ghost = -m) -- the operator the exact
 // patch solves invert (PatchSolvers/BiCGStabSolver.h:82-85 applies it). Same kernel as te_apply with patch-local face kinds.
 int te_patch_apply(te_gmg *g, int level, const te_vec *u, te_vec *f)
 {
+	return guarded([&]() -> int {
 	int rc;
 	if ((rc = checkLevelVec(g, level, u, "te_patch_apply")) || (rc = checkLevelVec(g, level, f, "te_patch_apply"))) return rc;
 	if (u == f) return te::fail(TE_EINVAL, "te_patch_apply: in-place apply is not supported");
@@ -2714,11 +2838,13 @@ int te_patch_apply(te_gmg *g, int level, const te_vec *u, te_vec *f)
 	rc            = launchStencil<MODE_APPLY>(g, L, u->d, nullptr, f->d, 0.0);
 	L.patch_local = false;
 	return rc;
+	});
 }
 // Vector<D>::getLocalData(i) for a run of patches (PetscVector.h:87-98): what Init::initDirichlet, the writers and
 // the C++ adaptor's host mirror move -- never the whole vector for one patch.
 int te_vec_upload_patches(te_vec *v, int first_patch, int npatches, const double *host)
 {
+	return guarded([&]() -> int {
 	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_upload_patches: null");
 	const size_t nc = v->g->levels[v->level]->nc;
 	if (first_patch < 0 || npatches < 0 || ((size_t) first_patch + npatches) * nc > v->n)
@@ -2729,9 +2855,11 @@ int te_vec_upload_patches(te_vec *v, int first_patch, int npatches, const double
 	HIPCHK(hipMemcpyAsync(v->d + (size_t) first_patch * nc, host, sizeof(double) * nc * npatches, hipMemcpyHostToDevice, v->g->stream));
 	HIPCHK(hipStreamSynchronize(v->g->stream));
 	return TE_OK;
+	});
 }
 int te_vec_download_patches(const te_vec *v, int first_patch, int npatches, double *host)
 {
+	return guarded([&]() -> int {
 	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_download_patches: null");
 	const size_t nc = v->g->levels[v->level]->nc;
 	if (first_patch < 0 || npatches < 0 || ((size_t) first_patch + npatches) * nc > v->n)
@@ -2740,17 +2868,21 @@ int te_vec_download_patches(const te_vec *v, int first_patch, int npatches, doub
 	HIPCHK(hipMemcpyAsync(host, v->d + (size_t) first_patch * nc, sizeof(double) * nc * npatches, hipMemcpyDeviceToHost, v->g->stream));
 	HIPCHK(hipStreamSynchronize(v->g->stream));
 	return TE_OK;
+	});
 }
 
 int te_gmg_profile(te_gmg *g, int enable)
 {
+	return guarded([&]() -> int {
 	if (!g) return te::fail(TE_EINVAL, "te_gmg_profile: null");
 	drainEvents(g);
 	g->profiling = enable != 0;
 	return TE_OK;
+	});
 }
 int te_integrate(te_gmg *g, int level, const te_vec *v, double *out)
 {
+	return guarded([&]() -> int {
 	int rc;
 	if (!out) return te::fail(TE_EINVAL, "te_integrate: null result");
 	if ((rc = checkLevelVec(g, level, v, "te_integrate"))) return rc;
@@ -2768,17 +2900,21 @@ int te_integrate(te_gmg *g, int level, const te_vec *v, double *out)
 	for (double x : h) sum += x; // patch order, as the reference's loop over its patch map
 	*out = sum;
 	return TE_OK;
+	});
 }
 int te_volume(te_gmg *g, int level, double *out)
 {
+	return guarded([&]() -> int {
 	if (!g || !out || level < 0 || level >= (int) g->levels.size()) return te::fail(TE_EINVAL, "te_volume: bad argument");
 	double sum = 0.0;
 	for (double x : g->levels[level]->patch_vol) sum += x;
 	*out = sum;
 	return TE_OK;
+	});
 }
 int te_gmg_profile_select(te_gmg *g, const char *name)
 {
+	return guarded([&]() -> int {
 	if (!g) return te::fail(TE_EINVAL, "te_gmg_profile_select: null");
 	drainEvents(g);
 	g->prof_only = -1;
@@ -2789,19 +2925,23 @@ int te_gmg_profile_select(te_gmg *g, const char *name)
 			return TE_OK;
 		}
 	return te::fail(TE_EINVAL, std::string("te_gmg_profile_select: unknown kernel class ") + name);
+	});
 }
 int te_gmg_profile_reset(te_gmg *g)
 {
+	return guarded([&]() -> int {
 	if (!g) return te::fail(TE_EINVAL, "te_gmg_profile_reset: null");
 	drainEvents(g);
 	memset(g->calls, 0, sizeof(g->calls));
 	memset(g->cells, 0, sizeof(g->cells));
 	memset(g->total_ms, 0, sizeof(g->total_ms));
 	return TE_OK;
+	});
 }
 int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *calls, double *total_ms,
                         int64_t *cells)
 {
+	return guarded([&]() -> int {
 	if (!g || !name || !calls || !total_ms || !cells) return te::fail(TE_EINVAL, "te_gmg_profile_rows: null");
 	drainEvents(g);
 	int n = 0;
@@ -2815,5 +2955,71 @@ int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *call
 		n++;
 	}
 	return n;
+	});
+}
+// Diagnostic for the watchdog's bookkeeping: for `seconds` of wall time the host enqueues, WITHOUT ever synchronising, a
+// level-0 vector kernel followed by an armed "exchange" (this rank as its own peer through the active back-end, or a
+// device-to-device copy when none is set). The host runs ahead of the GPU, so the newest exchange is never complete when
+// the watchdog polls; every exchange does complete within milliseconds, so a correct watchdog (deadline of the OLDEST
+// outstanding exchange) stays quiet even when `seconds` exceeds TE_EXCHANGE_TIMEOUT. Returns the number of exchanges issued.
+int te_gmg_watchdog_selftest(te_gmg *g, double seconds)
+{
+	return guarded([&]() -> int {
+		if (!g || seconds <= 0) return te::fail(TE_EINVAL, "te_gmg_watchdog_selftest: bad argument");
+		watchdogStart(g);
+		LevelHost &L = *g->levels[0];
+		const int  n = 256;
+		if ((size_t) 2 * n > L.r->n) return te::fail(TE_EINVAL, "te_gmg_watchdog_selftest: level 0 too small");
+		double *send = L.r->d, *recv = L.r->d + n;
+		ExPlan  pl;
+		pl.peers    = {g->rank};
+		pl.send_off = {0}, pl.send_cnt = {n}, pl.recv_off = {0}, pl.recv_cnt = {n};
+		const auto t0 = std::chrono::steady_clock::now();
+		int        count = 0;
+		while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+			int rc = vecop<VOP_SCALE>(L.t.get(), nullptr, nullptr, 1.0, 0, 0);
+			if (rc) return rc;
+			if (g->rccl.comm || g->exchange) {
+				if ((rc = doExchange(g, 9, pl, send, recv))) return rc;
+			} else {
+				WatchdogArm arm(g, g->stream, 9);
+				HIPCHK(hipMemcpyAsync(recv, send, sizeof(double) * n, hipMemcpyDeviceToDevice, g->stream));
+			}
+			count++;
+		}
+		HIPCHK(hipStreamSynchronize(g->stream));
+		return count;
+	});
+}
+// te_bicgstab keeps its eight level-0 work vectors between solves (8 GiB at 512^3); a caller that is done solving hands
+// them back with this call (they are allocated again by the next te_bicgstab)
+int te_gmg_release_workspace(te_gmg *g)
+{
+	return guarded([&]() -> int {
+		if (!g) return te::fail(TE_EINVAL, "te_gmg_release_workspace: null");
+		for (te_vec *&v : g->bicg_work) {
+			if (v) te_vec_destroy(v);
+			v = nullptr;
+		}
+		return TE_OK;
+	});
+}
+// One TE_* switch of this solver: value == NULL clears it (back to the default). te_gmg_create reads all of
+// them from the environment once; afterwards this is the only way to change one. Switches that shape the level tables
+// (TE_2D_SIMPLE, TE_NO_CFP, TE_2D_NO_MR_FUSE, TE_NO_OVERLAP, TE_EXCHANGE_TIMEOUT) are fixed at creation: TE_ESTATE.
+int te_gmg_set_option(te_gmg *g, const char *name, const char *value)
+{
+	return guarded([&]() -> int {
+		if (!g || !name) return te::fail(TE_EINVAL, "te_gmg_set_option: null argument");
+		for (int o = 0; o < O_COUNT; o++)
+			if (!strcmp(name, optName[o])) {
+				if (optStructural(o))
+					return te::fail(TE_ESTATE, std::string("te_gmg_set_option: ") + name + " is read when the solver is created; set it in the environment before te_gmg_create");
+				g->cfg.set(o, value);
+				g->verified_opts.clear(); // (an option may change which exchanges a cycle issues)
+				return TE_OK;
+			}
+		return te::fail(TE_EINVAL, std::string("te_gmg_set_option: unknown option ") + name);
+	});
 }
 } // extern "C"

@@ -319,13 +319,17 @@ Hierarchy Hierarchy::build(const Tree &t, int n, bool neumann, int max_levels,
 		// microseconds of compute but one latency-bound neighbour exchange per stencil operation when spread out; gathered,
 		// the cycle pays one block transfer down and one up (the inter-level blocks that exist anyway) and no exchange at
 		// all below. A global fact (patch counts, rank count, TE_AGGLOMERATE): the same on every rank.
+		// The per-rank threshold alone grows with the number of ranks (at 64 ranks a 512-patch level of 32^3 patches would land
+		// on one GPU): the first gathered level also has at most TE_AGGLOMERATE_MAX patches in total (default 64 -- the size
+		// below which one GPU runs a level in the same ~20 us however many patches it has).
 		if (nranks > 1) {
-			const char  *e   = getenv("TE_AGGLOMERATE");
+			const char  *e   = getenv("TE_AGGLOMERATE"), *em = getenv("TE_AGGLOMERATE_MAX");
 			const double agg = e ? atof(e) : 16.0;
+			const int    cap = em ? atoi(em) : 64;
 			bool         gathered = false;
 			for (size_t li = 1; li < h.levels.size(); li++) {
 				Level &lv = h.levels[li];
-				if (!gathered && lv.P_global < agg * nranks) gathered = true;
+				if (!gathered && lv.P_global < agg * nranks && lv.P_global <= cap) gathered = true;
 				if (gathered) std::fill(lv.g_rank.begin(), lv.g_rank.end(), 0);
 			}
 		}

@@ -110,10 +110,7 @@ def test_sharded_exported_ghost_terms(nranks, monkeypatch):
     nc = n ** 3
     want = {}
     for nofc in (False, True):
-        if nofc:
-            monkeypatch.setenv("TE_NO_FCORR", "1")
-        else:
-            monkeypatch.delenv("TE_NO_FCORR", raising=False)
+        g1.set_option("TE_NO_FCORR", "1" if nofc else None)
         df, du = g1.new_vector(0, f), g1.new_vector(0)
         g1.profile(True)
         g1.profile_reset()
@@ -124,7 +121,7 @@ def test_sharded_exported_ghost_terms(nranks, monkeypatch):
         assert rows["rbgs_zero_resid_restrict_faces"]["calls"] + rows.get("rbgs_zero_resid_restrict_faces_fcorr", {"calls": 0})["calls"] == 2
         assert ("fcorr_gather" in rows) == (not nofc) and ("rbgs_resweep_prolong_fcorr" in rows) == (not nofc)
     assert np.array_equal(want[False], want[True])
-    monkeypatch.delenv("TE_NO_FCORR", raising=False)
+    g1.set_option("TE_NO_FCORR", None)
 
     def per_rank(r, H, g, fab):
         idx = H.l2g(0)
@@ -284,6 +281,23 @@ def test_watchdog_ends_a_rank_whose_peer_never_answers():
     assert r.returncode != 0
     assert "te_hip watchdog" in r.stderr and "MR_WORKER_OK" not in r.stdout, r.stderr[-3000:]
     assert time.time() - t0 < 120
+
+
+def test_watchdog_stays_quiet_while_the_host_runs_ahead():
+    """A sync-free loop of exchanges that lasts three times TE_EXCHANGE_TIMEOUT: the host is always ahead of the GPU, so the
+    newest exchange is never complete when the watchdog polls. Its deadline belongs to the oldest OUTSTANDING exchange
+    (a ring of events), so the healthy run must survive (exit 0, not 86). Native RCCL back-end, the rank as its own peer."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from pressurepoissonsolver_amd import capi, dist as tedist\n"
+            "H = capi.Hierarchy(capi.Mesh.uniform(3, 2), 32)\n"
+            "g = capi.GMG(H)\n"
+            "tedist.attach_rccl(g, None, 0, 1)\n"
+            "n = capi.lib().te_gmg_watchdog_selftest(g.h, 6.0)\n"
+            "assert n > 100, n\n"
+            "print('WD_OK', n)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TE_EXCHANGE_TIMEOUT="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "WD_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
 
 
 @pytest.mark.parametrize("overlap_min", ["0", None], ids=["overlapped", "default"])

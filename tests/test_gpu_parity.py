@@ -111,14 +111,12 @@ def test_rbgs_z_slabs_bit_identical(case, monkeypatch):
     f = util.rand_vec(L.size, 52) / L.a["h"].min() ** 2
     got = {}
     for slabs in (True, False):
-        if slabs:
-            monkeypatch.delenv("TE_RBGS_NOSLAB", raising=False)
-        else:
-            monkeypatch.setenv("TE_RBGS_NOSLAB", "1")
+        g.set_option("TE_RBGS_NOSLAB", None if slabs else "1")
         du, df, dc = g.new_vector(0, u), g.new_vector(0, f), g.new_vector(0)
         g.smooth(df, du, level=0, smoother=capi.SMOOTH_RBGS)
         g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS, pre_sweeps=2, post_sweeps=2), df, dc)
         got[slabs] = (du.download(), dc.download())
+    g.set_option("TE_RBGS_NOSLAB", None)
     assert np.array_equal(got[True][0], got[False][0])
     assert np.array_equal(got[True][1], got[False][1])
 
@@ -136,10 +134,7 @@ def test_patch_solve_variants_agree(case, monkeypatch):
     f = util.rand_vec(L.size, 51) / L.a["h"].min() ** 2
     got = {}
     for mode in ("1pass", "1pass-dense", "3pass", None):
-        if mode:
-            monkeypatch.setenv("TE_PS_MODE", mode)
-        else:
-            monkeypatch.delenv("TE_PS_MODE", raising=False)
+        g.set_option("TE_PS_MODE", mode)
         du, df, dc = g.new_vector(0, u), g.new_vector(0, f), g.new_vector(0)
         g.smooth(df, du, level=0, smoother=capi.SMOOTH_PATCH_SOLVE)
         g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, dc)
@@ -240,7 +235,7 @@ def test_patch_solve_split_between_pure_and_mixed_axes(monkeypatch):
     f = util.rand_vec(L.size, 53) / L.a["h"].min() ** 2
     got = {}
     for mode in ("1pass", "3pass"):
-        monkeypatch.setenv("TE_PS_MODE", mode)
+        g.set_option("TE_PS_MODE", mode)
         du, df, dc = g.new_vector(0, u), g.new_vector(0, f), g.new_vector(0)
         g.smooth(df, du, level=0, smoother=capi.SMOOTH_PATCH_SOLVE)
         g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, dc)
@@ -265,10 +260,7 @@ def test_reference_smoother_pre_sweep_stores_face_layers_only(monkeypatch):
     for kw in (dict(), dict(post_sweeps=2)):
         got = {}
         for name, env, fuse in (("faces", None, 3), ("stored", "1", 3), ("fuse2", None, 2)):
-            if env:
-                monkeypatch.setenv("TE_NO_PS_FACES", env)
-            else:
-                monkeypatch.delenv("TE_NO_PS_FACES", raising=False)
+            g.set_option("TE_NO_PS_FACES", env)
             df, du = g.new_vector(0, f), g.new_vector(0)
             du.set(3.0)
             g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE, fuse=fuse, **kw), df, du)

@@ -105,12 +105,15 @@ def test_parent_links(name, dim, div):
                 assert np.allclose(2 * f["lengths"][p], c["lengths"][par])
 
 
-@pytest.mark.parametrize("agg", [0, 16])
+@pytest.mark.parametrize("agg,cap", [(0, 64), (16, 64), (16, 8)])
 @pytest.mark.parametrize("nranks", [2, 4, 8])
-def test_morton_partition(nranks, agg, monkeypatch):
+def test_morton_partition(nranks, agg, cap, monkeypatch):
     """agg = patches per rank below which a level (and every coarser one) is gathered on rank 0
-    (TE_AGGLOMERATE, default 16; SURVEY 8(e), CycleFactory3d.cpp:104 semantics); 0 = never."""
+    (TE_AGGLOMERATE, default 16; SURVEY 8(e), CycleFactory3d.cpp:104 semantics); 0 = never. cap = the largest level (patches
+    in total) that may be the first gathered one (TE_AGGLOMERATE_MAX, default 64): the per-rank threshold alone grows with
+    the number of ranks."""
     monkeypatch.setenv("TE_AGGLOMERATE", str(agg))
+    monkeypatch.setenv("TE_AGGLOMERATE_MAX", str(cap))
     m = util.mesh("uniform", 3)  # 8^3 patches
     hs = [capi.Hierarchy(m, 4, rank=r, nranks=nranks) for r in range(nranks)]
     gathered = False
@@ -118,7 +121,7 @@ def test_morton_partition(nranks, agg, monkeypatch):
         t = hs[0].tables(lvl)
         P = len(t["id"])
         counts = np.bincount(t["rank"], minlength=nranks)
-        gathered = gathered or (lvl > 0 and P < agg * nranks)
+        gathered = gathered or (lvl > 0 and P < agg * nranks and P <= cap)
         if gathered:
             assert counts[0] == P  # the whole level on rank 0
         elif P >= nranks:
@@ -128,7 +131,8 @@ def test_morton_partition(nranks, agg, monkeypatch):
         for r, h in enumerate(hs):
             assert np.all(t["rank"][h.l2g(lvl)] == r)
             assert np.array_equal(t["local"][h.l2g(lvl)], np.arange(len(h.l2g(lvl))))
-        nxt = lvl + 1 < hs[0].num_levels and not (gathered or len(hs[0].tables(lvl + 1)["id"]) < agg * nranks)
+        Pn = len(hs[0].tables(lvl + 1)["id"]) if lvl + 1 < hs[0].num_levels else 0
+        nxt = lvl + 1 < hs[0].num_levels and not (gathered or (Pn < agg * nranks and Pn <= cap))
         if nxt:  # a coarse patch lives where its orthant-0 child lives (above the gathered levels)
             c = hs[0].tables(lvl + 1)
             for p in range(P):

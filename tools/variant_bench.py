@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Tooling: V-cycle time and per-kernel times under different environment switches, in ONE process (the library
-reads its TE_* switches at launch time), with a checksum of the result so that variants that must be bit-identical
+reads its TE_* switches once at creation: the variants are set through te_gmg_set_option), with a checksum of the result so that variants that must be bit-identical
 can be seen to be.   usage: variant_bench.py [--size 512] [--smoother rbgs] [--steps 20] "A=1,B=2" "A=3" ...
 ("" = no switch)."""
 import argparse
@@ -41,7 +41,7 @@ for var in a.variants:
     keys = []
     for kv in filter(None, var.split(",")):
         k, v = kv.split("=")
-        os.environ[k] = v
+        g.set_option(k, v)
         keys.append(k)
     for _ in range(3):
         g.cycle(opts, f, u)
@@ -62,4 +62,4 @@ for var in a.variants:
     print(f"[{var or 'default':28s}] {ms:.4f} ms/cycle  {cells / ms / 1e6:.1f} G updates/s  sha {digest}  | "
           + "  ".join(f"{k} {v['ms'] / v['calls'] * 1e3:.1f}us x{v['calls'] // 5}" for k, v in top), flush=True)
     for k in keys:
-        del os.environ[k]
+        g.set_option(k, None)
