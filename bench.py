@@ -46,7 +46,11 @@ ALG_BYTES = {
     "resid_restrict": 17.0,      # read u, f; write coarse f (8/8): residual never stored
     "stencil_rbgs_zero": 16.0,   # first sweep from a zero guess: read f, write u
     "stencil_rbgs_prolong": 25.0,  # post-sweep on u + P(coarse): read u, f, coarse (8/8); write u
-    "patch_solve_mfma": 16.0,    # single-pass exact patch solve: read f, write u (+ face terms, not counted)
+    # single-pass exact patch solve. Inside the default cycle (fuse = 3) the launches of this class are the post-sweeps:
+    # read f (8) and the interface terms on the six face layers (1.5), write u (8) = 17.5; a zero-guess sweep that stores u
+    # moves 16. The pre-sweep that stores face layers only is a class of its own:
+    "patch_solve_mfma": 17.5,
+    "patch_solve_mfma_faces": 9.5,   # read f (8), write the six face layers (6/32 of a vector: 1.5)
     "rbgs_zero_resid_restrict": 17.0,  # fuse = 2: sweep from zero + residual + restriction: read f, write u and 1/8
     "restrict_fixup": 12.0,      # per face cell: read the neighbour's value (8), update a coarse cell per 2x2 (16/4)
     # fuse = 3 (default): the iterate between the two sweeps exists only as its six face layers (6/32 of a vector)
@@ -61,7 +65,14 @@ ALG_BYTES = {
     "stencil_rbgs_slabs": 20.5,  # z-slab RB-GS: a V(1,1) launches as many zero-guess (16) as fused-prolong (25) sweeps
     "stencil_slabs": 17.0,       # z-slab stencil kernel: residual+restrict is its only use in the fused cycle
     "patch_solve_3pass": 16.0,   # three-pass patch solve: read 8 + write 8 per launch
+    # the small classes (face layers, blocks between ranks): per cell they touch -- read 8, write 8
+    "cf_ghost": 16.0, "pack": 16.0, "reduce": 8.0,
+    "exchange": 0.0,             # RCCL / callback time on the solver stream: no HBM pass of this library's own
 }
+# fp64 matrix-core work of the exact patch solve per lattice site (DESIGN.md "The reference smoother"): k_ps_sym runs 3072
+# v_mfma_f64_16x16x4_f64 per 32^3 patch (half-size transforms), 2048 flop each
+MFMA_FLOPS_PER_SITE = {"patch_solve_mfma": 3072 * 2048 / 32 ** 3, "patch_solve_mfma_faces": 3072 * 2048 / 32 ** 3}
+MFMA_F64_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: dense fp64 matrix peak
 
 
 def vcycle_alg_bytes_per_finest_cell(levels_cells, fused=False):
@@ -86,8 +97,16 @@ def parse():
                                                  "--divide 2 or 3); --size is ignored")
     ap.add_argument("--divide", type=int, default=0, help="refineLeaves passes over --mesh (apps/3d/steady --divide)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the reference-smoother block (secondary.reference_smoother)")
     ap.add_argument("--cpu-size", type=int, default=0, help="cells per axis of the CPU baseline (default: --size)")
     return ap.parse_args()
+
+
+def workload_key(a):
+    """what profiles/traffic.json keys a PMC figure by, next to the kernel class and the rank count: a figure is only ever
+    quoted for the workload it was measured on"""
+    grid = f"{os.path.basename(a.mesh)}+{a.divide}" if a.mesh else f"u{a.size}"
+    return f"{a.dim}d:{grid}:p{a.patch}:{a.smoother}"
 
 
 def kernel_sources_sha():
@@ -111,12 +130,13 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(size, dim, n):
+def cpu_baseline(size, dim, n, gpu_smoother):
     """CPU restatement of the reference V-cycle (oracle/, pinned to the reference's golden vectors) timed on this
     host beside the GPU number, on the SAME workload: `size`^dim uniform, V(1,1), both smoothers (the reference's
     block-Jacobi patch solves and the patch-local RB-GS the GPU line uses), with all the cores this job may use
     (the reference's `mpirun -np cores` analogue: OpenMP over patches) and with 1 thread (= one reference MPI rank;
-    on a 1/8-size sample, 2x smaller per axis, because one 512^3 cycle takes ~25 s on one core). ~30 s in total."""
+    on a 1/8-size sample, 2x smaller per axis, because one 512^3 cycle takes ~25 s on one core). ~30 s in total.
+    `value` is the all-cores row of the smoother the GPU line ran; the reference-smoother row is quoted beside it."""
     from oracle import oracle as orc
     from pressurepoissonsolver_amd import capi, problems
     ncpu = os.cpu_count() or 1
@@ -136,6 +156,7 @@ def cpu_baseline(size, dim, n):
         pass
     phys = max(1, ncpu // 2)
     threads_all = int(os.environ.get("TE_CPU_THREADS", min(avail, quota or avail, phys)))
+    names = {0: "patch_solve", 2: "rbgs"}
 
     def run(sz, threads, smoother, budget):
         m = capi.Mesh.uniform(dim, int(round(np.log2(sz // n))))
@@ -153,19 +174,25 @@ def cpu_baseline(size, dim, n):
             orc.cycle(levels, o, f)
             ts.append(time.time() - t0)
         dt = float(np.median(ts))
-        return {"size": f"{sz}^{dim}", "threads": threads, "smoother": {0: "patch_solve", 2: "rbgs"}[smoother],
+        return {"size": f"{sz}^{dim}", "threads": threads, "smoother": names[smoother],
                 "ms_per_cycle": dt * 1e3, "updates_per_s": levels[0].size / dt, "cycles": len(ts)}
 
     small = max(size // 2, 2 * n)
     rows = [run(size, threads_all, 0, 8.0), run(size, threads_all, 2, 6.0), run(small, 1, 0, 6.0), run(small, 1, 2, 5.0)]
-    head = rows[0]
-    return {"value": head["updates_per_s"], "unit": "lattice-site updates/s", "cores": threads_all, "kind": "port",
-            "sample": f"{size}^{dim} uniform (the benchmarked workload), V(1,1), the reference's block-Jacobi patch-solve "
-                      f"smoother, median of {head['cycles']} cycles, {threads_all} OpenMP threads",
-            "ms_per_step": head["ms_per_cycle"], "cpu_model": cpu_model(), "nproc": ncpu, "cpus_available_to_job": avail, "cgroup_cpu_quota": quota,
+    match = {"patch_solve": rows[0], "rbgs": rows[1]}.get(gpu_smoother, rows[0])
+    label = {"patch_solve": "the reference's block-Jacobi patch-solve smoother", "rbgs": "the patch-local RB-GS smoother of the GPU line"}
+    return {"value": match["updates_per_s"], "unit": "lattice-site updates/s", "cores": threads_all, "kind": "port",
+            "smoother": match["smoother"],
+            "sample": f"{size}^{dim} uniform (the benchmarked workload), V(1,1), {label.get(match['smoother'])}, "
+                      f"median of {match['cycles']} cycles, {threads_all} OpenMP threads",
+            "ms_per_step": match["ms_per_cycle"],
+            "reference_smoother_value": rows[0]["updates_per_s"], "reference_smoother_ms_per_step": rows[0]["ms_per_cycle"],
+            "cpu_model": cpu_model(), "nproc": ncpu, "cpus_available_to_job": avail, "cgroup_cpu_quota": quota,
             "runs": rows,
             "note": "CPU restatement of the reference algorithm (oracle/te_oracle.cpp), not the reference binary "
-                    "(PETSc/FFTW/Zoltan are absent); 1-thread rows = one reference MPI rank, on a 2x-per-axis smaller grid"}
+                    "(PETSc/FFTW/Zoltan are absent); `value` = the row whose smoother matches the GPU line, "
+                    "`reference_smoother_value` = the reference's own smoother (what secondary.reference_smoother runs on the GPU); "
+                    "1-thread rows = one reference MPI rank, on a 2x-per-axis smaller grid"}
 
 
 def self_launch(ngpus, json_out):
@@ -195,6 +222,38 @@ def self_launch(ngpus, json_out):
         print("bench.py: the ranks exited without a JSON line", file=sys.stderr)
         return 1
     return p.returncode
+
+
+def roofline_of(name, st, tkey=None, world=1):
+    """the contract's `roofline` object for one kernel class from its HIP-event rows of the timed region"""
+    avg_ms = st["ms"] / st["calls"]
+    sites = st["cells"] / st["calls"]
+    achieved = ALG_BYTES.get(name, 24.0) * sites / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_src = None, None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if tkey is not None and os.path.exists(tf):
+        try:
+            tj = json.load(open(tf))
+            if tj.get("kernel_sources_sha") == kernel_sources_sha():  # measured on exactly these kernels ...
+                traffic = tj.get(f"{name}:{tkey}:{world}")              # ... and on exactly this workload
+                traffic_src = tj.get("commit") if traffic is not None else None
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_measured_at_commit": traffic_src,
+            "avg_launch_ms": avg_ms, "launches": st["calls"], "alg_bytes_per_site": ALG_BYTES.get(name, 24.0)}
+
+
+def roofline_mfma_of(name, st):
+    """second roof of the exact patch solve ('report it against both roofs'): its transform flops on the fp64
+    matrix cores"""
+    if name not in MFMA_FLOPS_PER_SITE:
+        return None
+    avg_ms = st["ms"] / st["calls"]
+    tf = MFMA_FLOPS_PER_SITE[name] * st["cells"] / st["calls"] / (avg_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": name, "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / MFMA_F64_PEAK_TFLOPS, "avg_launch_ms": avg_ms, "launches": st["calls"],
+            "flops_per_site": MFMA_FLOPS_PER_SITE[name]}
 
 
 def main():
@@ -234,10 +293,11 @@ def main():
         build.build_hip()
     if dist is not None:
         dist.barrier()
-    from pressurepoissonsolver_amd import capi, problems
+    from pressurepoissonsolver_amd import capi, problems  # noqa: F401
     from pressurepoissonsolver_amd import dist as tedist
 
     n = a.patch
+    t_setup0 = time.perf_counter()
     if a.mesh:
         mesh = capi.Mesh.read(a.mesh, a.dim)
         for _ in range(a.divide):
@@ -245,8 +305,13 @@ def main():
     else:
         assert a.size % n == 0 and (a.size // n) & (a.size // n - 1) == 0, "--size must be patch * 2^k"
         mesh = capi.Mesh.uniform(a.dim, int(round(np.log2(a.size // n))))
-    H = capi.Hierarchy(mesh, n, rank=rank, nranks=world)
-    g = capi.GMG(H, device=local_rank)
+    t_setup1 = time.perf_counter()
+    H = capi.Hierarchy(mesh, n, rank=rank, nranks=world)   # te_hier_build: level extraction + partition
+    t_setup2 = time.perf_counter()
+    g = capi.GMG(H, device=local_rank)                     # te_gmg_create: tables, plans, scratch (synchronised on return)
+    t_setup3 = time.perf_counter()
+    setup_ms = {"mesh": (t_setup1 - t_setup0) * 1e3, "te_hier_build": (t_setup2 - t_setup1) * 1e3,
+                "te_gmg_create": (t_setup3 - t_setup2) * 1e3}
     exchange_backend = "none"
     if world > 1:
         # RCCL point-to-point issued by the native library itself (no Python per exchange); the
@@ -266,13 +331,15 @@ def main():
             exchange_backend = "rccl (native ncclSend/ncclRecv groups)"
         else:
             tedist.attach(g, dist)
-    sm = {"rbgs": capi.SMOOTH_RBGS, "jacobi": capi.SMOOTH_JACOBI, "patch_solve": capi.SMOOTH_PATCH_SOLVE}[a.smoother]
-    opts = g.default_opts(smoother=sm)
+    smoothers = {"rbgs": capi.SMOOTH_RBGS, "jacobi": capi.SMOOTH_JACOBI, "patch_solve": capi.SMOOTH_PATCH_SOLVE}
+    opts = g.default_opts(smoother=smoothers[a.smoother])
 
     f = g.new_vector(0)
     g.init_problem(f, None, problem=capi.PROBLEM_RANDOM)  # U(-1,1) splitmix64(0x5EED + patch id), generated on the device
     u = g.new_vector(0)
     cells_global = [H.sizes(l)[1] * n ** a.dim for l in range(H.num_levels)]
+    placement = [[int(c) for c in np.bincount(H.tables(l)["rank"], minlength=world)] for l in range(H.num_levels)] if world > 1 else None
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():
         g.sync()
@@ -281,48 +348,65 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # warm-up, with every kernel class timed: gives the per-kernel table and names the dominant class
-    g.profile(True)
-    g.profile_select(None)
-    for i in range(a.warmup):
-        if i == (1 if a.warmup > 1 else 0):
-            g.profile_reset()  # the very first step pays one-time costs (code load, lazy attributes): not representative
-        g.cycle(opts, f, u)
-    barrier()
-    rows_all = g.profile_rows()
-    cand = {k: v for k, v in rows_all.items() if k in ALG_BYTES}
-    dom_name = max(cand.items(), key=lambda kv: kv[1]["ms"])[0] if cand else None
-    if dist is not None and dom_name is not None:  # same class on every rank (rank 0 decides)
-        names = [dom_name]
-        dist.broadcast_object_list(names, src=0)
-        dom_name = names[0]
-    # timed region: HIP events around the dominant class only (an event pair per launch costs a few
-    # microseconds of stream time; a V-cycle is a dozen launches)
-    if os.environ.get("TE_BENCH_NOPROFILE") is not None:  # tooling: wall time only
+    def measure(o, steps, warmup):
+        """W untimed warm-up cycles with every kernel class timed (per-kernel table; names the dominant class), then
+        exactly K cycles between two barriers with HIP events on the dominant class only; max over ranks"""
+        g.profile(True)
+        g.profile_select(None)
+        # the very first step pays one-time costs (code load, lazy attributes): its events are dropped, so the table
+        # covers `profiled_warm` cycles -- ONE variable for the reset rule and for every per-cycle figure derived from it
+        first_profiled = 1 if warmup > 1 else 0
+        profiled_warm = max(warmup - first_profiled, 0)
+        for i in range(warmup):
+            if i == first_profiled:
+                g.profile_reset()
+            g.cycle(o, f, u)
+        barrier()
+        rows_all = g.profile_rows()
+        cand = {k: v for k, v in rows_all.items() if k in ALG_BYTES and ALG_BYTES[k] > 0}
+        dom_name = max(cand.items(), key=lambda kv: kv[1]["ms"])[0] if cand else None
+        if dist is not None and dom_name is not None:  # same class on every rank (rank 0 decides)
+            names = [dom_name]
+            dist.broadcast_object_list(names, src=0)
+            dom_name = names[0]
+        # timed region: HIP events around the dominant class only (an event pair per launch costs a few
+        # microseconds of stream time; a V-cycle is a dozen launches)
+        if os.environ.get("TE_BENCH_NOPROFILE") is not None:  # tooling: wall time only
+            g.profile(False)
+        else:
+            g.profile_select(dom_name)  # (--warmup 0: no candidate yet, every class is timed)
+        g.profile_reset()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.cycle(o, f, u)
+        barrier()
+        dt = time.perf_counter() - t0
+        rows = g.profile_rows()
         g.profile(False)
-    else:
-        g.profile_select(dom_name)  # (--warmup 0: no candidate yet, every class is timed)
-    g.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        g.cycle(opts, f, u)
-    barrier()
-    dt = time.perf_counter() - t0
-    rows = g.profile_rows()
-    g.profile(False)
-    g.profile_select(None)
-    red_dev = "cuda" if backend == "nccl" else "cpu"
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        g.profile_select(None)
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return {"dt": dt, "rows_all": rows_all, "rows": rows, "profiled_warm": profiled_warm}
 
+    def reduction_per_cycle(r):
+        """sanity: the cycle must actually reduce the residual (guards against timing a no-op)"""
+        g.residual(u, f, r)
+        rn, fn = r.twoNormSqLocal(), f.twoNormSqLocal()
+        if dist is not None:
+            tt = torch.tensor([rn, fn], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tt)
+            rn, fn = tt.tolist()
+        return float(np.sqrt(rn / fn))
+
+    m = measure(opts, a.steps, a.warmup)
+    dt, rows_all, rows = m["dt"], m["rows_all"], m["rows"]
     ms_per_step = dt / a.steps * 1e3
     value = cells_global[0] / (dt / a.steps)
     # median of per-cycle times (SURVEY 8(d)): a second, untimed-by-the-contract pass with an event pair per cycle on
     # the solver stream (`value` above stays the contract's K steps between two synchronisations)
-    g.profile(False)
     ext = torch.cuda.ExternalStream(int(g.stream()))
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     barrier()
@@ -346,39 +430,44 @@ def main():
         r.scaleThenAddScaled(0.5, 0.25, f)
     g.sync()
     triad_gbs = 20 * 24.0 * (H.sizes(0)[0] * n ** a.dim) / (time.perf_counter() - t1) / 1e9
+    reduction = reduction_per_cycle(r)
 
-    # sanity: the cycle must actually reduce the residual (guards against timing a no-op)
-    g.residual(u, f, r)
-    rn, fn = r.twoNormSqLocal(), f.twoNormSqLocal()
-    if dist is not None:
-        tt = torch.tensor([rn, fn], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt)
-        rn, fn = tt.tolist()
-    reduction = float(np.sqrt(rn / fn))
+    # (f)1 beside the headline: the reference's own smoother (FFTBlockJacobiSmoother.h:55-58, the one cycle with per-V-cycle
+    # parity against the reference) timed by the same driver run, a dozen cycles, both roofs
+    secondary = None
+    if a.smoother == "rbgs" and not a.no_secondary and a.dim == 3 and n == 32 and os.environ.get("TE_BENCH_NOPROFILE") is None:
+        o2 = g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE)
+        k2 = 12
+        m2 = measure(o2, k2, 3)
+        red2 = reduction_per_cycle(r)
+        if rank == 0 and m2["rows"]:
+            name2, st2 = max(((k, v) for k, v in m2["rows"].items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
+            ps_key = workload_key(argparse.Namespace(**{**vars(a), "smoother": "patch_solve"}))
+            secondary = {"reference_smoother": {
+                "what": "the same workload with the reference's block-Jacobi smoother (exact patch solves on the fp64 matrix cores), "
+                        "default options (fuse = 3)",
+                "steps": k2, "warmup": 3, "ms_per_step": m2["dt"] / k2 * 1e3, "value": cells_global[0] / (m2["dt"] / k2),
+                "unit": "lattice-site updates/s", "residual_reduction_per_cycle": red2,
+                "roofline": roofline_of(name2, st2, ps_key, world), "roofline_mfma": roofline_mfma_of(name2, st2),
+                "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4)} for k, v in m2["rows_all"].items()}}}
 
     if rank == 0 and not rows:  # TE_BENCH_NOPROFILE=1 (tooling): wall time only
         print(json.dumps({"ms_per_step": ms_per_step, "value": value}), file=json_out, flush=True)
     elif rank == 0:
-        dom = max(((k, v) for k, v in rows.items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
-        name, st = dom
-        avg_ms = st["ms"] / st["calls"]
-        bytes_per_launch = ALG_BYTES.get(name, 24.0) * st["cells"] / st["calls"]
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                tj = json.load(open(tf))
-                if tj.get("kernel_sources_sha") == kernel_sources_sha():  # measured on exactly these kernels
-                    traffic = tj.get(f"{name}:{a.size}:{world}")
-                    traffic_src = tj.get("commit")
-            except Exception:
-                traffic = None
+        name, st = max(((k, v) for k, v in rows.items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
+        roof = roofline_of(name, st, workload_key(a), world)
+        roof["measured_triad_GBs"] = triad_gbs
+        roof["frac_of_measured_triad"] = roof["achieved"] / triad_gbs
         b_alg = vcycle_alg_bytes_per_finest_cell(cells_global)
-        # what the fused cycle's kernels must move at least: their own algorithmic bytes (warm-up table, every class)
-        fused_bytes = sum(ALG_BYTES.get(k, 0.0) * v["cells"] for k, v in rows_all.items()) / max(1, (a.warmup - 1) if a.warmup > 1 else 1)
+        # what the fused cycle's kernels must move at least: their own algorithmic bytes (warm-up table, every class that has
+        # an ALG_BYTES entry; the others are listed, not silently counted as zero)
+        counted = sorted(k for k in rows_all if k in ALG_BYTES)
+        uncounted = sorted(k for k in rows_all if k not in ALG_BYTES)
+        fused_bytes = sum(ALG_BYTES[k] * rows_all[k]["cells"] for k in counted) / max(1, m["profiled_warm"])
+        local_sites = H.sizes(0)[0] * n ** a.dim
+        default_wl = (a.size == 512 and a.dim == 3 and not a.mesh and n == 32)
         out = {
-            "metric": "V-cycle lattice-site updates/sec, 512^3 3D Poisson" if (a.size == 512 and a.dim == 3 and not a.mesh) else
+            "metric": "V-cycle lattice-site updates/sec, 512^3 3D Poisson" if default_wl else
                       (f"V-cycle lattice-site updates/sec, {os.path.basename(a.mesh)} --divide {a.divide}, {a.dim}D Poisson" if a.mesh else
                        f"V-cycle lattice-site updates/sec, {a.size}^{a.dim} {a.dim}D Poisson"),
             "value": value, "unit": "lattice-site updates/s", "n_gpus": world, "steps": a.steps,
@@ -387,33 +476,43 @@ def main():
             "config": {"workload": f"apps/{a.dim}d/steady-equivalent: " + (f"{os.path.basename(a.mesh)} --divide {a.divide}" if a.mesh else f"{a.size}^{a.dim} uniform") + f", {cells_global[0] // n ** a.dim} "
                                    f"patches of {n}^{a.dim}, {H.num_levels} levels, V(1,1), smoother={a.smoother}, "
                                    "Dirichlet, f ~ U(-1,1) splitmix64(0x5EED + patch id)",
+                       "workload_key": workload_key(a),
                        "parallelism": f"patch-sharded x{world} (Morton ranges)", "exchange": exchange_backend,
                        "levels": H.num_levels,
+                       "patches_per_level": [c // n ** a.dim for c in cells_global],
+                       # where every level lives (patches per rank): coarse levels gathered on rank 0 show up here
+                       "placement_patches_per_rank": placement,
+                       "agglomerate": {"TE_AGGLOMERATE": os.environ.get("TE_AGGLOMERATE", "16 (default)"),
+                                       "TE_AGGLOMERATE_MAX": os.environ.get("TE_AGGLOMERATE_MAX", "64 (default)")} if world > 1 else None,
                        "smoother": a.smoother, "residual_reduction_per_cycle": reduction},
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_measured_at_commit": traffic_src,
-                         "avg_launch_ms": avg_ms, "launches": st["calls"],
-                         "alg_bytes_per_site": ALG_BYTES.get(name, 24.0),
-                         "measured_triad_GBs": triad_gbs, "frac_of_measured_triad": achieved / triad_gbs},
+            "roofline": roof,
             # whole cycle: (i) against the bytes its fused kernels must move (a roofline fraction); (ii) SURVEY 8(d)'s
             # UNFUSED definition (113 B per finest site) divided by the fused cycle's time -- a work-equivalent rate that
             # can exceed the HBM peak because the fused cycle moves about a third of those bytes; not a roofline fraction
-            "vcycle_hbm": {"fused_alg_bytes_per_finest_site": fused_bytes / (H.sizes(0)[0] * n ** a.dim),
+            "vcycle_hbm": {"fused_alg_bytes_per_finest_site": fused_bytes / local_sites,
                            "fused_achieved_GBs": fused_bytes / (dt / a.steps) / 1e9,
                            "fused_frac_of_peak": fused_bytes / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+                           "classes_counted": counted, "classes_without_bytes": uncounted,
                            "unfused_definition_bytes_per_finest_site": b_alg,
                            "unfused_definition_equivalent_GBs": b_alg * cells_global[0] / (dt / a.steps) / 1e9,
                            "unfused_definition_equivalent_over_peak": b_alg * cells_global[0] / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world)},
             "ms_per_step_median": ms_median,
+            # host wall time of the set-up calls on this rank (SURVEY (f)3: 'removes the host setup bottleneck')
+            "setup_ms": setup_ms,
             # per-kernel table from the warm-up steps (every class timed there; the timed region times only `kernel`)
             "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4),
                                    "GBs": (ALG_BYTES.get(k, 0) * v["cells"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                                for k, v in rows_all.items()},
         }
+        rm = roofline_mfma_of(name, st)
+        if rm:
+            out["roofline_mfma"] = rm
+        if secondary:
+            out["secondary"] = secondary
         if world == 1 and not a.no_cpu_baseline:
             from oracle import build as obuild
             obuild.build_oracle()
-            out["cpu_baseline"] = cpu_baseline(a.cpu_size or a.size, a.dim, n)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_size or a.size, a.dim, n, a.smoother)
         print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()

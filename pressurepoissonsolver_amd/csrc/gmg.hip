@@ -53,14 +53,16 @@ enum KClass : int {
 	// that a class above is one kernel symbol and its average duration is the one rocprofv3 --stats reports
 	KC_RBGS_SLABS, KC_STENCIL_SLABS, KC_PS_3PASS, KC_ZERO_RESID, KC_FIXUP, KC_RESWEEP, KC_ZERO_RESID_FACES,
 	// the instantiations that read their right-hand side together with exported ghost terms (FCORR): other symbols again
-	KC_RESWEEP_FCORR, KC_ZERO_RESID_FACES_FCORR, KC_FCORR_GATHER, KC_COUNT
+	KC_RESWEEP_FCORR, KC_ZERO_RESID_FACES_FCORR, KC_FCORR_GATHER,
+	// the reference smoother's zero-guess pre-sweep that stores face layers only (k_ps_sym<false, FACES>): other bytes per site
+	KC_PS_MFMA_FACES, KC_COUNT
 };
 const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_jacobi", "stencil_rbgs",
                                     "cf_ghost", "restrict", "prolong_add", "patch_rhs", "dst_axis",
                                     "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict", "patch_solve_mfma", "stencil_rbgs_prolong",
                                     "stencil_rbgs_slabs", "stencil_slabs", "patch_solve_3pass", "rbgs_zero_resid_restrict",
                                     "restrict_fixup", "rbgs_resweep_prolong", "rbgs_zero_resid_restrict_faces",
-                                    "rbgs_resweep_prolong_fcorr", "rbgs_zero_resid_restrict_faces_fcorr", "fcorr_gather"};
+                                    "rbgs_resweep_prolong_fcorr", "rbgs_zero_resid_restrict_faces_fcorr", "fcorr_gather", "patch_solve_mfma_faces"};
 
 // Every TE_* switch of this library. They are read from the environment ONCE, in te_gmg_create;
 // te_gmg_set_option changes one afterwards (the tests pin one implementation against another that way). Nothing on a
@@ -1818,7 +1820,10 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 				                           hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS_BYTES));
 				lds_ok = true;
 			}
-			Timed         t(g, KC_PS_MFMA, total, true);
+			// (decided here as well as below: the class of the launch is part of its timing scope)
+			const bool dense_only0 = mode && !strcmp(mode, "1pass-dense");
+			const bool faces0 = faces_req && L.f6buf.p && !dense_only0 && (L.sym_ok ? L.P : L.n_pure) == L.P;
+			Timed         t(g, faces0 ? KC_PS_MFMA_FACES : KC_PS_MFMA, total, true);
 			const dim3    b512(512);
 			const double *cp = zero_guess ? (const double *) nullptr : (const double *) L.corr.p;
 			// pure axes: half-size transforms, one resident workgroup per CU walks over the patches (k_ps_sym);

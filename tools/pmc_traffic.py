@@ -7,7 +7,7 @@ gfx950 corrections applied (MI355X_MICROARCH.md, HBM): counters are in KiB; FETC
 exactly half of the bytes of a wide (16 B/lane) coalesced read stream, so it is doubled;
 WRITE_SIZE is exact for 16 B/lane streaming stores. All kernels priced here use 16 B/lane.
 
-usage: pmc_traffic.py <fetch_dir> <write_dir> <size> <world> [out.json]
+usage: pmc_traffic.py <fetch_dir> <write_dir> <workload-key> <world> [out.json]   (bench.workload_key, e.g. 3d:u512:p32:rbgs)
 """
 import collections
 import csv
@@ -27,7 +27,8 @@ CLASS = [(r"k_rbgs_zero_resid3d<\d+, false, \w+, true", "rbgs_zero_resid_restric
          (r"k_rbgs3d<", "stencil_rbgs"), (r"k_stencil3d<\d+, 0,", "stencil_apply"), (r"k_stencil3d<\d+, 1,", "stencil_resid"),
          (r"k_stencil3d<\d+, 2,", "stencil_jacobi"), (r"k_stencil3d<\d+, 3,", "resid_restrict"),
          (r"k_restrict3d", "restrict"), (r"k_prolong3d", "prolong_add"), (r"k_vecop", "vecop"),
-         (r"k_dst_axis3d", "dst_axis"), (r"k_patch_rhs3d|k_face_corr3d", "patch_rhs"), (r"k_ps_sym|k_ps_fused", "patch_solve_mfma"),
+         (r"k_dst_axis3d", "dst_axis"), (r"k_patch_rhs3d|k_face_corr3d", "patch_rhs"), (r"k_ps_sym<false, true", "patch_solve_mfma_faces"),
+         (r"k_ps_sym|k_ps_fused", "patch_solve_mfma"),
          (r"k_ps_xy|k_ps_z", "patch_solve_3pass")]
 
 

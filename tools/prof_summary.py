@@ -3,8 +3,8 @@
 commit it measured): kernel-trace stats, SQ counters (two passes of 8), FETCH_SIZE / WRITE_SIZE (separate passes;
 FETCH_SIZE doubled for 16-B/lane reads as MI355X_MICROARCH.md prescribes for gfx950).
 
-usage: prof_summary.py <run dir> <out prefix> <commit> <label> [size world]
-With size and world it also rewrites profiles/traffic.json (bytes per launch per kernel class, what bench.py quotes as
+usage: prof_summary.py <run dir> <out prefix> <commit> <label> [workload-key world]
+With the workload key (bench.py workload_key, e.g. 3d:u512:p32:rbgs) and world it also rewrites profiles/traffic.json (bytes per launch per kernel class, what bench.py quotes as
 roofline.traffic) stamped with the commit and a hash of the kernel sources it was measured on.
 """
 import collections
@@ -111,7 +111,9 @@ def main():
             sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
             from pmc_traffic import klass
             import bench
-            size, world = sys.argv[5], sys.argv[6]
+            size, world = sys.argv[5], sys.argv[6]  # size: bench.workload_key() of the profiled command
+            if re.fullmatch(r"\d+", size):
+                size = f"3d:u{size}:p32:rbgs"
             tot = collections.defaultdict(lambda: [0.0, 0.0, 0, 0])
             for k in set(fe) | set(wr):
                 c = klass("te::" + k + "(")
@@ -123,12 +125,18 @@ def main():
                 t[1] += 1024.0 * b[0]
                 t[2] += a[1]
                 t[3] += b[1]
-            res = {"commit": commit, "kernel_sources_sha": bench.kernel_sources_sha(),
+            tf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+            res = {}
+            if os.path.exists(tf):  # figures of other workloads measured on the same kernel sources stay
+                old = json.load(open(tf))
+                if old.get("kernel_sources_sha") == bench.kernel_sources_sha():
+                    res = old
+            res.update({"commit": commit, "kernel_sources_sha": bench.kernel_sources_sha(),
                    "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py; bytes per launch = "
-                          "2 x FETCH_SIZE KiB x 1024 + WRITE_SIZE KiB x 1024 (gfx950: wide reads are tallied at half)"}
+                          "2 x FETCH_SIZE KiB x 1024 + WRITE_SIZE KiB x 1024 (gfx950: wide reads are tallied at half); "
+                          "keys: <kernel class>:<bench.workload_key>:<ranks>"})
             for c, t in sorted(tot.items()):
                 res[f"{c}:{size}:{world}"] = t[0] / max(t[2], 1) + t[1] / max(t[3], 1)
-            tf = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
             json.dump(res, open(tf, "w"), indent=1, sort_keys=True)
 
 

@@ -10,10 +10,10 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/stats.json 2> $OUT/stats.log || { tail -5 $OUT/stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o s -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary "$@" > $OUT/stats.json 2> $OUT/stats.log || { tail -5 $OUT/stats.log; exit 1; }
 echo "stats pass done"
 pass() { # name, counters
-  rocprofv3 --pmc $2 -d $OUT/$1 -o c -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline "${@:3}" > $OUT/$1.json 2> $OUT/$1.log || { echo "pass $1 failed"; tail -3 $OUT/$1.log; return 1; }
+  rocprofv3 --pmc $2 -d $OUT/$1 -o c -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary "${@:3}" > $OUT/$1.json 2> $OUT/$1.log || { echo "pass $1 failed"; tail -3 $OUT/$1.log; return 1; }
   echo "pass $1 done"
 }
 pass sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "$@" &&
