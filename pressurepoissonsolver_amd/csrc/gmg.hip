@@ -70,12 +70,12 @@ const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_j
 enum Opt : int {
 	O_2D_SIMPLE, O_2D_NO_MFMA, O_2D_NO_PF, O_2D_NO_MR_FUSE, O_2D_TPB, O_NO_FUSE2, O_NO_FUSE3, O_NO_FUSE3_CF, O_NO_CFP, O_NO_XF,
 	O_NO_FCORR, O_NO_FCORR_CF, O_NO_GTAB, O_NO_OVERLAP, O_OVERLAP_MIN, O_NO_PS_FACES, O_PS_MODE, O_PS_SLOW, O_RBGS_NOSLAB,
-	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_COUNT
+	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_COUNT
 };
 const char *optName[O_COUNT] = {"TE_2D_SIMPLE", "TE_2D_NO_MFMA", "TE_2D_NO_PF", "TE_2D_NO_MR_FUSE", "TE_2D_TPB", "TE_NO_FUSE2", "TE_NO_FUSE3",
                                 "TE_NO_FUSE3_CF", "TE_NO_CFP", "TE_NO_XF", "TE_NO_FCORR", "TE_NO_FCORR_CF", "TE_NO_GTAB", "TE_NO_OVERLAP",
                                 "TE_OVERLAP_MIN", "TE_NO_PS_FACES", "TE_PS_MODE", "TE_PS_SLOW", "TE_RBGS_NOSLAB", "TE_ZS_FORCE", "TE_NO_ZS8",
-                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH"};
+                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH", "TE_RCCL_LOOPBACK"};
 // options that shape the level tables te_gmg_create builds: fixed for the solver's lifetime
 inline bool optStructural(int o) { return o == O_2D_SIMPLE || o == O_NO_CFP || o == O_2D_NO_MR_FUSE || o == O_NO_OVERLAP || o == O_EXCHANGE_TIMEOUT; }
 struct Cfg {
@@ -262,6 +262,7 @@ struct te_gmg {
 	int                                     dim = 3, n = 0;
 	std::vector<std::unique_ptr<LevelHost>> levels;
 	DevBuf<double>                          partial, result;
+	DevBuf<double>                          loopbuf; // TE_RCCL_LOOPBACK (diagnostic): source and sink of the self-addressed messages
 	double                                 *result_host = nullptr; // pinned
 	int                                     red_blocks  = 1024;
 	te_exchange_fn                          exchange    = nullptr;
@@ -965,6 +966,33 @@ int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double 
 		// one RCCL group per exchange, enqueued on the solver stream behind the pack kernel: every
 		// send/recv of the exchange progresses together over the direct xGMI links, no host round trip
 		std::unique_ptr<Timed> t(timed ? new Timed(g, KC_EXCHANGE, 0) : nullptr);
+		if (g->cfg.has(O_RCCL_LOOPBACK)) {
+			// DIAGNOSTIC (tools/mr8_budget.py): one rank of an N-rank hierarchy alone on a GPU, every peer replaced by the rank
+			// itself -- the same group of ncclRecv/ncclSend calls with the same message sizes, between scratch buffers. What
+			// is measured is real (host enqueue cost, RCCL's launch, this rank's kernels with the GPU to themselves); the
+			// exchanged DATA are not: results are meaningless in this mode.
+			int64_t total = 0;
+			for (size_t i = 0; i < pl.peers.size(); i++) total += std::max(pl.send_cnt[i], pl.recv_cnt[i]);
+			if ((size_t) (2 * total) > g->loopbuf.n) {
+				(void) hipStreamSynchronize(g->stream);
+				if (g->loopbuf.p) (void) hipFree(g->loopbuf.p);
+				g->loopbuf.p = nullptr;
+				int rc0     = g->loopbuf.alloc((size_t) (2 * total));
+				if (rc0) return rc0;
+			}
+			int     rc  = g->rccl.GroupStart();
+			int64_t off = 0;
+			for (size_t i = 0; i < pl.peers.size() && rc == 0; i++) {
+				const size_t c = (size_t) std::max(pl.send_cnt[i], pl.recv_cnt[i]);
+				if (c == 0) continue;
+				rc = g->rccl.Recv(g->loopbuf.p + total + off, c, ncclFloat64, 0, g->rccl.comm, stream);
+				if (rc == 0) rc = g->rccl.Send(g->loopbuf.p + off, c, ncclFloat64, 0, g->rccl.comm, stream);
+				off += (int64_t) c;
+			}
+			int rc2 = g->rccl.GroupEnd();
+			if (rc || rc2) return te::fail(TE_ESTATE, std::string("RCCL loopback exchange failed: ") + g->rccl.GetErrorString(rc ? rc : rc2));
+			return TE_OK;
+		}
 		int rc = g->rccl.GroupStart();
 		for (size_t i = 0; i < pl.peers.size() && rc == 0; i++) {
 			if (pl.recv_cnt[i] > 0)

@@ -1,0 +1,97 @@
+"""-m gpu: the sharded path at BASELINE.json's PRODUCTION shapes, default options, default switches (overlap path on,
+default TE_OVERLAP_MIN / TE_AGGLOMERATE), both smoothers, against the single-rank run BIT FOR BIT:
+
+  C3  512^3 uniform, 4096 patches of 32^3, 8 ranks (2x2x2 octants of 8^3 patches)
+  C4  2refine.bin --divide 2 (960 patches of 32^3, coarse/fine faces cut by rank boundaries), 4 ranks
+  C5  4096^2 uniform, 4096 patches of 64^2, 8 ranks
+
+Virtual ranks (dist.LocalFabric: one thread per rank on the one GPU of the test box, device-to-device copies behind the
+same exchange plans). What this replaces in the reference: the VecScatter pairs of SchurHelper.h:123-150 and
+GMG/InterLevelComm.h:169-189. The native RCCL back-end cannot carry these runs on a one-GPU box: RCCL refuses two ranks
+on one device (ncclCommInitRank: duplicate GPU), so it is exercised with the rank as its own peer
+(test_gpu_multirank.py::test_native_rccl_backend_selftest) and through bench.py on real multi-GPU nodes only; the
+exchange PLANS (who sends what to whom, in which order) are the same objects for every back-end."""
+import numpy as np
+import pytest
+
+from pressurepoissonsolver_amd import capi, dist as tedist, problems
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "C3-512^3-8ranks": dict(mesh="uniform", divides=4, n=32, dim=3, nranks=8),
+    "C4-2refine-div2-4ranks": dict(mesh="2refine.bin", divides=2, n=32, dim=3, nranks=4),
+    "C5-4096^2-8ranks": dict(mesh="uniform", divides=6, n=64, dim=2, nranks=8),
+}
+
+
+def cycle_single(mesh, n, sm, f):
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    df, du = g1.new_vector(0, f), g1.new_vector(0)
+    g1.profile(True)
+    g1.profile_reset()
+    g1.cycle(g1.default_opts(smoother=sm), df, du)
+    rows = g1.profile_rows()
+    g1.profile(False)
+    want = du.download()
+    del df, du, g1
+    return want, rows
+
+
+@pytest.mark.parametrize("smoother", [capi.SMOOTH_RBGS, capi.SMOOTH_PATCH_SOLVE], ids=["rbgs", "patch_solve"])
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_production_shape_sharded_cycle_equals_single_rank(name, smoother, monkeypatch):
+    for k in ("TE_OVERLAP_MIN", "TE_AGGLOMERATE", "TE_AGGLOMERATE_MAX", "TE_NO_OVERLAP"):
+        monkeypatch.delenv(k, raising=False)  # the defaults are what is under test
+    c = CONFIGS[name]
+    n, dim, nranks = c["n"], c["dim"], c["nranks"]
+    mesh = util.mesh(c["mesh"], c["divides"], dim)
+    nc = n ** dim
+    H0 = capi.Hierarchy(mesh, n)
+    P = H0.sizes(0)[1]
+    f = problems.random_rhs(H0.tables(0)["id"], nc)  # the timing input of bench.py
+    del H0
+    want, rows1 = cycle_single(mesh, n, smoother, f)
+    if smoother == capi.SMOOTH_RBGS and c["mesh"] == "uniform":
+        assert "rbgs_resweep_prolong" in rows1  # the benchmarked fused path is what is being compared
+
+    fab = tedist.LocalFabric(nranks)
+    fab.timeout = 600.0
+    hs = [capi.Hierarchy(mesh, n, rank=r, nranks=nranks) for r in range(nranks)]
+    gs = [capi.GMG(h) for h in hs]
+    for r, g in enumerate(gs):
+        fab.attach(g, r)
+
+    def per_rank(r):
+        H, g = hs[r], gs[r]
+        idx = H.l2g(0)
+        df, du = g.new_vector(0, f.reshape(-1, nc)[idx].ravel()), g.new_vector(0)
+        g.profile(True)
+        g.profile_reset()
+        g.cycle(g.default_opts(smoother=smoother), df, du)
+        rows = g.profile_rows()
+        g.profile(False)
+        return idx, du.download(), rows
+
+    outs = fab.run(per_rank)
+    got = np.zeros(P * nc)
+    for idx, u, _ in outs:
+        got.reshape(P, nc)[idx] = u.reshape(len(idx), nc)
+    assert np.array_equal(got, want), np.abs(got - want).max()
+
+    rows = [o[2] for o in outs]
+    if name.startswith("C3") and smoother == capi.SMOOTH_RBGS:
+        # 512 local patches on level 0 >= TE_OVERLAP_MIN (128): interior (343) and boundary (169) patches of the post-sweep are
+        # two launches with the exchange under the first; level 1 (64 local patches) runs in one launch of the FCORR symbol
+        for r in rows:
+            assert r["rbgs_resweep_prolong"]["calls"] == 2, r["rbgs_resweep_prolong"]
+            assert r["rbgs_zero_resid_restrict_faces"]["calls"] == 1
+            assert r["pack"]["calls"] >= 2 and r["exchange"]["calls"] >= 1
+    if name.startswith("C3"):
+        # levels with 64, 8 and 1 patches live on rank 0 (agglomeration): the other ranks launch nothing there
+        assert hs[1].sizes(2)[0] == 0 and hs[0].sizes(2)[0] == 64
+    if name.startswith("C5") and smoother == capi.SMOOTH_RBGS:
+        for r in rows:
+            assert r["rbgs_resweep_prolong"]["calls"] >= 2  # levels 0 and 1 are cut by rank boundaries and stay fused
