@@ -1782,7 +1782,9 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 		// leave most of the chip idle and a single solve takes ~80 us); otherwise the single-pass kernel
 		// (TE_PS_MODE = 1pass | 1pass-dense | 3pass pins the choice; 3pass also pins one workgroup per patch: tests)
 		const char *mode     = g->cfg.str(O_PS_MODE);
-		const bool  one_pass = mode ? !strncmp(mode, "1pass", 5) : L.P >= 256;
+		// (the GLOBAL patch count decides: k_ps_sym and the three-pass kernels differ in the last bits, and a sharded run must
+		// take the arithmetic path of the single-rank run -- 512^3 on 8 ranks has 64 local patches of 512 on level 1)
+		const bool  one_pass = mode ? !strncmp(mode, "1pass", 5) : L.P_global >= 256;
 		const int   seg      = (one_pass || mode) ? 1 : (L.P >= 128 ? 2 : (L.P >= 64 ? 4 : 8));
 		const dim3 gp(L.P, seg), b256(256);
 		// x-face columns of the old iterate, if its producer exported them (te_vcycle only: see xfFor)
@@ -2224,7 +2226,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		u_zero = false;
 		// opts.fuse = 3: ... and so does everything the post-sweep reads of this iterate (its interface terms, k_face_corr3d
 		// on u + P e): the pre-sweep stores the six face layers of its result and nothing else (bit-identical; rank-local)
-		L.ps_faces_req = o->fuse >= 3 && o->cycle_type == 0 && o->post_sweeps >= 1 && L.n == 32 && L.P >= 256 && L.prolong_fusable
+		L.ps_faces_req = o->fuse >= 3 && o->cycle_type == 0 && o->post_sweeps >= 1 && L.n == 32 && L.P_global >= 256 && L.prolong_fusable
 		                 && (L.sym_ok || L.n_pure == L.P) && L.f6buf.p && !g->cfg.has(O_PS_SLOW) && !g->cfg.has(O_PS_MODE)
 		                 && !g->cfg.has(O_NO_PS_FACES);
 		if ((rc = smoothOnce(g, l, f, u, TE_SMOOTH_PATCH_SOLVE, o->omega, true))) return rc;

@@ -1241,8 +1241,14 @@ __global__ void k_pack_faces6_3d(const int32_t *__restrict__ faces, const double
 	const int     ax = s >> 1;
 	const int     sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
 	const double *fp = f6 + ((size_t) p * 6 + s) * NN;
-	const double *cp = ps.coarse ? coarseOctant<N>(ps, p) + ((s & 1) ? (H - 1) * sn : 0) : nullptr;
 	double       *o  = sendbuf + (size_t) blockIdx.x * NN;
+	if (ps.coarse && ps.orth[p] < 0) { // a patch that copies through (refined level): its correction is the same-size coarse
+		// patch, cell by cell -- as k_pack_faces_prolong3d and k_cf_ghost6_3d<N, true> form it for local readers
+		const int face = (s & 1) ? (N - 1) * sn : 0;
+		for (int i = threadIdx.x; i < NN; i += blockDim.x) o[i] = fp[i] + coarseAtCell<N>(ps, p, face + (i % N) * sa + (i / N) * sb);
+		return;
+	}
+	const double *cp = ps.coarse ? coarseOctant<N>(ps, p) + ((s & 1) ? (H - 1) * sn : 0) : nullptr;
 	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
 		const int a = i % N, b = i / N;
 		o[i] = cp ? fp[i] + cp[(a / 2) * sa + (b / 2) * sb] : fp[i];

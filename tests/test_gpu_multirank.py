@@ -44,7 +44,10 @@ def shard_run(mesh, n, nranks, fn, dim=3):
 @pytest.mark.parametrize("nranks", [2, 3, 4, 8])
 @pytest.mark.parametrize("name,divides,n,dim", [("uniform", 2, 8, 3), ("uniform", 3, 4, 3), ("uniform", 3, 8, 2),
                                                 # refined trees: coarse/fine faces cut by rank boundaries (config C4)
-                                                ("2refine.bin", 1, 8, 3), ("2d2ref.bin", 2, 8, 2)])
+                                                ("2refine.bin", 1, 8, 3), ("2d2ref.bin", 2, 8, 2),
+                                                # >= 256 patches on the refined finest level: the default fuse = 3 path there
+                                                # (copy-through patches and coarse/fine faces with neighbours on other ranks)
+                                                ("2refine.bin", 2, 4, 3)])
 def test_sharded_ops_equal_single_rank(nranks, name, divides, n, dim, monkeypatch):
     # levels with fewer than 128 local patches skip the interior/boundary overlap by default: these small meshes must
     # exercise it (the 8-rank run keeps the default, i.e. covers the non-overlapped path too)

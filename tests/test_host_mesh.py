@@ -144,3 +144,63 @@ def test_morton_partition(nranks, agg, cap, monkeypatch):
         for r in range(8):
             s = t["starts"][t["rank"] == r]
             assert np.all(s.max(0) - s.min(0) < 0.5)
+
+
+DEEP = [("multi_refine.bin", 3, 0), ("multi_refine_8.bin", 3, 0), ("2d_multi_refine_8.bin", 2, 0), ("2refine.bin", 3, 1),
+        ("2d2ref.bin", 2, 2), ("multi_refine.bin", 3, 1)]
+
+
+@pytest.mark.parametrize("name,dim,div", DEEP)
+def test_level_tables_equal_independent_breadth_first_extraction(name, dim, div):
+    """Every level table of the product (csrc/mesh.cpp: membership rule + Morton sort) against a second, independent
+    statement of the reference's level extraction -- the breadth-first walk of ThundereggDomGen.h:127-222 in plain Python
+    (oracle/levels_bfs.py) -- table for table: patch set, geometry, neighbour kinds / ids / quadrants, parents and orthants.
+    Deep AMR trees included (apps/3d/meshes/multi_refine.bin: 137 nodes, 5 levels; multi_refine_8.bin: 9 levels; the mesh of
+    apps/3d/config/gmg_example.ini)."""
+    from oracle import levels_bfs
+    m = util.mesh(name, div, dim)
+    H = capi.Hierarchy(m, 4)
+    nodes = m.nodes()
+    levels = levels_bfs.extract_levels(nodes, dim)
+    assert len(levels) == H.num_levels
+    prod = [H.tables(l) for l in range(H.num_levels)]
+    want = levels_bfs.tables_in_order(levels, nodes, dim, [t["id"] for t in prod])
+    for l, (t, w) in enumerate(zip(prod, want)):
+        for k in ("id", "starts", "lengths", "nbr_kind", "nbr", "nbr_orth", "orth_on_parent"):
+            assert np.array_equal(t[k], w[k]), (l, k)
+        if l + 1 < H.num_levels:
+            assert np.array_equal(t["parent"], w["parent"]), (l, "parent")
+
+
+@pytest.mark.parametrize("name,dim,div", DEEP)
+def test_level_table_properties_deep_trees(name, dim, div):
+    """Per level: every coarse patch has all its children (or is a copy of one fine patch), neighbour links are symmetric
+    (normal <-> normal, coarse <-> fine with matching quadrant), refinement is 2:1 across every face."""
+    m = util.mesh(name, div, dim)
+    H = capi.Hierarchy(m, 4)
+    for l in range(H.num_levels):
+        t = H.tables(l)
+        P = len(t["id"])
+        for p in range(P):
+            for s in range(2 * dim):
+                k = t["nbr_kind"][p, s]
+                if k == 1:
+                    q = t["nbr"][p, s, 0]
+                    assert t["nbr_kind"][q, s ^ 1] == 1 and t["nbr"][q, s ^ 1, 0] == p
+                    assert np.allclose(t["lengths"][q], t["lengths"][p])
+                elif k == 2:  # my neighbour is coarser: exactly twice my size, and it lists me in my quadrant
+                    q, quad = t["nbr"][p, s, 0], t["nbr_orth"][p, s]
+                    assert np.allclose(t["lengths"][q], 2 * t["lengths"][p])
+                    assert t["nbr_kind"][q, s ^ 1] == 3 and t["nbr"][q, s ^ 1, quad] == p
+                elif k == 3:
+                    for quad in range(1 << (dim - 1)):
+                        q = t["nbr"][p, s, quad]
+                        assert np.allclose(2 * t["lengths"][q], t["lengths"][p])
+                        assert t["nbr_kind"][q, s ^ 1] == 2 and t["nbr"][q, s ^ 1, 0] == p and t["nbr_orth"][q, s ^ 1] == quad
+        if l + 1 < H.num_levels:
+            c = H.tables(l + 1)
+            kids = [[] for _ in range(len(c["id"]))]
+            for p in range(P):
+                kids[t["parent"][p]].append(t["orth_on_parent"][p])
+            for pc, ks in enumerate(kids):
+                assert sorted(ks) == list(range(1 << dim)) or ks == [-1], (l, pc, ks)
