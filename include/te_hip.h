@@ -147,6 +147,10 @@ int te_apply(te_gmg *g, int level, const te_vec *u, te_vec *f);
 int te_patch_apply(te_gmg *g, int level, const te_vec *u, te_vec *f);
 /* r = f - A u  (Cycle.h:60-61 fused: apply + scaleThenAdd(-1, f)) */
 int te_residual(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *r);
+/* the same with ||r||^2 (this rank's part; Vector.h:294 twoNorm before its MPI_Allreduce and sqrt) summed by the residual
+ * kernel itself while r is in registers: per thread in plane order, then wave shuffles -> LDS -> one partial per workgroup
+ * -> a fixed-order final pass. No second pass over r (3D; 2D runs the two kernels). */
+int te_residual_norm_sq(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *r, double *norm_sq);
 /* GMG::Smoother<D>::smooth(f, u) (GMG/Smoother.h:39), `sweeps` times */
 int te_smooth(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega,
               int sweeps);

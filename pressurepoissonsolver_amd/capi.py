@@ -99,6 +99,7 @@ SYMBOLS = {
     "te_apply": (_I, [_P, _I, _P, _P]),
     "te_patch_apply": (_I, [_P, _I, _P, _P]),
     "te_residual": (_I, [_P, _I, _P, _P, _P]),
+    "te_residual_norm_sq": (_I, [_P, _I, _P, _P, _P, _PD]),
     "te_smooth": (_I, [_P, _I, _P, _P, _I, _D, _I]),
     "te_restrict": (_I, [_P, _I, _P, _P]),
     "te_prolong_add": (_I, [_P, _I, _P, _P]),
@@ -378,6 +379,12 @@ class GMG:
 
     def apply(self, u, f, level=0): check(lib().te_apply(self.h, level, u.h, f.h))
     def residual(self, u, f, r, level=0): check(lib().te_residual(self.h, level, u.h, f.h, r.h))
+    def residual_norm_sq(self, u, f, r, level=0):
+        """r = f - A u and this rank's part of ||r||^2, formed by the residual kernel itself"""
+        out = C.c_double()
+        check(lib().te_residual_norm_sq(self.h, level, u.h, f.h, r.h, C.byref(out)))
+        return out.value
+
     def patch_apply(self, u, f, level=0): check(lib().te_patch_apply(self.h, level, u.h, f.h))
     def verify_schedule(self, opts): check(lib().te_gmg_verify_schedule(self.h, C.byref(opts)))
 

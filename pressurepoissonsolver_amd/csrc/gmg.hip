@@ -70,12 +70,12 @@ const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_j
 enum Opt : int {
 	O_2D_SIMPLE, O_2D_NO_MFMA, O_2D_NO_PF, O_2D_NO_MR_FUSE, O_2D_TPB, O_NO_FUSE2, O_NO_FUSE3, O_NO_FUSE3_CF, O_NO_CFP, O_NO_XF,
 	O_NO_FCORR, O_NO_FCORR_CF, O_NO_GTAB, O_NO_OVERLAP, O_OVERLAP_MIN, O_NO_PS_FACES, O_PS_MODE, O_PS_SLOW, O_RBGS_NOSLAB,
-	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_COUNT
+	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_COUNT
 };
 const char *optName[O_COUNT] = {"TE_2D_SIMPLE", "TE_2D_NO_MFMA", "TE_2D_NO_PF", "TE_2D_NO_MR_FUSE", "TE_2D_TPB", "TE_NO_FUSE2", "TE_NO_FUSE3",
                                 "TE_NO_FUSE3_CF", "TE_NO_CFP", "TE_NO_XF", "TE_NO_FCORR", "TE_NO_FCORR_CF", "TE_NO_GTAB", "TE_NO_OVERLAP",
                                 "TE_OVERLAP_MIN", "TE_NO_PS_FACES", "TE_PS_MODE", "TE_PS_SLOW", "TE_RBGS_NOSLAB", "TE_ZS_FORCE", "TE_NO_ZS8",
-                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH", "TE_RCCL_LOOPBACK"};
+                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE"};
 // options that shape the level tables te_gmg_create builds: fixed for the solver's lifetime
 inline bool optStructural(int o) { return o == O_2D_SIMPLE || o == O_NO_CFP || o == O_2D_NO_MR_FUSE || o == O_NO_OVERLAP || o == O_EXCHANGE_TIMEOUT; }
 struct Cfg {
@@ -1107,36 +1107,63 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 	launch(L.devPart(true)); // boundary
 	return TE_OK;
 }
-template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out,
-                                              double omega, RestrictDst rd = RestrictDst(), const double *xf_in = nullptr)
+// one launch of k_stencil3d<N, MODE, ZS> with or without fused sums (RED: march3d.hpp StencilRed)
+template <int N, int MODE, int ZS>
+void launchStencilZS(te_gmg *g, dim3 grid, const LevelDev &D, const double *u, const double *f, double *out, double omega,
+                     const RestrictDst &rd, int redmode, const RedSrc &rs)
 {
-	const int tpb = Tile3<N>::TPB;
+	const dim3 blk(Tile3<N>::TPB);
+	if constexpr (MODE == MODE_APPLY) {
+		if (redmode == RED_OUT_A) {
+			hipLaunchKernelGGL((k_stencil3d<N, MODE, ZS, RED_OUT_A>), grid, blk, 0, g->stream, D, u, f, out, omega, rd, rs);
+			return;
+		}
+		if (redmode == RED_OUT_A_OUT) {
+			hipLaunchKernelGGL((k_stencil3d<N, MODE, ZS, RED_OUT_A_OUT>), grid, blk, 0, g->stream, D, u, f, out, omega, rd, rs);
+			return;
+		}
+	}
+	if constexpr (MODE == MODE_RESID) {
+		if (redmode == RED_OUT_OUT) {
+			hipLaunchKernelGGL((k_stencil3d<N, MODE, ZS, RED_OUT_OUT>), grid, blk, 0, g->stream, D, u, f, out, omega, rd, rs);
+			return;
+		}
+	}
+	hipLaunchKernelGGL((k_stencil3d<N, MODE, ZS, RED_NONE>), grid, blk, 0, g->stream, D, u, f, out, omega, rd, rs);
+}
+// redmode != RED_NONE: the kernel leaves one pair of partial sums per work item in g->partial (red_a: the second operand
+// of the dot product); *red_items = their number (the caller runs k_reduce_final2 over them)
+template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out,
+                                              double omega, RestrictDst rd = RestrictDst(), const double *xf_in = nullptr,
+                                              int redmode = RED_NONE, const double *red_a = nullptr, int *red_items = nullptr)
+{
 	// enough workgroups to fill 256 CUs a few times over: split patches into z-slabs when few
 	int zs = 1;
 	if (N >= 8) {
 		while (zs < 4 && (g->cfg.has(O_ZS_FORCE) || (size_t) L.P * zs < 2048) && N / (zs * 2) >= 4) zs *= 2;
 		if (zs == 4 && N == 32 && L.P <= 64 && !g->cfg.has(O_NO_ZS8)) zs = 8; // (see rbgsSlabs)
 	}
+	if (redmode != RED_NONE) {
+		if ((size_t) 2 * L.P * zs > g->partial.n) return te::fail(TE_ESTATE, "launchStencil: partial-sum buffer too small");
+		if (red_items) *red_items = L.P * zs;
+	}
 	auto launch = [&](LevelDev D) {
 		if (D.count == 0) return;
 		Timed t(g, zs > 1 ? KC_STENCIL_SLABS
 		                  : (MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : (MODE == MODE_JACOBI ? KC_JACOBI : KC_RESID_RESTRICT))),
 		        (size_t) D.count * L.nc);
-		auto grid = [&](int z) { return dim3(8 * ((D.count * z + 7) / 8)); };
+		auto         grid = [&](int z) { return dim3(8 * ((D.count * z + 7) / 8)); };
+		const RedSrc rs{red_a, g->partial.p, D.first * zs}; // (interior patches are launched before the boundary patches)
 		switch (zs) {
-			case 1: hipLaunchKernelGGL((k_stencil3d<N, MODE, 1>), grid(1), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd); break;
+			case 1: launchStencilZS<N, MODE, 1>(g, grid(1), D, u, f, out, omega, rd, redmode, rs); break;
 			case 2:
-				if constexpr (N >= 8)
-					hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
+				if constexpr (N >= 8) launchStencilZS<N, MODE, 2>(g, grid(2), D, u, f, out, omega, rd, redmode, rs);
 				break;
 			case 8:
-				if constexpr (N >= 32) hipLaunchKernelGGL((k_stencil3d<N, MODE, 8>), grid(8), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
+				if constexpr (N >= 32) launchStencilZS<N, MODE, 8>(g, grid(8), D, u, f, out, omega, rd, redmode, rs);
 				break;
 			default:
-				if constexpr (N >= 16)
-					hipLaunchKernelGGL((k_stencil3d<N, MODE, 4>), grid(4), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
-				else if constexpr (N >= 8)
-					hipLaunchKernelGGL((k_stencil3d<N, MODE, 2>), grid(2), dim3(tpb), 0, g->stream, D, u, f, out, omega, rd);
+				if constexpr (N >= 16) launchStencilZS<N, MODE, 4>(g, grid(4), D, u, f, out, omega, rd, redmode, rs);
 				break;
 		}
 	};
@@ -1430,20 +1457,23 @@ int resweepProlong2d(te_gmg *g, LevelHost &L, const double *f, double *out, cons
 }
 
 template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega,
-                                      RestrictDst rd = RestrictDst(), const double *xf_in = nullptr)
+                                      RestrictDst rd = RestrictDst(), const double *xf_in = nullptr, int redmode = RED_NONE,
+                                      const double *red_a = nullptr, int *red_items = nullptr)
 {
+	if (red_items) *red_items = 0;
 	if (L.P == 0) return TE_OK;
 	if (L.dim == 2) {
+		if (redmode != RED_NONE) return te::fail(TE_EUNSUPPORTED, "fused sums exist for the 3D stencil kernel only");
 		if constexpr (MODE == MODE_RESID_RESTRICT)
 			return te::fail(TE_EUNSUPPORTED, "fused residual+restrict has no 2D kernel");
 		else
 			return launchStencil2d<MODE>(g, L, u, f, out, omega);
 	}
 	switch (L.n) {
-		case 4: return launchStencilN<4, MODE>(g, L, u, f, out, omega, rd, xf_in);
-		case 8: return launchStencilN<8, MODE>(g, L, u, f, out, omega, rd, xf_in);
-		case 16: return launchStencilN<16, MODE>(g, L, u, f, out, omega, rd, xf_in);
-		default: return launchStencilN<32, MODE>(g, L, u, f, out, omega, rd, xf_in);
+		case 4: return launchStencilN<4, MODE>(g, L, u, f, out, omega, rd, xf_in, redmode, red_a, red_items);
+		case 8: return launchStencilN<8, MODE>(g, L, u, f, out, omega, rd, xf_in, redmode, red_a, red_items);
+		case 16: return launchStencilN<16, MODE>(g, L, u, f, out, omega, rd, xf_in, redmode, red_a, red_items);
+		default: return launchStencilN<32, MODE>(g, L, u, f, out, omega, rd, xf_in, redmode, red_a, red_items);
 	}
 }
 // z-slabs per patch for the RB-GS kernels: enough workgroups to occupy 256 CUs x 4 when the level has few patches
@@ -1543,14 +1573,23 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 		} else {
 			D.f6_out = L.f6buf.p;
 			D.fcorr  = fcorr_in;
-			if (export_rs6 && fcorr_in)
-				launchT(t, (k_rbgs_zero_resid3d<N, false, true, true>), grid, blk, 0, g->stream, D, f, out, rd);
-			else if (export_rs6)
-				launchT(t, (k_rbgs_zero_resid3d<N, false, true, false>), grid, blk, 0, g->stream, D, f, out, rd);
-			else if (fcorr_in)
-				launchT(t, (k_rbgs_zero_resid3d<N, false, false, true>), grid, blk, 0, g->stream, D, f, out, rd);
-			else
-				launchT(t, (k_rbgs_zero_resid3d<N, false, false, false>), grid, blk, 0, g->stream, D, f, out, rd);
+			// TE_ZR_AHEAD = 1: the right-hand side requested one plane ahead only (the form before round 3; bit-identical)
+			const bool ah1 = g->cfg.num(O_ZR_AHEAD, 3) == 1;
+#define TE_ZR(EXP, FC)                                                                                                   \
+	if (ah1)                                                                                                             \
+		launchT(t, (k_rbgs_zero_resid3d<N, false, EXP, FC, 1>), grid, blk, 0, g->stream, D, f, out, rd);                 \
+	else                                                                                                                 \
+		launchT(t, (k_rbgs_zero_resid3d<N, false, EXP, FC, 3>), grid, blk, 0, g->stream, D, f, out, rd)
+			if (export_rs6 && fcorr_in) {
+				TE_ZR(true, true);
+			} else if (export_rs6) {
+				TE_ZR(true, false);
+			} else if (fcorr_in) {
+				TE_ZR(false, true);
+			} else {
+				TE_ZR(false, false);
+			}
+#undef TE_ZR
 		}
 	}
 	// the new face layers of neighbours on other ranks (no-op on one rank)
@@ -2302,7 +2341,11 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 	int rc;
 	for (int li = 0; li < (int) h->h.levels.size(); li++)
 		if ((rc = buildLevel(g.get(), h->h, li))) return rc;
-	if ((rc = g->partial.alloc(2 * g->red_blocks)) || (rc = g->result.alloc(8))) return rc;
+	{ // partial sums: the reduction kernels' blocks, or one pair per work item of a stencil launch with fused sums (<= 8 slabs per patch)
+		size_t items = (size_t) g->red_blocks;
+		for (auto &L : g->levels) items = std::max(items, (size_t) L->P * (L->P <= 64 ? 8 : (L->P < 2048 ? 4 : 1)));
+		if ((rc = g->partial.alloc(2 * items)) || (rc = g->result.alloc(8))) return rc;
+	}
 	HIPCHK(hipHostMalloc((void **) &g->result_host, 8 * sizeof(double), hipHostMallocDefault));
 	for (int li = 0; li < (int) g->levels.size(); li++) {
 		LevelHost &L = *g->levels[li];
@@ -2556,6 +2599,31 @@ int te_residual(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *
 	return launchStencil<MODE_RESID>(g, *g->levels[level], u->d, f->d, r->d, 0.0);
 	});
 }
+int te_residual_norm_sq(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *r, double *norm_sq)
+{
+	return guarded([&]() -> int {
+	int rc;
+	if (!norm_sq) return te::fail(TE_EINVAL, "te_residual_norm_sq: null result");
+	if ((rc = checkLevelVec(g, level, u, "te_residual_norm_sq")) || (rc = checkLevelVec(g, level, f, "te_residual_norm_sq"))
+	    || (rc = checkLevelVec(g, level, r, "te_residual_norm_sq")))
+		return rc;
+	if (u == r) return te::fail(TE_EINVAL, "te_residual_norm_sq: r must not alias u");
+	LevelHost &L = *g->levels[level];
+	if (L.dim == 2) { // (2D: the residual kernel, then the reduction pass)
+		if ((rc = launchStencil<MODE_RESID>(g, L, u->d, f->d, r->d, 0.0))) return rc;
+		return reduce<RED_SUMSQ>(r, nullptr, norm_sq);
+	}
+	int items = 0;
+	if ((rc = launchStencil<MODE_RESID>(g, L, u->d, f->d, r->d, 0.0, RestrictDst(), nullptr, RED_OUT_OUT, nullptr, &items))) return rc;
+	if (items > 0)
+		hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(256), 0, g->stream, items, g->partial.p, g->result.p);
+	else
+		HIPCHK(hipMemsetAsync(g->result.p, 0, 2 * sizeof(double), g->stream));
+	if ((rc = finishReduce(g, 1, 0, false))) return rc;
+	*norm_sq = g->result_host[0];
+	return TE_OK;
+	});
+}
 int te_smooth(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega, int sweeps)
 {
 	return guarded([&]() -> int {
@@ -2738,19 +2806,17 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 	double r0sq, rsq, rho, tmp, tmp2;
 #define TE_TRY(x)                \
 	if ((rc = (x))) return done(rc)
-	TE_TRY(te_apply(g, 0, x, resid));
-	TE_TRY(te_vec_scale_then_add(resid, -1, b));
-	TE_TRY(reduce<RED_SUMSQ>(resid, nullptr, &r0sq, true));
-	const double r0_norm = sqrt(r0sq);
-	TE_TRY(te_vec_copy(rhat, resid));
-	TE_TRY(te_vec_copy(p, resid));
-	TE_TRY(reduce<RED_DOT>(rhat, resid, &rho, true));
-	int          num_its = 0;
-	const size_t n2      = x->n / 2;
-	const int    fat     = gridFor(n2, 256, 1 << 30), rb = gridFor(n2, 256, g->red_blocks / 2);
-	auto         two     = [&](double *a, double *b2) -> int { // fixed-order sum of the per-block pairs -> all ranks -> host
-        if (n2 > 0)
-            hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(256), 0, g->stream, rb, g->partial.p, g->result.p);
+	// The dot products that follow an operator application (BiCGStab.h:73-74, 85-87) and the norm of the first residual
+	// (:57-60) are formed by the stencil kernel itself while its result is in registers (k_stencil3d RED, 3D; fixed
+	// summation order per launch geometry): 16 B/site per dot that a separate pass over stored vectors would read.
+	// TE_NO_BICG_FUSE: the separate passes (k_reduce / k_bicg_omega), as before round 3.
+	const bool   fused = g->dim == 3 && !g->cfg.has(O_NO_BICG_FUSE);
+	LevelHost   &L0    = *g->levels[0];
+	const size_t n2    = x->n / 2;
+	const int    fat   = gridFor(n2, 256, 1 << 30), rb = gridFor(n2, 256, g->red_blocks / 2);
+	auto         two   = [&](int nparts, double *a, double *b2) -> int { // fixed-order sum of the per-block pairs -> all ranks -> host
+        if (nparts > 0)
+            hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(256), 0, g->stream, nparts, g->partial.p, g->result.p);
         else
             HIPCHK(hipMemsetAsync(g->result.p, 0, 2 * sizeof(double), g->stream));
         int r2 = finishReduce(g, 2, 0, true);
@@ -2759,36 +2825,65 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
         *b2 = g->result_host[1];
         return TE_OK;
 	};
-	rsq = r0sq;
+	// out = A in together with the sums `redmode` asks for (second operand a)
+	auto applySums = [&](const te_vec *in, te_vec *outv, int redmode, const te_vec *a, double *s0, double *s1) -> int {
+		if (L0.xf_valid_for == outv->d) L0.xf_valid_for = nullptr;
+		int items = 0;
+		int r2    = launchStencil<MODE_APPLY>(g, L0, in->d, nullptr, outv->d, 0.0, RestrictDst(), nullptr, redmode, a->d, &items);
+		if (r2) return r2;
+		return two(items, s0, s1);
+	};
+	if (fused) {
+		int    items = 0;
+		double dummy;
+		TE_TRY(launchStencil<MODE_RESID>(g, L0, x->d, b->d, resid->d, 0.0, RestrictDst(), nullptr, RED_OUT_OUT, nullptr, &items));
+		TE_TRY(two(items, &r0sq, &dummy));
+	} else {
+		TE_TRY(te_apply(g, 0, x, resid));
+		TE_TRY(te_vec_scale_then_add(resid, -1, b));
+		TE_TRY(reduce<RED_SUMSQ>(resid, nullptr, &r0sq, true));
+	}
+	const double r0_norm = sqrt(r0sq);
+	TE_TRY(te_vec_copy(rhat, resid));
+	TE_TRY(te_vec_copy(p, resid));
+	if (fused)
+		rho = r0sq; // rhat == resid at this point: the dot product is the sum of the same squares as the norm above
+	else
+		TE_TRY(reduce<RED_DOT>(rhat, resid, &rho, true));
+	int num_its = 0;
+	rsq         = r0sq;
 	// Loop body = BiCGStab.h:71-104 statement for statement; the vector statements between two operator
-	// applications are fused into one kernel each (same expressions per element, 160 instead of 232 B/site).
+	// applications are fused into one kernel each (same expressions per element).
 	while (sqrt(rsq) / r0_norm > tol && num_its < max_it) {
-		if (o) {
-			TE_TRY(te_vcycle(g, o, p, mp));
-			TE_TRY(te_apply(g, 0, mp, ap));
+		const te_vec *ain = o ? mp : p;
+		if (o) TE_TRY(te_vcycle(g, o, p, mp));
+		if (fused) {
+			double dummy;
+			TE_TRY(applySums(ain, ap, RED_OUT_A, rhat, &tmp, &dummy));
 		} else {
-			TE_TRY(te_apply(g, 0, p, ap));
+			TE_TRY(te_apply(g, 0, ain, ap));
+			TE_TRY(reduce<RED_DOT>(rhat, ap, &tmp, true));
 		}
-		TE_TRY(reduce<RED_DOT>(rhat, ap, &tmp, true));
 		const double alpha = rho / tmp;
 		if (n2 > 0) {
 			Timed t(g, KC_VECOP, x->n);
 			hipLaunchKernelGGL(k_bicg_s, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) s->d, (const double2 *) resid->d,
 			                   (const double2 *) ap->d, -alpha);
 		}
-		if (o) {
-			TE_TRY(te_vcycle(g, o, s, ms));
-			TE_TRY(te_apply(g, 0, ms, as));
-		} else {
-			TE_TRY(te_apply(g, 0, s, as));
-		}
+		const te_vec *sin = o ? ms : s;
+		if (o) TE_TRY(te_vcycle(g, o, s, ms));
 		tmp = tmp2 = 0.0;
-		if (n2 > 0) {
-			Timed t(g, KC_REDUCE, x->n);
-			hipLaunchKernelGGL(k_bicg_omega, dim3(rb), dim3(256), 0, g->stream, n2, (const double2 *) as->d,
-			                   (const double2 *) s->d, g->partial.p);
+		if (fused) {
+			TE_TRY(applySums(sin, as, RED_OUT_A_OUT, s, &tmp, &tmp2));
+		} else {
+			TE_TRY(te_apply(g, 0, sin, as));
+			if (n2 > 0) {
+				Timed t(g, KC_REDUCE, x->n);
+				hipLaunchKernelGGL(k_bicg_omega, dim3(rb), dim3(256), 0, g->stream, n2, (const double2 *) as->d,
+				                   (const double2 *) s->d, g->partial.p);
+			}
+			if (n2 > 0 || g->nranks > 1) TE_TRY(two(n2 > 0 ? rb : 0, &tmp, &tmp2));
 		}
-		if (n2 > 0 || g->nranks > 1) TE_TRY(two(&tmp, &tmp2));
 		const double   omega = tmp / tmp2;
 		const te_vec *dp = o ? mp : p, *ds = o ? ms : s;
 		double         rho_new = 0.0;
@@ -2798,7 +2893,7 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 			                   (const double2 *) dp->d, (const double2 *) ds->d, (const double2 *) ap->d,
 			                   (const double2 *) as->d, (const double2 *) rhat->d, alpha, omega, g->partial.p);
 		}
-		if (n2 > 0 || g->nranks > 1) TE_TRY(two(&rho_new, &rsq));
+		if (n2 > 0 || g->nranks > 1) TE_TRY(two(n2 > 0 ? rb : 0, &rho_new, &rsq));
 		const double beta = rho_new * alpha / (rho * omega);
 		if (n2 > 0) {
 			Timed t(g, KC_VECOP, x->n);

@@ -59,11 +59,25 @@ template <int N> struct Tile3 {
 // The steady-state loop is branch-free: every load of an iteration is issued unconditionally from a
 // (pointer, sign) pair chosen with scalar selects, so the whole next plane stays in flight behind the
 // LDS barrier.
-template <int N, int MODE, int ZS>
+// RED (MODE_APPLY, MODE_RESID): sums over the result that the caller needs next, formed while the values are in registers
+// instead of in a pass of their own over a stored vector (Vector.h:284-321 dot / twoNorm; BiCGStab.h:73-87 calls them right
+// after the operator application): RED_OUT_A: sum out*a; RED_OUT_A_OUT: sum out*a and sum out*out; RED_OUT_OUT: sum out*out
+// (the residual norm, Cycle.h:60-61 + Vector.h:294). Per thread the products are added in plane order, then wave shuffles ->
+// LDS -> one pair per workgroup in red.partial[2 (red.base + work item)]: a fixed order whatever the launch geometry; the
+// caller's k_reduce_final2 adds the pairs in index order.
+enum StencilRed : int { RED_NONE = 0, RED_OUT_A = 1, RED_OUT_A_OUT = 2, RED_OUT_OUT = 3 };
+struct RedSrc {
+	const double *a;       // second operand of the dot product (same level and layout as out), or null
+	double       *partial; // [2 * work items of the level]
+	int           base;    // work items of the launches that precede this one on the level (interior before boundary)
+};
+template <int N, int MODE, int ZS, int RED = RED_NONE>
 __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const double *__restrict__ u,
                                                              const double *__restrict__ f,
-                                                             double *__restrict__ out, double omega, RestrictDst rd)
+                                                             double *__restrict__ out, double omega, RestrictDst rd,
+                                                             RedSrc red = RedSrc())
 {
+	static_assert(RED == RED_NONE || MODE == MODE_APPLY || MODE == MODE_RESID, "fused sums exist for apply and residual");
 	using T            = Tile3<N>;
 	constexpr int TPB  = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
 	constexpr int NN   = N * N, NNN = N * N * N;
@@ -147,6 +161,14 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 		if (MODE != MODE_APPLY) fc[k] = fp2[z0 * NP + q[k]];
 	}
 	double hv = hs.s * hs.p[z0 * hs.stride];
+	// fused sums: the second operand travels one plane ahead, like f
+	const double2 *ap2 = (RED == RED_OUT_A || RED == RED_OUT_A_OUT) ? reinterpret_cast<const double2 *>(red.a + (size_t) pid * NNN) : nullptr;
+	double2        ac[2], an[2];
+	double         acc0 = 0.0, acc1 = 0.0;
+	if (RED == RED_OUT_A || RED == RED_OUT_A_OUT) {
+#pragma unroll
+		for (int k = 0; k < 2; k++) ac[k] = ap2[z0 * NP + q[k]];
+	}
 
 #pragma unroll 1
 	for (int zz = 0; zz < ZL; zz++) {
@@ -161,6 +183,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 			double2 a = pn[q[k]];
 			un2[k]    = double2{sn * a.x, sn * a.y};
 			if (MODE != MODE_APPLY) fn[k] = fp2[zc * NP + q[k]];
+			if (RED == RED_OUT_A || RED == RED_OUT_A_OUT) an[k] = ap2[zc * NP + q[k]];
 		}
 		const double hvn = hs.s * hs.p[zc * hs.stride];
 
@@ -213,14 +236,40 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 			op2[z * NP + q[0]] = r[0];
 			op2[z * NP + q[1]] = r[1];
 		}
+		if (RED != RED_NONE && act) { // (products added one by one, as k_reduce does: no contraction across the two sums)
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				if (RED == RED_OUT_A || RED == RED_OUT_A_OUT) {
+					acc0 += r[k].x * ac[k].x;
+					acc0 += r[k].y * ac[k].y;
+				}
+				if (RED == RED_OUT_A_OUT) {
+					acc1 += r[k].x * r[k].x;
+					acc1 += r[k].y * r[k].y;
+				}
+				if (RED == RED_OUT_OUT) {
+					acc0 += r[k].x * r[k].x;
+					acc0 += r[k].y * r[k].y;
+				}
+			}
+		}
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
 			um[k] = uc[k];
 			uc[k] = un[k];
 			un[k] = un2[k];
 			if (MODE != MODE_APPLY) fc[k] = fn[k];
+			if (RED == RED_OUT_A || RED == RED_OUT_A_OUT) ac[k] = an[k];
 		}
 		hv = hvn;
+	}
+	if (RED != RED_NONE) {
+		__syncthreads(); // (the LDS of blockReduce2 is its own, but every wave must have left the plane loop's barriers)
+		blockReduce2(acc0, acc1);
+		if (tid == 0) {
+			red.partial[2 * ((size_t) red.base + work)]     = acc0;
+			red.partial[2 * ((size_t) red.base + work) + 1] = acc1;
+		}
 	}
 }
 
@@ -892,7 +941,9 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 // EXPORT: the ghost terms of the restricted residual that this patch's face values contribute to its neighbours' coarse
 // cells go to rd.fcorr (see above) -- no k_restrict_fixup3d pass; FCORR: this level's own right-hand side carries such
 // terms in L.fcorr (it was produced that way by the finer level).
-template <int N, bool STORE_U, bool EXPORT = false, bool FCORR = false>
+// AH: how many planes ahead of the red update the right-hand side is requested (1: the plane of the next step only -- then
+// every step waits for a load issued one step earlier, and a step is shorter than an HBM miss under load; 3: the default).
+template <int N, bool STORE_U, bool EXPORT = false, bool FCORR = false, int AH = 3>
 __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L, const double *__restrict__ f,
                                                                      double *__restrict__ out, RestrictDst rd)
 {
@@ -969,10 +1020,13 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 	double racc = 0.0;
 
 	// new iterate: u3 = plane z-3, u2 = z-2, u1 = z-1, u0 = z (all start from zero); right-hand sides alongside
-	double2 u3[2], u2[2], u1[2], u0[2], f2[2], f1[2], f0[2], fn[2];
+	static_assert(AH >= 1 && AH <= 4, "planes of f in flight");
+	double2 u3[2], u2[2], u1[2], u0[2], f2[2], f1[2], f0[2];
+	double2 fa[AH][2];                       // planes z+1 .. z+AH, requested AH steps before their first use
 	const double2 zero2 = double2{0.0, 0.0};
 	FCorrSrc<N>   fc;
-	double2       ccx[FCorrSrc<N>::NX]; // FCORR: the x terms of the plane in fn
+	double2       ccx[FCorrSrc<N>::NX];      // FCORR: the x terms of plane z ...
+	double2       cca[AH][FCorrSrc<N>::NX];  // ... and of the planes in fa (added when a plane becomes f0: the add must not wait for the newest load)
 	if (FCORR) fc.init(L.fcorr, pid, X, Yp);
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
@@ -980,19 +1034,24 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 		f2[k] = f1[k] = zero2;
 		f0[k] = fp2[q[k]];
 	}
-	if (FCORR) {
-		fc.load(0, ccx);
-		fc.apply(f0, ccx);
+	if (FCORR) fc.load(0, ccx);
+#pragma unroll
+	for (int a = 0; a + 1 < AH; a++) { // planes 1 .. AH-1 (the loop requests plane z+AH at step z)
+		const int za = (a + 1 < N) ? a + 1 : N - 1;
+#pragma unroll
+		for (int k = 0; k < 2; k++) fa[a][k] = ldStream<TE_ZR_NT != 0>(fp2 + za * NP + q[k]);
+		if (FCORR) fc.load(za, cca[a]);
 	}
+	if (FCORR) fc.apply(f0, ccx);
 	__syncthreads(); // idiag and the zeroed tiles
 
 	int bz = 0; // z % 4
 	auto step = [&](auto zpar, int z) {
 		constexpr int ZPAR = decltype(zpar)::value;
-		const int     zc   = (z + 1 < N) ? z + 1 : N - 1;
+		const int     zc   = (z + AH < N) ? z + AH : N - 1;
 #pragma unroll
-		for (int k = 0; k < 2; k++) fn[k] = ldStream<TE_ZR_NT != 0>(fp2 + zc * NP + q[k]);
-		if (FCORR) fc.load(zc, ccx);
+		for (int k = 0; k < 2; k++) fa[AH - 1][k] = ldStream<TE_ZR_NT != 0>(fp2 + zc * NP + q[k]);
+		if (FCORR) fc.load(zc, cca[AH - 1]);
 		double *tz = tile[bz];            // plane z
 		double *t1 = tile[(bz + 3) & 3];  // plane z-1
 		double *t2 = tile[(bz + 2) & 3];  // plane z-2
@@ -1104,9 +1163,17 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 			u0[k] = zero2;
 			f2[k] = f1[k];
 			f1[k] = f0[k];
-			f0[k] = fn[k];
+			f0[k] = fa[0][k];
+#pragma unroll
+			for (int a = 0; a + 1 < AH; a++) fa[a][k] = fa[a + 1][k];
 		}
-		if (FCORR) fc.apply(f0, ccx);
+		if (FCORR) {
+			fc.apply(f0, cca[0]);
+#pragma unroll
+			for (int a = 0; a + 1 < AH; a++)
+#pragma unroll
+				for (int c = 0; c < FCorrSrc<N>::NX; c++) cca[a][c] = cca[a + 1][c];
+		}
 		bz = (bz + 1) & 3;
 	};
 #pragma unroll 1

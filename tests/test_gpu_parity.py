@@ -376,3 +376,35 @@ def test_bicgstab_trig(case):
         # same discretisation error against the analytic solution (3 significant digits)
         e, e_ref = rel(x, exact), rel(x_ref, exact)
         assert abs(e - e_ref) <= 1e-3 * e_ref
+
+
+def test_fused_sums_of_the_stencil_kernel(case):
+    """The residual norm and BiCGStab's dot products formed inside the stencil kernel (k_stencil3d RED: per thread in plane
+    order, wave shuffles, LDS, one partial per workgroup, fixed-order final pass) against the separate reduction passes:
+    te_residual_norm_sq == ||te_residual||^2 to rounding (another summation order), r itself bit-identical; te_bicgstab
+    with and without the fused sums (TE_NO_BICG_FUSE): same iteration count, same solution to 1e-10."""
+    g, L, H = case["g"], case["levels"][0], case["H"]
+    u = util.rand_vec(L.size, 81)
+    f = util.rand_vec(L.size, 82) / L.a["h"].min() ** 2
+    du, df, r0, r1 = g.new_vector(0, u), g.new_vector(0, f), g.new_vector(0), g.new_vector(0)
+    g.residual(du, df, r0)
+    nsq = g.residual_norm_sq(du, df, r1)
+    assert np.array_equal(r0.download(), r1.download())
+    want = float(np.sum(r0.download() ** 2))
+    assert abs(nsq - want) <= 1e-13 * want
+    if case["neumann"]:
+        return
+    init = problems.init_dirichlet if case["dim"] == 3 else problems.init_dirichlet_2d
+    b, _ = init(H.tables(0), case["n"])
+    got = {}
+    for fuse in (True, False):
+        g.set_option("TE_NO_BICG_FUSE", None if fuse else "1")
+        for o in (None, g.default_opts(smoother=capi.SMOOTH_RBGS)):
+            db, dx = g.new_vector(0, b), g.new_vector(0)
+            its, rr = g.bicgstab(dx, db, o, tol=1e-12 if o is not None else 1e-8, max_it=400)
+            got[(fuse, o is None)] = (its, rr, dx.download())
+    g.set_option("TE_NO_BICG_FUSE", None)
+    for unprec in (True, False):
+        a, c = got[(True, unprec)], got[(False, unprec)]
+        assert abs(a[0] - c[0]) <= (1 if not unprec else max(2, c[0] // 50)), (a[0], c[0])
+        assert rel(a[2], c[2]) <= (1e-10 if not unprec else 1e-6)
