@@ -43,6 +43,16 @@ def build_hip(force=False):
     return LIB_HIP
 
 
+def build_variant(name, defines):
+    """tooling: a second library with other compile-time switches (e.g. build_variant("noskew", ["-DTE_LDS_SKEW=0"])) for
+    same-box A/B runs: TE_HIP_LIB_PATH=<returned path> python tools/variant_bench.py ..."""
+    out = os.path.join(ROOT, "pressurepoissonsolver_amd", f"libte_hip_{name}.so")
+    srcs = [os.path.join(CSRC, f) for f in ("gmg.hip", "capi_mesh.cpp", "mesh.cpp")]
+    _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"] + list(defines)
+         + ["-Wl,-soname," + os.path.basename(out), "-x", "hip", srcs[0], "-x", "hip", srcs[1], "-x", "hip", srcs[2], "-o", out])
+    return out
+
+
 def build_all(force=False):
     return {"hip": build_hip(force)}
 

@@ -78,10 +78,29 @@ __device__ __forceinline__ void ldsBarrier() { asm volatile("s_waitcnt lgkmcnt(0
 
 // LDS plane of the marching kernels (march3d.hpp): [pad, west halo, N cells, east halo, pad] per row so that
 // the interior is 16-B aligned for ds_read/write_b128, plus one halo row below and above.
+// Row pairs (1,2), (3,4), ... (r = y + 1) alternate a skew of ONE double. A 32-lane group of the thread map (16 x-pairs x
+// 2 row pairs, march3d.hpp) reads single doubles with ds_read_b64 (banks (a/4) mod 64 per 32 lanes): without the skew the
+// rows of lanes (X, Yp) and (X, Yp+1) lie 2 LW doubles = 144 dwords = 16 (mod 64) apart, so lane (X, Yp+1) meets lane
+// (X+4, Yp) on its two banks -- every such read was two-way conflicted (round 2 counters: 40-46 % of the LDS cycles of
+// the sweep kernels). With it the two row pairs lie an odd number of doubles apart and occupy disjoint banks. The price:
+// an interior row start is only 8-B aligned, so pairs are moved with ds_read2/write2_b64 (ldsLoad2 / ldsStore2), not b128.
+#ifndef TE_LDS_SKEW
+#define TE_LDS_SKEW 1 // (0: rows at plain multiples of LW -- tooling builds a second library with it for same-box comparisons)
+#endif
 template <int N> struct Tile2 {
 	static constexpr int LW  = N + 4;
-	static constexpr int LSZ = LW * (N + 2);
+	static constexpr int LSZ = LW * (N + 2) + 2;
+	__host__ __device__ static constexpr int row(int r) { return r * LW + (TE_LDS_SKEW ? (((r + 1) >> 1) & 1) : 0); }
 };
+struct __attribute__((packed, aligned(8))) double2a8 {
+	double x, y;
+};
+__device__ __forceinline__ double2 ldsLoad2(const double *p)
+{
+	const double2a8 v = *reinterpret_cast<const double2a8 *>(p);
+	return double2{v.x, v.y};
+}
+__device__ __forceinline__ void ldsStore2(double *p, double2 v) { *reinterpret_cast<double2a8 *>(p) = double2a8{v.x, v.y}; }
 
 // A plane just outside the patch in z, as "sign * memory": FACE_LOCAL -> the neighbour's facing
 // plane, FACE_GHOST -> the ghost slot, physical -> +-(own boundary plane) (or 0 when the caller
@@ -118,7 +137,8 @@ __device__ __forceinline__ HaloSrc haloSrc(int tid, const int32_t *fk, const int
                                            const double *up, const double *ghost, double dir_sign, double neu_sign,
                                            const double *xf = nullptr)
 {
-	constexpr int NN = N * N, NNN = N * N * N, LW = Tile2<N>::LW;
+	constexpr int NN = N * N, NNN = N * N * N;
+	using T2 = Tile2<N>;
 	HaloSrc       h;
 	h.p      = up;
 	h.stride = 0;
@@ -131,19 +151,19 @@ __device__ __forceinline__ HaloSrc haloSrc(int tid, const int32_t *fk, const int
 		if (side == 0) { // west: own (0,t), neighbour's (N-1,t)
 			own   = t * N;
 			nbr   = t * N + (N - 1);
-			h.lds = (t + 1) * LW + 1;
+			h.lds = T2::row(t + 1) + 1;
 		} else if (side == 1) {
 			own   = t * N + (N - 1);
 			nbr   = t * N;
-			h.lds = (t + 1) * LW + N + 2;
+			h.lds = T2::row(t + 1) + N + 2;
 		} else if (side == 2) { // south: own (t,0), neighbour's (t,N-1)
 			own   = t;
 			nbr   = (N - 1) * N + t;
-			h.lds = t + 2;
+			h.lds = T2::row(0) + t + 2;
 		} else {
 			own   = (N - 1) * N + t;
 			nbr   = t;
-			h.lds = (N + 1) * LW + t + 2;
+			h.lds = T2::row(N + 1) + t + 2;
 		}
 		h.stride = NN;
 		h.s      = 1.0;
@@ -180,7 +200,8 @@ __device__ __forceinline__ PlaneSrc zPlaneSrc6(int kind, int src, bool top, cons
 template <int N>
 __device__ __forceinline__ HaloSrc haloSrc6(int tid, const int32_t *fk, const int32_t *fs, const double *f6, const double *ghost)
 {
-	constexpr int NN = N * N, LW = Tile2<N>::LW;
+	constexpr int NN = N * N;
+	using T2 = Tile2<N>;
 	HaloSrc       h;
 	h.p      = f6;
 	h.stride = 0;
@@ -189,7 +210,7 @@ __device__ __forceinline__ HaloSrc haloSrc6(int tid, const int32_t *fk, const in
 	if (tid < 4 * N) {
 		const int side = tid / N, t = tid % N;
 		const int kind = fk[side], src = fs[side];
-		h.lds = (side == 0) ? (t + 1) * LW + 1 : (side == 1) ? (t + 1) * LW + N + 2 : (side == 2) ? t + 2 : (N + 1) * LW + t + 2;
+		h.lds = (side == 0) ? T2::row(t + 1) + 1 : (side == 1) ? T2::row(t + 1) + N + 2 : (side == 2) ? T2::row(0) + t + 2 : T2::row(N + 1) + t + 2;
 		if (kind == FACE_LOCAL) h.p = f6 + ((size_t) src * 6 + (side ^ 1)) * NN + t, h.stride = N, h.s = 1.0;
 		if (kind == FACE_GHOST) h.p = ghost + (size_t) src * NN + t, h.stride = N, h.s = 1.0;
 	}

@@ -46,6 +46,7 @@ template <int N> struct Tile3 {
 	static constexpr int NP  = N * N / 2;           // pairs per plane
 	static constexpr int LW  = Tile2<N>::LW;
 	static constexpr int LSZ = Tile2<N>::LSZ;
+	__host__ __device__ static constexpr int row(int r) { return Tile2<N>::row(r); }
 	static_assert(4 * N <= TPB, "one halo entry per thread");
 };
 
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 {
 	static_assert(RED == RED_NONE || MODE == MODE_APPLY || MODE == MODE_RESID, "fused sums exist for apply and residual");
 	using T            = Tile3<N>;
-	constexpr int TPB  = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
+	constexpr int TPB  = T::TPB, NP = T::NP, H = T::H;
 	constexpr int NN   = N * N, NNN = N * N * N;
 	constexpr int ZL   = N / ZS; // planes per slab
 	const int nblocks  = L.count * ZS;
@@ -103,10 +104,11 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 	const bool act = (T::NT == TPB) || tid < T::NT;
 	const int  X = act ? tid % H : 0, Yp = act ? tid / H : 0;
 	int        q[2], lds[2];
+	const int  ldo[2] = {T::row(2 * Yp) + 2 * X + 2, T::row(2 * Yp + 3) + 2 * X + 2}; // the rows below / above the pair
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		q[k]   = (2 * Yp + k) * H + X;
-		lds[k] = (2 * Yp + k + 1) * LW + 2 * X + 2;
+		lds[k] = T::row(2 * Yp + k + 1) + 2 * X + 2;
 	}
 
 	// fused restriction target
@@ -189,15 +191,15 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 
 		double *tl = tile[zz & 1];
 		if (act) {
-			*reinterpret_cast<double2 *>(tl + lds[0]) = uc[0];
-			*reinterpret_cast<double2 *>(tl + lds[1]) = uc[1];
+			ldsStore2(tl + lds[0], uc[0]);
+			ldsStore2(tl + lds[1], uc[1]);
 		}
 		if (hs.lds >= 0) tl[hs.lds] = hv;
 		ldsBarrier();
 
 		// outer y-neighbours from LDS, inner ones are the other row's registers
-		const double2 ylo = *reinterpret_cast<const double2 *>(tl + lds[0] - LW);
-		const double2 yhi = *reinterpret_cast<const double2 *>(tl + lds[1] + LW);
+		const double2 ylo = ldsLoad2(tl + ldo[0]);
+		const double2 yhi = ldsLoad2(tl + ldo[1]);
 		double2       r[2];
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
@@ -428,7 +430,7 @@ __global__ void k_pack_faces_prolong3d(const int32_t *__restrict__ faces, const 
 // Relax cell CB (0: even x, 1: odd x) of row k of the plane held in `cen` (LDS copy in tl):
 // v = (sum of off-diagonal neighbours / h^2 - f) / diag. Everything about the cell's position is static.
 template <int N, int K, int CB, bool ZERO_NBRS, bool STORE = true>
-__device__ __forceinline__ void relaxCell(double *tl, const double *idiag, int cz9, const int (&lds)[2], const int (&dix)[2][2],
+__device__ __forceinline__ void relaxCell(double *tl, const double *idiag, int cz9, const int (&lds)[2], const int (&ldo)[2], const int (&dix)[2][2],
                                           bool act, double rhx, double rhy, double rhz, double2 (&cen)[2],
                                           const double2 (&below)[2], const double2 (&above)[2], const double2 (&rhs)[2])
 {
@@ -437,14 +439,13 @@ __device__ __forceinline__ void relaxCell(double *tl, const double *idiag, int c
 	// on the instantiation (ZS, PROLONG) -- the variants must stay bit-identical to each other. The two
 	// intended FMAs are explicit.
 #pragma clang fp contract(off)
-	constexpr int LW = Tile3<N>::LW;
 	const double  rh = CB ? rhs[K].y : rhs[K].x;
 	double        o  = 0.0;
 	if (!ZERO_NBRS) { // ZERO_NBRS: every neighbour is known to be 0 (first red half-sweep from a zero guess)
 		const double side  = CB ? tl[lds[K] + 2] : tl[lds[K] - 1]; // the x-neighbour outside the pair
 		const double mate  = CB ? cen[K].x : cen[K].y;
 		const double inner = CB ? cen[1 - K].y : cen[1 - K].x;                            // other row of the pair: a register
-		const double outer = (K == 0) ? tl[lds[0] - LW + CB] : tl[lds[1] + LW + CB];        // row y-1 / y+2: LDS
+		const double outer = (K == 0) ? tl[ldo[0] + CB] : tl[ldo[1] + CB];                    // row y-1 / y+2: LDS
 		const double ym = (K == 0) ? outer : inner, yp = (K == 0) ? inner : outer;
 		const double zb = CB ? below[K].y : below[K].x, za = CB ? above[K].y : above[K].x;
 		o = __builtin_fma(zb + za, rhz, __builtin_fma(ym + yp, rhy, (side + mate) * rhx));
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
                                                           double *__restrict__ out, ProlongSrc ps)
 {
 	using T           = Tile3<N>;
-	constexpr int TPB = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
+	constexpr int TPB = T::TPB, NP = T::NP, H = T::H;
 	constexpr int NN  = N * N, NNN = N * N * N;
 	constexpr int ZL  = N / ZS; // planes per slab (even)
 	static_assert(ZL % 2 == 0 && ZL >= 2, "slabs start on even planes");
@@ -530,10 +531,11 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	const bool act = (T::NT == TPB) || tid < T::NT;
 	const int  X = act ? tid % H : 0, Yp = act ? tid / H : 0;
 	int        q[2], lds[2], dix[2][2];
+	const int  ldo[2] = {T::row(2 * Yp) + 2 * X + 2, T::row(2 * Yp + 3) + 2 * X + 2}; // the rows below / above the pair
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		q[k]   = (2 * Yp + k) * H + X;
-		lds[k] = (2 * Yp + k + 1) * LW + 2 * X + 2;
+		lds[k] = T::row(2 * Yp + k + 1) + 2 * X + 2;
 	}
 	{
 		const int cy0 = (Yp == 0) ? 0 : 1, cy1 = (Yp == H - 1) ? 2 : 1;
@@ -676,8 +678,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		double *tm = tile[bz == 0 ? 2 : bz - 1];  // plane z-1
 		if (!ZERO && z < N) {
 			if (act) {
-				*reinterpret_cast<double2 *>(tz + lds[0]) = uc[0];
-				*reinterpret_cast<double2 *>(tz + lds[1]) = uc[1];
+				ldsStore2(tz + lds[0], uc[0]);
+				ldsStore2(tz + lds[1], uc[1]);
 			}
 			if (hs.lds >= 0) tz[hs.lds] = hv;
 		}
@@ -686,16 +688,16 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		if (z < N) {
 			// red cells of plane z from old black values: cell parity = (0 + k + z) & 1
 			const int cz9 = (z == 0) ? 0 : (z == N - 1 ? 18 : 9);
-			relaxCell<N, 0, (0 + ZPAR) & 1, ZERO>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, uc, um, un, fc);
-			relaxCell<N, 1, (1 + ZPAR) & 1, ZERO>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, uc, um, un, fc);
+			relaxCell<N, 0, (0 + ZPAR) & 1, ZERO>(tz, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, uc, um, un, fc);
+			relaxCell<N, 1, (1 + ZPAR) & 1, ZERO>(tz, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, uc, um, un, fc);
 		}
 		if (z > z0) { // (the plane below a slab only lends its red values: no black update, nothing stored)
 			// black cells of plane z-1: x/y neighbours = new red (LDS / registers); z neighbours = umm (new
 			// red, or the frozen bottom ghost) and uc (new red, or the frozen top ghost when z == N).
 			// plane z-1 has parity 1-ZPAR; black: (x + y + z - 1) odd -> cell parity = (1 + k + (1-ZPAR)) & 1
 			const int cz9 = (z - 1 == 0) ? 0 : (z - 1 == N - 1 ? 18 : 9);
-			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
-			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
+			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false>(tm, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
+			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false>(tm, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
 			if (act) {
 				op2[(z - 1) * NP + q[0]] = um[0];
 				op2[(z - 1) * NP + q[1]] = um[1];
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
                                                                      double *__restrict__ out, RestrictDst rd)
 {
 	using T           = Tile3<N>;
-	constexpr int TPB = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
+	constexpr int TPB = T::TPB, NP = T::NP, H = T::H;
 	constexpr int NN  = N * N, NNN = N * N * N;
 	const int     slot = xcdRemap(blockIdx.x, L.count);
 	if (slot >= L.count) return;
@@ -985,10 +987,11 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 	const bool act = (T::NT == TPB) || tid < T::NT;
 	const int  X = act ? tid % H : 0, Yp = act ? tid / H : 0;
 	int        q[2], lds[2], dix[2][2];
+	const int  ldo[2] = {T::row(2 * Yp) + 2 * X + 2, T::row(2 * Yp + 3) + 2 * X + 2}; // the rows below / above the pair
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		q[k]   = (2 * Yp + k) * H + X;
-		lds[k] = (2 * Yp + k + 1) * LW + 2 * X + 2;
+		lds[k] = T::row(2 * Yp + k + 1) + 2 * X + 2;
 	}
 	{
 		const int cy0 = (Yp == 0) ? 0 : 1, cy1 = (Yp == H - 1) ? 2 : 1;
@@ -1058,14 +1061,14 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 		ldsBarrier(); // plane z's buffer was last read (residual of plane z-4) two steps ago
 		if (z < N) { // red cells of plane z: every neighbour is zero
 			const int cz9 = (z == 0) ? 0 : (z == N - 1 ? 18 : 9);
-			relaxCell<N, 0, (0 + ZPAR) & 1, true>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, u0, u1, u1, f0);
-			relaxCell<N, 1, (1 + ZPAR) & 1, true>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, u0, u1, u1, f0);
+			relaxCell<N, 0, (0 + ZPAR) & 1, true>(tz, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, u0, u1, u1, f0);
+			relaxCell<N, 1, (1 + ZPAR) & 1, true>(tz, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, u0, u1, u1, f0);
 			// (the buffer still holds an older plane at the black cells: nobody reads them before step z+1 rewrites them)
 		}
 		if (z > 0 && z <= N) { // black cells of plane z-1 from the new red values
 			const int cz9 = (z - 1 == 0) ? 0 : (z - 1 == N - 1 ? 18 : 9);
-			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false>(t1, idiag, cz9, lds, dix, act, rhx, rhy, rhz, u1, u2, u0, f1);
-			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false>(t1, idiag, cz9, lds, dix, act, rhx, rhy, rhz, u1, u2, u0, f1);
+			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false>(t1, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, u1, u2, u0, f1);
+			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false>(t1, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, u1, u2, u0, f1);
 			if (act && STORE_U) {
 				op2[(z - 1) * NP + q[0]] = u1[0];
 				op2[(z - 1) * NP + q[1]] = u1[1];
@@ -1126,8 +1129,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 			// waves, and of plane z-1, just written by this thread's own registers) and its restriction
 			const int zr = z - 2;
 			// the black values of plane z-2 other waves wrote in the previous step are visible (barrier above)
-			const double2 ylo = *reinterpret_cast<const double2 *>(t2 + lds[0] - LW);
-			const double2 yhi = *reinterpret_cast<const double2 *>(t2 + lds[1] + LW);
+			const double2 ylo = ldsLoad2(t2 + ldo[0]);
+			const double2 yhi = ldsLoad2(t2 + ldo[1]);
 			double        a   = (zr & 1) ? racc : 0.0;
 #pragma unroll
 			for (int k = 0; k < 2; k++) {
@@ -1336,7 +1339,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 {
 	constexpr bool LDS_ALL = !(V & 1), TG_ALWAYS = !(V & 2), DEEP = (V & 4) != 0, NTL = (V & 8) != 0, NTS = (V & 16) != 0;
 	using T           = Tile3<N>;
-	constexpr int TPB = T::TPB, LW = T::LW, NP = T::NP, H = T::H;
+	constexpr int TPB = T::TPB, NP = T::NP, H = T::H;
 	constexpr int NN  = N * N, NNN = N * N * N;
 	static_assert(N >= 4, "the pipeline looks three planes ahead");
 	const int     slot = xcdRemap(blockIdx.x, L.count);
@@ -1377,10 +1380,11 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 	const bool act = (T::NT == TPB) || tid < T::NT;
 	const int  X = act ? tid % H : 0, Yp = act ? tid / H : 0;
 	int        q[2], lds[2], dix[2][2];
+	const int  ldo[2] = {T::row(2 * Yp) + 2 * X + 2, T::row(2 * Yp + 3) + 2 * X + 2}; // the rows below / above the pair
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		q[k]   = (2 * Yp + k) * H + X;
-		lds[k] = (2 * Yp + k + 1) * LW + 2 * X + 2;
+		lds[k] = T::row(2 * Yp + k + 1) + 2 * X + 2;
 	}
 	{
 		const int cy0 = (Yp == 0) ? 0 : 1, cy1 = (Yp == H - 1) ? 2 : 1;
@@ -1471,8 +1475,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 	auto fillBlack = [&](auto zpar, int z, double *tv, double2(&cen)[2], const double2(&below)[2], const double2(&above)[2],
 	                     const double2(&rhs)[2]) {
 		constexpr int ZP = decltype(zpar)::value;
-		relaxCell<N, 0, (1 + 0 + ZP) & 1, false, LDS_ALL>(tv, idiag, cz9of(z), lds, dix, act, rhx, rhy, rhz, cen, below, above, rhs);
-		relaxCell<N, 1, (1 + 1 + ZP) & 1, false, LDS_ALL>(tv, idiag, cz9of(z), lds, dix, act, rhx, rhy, rhz, cen, below, above, rhs);
+		relaxCell<N, 0, (1 + 0 + ZP) & 1, false, LDS_ALL>(tv, idiag, cz9of(z), lds, ldo, dix, act, rhx, rhy, rhz, cen, below, above, rhs);
+		relaxCell<N, 1, (1 + 1 + ZP) & 1, false, LDS_ALL>(tv, idiag, cz9of(z), lds, ldo, dix, act, rhx, rhy, rhz, cen, below, above, rhs);
 	};
 	using P0 = std::integral_constant<int, 0>;
 	using P1 = std::integral_constant<int, 1>;
@@ -1574,8 +1578,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 		double *tm = tileS[bz == 0 ? 2 : bz - 1];
 		if (z < N) {
 			if (act) {
-				*reinterpret_cast<double2 *>(tz + lds[0]) = uc[0];
-				*reinterpret_cast<double2 *>(tz + lds[1]) = uc[1];
+				ldsStore2(tz + lds[0], uc[0]);
+				ldsStore2(tz + lds[1], uc[1]);
 			}
 			if (hs.lds >= 0) tz[hs.lds] = hv;
 		}
@@ -1594,13 +1598,13 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelD
 		// the sweep itself (k_rbgs3d)
 		if (z < N) {
 			const int cz9 = cz9of(z);
-			relaxCell<N, 0, (0 + ZPAR) & 1, false>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, uc, um, un, f0);
-			relaxCell<N, 1, (1 + ZPAR) & 1, false>(tz, idiag, cz9, lds, dix, act, rhx, rhy, rhz, uc, um, un, f0);
+			relaxCell<N, 0, (0 + ZPAR) & 1, false>(tz, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, uc, um, un, f0);
+			relaxCell<N, 1, (1 + ZPAR) & 1, false>(tz, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, uc, um, un, f0);
 		}
 		if (z > 0) {
 			const int cz9 = cz9of(z - 1);
-			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false, LDS_ALL>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
-			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false, LDS_ALL>(tm, idiag, cz9, lds, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
+			relaxCell<N, 0, (1 + 0 + 1 - ZPAR) & 1, false, LDS_ALL>(tm, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
+			relaxCell<N, 1, (1 + 1 + 1 - ZPAR) & 1, false, LDS_ALL>(tm, idiag, cz9, lds, ldo, dix, act, rhx, rhy, rhz, um, umm, uc, fm);
 			if (act) {
 				stStream<NTS>(op2 + (z - 1) * NP + q[0], um[0]);
 				stStream<NTS>(op2 + (z - 1) * NP + q[1], um[1]);

@@ -21,8 +21,11 @@ ap.add_argument("--mesh", default=None)
 ap.add_argument("--divide", type=int, default=0)
 ap.add_argument("--smoother", default="rbgs")
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--lib", default=None, help="another build of the library (pressurepoissonsolver_amd.build.build_variant) instead of libte_hip.so")
 ap.add_argument("variants", nargs="*", default=[""])
 a = ap.parse_args()
+if a.lib:
+    capi.LIB_PATH = os.path.abspath(a.lib)
 n = a.patch
 if a.mesh:
     mesh = capi.Mesh.read(a.mesh, a.dim)
