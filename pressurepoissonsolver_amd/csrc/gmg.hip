@@ -242,6 +242,15 @@ struct LevelHost {
 	}
 };
 
+// A vector statement of te_bicgstab whose result is the right-hand side of the next cycle and that has not been executed:
+// kind 1: s = resid + ap * (-alpha) (BiCGStab.h:79-80); kind 2: p = beta (p + ap * (-omega)) + resid (:99-100). The first
+// kernel of the cycle that reads its right-hand side forms it (march3d.hpp FSrc) -- or, on any other path, the stand-alone
+// kernel k_bicg_s / k_bicg_p runs first (visit()).
+struct PendingRhs {
+	int    kind;
+	FSrc   args;
+	size_t n2; // double2 elements of the vectors
+};
 struct EventPair {
 	hipEvent_t a, b;
 	int        kc;
@@ -274,6 +283,7 @@ struct te_gmg {
 	void                                   *allreduce_user = nullptr;
 	// schedule check (te_gmg_verify_schedule): exchanges are recorded instead of performed
 	te_vec *bicg_work[8] = {nullptr}; // te_bicgstab's work vectors (level 0), allocated at its first call
+	const PendingRhs *pending_rhs = nullptr; // set by te_bicgstab around a cycle: level 0's right-hand side is still to be formed
 	bool recording = false;
 	bool ps2d_attr = false, ps_lds_ok = false; // dynamic-LDS attributes of the patch-solve kernels set on this solver's device
 	int  ncu = 0;
@@ -1550,7 +1560,7 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 // store_u = false (opts.fuse = 3): the new iterate is left in L.f6buf as its six face layers only
 template <int N>
 int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out, bool store_u,
-                    double *fcorr_out, const double *fcorr_in)
+                    double *fcorr_out, const double *fcorr_in, const PendingRhs *fs)
 {
 	RestrictDst rd = RestrictDst();
 	rd.parent     = L.parent.p;
@@ -1569,7 +1579,7 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 		const dim3 grid(8 * ((L.P + 7) / 8)), blk(Tile3<N>::TPB);
 		if (store_u) {
 			D.xf_out = xf_out;
-			launchT(t, (k_rbgs_zero_resid3d<N, true>), grid, blk, 0, g->stream, D, f, out, rd);
+			launchT(t, (k_rbgs_zero_resid3d<N, true>), grid, blk, 0, g->stream, D, f, out, rd, FSrc());
 		} else {
 			D.f6_out = L.f6buf.p;
 			D.fcorr  = fcorr_in;
@@ -1577,10 +1587,20 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 			const bool ah1 = g->cfg.num(O_ZR_AHEAD, 3) == 1;
 #define TE_ZR(EXP, FC)                                                                                                   \
 	if (ah1)                                                                                                             \
-		launchT(t, (k_rbgs_zero_resid3d<N, false, EXP, FC, 1>), grid, blk, 0, g->stream, D, f, out, rd);                 \
+		launchT(t, (k_rbgs_zero_resid3d<N, false, EXP, FC, 1>), grid, blk, 0, g->stream, D, f, out, rd, FSrc());         \
 	else                                                                                                                 \
-		launchT(t, (k_rbgs_zero_resid3d<N, false, EXP, FC, 3>), grid, blk, 0, g->stream, D, f, out, rd)
-			if (export_rs6 && fcorr_in) {
+		launchT(t, (k_rbgs_zero_resid3d<N, false, EXP, FC, 3>), grid, blk, 0, g->stream, D, f, out, rd, FSrc())
+			if (fs) { // the right-hand side is a pending vector statement of te_bicgstab (march3d.hpp FSrc): formed and stored here
+				const FSrc a = fs->args;
+				if (fs->kind == 1 && export_rs6)
+					launchT(t, (k_rbgs_zero_resid3d<N, false, true, false, 3, 1>), grid, blk, 0, g->stream, D, f, out, rd, a);
+				else if (fs->kind == 1)
+					launchT(t, (k_rbgs_zero_resid3d<N, false, false, false, 3, 1>), grid, blk, 0, g->stream, D, f, out, rd, a);
+				else if (export_rs6)
+					launchT(t, (k_rbgs_zero_resid3d<N, false, true, false, 3, 2>), grid, blk, 0, g->stream, D, f, out, rd, a);
+				else
+					launchT(t, (k_rbgs_zero_resid3d<N, false, false, false, 3, 2>), grid, blk, 0, g->stream, D, f, out, rd, a);
+			} else if (export_rs6 && fcorr_in) {
 				TE_ZR(true, true);
 			} else if (export_rs6) {
 				TE_ZR(true, false);
@@ -1744,14 +1764,14 @@ int interfaceResidRestrict(te_gmg *g, LevelHost &L, const double *u, const doubl
 	}
 }
 int zeroSweepResid(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out, bool store_u,
-                   double *fcorr_out = nullptr, const double *fcorr_in = nullptr)
+                   double *fcorr_out = nullptr, const double *fcorr_in = nullptr, const PendingRhs *fs = nullptr)
 {
 	if (L.dim == 2) return zeroSweepResid2d(g, L, f, out, coarse, store_u);
 	switch (L.n) {
-		case 4: return zeroSweepResidN<4>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in);
-		case 8: return zeroSweepResidN<8>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in);
-		case 16: return zeroSweepResidN<16>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in);
-		default: return zeroSweepResidN<32>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in);
+		case 4: return zeroSweepResidN<4>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in, fs);
+		case 8: return zeroSweepResidN<8>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in, fs);
+		case 16: return zeroSweepResidN<16>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in, fs);
+		default: return zeroSweepResidN<32>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in, fs);
 	}
 }
 int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false,
@@ -2141,6 +2161,26 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	g->cur_level        = l;
 	const double *fcorr_in = (L.f_has_corr && L.fcorr.p) ? L.fcorr.p : nullptr; // ghost terms that still belong to f (see below)
 	L.f_has_corr           = false;
+	// te_bicgstab may hand over a right-hand side that is still a pending vector statement (PendingRhs): the fused pre-sweep
+	// of level 0 forms it while reading its operands; every other path runs the stand-alone kernel first
+	const PendingRhs *pend = (l == 0) ? g->pending_rhs : nullptr;
+	if (l == 0) g->pending_rhs = nullptr;
+	auto formRhs = [&]() -> int {
+		if (!pend) return TE_OK;
+		const PendingRhs &r = *pend;
+		pend                = nullptr;
+		if (r.n2 == 0 || g->recording) return TE_OK;
+		Timed      t(g, KC_VECOP, r.n2 * 2);
+		const dim3 grid(gridFor(r.n2, 256, 1 << 30));
+		if (r.kind == 1)
+			hipLaunchKernelGGL(k_bicg_s, grid, dim3(256), 0, g->stream, r.n2, (double2 *) r.args.out, (const double2 *) r.args.a,
+			                   (const double2 *) r.args.b, r.args.s1);
+		else
+			hipLaunchKernelGGL(k_bicg_p, grid, dim3(256), 0, g->stream, r.n2, (double2 *) r.args.out, (const double2 *) r.args.b,
+			                   (const double2 *) r.args.c, r.args.s1, r.args.s2);
+		HIPCHK(hipGetLastError());
+		return TE_OK;
+	};
 	auto       materialise = [&]() -> int {
         if (!u_zero) return TE_OK;
         u_zero         = false;
@@ -2195,6 +2235,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		return TE_OK;
 	};
 	if (coarsest) {
+		if ((rc = formRhs())) return rc;
 		if ((rc = smooth(o->coarse_sweeps, true))) return rc;
 		return materialise();
 	}
@@ -2250,7 +2291,13 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		                        ? C.fcorr.p
 		                        : nullptr; // (the next level uniformly refined; this one may be refined: the gather forms the terms)
 		if (fcorr_in && !u_unstored) return te::fail(TE_ESTATE, "te_vcycle: exported ghost terms without a reader");
-		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p, !u_unstored, fcorr_out, fcorr_in))) return rc;
+		// (the kernel variants that form a pending right-hand side exist for the 3D path that does not store the iterate)
+		const PendingRhs *fs = (pend && u_unstored && L.dim == 3 && !fcorr_in && L.P > 0 && !g->recording) ? pend : nullptr;
+		if (fs)
+			pend = nullptr;
+		else if ((rc = formRhs()))
+			return rc;
+		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p, !u_unstored, fcorr_out, fcorr_in, fs))) return rc;
 		C.f_has_corr = fcorr_out != nullptr;
 		if (u_unstored) {
 			L.xf_valid_for = nullptr;
@@ -2262,6 +2309,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	} else if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_PATCH_SOLVE && L.fuse2_ok && L.dim == 3
 	           && !g->cfg.has(O_NO_FUSE2)) {
 		// block Jacobi from the zero iterate: the residual lives on the face layers only (interfaceResidRestrictN)
+		if ((rc = formRhs())) return rc;
 		u_zero = false;
 		// opts.fuse = 3: ... and so does everything the post-sweep reads of this iterate (its interface terms, k_face_corr3d
 		// on u + P e): the pre-sweep stores the six face layers of its result and nothing else (bit-identical; rank-local)
@@ -2273,7 +2321,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		have_coarse_f = true;
 	} else if (fcorr_in) {
 		return te::fail(TE_ESTATE, "te_vcycle: exported ghost terms without a reader");
-	} else if ((rc = smooth(o->pre_sweeps, false))) {
+	} else if ((rc = formRhs()) || (rc = smooth(o->pre_sweeps, false))) {
 		return rc;
 	}
 	next_sweeps = (o->cycle_type == 1) ? o->mid_sweeps : o->post_sweeps;
@@ -2762,9 +2810,15 @@ int te_gmg_verify_schedule(te_gmg *g, const te_cycle_opts *o)
 	return rc;
 	});
 }
+static int vcycleWith(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u, const PendingRhs *pending);
 int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u)
 {
-	return guarded([&]() -> int {
+	return guarded([&]() -> int { return vcycleWith(g, o, f, u, nullptr); });
+}
+// te_vcycle; `pending`: f is still to be formed (te_bicgstab; consumed by level 0's first reader, visit())
+static int vcycleWith(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u, const PendingRhs *pending)
+{
+	{
 	int rc;
 	if (!o) return te::fail(TE_EINVAL, "te_vcycle: null options");
 	if ((rc = checkLevelVec(g, 0, f, "te_vcycle")) || (rc = checkLevelVec(g, 0, u, "te_vcycle"))) return rc;
@@ -2777,12 +2831,14 @@ int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u)
 	}
 	if (!o->fuse && (rc = te_vec_set(u, 0.0))) return rc; // Cycle.h:118
 	for (auto &L : g->levels) L->xf_valid_for = nullptr, L->ps_faces = L->ps_faces_req = false;
-	g->in_cycle = !g->cfg.has(O_NO_XF);
-	rc          = visit(g, o, 0, f, u, o->fuse != 0);
-	g->in_cycle = false;
+	g->in_cycle    = !g->cfg.has(O_NO_XF);
+	g->pending_rhs = pending;
+	rc             = visit(g, o, 0, f, u, o->fuse != 0);
+	g->pending_rhs = nullptr;
+	g->in_cycle    = false;
 	for (auto &L : g->levels) L->xf_valid_for = nullptr, L->ps_faces = L->ps_faces_req = false;
 	return rc;
-	});
+	}
 }
 
 // BiCGStab.h:45-106, statement for statement, on device vectors. Several ranks: every scalar is summed over the
@@ -2852,11 +2908,17 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 		TE_TRY(reduce<RED_DOT>(rhat, resid, &rho, true));
 	int num_its = 0;
 	rsq         = r0sq;
+	// with a preconditioner the two vector statements whose results are right-hand sides of cycles (s, p) are left to the
+	// cycle's first reader (PendingRhs)
+	const bool defer       = fused && o != nullptr;
+	PendingRhs pend_p{};
+	bool       have_pend_p = false;
 	// Loop body = BiCGStab.h:71-104 statement for statement; the vector statements between two operator
 	// applications are fused into one kernel each (same expressions per element).
 	while (sqrt(rsq) / r0_norm > tol && num_its < max_it) {
 		const te_vec *ain = o ? mp : p;
-		if (o) TE_TRY(te_vcycle(g, o, p, mp));
+		if (o) TE_TRY(vcycleWith(g, o, p, mp, have_pend_p ? &pend_p : nullptr)); // (p = beta (p - omega ap) + resid of the previous iteration rides along)
+		have_pend_p = false;
 		if (fused) {
 			double dummy;
 			TE_TRY(applySums(ain, ap, RED_OUT_A, rhat, &tmp, &dummy));
@@ -2865,13 +2927,18 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 			TE_TRY(reduce<RED_DOT>(rhat, ap, &tmp, true));
 		}
 		const double alpha = rho / tmp;
-		if (n2 > 0) {
-			Timed t(g, KC_VECOP, x->n);
-			hipLaunchKernelGGL(k_bicg_s, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) s->d, (const double2 *) resid->d,
-			                   (const double2 *) ap->d, -alpha);
-		}
 		const te_vec *sin = o ? ms : s;
-		if (o) TE_TRY(te_vcycle(g, o, s, ms));
+		if (defer) { // s = resid - alpha ap is formed by the first kernel of the cycle that reads it (or just before it)
+			const PendingRhs ps{1, FSrc{resid->d, ap->d, nullptr, s->d, -alpha, 0.0}, n2};
+			TE_TRY(vcycleWith(g, o, s, ms, &ps));
+		} else {
+			if (n2 > 0) {
+				Timed t(g, KC_VECOP, x->n);
+				hipLaunchKernelGGL(k_bicg_s, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) s->d, (const double2 *) resid->d,
+				                   (const double2 *) ap->d, -alpha);
+			}
+			if (o) TE_TRY(te_vcycle(g, o, s, ms));
+		}
 		tmp = tmp2 = 0.0;
 		if (fused) {
 			TE_TRY(applySums(sin, as, RED_OUT_A_OUT, s, &tmp, &tmp2));
@@ -2895,7 +2962,10 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 		}
 		if (n2 > 0 || g->nranks > 1) TE_TRY(two(n2 > 0 ? rb : 0, &rho_new, &rsq));
 		const double beta = rho_new * alpha / (rho * omega);
-		if (n2 > 0) {
+		if (defer) { // p's only reader is the next iteration's cycle (ap and resid stay as they are until then)
+			pend_p      = PendingRhs{2, FSrc{p->d, ap->d, resid->d, p->d, -omega, beta}, n2};
+			have_pend_p = true;
+		} else if (n2 > 0) {
 			Timed t(g, KC_VECOP, x->n);
 			hipLaunchKernelGGL(k_bicg_p, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) p->d, (const double2 *) ap->d,
 			                   (const double2 *) resid->d, -omega, beta);

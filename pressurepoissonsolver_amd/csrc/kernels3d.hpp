@@ -678,7 +678,7 @@ __global__ __launch_bounds__(256) void k_bicg_s(size_t n2, double2 *__restrict__
 	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
 	if (i >= n2) return;
 	const double2 r = resid[i], a = ap[i];
-	s[i]            = double2{r.x + a.x * malpha, r.y + a.y * malpha};
+	s[i]            = double2{__builtin_fma(a.x, malpha, r.x), __builtin_fma(a.y, malpha, r.y)}; // (as march3d.hpp fsrcCombine<1>)
 }
 // (as . s, as . as)                      (BiCGStab.h:87)
 __global__ __launch_bounds__(256) void k_bicg_omega(size_t n2, const double2 *__restrict__ as, const double2 *__restrict__ s,
@@ -734,8 +734,8 @@ __global__ __launch_bounds__(256) void k_bicg_p(size_t n2, double2 *__restrict__
 	if (i >= n2) return;
 	double2       pv = p[i];
 	const double2 a = ap[i], r = resid[i];
-	pv.x += a.x * momega;
-	pv.y += a.y * momega;
-	p[i] = double2{beta * pv.x + r.x, beta * pv.y + r.y};
+	pv.x = __builtin_fma(a.x, momega, pv.x); // (as march3d.hpp fsrcCombine<2>)
+	pv.y = __builtin_fma(a.y, momega, pv.y);
+	p[i] = double2{__builtin_fma(beta, pv.x, r.x), __builtin_fma(beta, pv.y, r.y)};
 }
 } // namespace te

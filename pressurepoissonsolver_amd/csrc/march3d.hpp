@@ -945,10 +945,29 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 // terms in L.fcorr (it was produced that way by the finer level).
 // AH: how many planes ahead of the red update the right-hand side is requested (1: the plane of the next step only -- then
 // every step waits for a load issued one step earlier, and a step is shorter than an HBM miss under load; 3: the default).
-template <int N, bool STORE_U, bool EXPORT = false, bool FCORR = false, int AH = 3>
-__global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L, const double *__restrict__ f,
-                                                                     double *__restrict__ out, RestrictDst rd)
+// FS (te_bicgstab, level 0): the right-hand side of the cycle is itself a vector statement of the Krylov loop that nobody has
+// executed yet -- FS = 1: s = resid + ap * (-alpha) (BiCGStab.h:79-80); FS = 2: p = beta (p + ap * (-omega)) + resid (:99-100).
+// This kernel, the first reader, forms it from its operands (the expressions of k_bicg_s / k_bicg_p, explicit FMAs in both
+// places: bit-identical) and stores it once for the readers that follow (the post-sweep, the dot products): 16 / 24 B/site
+// in this pass instead of 24 / 32 in a pass of their own plus the 8 this kernel reads anyway. The operands of a plane are
+// requested at the usual distance and combined one step later (not in the step that requests them: that would wait for
+// loads just issued), so they add one raw stage to the ring of planes in flight.
+struct FSrc {
+	const double *a, *b, *c; // FS = 1: resid, ap, -; FS = 2: p, ap, resid
+	double       *out;       // s, or p (in place: every thread rewrites exactly the cells it has read)
+	double        s1, s2;    // -alpha, - ; -omega, beta
+};
+template <int FS> __device__ __forceinline__ double2 fsrcCombine(const FSrc &fs, double2 a, double2 b, double2 c)
 {
+	if (FS == 1) return double2{__builtin_fma(b.x, fs.s1, a.x), __builtin_fma(b.y, fs.s1, a.y)};
+	const double tx = __builtin_fma(b.x, fs.s1, a.x), ty = __builtin_fma(b.y, fs.s1, a.y);
+	return double2{__builtin_fma(fs.s2, tx, c.x), __builtin_fma(fs.s2, ty, c.y)};
+}
+template <int N, bool STORE_U, bool EXPORT = false, bool FCORR = false, int AH = 3, int FS = 0>
+__global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L, const double *__restrict__ f,
+                                                                     double *__restrict__ out, RestrictDst rd, FSrc fs = FSrc())
+{
+	static_assert(FS == 0 || (!FCORR && !STORE_U && AH >= 2), "the fused right-hand sides exist for the level-0 path of te_bicgstab");
 	using T           = Tile3<N>;
 	constexpr int TPB = T::TPB, NP = T::NP, H = T::H;
 	constexpr int NN  = N * N, NNN = N * N * N;
@@ -1031,19 +1050,51 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 	double2       ccx[FCorrSrc<N>::NX];      // FCORR: the x terms of plane z ...
 	double2       cca[AH][FCorrSrc<N>::NX];  // ... and of the planes in fa (added when a plane becomes f0: the add must not wait for the newest load)
 	if (FCORR) fc.init(L.fcorr, pid, X, Yp);
+	// FS: the operands of the plane requested last (plane z + AH - 1 at the start of step z), and where the combined plane goes
+	const double2 *sa2 = FS ? reinterpret_cast<const double2 *>(fs.a + (size_t) pid * NNN) : nullptr;
+	const double2 *sb2 = FS ? reinterpret_cast<const double2 *>(fs.b + (size_t) pid * NNN) : nullptr;
+	const double2 *sc2 = FS == 2 ? reinterpret_cast<const double2 *>(fs.c + (size_t) pid * NNN) : nullptr;
+	double2       *so2 = FS ? reinterpret_cast<double2 *>(fs.out + (size_t) pid * NNN) : nullptr;
+	double2        ra[2], rb[2], rc[2];
+	auto           rawLoad = [&](int z) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            ra[k] = sa2[z * NP + q[k]];
+            rb[k] = sb2[z * NP + q[k]];
+            rc[k] = FS == 2 ? sc2[z * NP + q[k]] : zero2;
+        }
+	};
+	auto rawCombineStore = [&](int z, double2(&dst)[2]) { // plane z of the right-hand side from the raw operands; stored once
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			dst[k] = fsrcCombine<FS>(fs, ra[k], rb[k], rc[k]);
+			if (act && z < N) so2[z * NP + q[k]] = dst[k];
+		}
+	};
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		u3[k] = u2[k] = u1[k] = u0[k] = zero2;
 		f2[k] = f1[k] = zero2;
-		f0[k] = fp2[q[k]];
+		if (!FS) f0[k] = fp2[q[k]];
 	}
 	if (FCORR) fc.load(0, ccx);
+	if constexpr (FS != 0) { // planes 0 .. AH-2 combined here (a one-time wait), plane AH-1 left raw for step 0
+		rawLoad(0);
+		rawCombineStore(0, f0);
 #pragma unroll
-	for (int a = 0; a + 1 < AH; a++) { // planes 1 .. AH-1 (the loop requests plane z+AH at step z)
-		const int za = (a + 1 < N) ? a + 1 : N - 1;
+		for (int a = 0; a + 2 < AH; a++) {
+			rawLoad(a + 1 < N ? a + 1 : N - 1);
+			rawCombineStore(a + 1, fa[a]);
+		}
+		rawLoad(AH - 1 < N ? AH - 1 : N - 1);
+	} else {
 #pragma unroll
-		for (int k = 0; k < 2; k++) fa[a][k] = ldStream<TE_ZR_NT != 0>(fp2 + za * NP + q[k]);
-		if (FCORR) fc.load(za, cca[a]);
+		for (int a = 0; a + 1 < AH; a++) { // planes 1 .. AH-1 (the loop requests plane z+AH at step z)
+			const int za = (a + 1 < N) ? a + 1 : N - 1;
+#pragma unroll
+			for (int k = 0; k < 2; k++) fa[a][k] = ldStream<TE_ZR_NT != 0>(fp2 + za * NP + q[k]);
+			if (FCORR) fc.load(za, cca[a]);
+		}
 	}
 	if (FCORR) fc.apply(f0, ccx);
 	__syncthreads(); // idiag and the zeroed tiles
@@ -1052,8 +1103,13 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 	auto step = [&](auto zpar, int z) {
 		constexpr int ZPAR = decltype(zpar)::value;
 		const int     zc   = (z + AH < N) ? z + AH : N - 1;
+		if constexpr (FS != 0) { // the plane requested in the previous step takes its place in the ring, the next one is requested
+			rawCombineStore(z + AH - 1, fa[AH - 2]);
+			rawLoad(zc);
+		} else {
 #pragma unroll
-		for (int k = 0; k < 2; k++) fa[AH - 1][k] = ldStream<TE_ZR_NT != 0>(fp2 + zc * NP + q[k]);
+			for (int k = 0; k < 2; k++) fa[AH - 1][k] = ldStream<TE_ZR_NT != 0>(fp2 + zc * NP + q[k]);
+		}
 		if (FCORR) fc.load(zc, cca[AH - 1]);
 		double *tz = tile[bz];            // plane z
 		double *t1 = tile[(bz + 3) & 3];  // plane z-1
@@ -1334,7 +1390,7 @@ __global__ void k_pack_faces6_3d(const int32_t *__restrict__ faces, const double
 // CFP: a refined level, as k_rbgs3d<..., CFP>: patches that copy through take their correction cell by cell from the
 // same-size coarse patch, coarse/fine ghost slots hold u + P e already (k_cf_ghost6_3d<N, true>)
 template <int N, int V = 0, bool FCORR = false, bool CFP = false>
-__global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_resweep_prolong3d(LevelDev L, const double *__restrict__ f,
+__global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_resweep_prolong3d(LevelDev L, const double *__restrict__ f,
                                                                           double *__restrict__ out, ProlongSrc ps)
 {
 	constexpr bool LDS_ALL = !(V & 1), TG_ALWAYS = !(V & 2), DEEP = (V & 4) != 0, NTL = (V & 8) != 0, NTS = (V & 16) != 0;
