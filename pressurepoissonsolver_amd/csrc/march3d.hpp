@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 	for (int i = tid; i < 4 * T::LSZ; i += TPB) (&tile[0][0])[i] = 0.0; // halo ring stays zero: ghosts of a zero iterate
 	// EXPORT: the 2x2 sums of this patch's six face layers, [6][H*H] next to the patch's other face data
 	double *const rs = EXPORT ? rd.rs6 + (size_t) pid * 6 * (H * H) : nullptr;
-	double        eW = 0.0, eE = 0.0, eS = 0.0, eN = 0.0; // sums in progress (the z pair spans two steps)
+	double        eX = 0.0, eY = 0.0; // sums in progress on this thread's x face / y face (the z pair spans two steps)
 
 	const bool act = (T::NT == TPB) || tid < T::NT;
 	const int  X = act ? tid % H : 0, Yp = act ? tid / H : 0;
@@ -1017,6 +1017,13 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 		const int cx0 = (X == 0) ? 0 : 1, cx1 = (X == H - 1) ? 2 : 1;
 		dix[0][0] = cx0 + 3 * cy0, dix[0][1] = cx1 + 3 * cy0, dix[1][0] = cx0 + 3 * cy1, dix[1][1] = cx1 + 3 * cy1;
 	}
+	// which x face (0 W, 1 E) and which y face (0 S, 1 N) this thread's cells lie on, or -1 (at most one of each: H >= 2),
+	// and where its entries of plane 0 go in the face layers / in the 2x2 sums
+	const int     xs  = !act ? -1 : (X == 0 ? 0 : (X == H - 1 ? 1 : -1)), ys = !act ? -1 : (Yp == 0 ? 0 : (Yp == H - 1 ? 1 : -1));
+	double *const xfo = STORE_U ? nullptr : L.f6_out + (size_t) pid * 6 * NN + (xs > 0 ? NN : 0) + 2 * Yp;
+	double *const yfo = STORE_U ? nullptr : L.f6_out + (size_t) pid * 6 * NN + (2 + (ys > 0 ? 1 : 0)) * NN + 2 * X;
+	double *const xrs = EXPORT ? rs + (xs > 0 ? H * H : 0) + Yp : nullptr;
+	double *const yrs = EXPORT ? rs + (2 + (ys > 0 ? 1 : 0)) * (H * H) + X : nullptr;
 	// ghost of the residual's stencil on each side, as a multiple of the cell just inside: -1 Dirichlet, +1 Neumann
 	// (StarPatchOp.h:39-65); 0 on faces with a neighbour (that term is k_restrict_fixup3d's)
 	auto phys = [&](int s) { return fk[s] == FACE_DIRICHLET ? -1.0 : (fk[s] == FACE_NEUMANN ? 1.0 : 0.0); };
@@ -1134,21 +1141,12 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 					if (X == H - 1) *reinterpret_cast<double2 *>(xo + NN) = double2{u1[0].y, u1[1].y};
 				}
 			}
-			if (act && !STORE_U) { // the six face layers only: W,E at y + N z; S,N at x + N z; B,T at x + N y
-				double   *fo = L.f6_out + (size_t) pid * 6 * NN;
-				const int zz = z - 1;
-				if (X == 0) *reinterpret_cast<double2 *>(fo + 0 * NN + N * zz + 2 * Yp) = double2{u1[0].x, u1[1].x};
-				if (X == H - 1) *reinterpret_cast<double2 *>(fo + 1 * NN + N * zz + 2 * Yp) = double2{u1[0].y, u1[1].y};
-				if (Yp == 0) *reinterpret_cast<double2 *>(fo + 2 * NN + N * zz + 2 * X) = u1[0];
-				if (Yp == H - 1) *reinterpret_cast<double2 *>(fo + 3 * NN + N * zz + 2 * X) = u1[1];
-				if (zz == 0 || zz == N - 1) {
-					double *zo = fo + (zz == 0 ? 4 : 5) * NN + 2 * X;
-					*reinterpret_cast<double2 *>(zo + N * (2 * Yp))     = u1[0];
-					*reinterpret_cast<double2 *>(zo + N * (2 * Yp + 1)) = u1[1];
-				}
-			}
-			if (EXPORT && act) { // this plane's face values as ghost terms of the neighbours' restricted residuals
-				// (k_restrict_fixup3d's sum: (w g)/8 over the 2x2 block, first face coordinate fastest)
+			if (!STORE_U || EXPORT) {
+				// The six face layers (W,E at y + N z; S,N at x + N z; B,T at x + N y) and, EXPORT, this plane's face values as
+				// ghost terms of the neighbours' restricted residuals (k_restrict_fixup3d's sum: (w g)/8 over the 2x2 block,
+				// first face coordinate fastest). A thread lies on at most one x face and one y face: one predicated region
+				// per axis serves both sides (value and address chosen per lane) and both jobs -- the kernel is bound by
+				// instruction issue, and eight separately predicated regions per plane were a sixth of its instructions.
 				const int  zz = z - 1, zh = zz >> 1;
 				const bool second = zz & 1;
 				auto       pair = [&](double &e, double a, double b, double w) { // two cells of this plane join the block's sum
@@ -1158,26 +1156,33 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
                     e = t;
 				};
 				constexpr int HH = H * H;
-				if (X == 0) { // x faces: block = rows (2Yp, 2Yp+1) x planes (zz, zz+1); entry (y, z)
-					pair(eW, u1[0].x, u1[1].x, -rhx);
-					if (second) rs[0 * HH + Yp + H * zh] = eW;
+				if (xs >= 0) { // x faces: block = rows (2Yp, 2Yp+1) x planes (zz, zz+1); entry (y, z)
+					const double2 xv = xs == 1 ? double2{u1[0].y, u1[1].y} : double2{u1[0].x, u1[1].x};
+					if (!STORE_U) *reinterpret_cast<double2 *>(xfo + N * zz) = xv;
+					if (EXPORT) {
+						pair(eX, xv.x, xv.y, -rhx);
+						if (second) xrs[H * zh] = eX;
+					}
 				}
-				if (X == H - 1) {
-					pair(eE, u1[0].y, u1[1].y, -rhx);
-					if (second) rs[1 * HH + Yp + H * zh] = eE;
+				if (ys >= 0) { // y faces: block = cells (2X, 2X+1) x planes; entry (x, z)
+					const double2 yv = ys == 1 ? u1[1] : u1[0];
+					if (!STORE_U) *reinterpret_cast<double2 *>(yfo + N * zz) = yv;
+					if (EXPORT) {
+						pair(eY, yv.x, yv.y, -rhy);
+						if (second) yrs[H * zh] = eY;
+					}
 				}
-				if (Yp == 0) { // y faces: block = cells (2X, 2X+1) x planes; entry (x, z)
-					pair(eS, u1[0].x, u1[0].y, -rhy);
-					if (second) rs[2 * HH + X + H * zh] = eS;
-				}
-				if (Yp == H - 1) {
-					pair(eN, u1[1].x, u1[1].y, -rhy);
-					if (second) rs[3 * HH + X + H * zh] = eN;
-				}
-				if (zz == 0 || zz == N - 1) { // z faces: the whole block is in this thread; entry (x, y)
-					double t = 0.0;
-					t += (-rhz * u1[0].x) / 8, t += (-rhz * u1[0].y) / 8, t += (-rhz * u1[1].x) / 8, t += (-rhz * u1[1].y) / 8;
-					rs[(zz == 0 ? 4 : 5) * HH + X + H * Yp] = t;
+				if (act && (zz == 0 || zz == N - 1)) { // z faces: the whole 2x2 block is in this thread; entry (x, y)
+					if (!STORE_U) {
+						double *zo = L.f6_out + (size_t) pid * 6 * NN + (zz == 0 ? 4 : 5) * NN + 2 * X;
+						*reinterpret_cast<double2 *>(zo + N * (2 * Yp))     = u1[0];
+						*reinterpret_cast<double2 *>(zo + N * (2 * Yp + 1)) = u1[1];
+					}
+					if (EXPORT) {
+						double t = 0.0;
+						t += (-rhz * u1[0].x) / 8, t += (-rhz * u1[0].y) / 8, t += (-rhz * u1[1].x) / 8, t += (-rhz * u1[1].y) / 8;
+						rs[(zz == 0 ? 4 : 5) * HH + X + H * Yp] = t;
+					}
 				}
 			}
 		}
