@@ -2365,53 +2365,53 @@ void te_cycle_opts_default(te_cycle_opts *o)
 int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 {
 	return guarded([&]() -> int {
-	if (!h || !out) return te::fail(TE_EINVAL, "te_gmg_create: null argument");
-	int ndev = 0;
-	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-		return te::fail(TE_EHIP, "te_gmg_create: no HIP device visible (this library has no CPU fallback)");
-	if (device < 0) HIPCHK(hipGetDevice(&device));
-	HIPCHK(hipSetDevice(device));
-	auto g    = std::make_unique<te_gmg>();
-	g->device = device;
-	g->dim    = h->h.dim;
-	g->n      = h->h.n;
-	g->rank   = h->h.rank;
-	g->nranks = h->h.nranks;
-	memset(g->calls, 0, sizeof(g->calls));
-	memset(g->cells, 0, sizeof(g->cells));
-	memset(g->total_ms, 0, sizeof(g->total_ms));
-	HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-	HIPCHK(hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking));
-	HIPCHK(hipEventCreateWithFlags(&g->ev_pack, hipEventDisableTiming));
-	HIPCHK(hipEventCreateWithFlags(&g->ev_recv, hipEventDisableTiming));
-	g->cfg.fromEnv();
-	g->overlap = !g->cfg.has(O_NO_OVERLAP);
-	int rc;
-	for (int li = 0; li < (int) h->h.levels.size(); li++)
-		if ((rc = buildLevel(g.get(), h->h, li))) return rc;
-	{ // partial sums: the reduction kernels' blocks, or one pair per work item of a stencil launch with fused sums (<= 8 slabs per patch)
-		size_t items = (size_t) g->red_blocks;
-		for (auto &L : g->levels) items = std::max(items, (size_t) L->P * (L->P <= 64 ? 8 : (L->P < 2048 ? 4 : 1)));
-		if ((rc = g->partial.alloc(2 * items)) || (rc = g->result.alloc(8))) return rc;
-	}
-	HIPCHK(hipHostMalloc((void **) &g->result_host, 8 * sizeof(double), hipHostMallocDefault));
-	for (int li = 0; li < (int) g->levels.size(); li++) {
-		LevelHost &L = *g->levels[li];
-		te_vec    *v;
-		if ((rc = newVec(g.get(), li, &v))) return rc;
-		L.r.reset(v);
-		if ((rc = newVec(g.get(), li, &v))) return rc;
-		L.t.reset(v);
-		if (li > 0) {
-			if ((rc = newVec(g.get(), li, &v))) return rc;
-			L.u.reset(v);
-			if ((rc = newVec(g.get(), li, &v))) return rc;
-			L.f.reset(v);
+		if (!h || !out) return te::fail(TE_EINVAL, "te_gmg_create: null argument");
+		int ndev = 0;
+		if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+			return te::fail(TE_EHIP, "te_gmg_create: no HIP device visible (this library has no CPU fallback)");
+		if (device < 0) HIPCHK(hipGetDevice(&device));
+		HIPCHK(hipSetDevice(device));
+		auto g    = std::make_unique<te_gmg>();
+		g->device = device;
+		g->dim    = h->h.dim;
+		g->n      = h->h.n;
+		g->rank   = h->h.rank;
+		g->nranks = h->h.nranks;
+		memset(g->calls, 0, sizeof(g->calls));
+		memset(g->cells, 0, sizeof(g->cells));
+		memset(g->total_ms, 0, sizeof(g->total_ms));
+		HIPCHK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+		HIPCHK(hipStreamCreateWithFlags(&g->comm_stream, hipStreamNonBlocking));
+		HIPCHK(hipEventCreateWithFlags(&g->ev_pack, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&g->ev_recv, hipEventDisableTiming));
+		g->cfg.fromEnv();
+		g->overlap = !g->cfg.has(O_NO_OVERLAP);
+		int rc;
+		for (int li = 0; li < (int) h->h.levels.size(); li++)
+			if ((rc = buildLevel(g.get(), h->h, li))) return rc;
+		{ // partial sums: the reduction kernels' blocks, or one pair per work item of a stencil launch with fused sums (<= 8 slabs per patch)
+			size_t items = (size_t) g->red_blocks;
+			for (auto &L : g->levels) items = std::max(items, (size_t) L->P * (L->P <= 64 ? 8 : (L->P < 2048 ? 4 : 1)));
+			if ((rc = g->partial.alloc(2 * items)) || (rc = g->result.alloc(8))) return rc;
 		}
-	}
-	HIPCHK(hipStreamSynchronize(g->stream));
-	*out = g.release();
-	return TE_OK;
+		HIPCHK(hipHostMalloc((void **) &g->result_host, 8 * sizeof(double), hipHostMallocDefault));
+		for (int li = 0; li < (int) g->levels.size(); li++) {
+			LevelHost &L = *g->levels[li];
+			te_vec    *v;
+			if ((rc = newVec(g.get(), li, &v))) return rc;
+			L.r.reset(v);
+			if ((rc = newVec(g.get(), li, &v))) return rc;
+			L.t.reset(v);
+			if (li > 0) {
+				if ((rc = newVec(g.get(), li, &v))) return rc;
+				L.u.reset(v);
+				if ((rc = newVec(g.get(), li, &v))) return rc;
+				L.f.reset(v);
+			}
+		}
+		HIPCHK(hipStreamSynchronize(g->stream));
+		*out = g.release();
+		return TE_OK;
 	});
 }
 void te_gmg_destroy(te_gmg *g)
@@ -2442,33 +2442,33 @@ int   te_gmg_num_levels(const te_gmg *g) { return guarded([&]() -> int { return 
 int   te_gmg_sync(te_gmg *g)
 {
 	return guarded([&]() -> int {
-	if (!g) return te::fail(TE_EINVAL, "te_gmg_sync: null");
-	HIPCHK(hipStreamSynchronize(g->stream));
-	return TE_OK;
+		if (!g) return te::fail(TE_EINVAL, "te_gmg_sync: null");
+		HIPCHK(hipStreamSynchronize(g->stream));
+		return TE_OK;
 	});
 }
 void *te_gmg_stream(te_gmg *g) { return g ? (void *) g->stream : nullptr; }
 int   te_gmg_set_exchange(te_gmg *g, te_exchange_fn fn, void *user)
 {
 	return guarded([&]() -> int {
-	if (!g) return te::fail(TE_EINVAL, "te_gmg_set_exchange: null");
-	if (fn && g->rccl.comm) { // an explicit callback replaces the native RCCL back-end
-		(void) g->rccl.CommDestroy(g->rccl.comm);
-		g->rccl.comm = nullptr;
-	}
-	g->exchange      = fn;
-	g->exchange_user = user;
-	if (fn) watchdogStart(g);
-	return TE_OK;
+		if (!g) return te::fail(TE_EINVAL, "te_gmg_set_exchange: null");
+		if (fn && g->rccl.comm) { // an explicit callback replaces the native RCCL back-end
+			(void) g->rccl.CommDestroy(g->rccl.comm);
+			g->rccl.comm = nullptr;
+		}
+		g->exchange      = fn;
+		g->exchange_user = user;
+		if (fn) watchdogStart(g);
+		return TE_OK;
 	});
 }
 int te_gmg_set_allreduce(te_gmg *g, te_allreduce_fn fn, void *user)
 {
 	return guarded([&]() -> int {
-	if (!g) return te::fail(TE_EINVAL, "te_gmg_set_allreduce: null");
-	g->allreduce      = fn;
-	g->allreduce_user = user;
-	return TE_OK;
+		if (!g) return te::fail(TE_EINVAL, "te_gmg_set_allreduce: null");
+		g->allreduce      = fn;
+		g->allreduce_user = user;
+		return TE_OK;
 	});
 }
 
@@ -2476,46 +2476,46 @@ static void *rcclSym(void *lib, const char *name) { return dlsym(lib, name); }
 int te_rccl_unique_id(const char *libpath, char *id128)
 {
 	return guarded([&]() -> int {
-	if (!libpath || !id128) return te::fail(TE_EINVAL, "te_rccl_unique_id: null argument");
-	void *lib = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
-	if (!lib) return te::fail(TE_EIO, std::string("te_rccl_unique_id: dlopen failed: ") + dlerror());
-	auto get = (int (*)(void *)) rcclSym(lib, "ncclGetUniqueId");
-	if (!get) return te::fail(TE_EIO, "te_rccl_unique_id: ncclGetUniqueId not found");
-	int rc = get(id128);
-	if (rc) return te::fail(TE_ESTATE, "ncclGetUniqueId failed");
-	return TE_OK;
+		if (!libpath || !id128) return te::fail(TE_EINVAL, "te_rccl_unique_id: null argument");
+		void *lib = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
+		if (!lib) return te::fail(TE_EIO, std::string("te_rccl_unique_id: dlopen failed: ") + dlerror());
+		auto get = (int (*)(void *)) rcclSym(lib, "ncclGetUniqueId");
+		if (!get) return te::fail(TE_EIO, "te_rccl_unique_id: ncclGetUniqueId not found");
+		int rc = get(id128);
+		if (rc) return te::fail(TE_ESTATE, "ncclGetUniqueId failed");
+		return TE_OK;
 	});
 }
 int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank, int nranks)
 {
 	return guarded([&]() -> int {
-	if (!g || !libpath || !id128) return te::fail(TE_EINVAL, "te_gmg_use_rccl: null argument");
-	HIPCHK(hipSetDevice(g->device));
-	void *lib = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
-	if (!lib) return te::fail(TE_EIO, std::string("te_gmg_use_rccl: dlopen failed: ") + dlerror());
-	static_assert(sizeof(ncclUniqueId) == 128, "te_rccl_unique_id hands out 128 bytes");
-	ncclUniqueId id;
-	memcpy(&id, id128, 128);
-	auto init = (int (*)(void **, int, ncclUniqueId, int)) rcclSym(lib, "ncclCommInitRank");
-	te_gmg::Rccl r;
-	r.lib            = lib;
-	r.GroupStart     = (int (*)()) rcclSym(lib, "ncclGroupStart");
-	r.GroupEnd       = (int (*)()) rcclSym(lib, "ncclGroupEnd");
-	r.Send           = (int (*)(const void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclSend");
-	r.Recv           = (int (*)(void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclRecv");
-	r.CommDestroy    = (int (*)(void *)) rcclSym(lib, "ncclCommDestroy");
-	r.AllReduce      = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclAllReduce");
-	r.GetErrorString = (const char *(*) (int) ) rcclSym(lib, "ncclGetErrorString");
-	if (!init || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.CommDestroy || !r.GetErrorString || !r.AllReduce)
-		return te::fail(TE_EIO, "te_gmg_use_rccl: RCCL symbols missing in " + std::string(libpath));
-	if (nranks > 1 && (rank != g->rank || nranks != g->nranks)) // (before the communicator exists: nothing to leak)
-		return te::fail(TE_EINVAL, "te_gmg_use_rccl: rank / nranks differ from the hierarchy's");
-	int rc = init(&r.comm, nranks, id, rank);
-	if (rc) return te::fail(TE_ESTATE, std::string("ncclCommInitRank failed: ") + r.GetErrorString(rc));
-	if (g->rccl.comm && g->rccl.CommDestroy) (void) g->rccl.CommDestroy(g->rccl.comm); // a second call replaces the first communicator
-	g->rccl = r;
-	watchdogStart(g);
-	return TE_OK;
+		if (!g || !libpath || !id128) return te::fail(TE_EINVAL, "te_gmg_use_rccl: null argument");
+		HIPCHK(hipSetDevice(g->device));
+		void *lib = dlopen(libpath, RTLD_NOW | RTLD_LOCAL);
+		if (!lib) return te::fail(TE_EIO, std::string("te_gmg_use_rccl: dlopen failed: ") + dlerror());
+		static_assert(sizeof(ncclUniqueId) == 128, "te_rccl_unique_id hands out 128 bytes");
+		ncclUniqueId id;
+		memcpy(&id, id128, 128);
+		auto init = (int (*)(void **, int, ncclUniqueId, int)) rcclSym(lib, "ncclCommInitRank");
+		te_gmg::Rccl r;
+		r.lib            = lib;
+		r.GroupStart     = (int (*)()) rcclSym(lib, "ncclGroupStart");
+		r.GroupEnd       = (int (*)()) rcclSym(lib, "ncclGroupEnd");
+		r.Send           = (int (*)(const void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclSend");
+		r.Recv           = (int (*)(void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclRecv");
+		r.CommDestroy    = (int (*)(void *)) rcclSym(lib, "ncclCommDestroy");
+		r.AllReduce      = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclAllReduce");
+		r.GetErrorString = (const char *(*) (int) ) rcclSym(lib, "ncclGetErrorString");
+		if (!init || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.CommDestroy || !r.GetErrorString || !r.AllReduce)
+			return te::fail(TE_EIO, "te_gmg_use_rccl: RCCL symbols missing in " + std::string(libpath));
+		if (nranks > 1 && (rank != g->rank || nranks != g->nranks)) // (before the communicator exists: nothing to leak)
+			return te::fail(TE_EINVAL, "te_gmg_use_rccl: rank / nranks differ from the hierarchy's");
+		int rc = init(&r.comm, nranks, id, rank);
+		if (rc) return te::fail(TE_ESTATE, std::string("ncclCommInitRank failed: ") + r.GetErrorString(rc));
+		if (g->rccl.comm && g->rccl.CommDestroy) (void) g->rccl.CommDestroy(g->rccl.comm); // a second call replaces the first communicator
+		g->rccl = r;
+		watchdogStart(g);
+		return TE_OK;
 	});
 }
 // moves n doubles from a scratch send buffer to a scratch receive buffer of level 0 through the same
@@ -2523,45 +2523,45 @@ int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank,
 int te_gmg_exchange_selftest(te_gmg *g, int n)
 {
 	return guarded([&]() -> int {
-	if (!g || n < 1) return te::fail(TE_EINVAL, "te_gmg_exchange_selftest: bad argument");
-	LevelHost &L = *g->levels[0];
-	if ((size_t) 2 * n > L.r->n) return te::fail(TE_EINVAL, "te_gmg_exchange_selftest: n too large");
-	std::vector<double> h(n), back(n);
-	for (int i = 0; i < n; i++) h[i] = 1.0 + i * 0.5;
-	double *send = L.r->d, *recv = L.r->d + n;
-	HIPCHK(hipMemcpyAsync(send, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, g->stream));
-	HIPCHK(hipMemsetAsync(recv, 0, sizeof(double) * n, g->stream));
-	ExPlan pl;
-	int    me = 0;
-	pl.peers  = {me};
-	pl.send_off = {0}, pl.send_cnt = {n}, pl.recv_off = {0}, pl.recv_cnt = {n};
-	int rc = doExchange(g, 9, pl, send, recv);
-	if (rc) return rc;
-	HIPCHK(hipMemcpyAsync(back.data(), recv, sizeof(double) * n, hipMemcpyDeviceToHost, g->stream));
-	HIPCHK(hipStreamSynchronize(g->stream));
-	for (int i = 0; i < n; i++)
-		if (back[i] != h[i]) return te::fail(TE_ESTATE, "te_gmg_exchange_selftest: data mismatch");
-	if (g->rccl.comm) { // the scalar reduction of te_bicgstab / te_gmg_verify_schedule: ncclAllReduce on the solver stream
-		const double v[4] = {1.5, -2.25, 3.0, 0.125};
-		HIPCHK(hipMemcpyAsync(g->result.p, v, sizeof v, hipMemcpyHostToDevice, g->stream));
-		int r2 = g->rccl.AllReduce(g->result.p, g->result.p, 4, ncclFloat64, ncclSum, g->rccl.comm, g->stream);
-		if (r2) return te::fail(TE_ESTATE, std::string("ncclAllReduce failed: ") + g->rccl.GetErrorString(r2));
-		HIPCHK(hipMemcpyAsync(g->result_host, g->result.p, sizeof v, hipMemcpyDeviceToHost, g->stream));
+		if (!g || n < 1) return te::fail(TE_EINVAL, "te_gmg_exchange_selftest: bad argument");
+		LevelHost &L = *g->levels[0];
+		if ((size_t) 2 * n > L.r->n) return te::fail(TE_EINVAL, "te_gmg_exchange_selftest: n too large");
+		std::vector<double> h(n), back(n);
+		for (int i = 0; i < n; i++) h[i] = 1.0 + i * 0.5;
+		double *send = L.r->d, *recv = L.r->d + n;
+		HIPCHK(hipMemcpyAsync(send, h.data(), sizeof(double) * n, hipMemcpyHostToDevice, g->stream));
+		HIPCHK(hipMemsetAsync(recv, 0, sizeof(double) * n, g->stream));
+		ExPlan pl;
+		int    me = 0;
+		pl.peers  = {me};
+		pl.send_off = {0}, pl.send_cnt = {n}, pl.recv_off = {0}, pl.recv_cnt = {n};
+		int rc = doExchange(g, 9, pl, send, recv);
+		if (rc) return rc;
+		HIPCHK(hipMemcpyAsync(back.data(), recv, sizeof(double) * n, hipMemcpyDeviceToHost, g->stream));
 		HIPCHK(hipStreamSynchronize(g->stream));
-		for (int i = 0; i < 4; i++)
-			if (g->result_host[i] != v[i] * g->nranks) return te::fail(TE_ESTATE, "te_gmg_exchange_selftest: all-reduce mismatch");
-	}
-	return TE_OK;
+		for (int i = 0; i < n; i++)
+			if (back[i] != h[i]) return te::fail(TE_ESTATE, "te_gmg_exchange_selftest: data mismatch");
+		if (g->rccl.comm) { // the scalar reduction of te_bicgstab / te_gmg_verify_schedule: ncclAllReduce on the solver stream
+			const double v[4] = {1.5, -2.25, 3.0, 0.125};
+			HIPCHK(hipMemcpyAsync(g->result.p, v, sizeof v, hipMemcpyHostToDevice, g->stream));
+			int r2 = g->rccl.AllReduce(g->result.p, g->result.p, 4, ncclFloat64, ncclSum, g->rccl.comm, g->stream);
+			if (r2) return te::fail(TE_ESTATE, std::string("ncclAllReduce failed: ") + g->rccl.GetErrorString(r2));
+			HIPCHK(hipMemcpyAsync(g->result_host, g->result.p, sizeof v, hipMemcpyDeviceToHost, g->stream));
+			HIPCHK(hipStreamSynchronize(g->stream));
+			for (int i = 0; i < 4; i++)
+				if (g->result_host[i] != v[i] * g->nranks) return te::fail(TE_ESTATE, "te_gmg_exchange_selftest: all-reduce mismatch");
+		}
+		return TE_OK;
 	});
 }
 
 int te_vec_create(te_gmg *g, int level, te_vec **out)
 {
 	return guarded([&]() -> int {
-	if (!g || !out || level < 0 || level >= (int) g->levels.size())
-		return te::fail(TE_EINVAL, "te_vec_create: bad argument");
-	HIPCHK(hipSetDevice(g->device));
-	return newVec(g, level, out);
+		if (!g || !out || level < 0 || level >= (int) g->levels.size())
+			return te::fail(TE_EINVAL, "te_vec_create: bad argument");
+		HIPCHK(hipSetDevice(g->device));
+		return newVec(g, level, out);
 	});
 }
 void te_vec_destroy(te_vec *v)
@@ -2575,19 +2575,19 @@ size_t te_vec_size(const te_vec *v) { return v ? v->n : 0; }
 int    te_vec_upload(te_vec *v, const double *host)
 {
 	return guarded([&]() -> int {
-	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_upload: null");
-	HIPCHK(hipMemcpyAsync(v->d, host, sizeof(double) * v->n, hipMemcpyHostToDevice, v->g->stream));
-	HIPCHK(hipStreamSynchronize(v->g->stream));
-	return TE_OK;
+		if (!v || !host) return te::fail(TE_EINVAL, "te_vec_upload: null");
+		HIPCHK(hipMemcpyAsync(v->d, host, sizeof(double) * v->n, hipMemcpyHostToDevice, v->g->stream));
+		HIPCHK(hipStreamSynchronize(v->g->stream));
+		return TE_OK;
 	});
 }
 int te_vec_download(const te_vec *v, double *host)
 {
 	return guarded([&]() -> int {
-	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_download: null");
-	HIPCHK(hipMemcpyAsync(host, v->d, sizeof(double) * v->n, hipMemcpyDeviceToHost, v->g->stream));
-	HIPCHK(hipStreamSynchronize(v->g->stream));
-	return TE_OK;
+		if (!v || !host) return te::fail(TE_EINVAL, "te_vec_download: null");
+		HIPCHK(hipMemcpyAsync(host, v->d, sizeof(double) * v->n, hipMemcpyDeviceToHost, v->g->stream));
+		HIPCHK(hipStreamSynchronize(v->g->stream));
+		return TE_OK;
 	});
 }
 void *te_vec_device_ptr(te_vec *v) { return v ? v->d : nullptr; }
@@ -2601,20 +2601,20 @@ int te_vec_add_scaled(te_vec *v, double a, const te_vec *b) { return guarded([&]
 int te_vec_add_scaled2(te_vec *v, double alpha, const te_vec *a, double beta, const te_vec *b)
 {
 	return guarded([&]() -> int {
-	return vecop<VOP_ADD_SCALED2>(v, a, b, alpha, beta, 0);
+		return vecop<VOP_ADD_SCALED2>(v, a, b, alpha, beta, 0);
 	});
 }
 int te_vec_scale_then_add(te_vec *v, double a, const te_vec *b) { return guarded([&]() -> int { return vecop<VOP_SCALE_THEN_ADD>(v, b, nullptr, a, 0, 0); }); }
 int te_vec_scale_then_add_scaled(te_vec *v, double a, double be, const te_vec *b)
 {
 	return guarded([&]() -> int {
-	return vecop<VOP_SCALE_THEN_ADD_SCALED>(v, b, nullptr, a, be, 0);
+		return vecop<VOP_SCALE_THEN_ADD_SCALED>(v, b, nullptr, a, be, 0);
 	});
 }
 int te_vec_scale_then_add_scaled2(te_vec *v, double a, double be, const te_vec *b, double ga, const te_vec *c)
 {
 	return guarded([&]() -> int {
-	return vecop<VOP_SCALE_THEN_ADD_SCALED2>(v, b, c, a, be, ga);
+		return vecop<VOP_SCALE_THEN_ADD_SCALED2>(v, b, c, a, be, ga);
 	});
 }
 int te_vec_two_norm_sq(const te_vec *v, double *out) { return guarded([&]() -> int { return reduce<RED_SUMSQ>(v, nullptr, out); }); }
@@ -2630,76 +2630,76 @@ static int checkLevelVec(te_gmg *g, int level, const te_vec *v, const char *who)
 int te_apply(te_gmg *g, int level, const te_vec *u, te_vec *f)
 {
 	return guarded([&]() -> int {
-	int rc;
-	if ((rc = checkLevelVec(g, level, u, "te_apply")) || (rc = checkLevelVec(g, level, f, "te_apply"))) return rc;
-	if (u == f) return te::fail(TE_EINVAL, "te_apply: in-place apply is not supported");
-	return launchStencil<MODE_APPLY>(g, *g->levels[level], u->d, nullptr, f->d, 0.0);
+		int rc;
+		if ((rc = checkLevelVec(g, level, u, "te_apply")) || (rc = checkLevelVec(g, level, f, "te_apply"))) return rc;
+		if (u == f) return te::fail(TE_EINVAL, "te_apply: in-place apply is not supported");
+		return launchStencil<MODE_APPLY>(g, *g->levels[level], u->d, nullptr, f->d, 0.0);
 	});
 }
 int te_residual(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *r)
 {
 	return guarded([&]() -> int {
-	int rc;
-	if ((rc = checkLevelVec(g, level, u, "te_residual")) || (rc = checkLevelVec(g, level, f, "te_residual"))
-	    || (rc = checkLevelVec(g, level, r, "te_residual")))
-		return rc;
-	if (u == r) return te::fail(TE_EINVAL, "te_residual: r must not alias u");
-	return launchStencil<MODE_RESID>(g, *g->levels[level], u->d, f->d, r->d, 0.0);
+		int rc;
+		if ((rc = checkLevelVec(g, level, u, "te_residual")) || (rc = checkLevelVec(g, level, f, "te_residual"))
+		    || (rc = checkLevelVec(g, level, r, "te_residual")))
+			return rc;
+		if (u == r) return te::fail(TE_EINVAL, "te_residual: r must not alias u");
+		return launchStencil<MODE_RESID>(g, *g->levels[level], u->d, f->d, r->d, 0.0);
 	});
 }
 int te_residual_norm_sq(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *r, double *norm_sq)
 {
 	return guarded([&]() -> int {
-	int rc;
-	if (!norm_sq) return te::fail(TE_EINVAL, "te_residual_norm_sq: null result");
-	if ((rc = checkLevelVec(g, level, u, "te_residual_norm_sq")) || (rc = checkLevelVec(g, level, f, "te_residual_norm_sq"))
-	    || (rc = checkLevelVec(g, level, r, "te_residual_norm_sq")))
-		return rc;
-	if (u == r) return te::fail(TE_EINVAL, "te_residual_norm_sq: r must not alias u");
-	LevelHost &L = *g->levels[level];
-	if (L.dim == 2) { // (2D: the residual kernel, then the reduction pass)
-		if ((rc = launchStencil<MODE_RESID>(g, L, u->d, f->d, r->d, 0.0))) return rc;
-		return reduce<RED_SUMSQ>(r, nullptr, norm_sq);
-	}
-	int items = 0;
-	if ((rc = launchStencil<MODE_RESID>(g, L, u->d, f->d, r->d, 0.0, RestrictDst(), nullptr, RED_OUT_OUT, nullptr, &items))) return rc;
-	if (items > 0)
-		hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(256), 0, g->stream, items, g->partial.p, g->result.p);
-	else
-		HIPCHK(hipMemsetAsync(g->result.p, 0, 2 * sizeof(double), g->stream));
-	if ((rc = finishReduce(g, 1, 0, false))) return rc;
-	*norm_sq = g->result_host[0];
-	return TE_OK;
+		int rc;
+		if (!norm_sq) return te::fail(TE_EINVAL, "te_residual_norm_sq: null result");
+		if ((rc = checkLevelVec(g, level, u, "te_residual_norm_sq")) || (rc = checkLevelVec(g, level, f, "te_residual_norm_sq"))
+		    || (rc = checkLevelVec(g, level, r, "te_residual_norm_sq")))
+			return rc;
+		if (u == r) return te::fail(TE_EINVAL, "te_residual_norm_sq: r must not alias u");
+		LevelHost &L = *g->levels[level];
+		if (L.dim == 2) { // (2D: the residual kernel, then the reduction pass)
+			if ((rc = launchStencil<MODE_RESID>(g, L, u->d, f->d, r->d, 0.0))) return rc;
+			return reduce<RED_SUMSQ>(r, nullptr, norm_sq);
+		}
+		int items = 0;
+		if ((rc = launchStencil<MODE_RESID>(g, L, u->d, f->d, r->d, 0.0, RestrictDst(), nullptr, RED_OUT_OUT, nullptr, &items))) return rc;
+		if (items > 0)
+			hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(256), 0, g->stream, items, g->partial.p, g->result.p);
+		else
+			HIPCHK(hipMemsetAsync(g->result.p, 0, 2 * sizeof(double), g->stream));
+		if ((rc = finishReduce(g, 1, 0, false))) return rc;
+		*norm_sq = g->result_host[0];
+		return TE_OK;
 	});
 }
 int te_smooth(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega, int sweeps)
 {
 	return guarded([&]() -> int {
-	int rc;
-	if ((rc = checkLevelVec(g, level, u, "te_smooth")) || (rc = checkLevelVec(g, level, f, "te_smooth"))) return rc;
-	for (int i = 0; i < sweeps; i++)
-		if ((rc = smoothOnce(g, level, f, u, smoother, omega))) return rc;
-	return TE_OK;
+		int rc;
+		if ((rc = checkLevelVec(g, level, u, "te_smooth")) || (rc = checkLevelVec(g, level, f, "te_smooth"))) return rc;
+		for (int i = 0; i < sweeps; i++)
+			if ((rc = smoothOnce(g, level, f, u, smoother, omega))) return rc;
+		return TE_OK;
 	});
 }
 int te_restrict(te_gmg *g, int fine_level, const te_vec *fine, te_vec *coarse)
 {
 	return guarded([&]() -> int {
-	int rc;
-	if ((rc = checkLevelVec(g, fine_level, fine, "te_restrict"))
-	    || (rc = checkLevelVec(g, fine_level + 1, coarse, "te_restrict")))
-		return rc;
-	return doRestrict(g, fine_level, fine->d, coarse->d);
+		int rc;
+		if ((rc = checkLevelVec(g, fine_level, fine, "te_restrict"))
+		    || (rc = checkLevelVec(g, fine_level + 1, coarse, "te_restrict")))
+			return rc;
+		return doRestrict(g, fine_level, fine->d, coarse->d);
 	});
 }
 int te_prolong_add(te_gmg *g, int fine_level, const te_vec *coarse, te_vec *fine)
 {
 	return guarded([&]() -> int {
-	int rc;
-	if ((rc = checkLevelVec(g, fine_level, fine, "te_prolong_add"))
-	    || (rc = checkLevelVec(g, fine_level + 1, coarse, "te_prolong_add")))
-		return rc;
-	return doProlong(g, fine_level, coarse->d, fine->d);
+		int rc;
+		if ((rc = checkLevelVec(g, fine_level, fine, "te_prolong_add"))
+		    || (rc = checkLevelVec(g, fine_level + 1, coarse, "te_prolong_add")))
+			return rc;
+		return doProlong(g, fine_level, coarse->d, fine->d);
 	});
 }
 
@@ -2804,10 +2804,10 @@ static uint64_t optsKey(const te_cycle_opts *o)
 int te_gmg_verify_schedule(te_gmg *g, const te_cycle_opts *o)
 {
 	return guarded([&]() -> int {
-	if (!g || !o) return te::fail(TE_EINVAL, "te_gmg_verify_schedule: null argument");
-	int rc = verifySchedule(g, o);
-	if (rc == TE_OK) g->verified_opts.insert(optsKey(o));
-	return rc;
+		if (!g || !o) return te::fail(TE_EINVAL, "te_gmg_verify_schedule: null argument");
+		int rc = verifySchedule(g, o);
+		if (rc == TE_OK) g->verified_opts.insert(optsKey(o));
+		return rc;
 	});
 }
 static int vcycleWith(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u, const PendingRhs *pending);
@@ -2848,135 +2848,135 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
                 int *iterations, double *rel_resid)
 {
 	return guarded([&]() -> int {
-	int rc;
-	if ((rc = checkLevelVec(g, 0, x, "te_bicgstab")) || (rc = checkLevelVec(g, 0, b, "te_bicgstab"))) return rc;
-	if (g->nranks > 1 && !g->rccl.comm && !g->allreduce)
-		return te::fail(TE_ESTATE, "te_bicgstab on a sharded hierarchy needs te_gmg_use_rccl or te_gmg_set_allreduce");
-	// the eight work vectors stay with the solver (a driver solves again and again: allocating and freeing 8 GiB at 512^3
-	// cost 2.5 ms per solve); released in te_gmg_destroy
-	te_vec **w   = g->bicg_work;
-	auto    done = [&](int code) { return code; };
-	for (int i = 0; i < 8; i++)
-		if (!w[i] && (rc = newVec(g, 0, &w[i]))) return rc;
-	te_vec *resid = w[0], *ms = w[1], *mp = w[2], *rhat = w[3], *p = w[4], *ap = w[5], *as = w[6], *s = w[7];
-	double r0sq, rsq, rho, tmp, tmp2;
+		int rc;
+		if ((rc = checkLevelVec(g, 0, x, "te_bicgstab")) || (rc = checkLevelVec(g, 0, b, "te_bicgstab"))) return rc;
+		if (g->nranks > 1 && !g->rccl.comm && !g->allreduce)
+			return te::fail(TE_ESTATE, "te_bicgstab on a sharded hierarchy needs te_gmg_use_rccl or te_gmg_set_allreduce");
+		// the eight work vectors stay with the solver (a driver solves again and again: allocating and freeing 8 GiB at 512^3
+		// cost 2.5 ms per solve); released in te_gmg_destroy
+		te_vec **w   = g->bicg_work;
+		auto    done = [&](int code) { return code; };
+		for (int i = 0; i < 8; i++)
+			if (!w[i] && (rc = newVec(g, 0, &w[i]))) return rc;
+		te_vec *resid = w[0], *ms = w[1], *mp = w[2], *rhat = w[3], *p = w[4], *ap = w[5], *as = w[6], *s = w[7];
+		double r0sq, rsq, rho, tmp, tmp2;
 #define TE_TRY(x)                \
-	if ((rc = (x))) return done(rc)
-	// The dot products that follow an operator application (BiCGStab.h:73-74, 85-87) and the norm of the first residual
-	// (:57-60) are formed by the stencil kernel itself while its result is in registers (k_stencil3d RED, 3D; fixed
-	// summation order per launch geometry): 16 B/site per dot that a separate pass over stored vectors would read.
-	// TE_NO_BICG_FUSE: the separate passes (k_reduce / k_bicg_omega), as before round 3.
-	const bool   fused = g->dim == 3 && !g->cfg.has(O_NO_BICG_FUSE);
-	LevelHost   &L0    = *g->levels[0];
-	const size_t n2    = x->n / 2;
-	const int    fat   = gridFor(n2, 256, 1 << 30), rb = gridFor(n2, 256, g->red_blocks / 2);
-	auto         two   = [&](int nparts, double *a, double *b2) -> int { // fixed-order sum of the per-block pairs -> all ranks -> host
-        if (nparts > 0)
-            hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(256), 0, g->stream, nparts, g->partial.p, g->result.p);
-        else
-            HIPCHK(hipMemsetAsync(g->result.p, 0, 2 * sizeof(double), g->stream));
-        int r2 = finishReduce(g, 2, 0, true);
-        if (r2) return r2;
-        *a  = g->result_host[0];
-        *b2 = g->result_host[1];
-        return TE_OK;
-	};
-	// out = A in together with the sums `redmode` asks for (second operand a)
-	auto applySums = [&](const te_vec *in, te_vec *outv, int redmode, const te_vec *a, double *s0, double *s1) -> int {
-		if (L0.xf_valid_for == outv->d) L0.xf_valid_for = nullptr;
-		int items = 0;
-		int r2    = launchStencil<MODE_APPLY>(g, L0, in->d, nullptr, outv->d, 0.0, RestrictDst(), nullptr, redmode, a->d, &items);
-		if (r2) return r2;
-		return two(items, s0, s1);
-	};
-	if (fused) {
-		int    items = 0;
-		double dummy;
-		TE_TRY(launchStencil<MODE_RESID>(g, L0, x->d, b->d, resid->d, 0.0, RestrictDst(), nullptr, RED_OUT_OUT, nullptr, &items));
-		TE_TRY(two(items, &r0sq, &dummy));
-	} else {
-		TE_TRY(te_apply(g, 0, x, resid));
-		TE_TRY(te_vec_scale_then_add(resid, -1, b));
-		TE_TRY(reduce<RED_SUMSQ>(resid, nullptr, &r0sq, true));
-	}
-	const double r0_norm = sqrt(r0sq);
-	TE_TRY(te_vec_copy(rhat, resid));
-	TE_TRY(te_vec_copy(p, resid));
-	if (fused)
-		rho = r0sq; // rhat == resid at this point: the dot product is the sum of the same squares as the norm above
-	else
-		TE_TRY(reduce<RED_DOT>(rhat, resid, &rho, true));
-	int num_its = 0;
-	rsq         = r0sq;
-	// with a preconditioner the two vector statements whose results are right-hand sides of cycles (s, p) are left to the
-	// cycle's first reader (PendingRhs)
-	const bool defer       = fused && o != nullptr;
-	PendingRhs pend_p{};
-	bool       have_pend_p = false;
-	// Loop body = BiCGStab.h:71-104 statement for statement; the vector statements between two operator
-	// applications are fused into one kernel each (same expressions per element).
-	while (sqrt(rsq) / r0_norm > tol && num_its < max_it) {
-		const te_vec *ain = o ? mp : p;
-		if (o) TE_TRY(vcycleWith(g, o, p, mp, have_pend_p ? &pend_p : nullptr)); // (p = beta (p - omega ap) + resid of the previous iteration rides along)
-		have_pend_p = false;
+		if ((rc = (x))) return done(rc)
+		// The dot products that follow an operator application (BiCGStab.h:73-74, 85-87) and the norm of the first residual
+		// (:57-60) are formed by the stencil kernel itself while its result is in registers (k_stencil3d RED, 3D; fixed
+		// summation order per launch geometry): 16 B/site per dot that a separate pass over stored vectors would read.
+		// TE_NO_BICG_FUSE: the separate passes (k_reduce / k_bicg_omega), as before round 3.
+		const bool   fused = g->dim == 3 && !g->cfg.has(O_NO_BICG_FUSE);
+		LevelHost   &L0    = *g->levels[0];
+		const size_t n2    = x->n / 2;
+		const int    fat   = gridFor(n2, 256, 1 << 30), rb = gridFor(n2, 256, g->red_blocks / 2);
+		auto         two   = [&](int nparts, double *a, double *b2) -> int { // fixed-order sum of the per-block pairs -> all ranks -> host
+	        if (nparts > 0)
+	            hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(256), 0, g->stream, nparts, g->partial.p, g->result.p);
+	        else
+	            HIPCHK(hipMemsetAsync(g->result.p, 0, 2 * sizeof(double), g->stream));
+	        int r2 = finishReduce(g, 2, 0, true);
+	        if (r2) return r2;
+	        *a  = g->result_host[0];
+	        *b2 = g->result_host[1];
+	        return TE_OK;
+		};
+		// out = A in together with the sums `redmode` asks for (second operand a)
+		auto applySums = [&](const te_vec *in, te_vec *outv, int redmode, const te_vec *a, double *s0, double *s1) -> int {
+			if (L0.xf_valid_for == outv->d) L0.xf_valid_for = nullptr;
+			int items = 0;
+			int r2    = launchStencil<MODE_APPLY>(g, L0, in->d, nullptr, outv->d, 0.0, RestrictDst(), nullptr, redmode, a->d, &items);
+			if (r2) return r2;
+			return two(items, s0, s1);
+		};
 		if (fused) {
+			int    items = 0;
 			double dummy;
-			TE_TRY(applySums(ain, ap, RED_OUT_A, rhat, &tmp, &dummy));
+			TE_TRY(launchStencil<MODE_RESID>(g, L0, x->d, b->d, resid->d, 0.0, RestrictDst(), nullptr, RED_OUT_OUT, nullptr, &items));
+			TE_TRY(two(items, &r0sq, &dummy));
 		} else {
-			TE_TRY(te_apply(g, 0, ain, ap));
-			TE_TRY(reduce<RED_DOT>(rhat, ap, &tmp, true));
+			TE_TRY(te_apply(g, 0, x, resid));
+			TE_TRY(te_vec_scale_then_add(resid, -1, b));
+			TE_TRY(reduce<RED_SUMSQ>(resid, nullptr, &r0sq, true));
 		}
-		const double alpha = rho / tmp;
-		const te_vec *sin = o ? ms : s;
-		if (defer) { // s = resid - alpha ap is formed by the first kernel of the cycle that reads it (or just before it)
-			const PendingRhs ps{1, FSrc{resid->d, ap->d, nullptr, s->d, -alpha, 0.0}, n2};
-			TE_TRY(vcycleWith(g, o, s, ms, &ps));
-		} else {
+		const double r0_norm = sqrt(r0sq);
+		TE_TRY(te_vec_copy(rhat, resid));
+		TE_TRY(te_vec_copy(p, resid));
+		if (fused)
+			rho = r0sq; // rhat == resid at this point: the dot product is the sum of the same squares as the norm above
+		else
+			TE_TRY(reduce<RED_DOT>(rhat, resid, &rho, true));
+		int num_its = 0;
+		rsq         = r0sq;
+		// with a preconditioner the two vector statements whose results are right-hand sides of cycles (s, p) are left to the
+		// cycle's first reader (PendingRhs)
+		const bool defer       = fused && o != nullptr;
+		PendingRhs pend_p{};
+		bool       have_pend_p = false;
+		// Loop body = BiCGStab.h:71-104 statement for statement; the vector statements between two operator
+		// applications are fused into one kernel each (same expressions per element).
+		while (sqrt(rsq) / r0_norm > tol && num_its < max_it) {
+			const te_vec *ain = o ? mp : p;
+			if (o) TE_TRY(vcycleWith(g, o, p, mp, have_pend_p ? &pend_p : nullptr)); // (p = beta (p - omega ap) + resid of the previous iteration rides along)
+			have_pend_p = false;
+			if (fused) {
+				double dummy;
+				TE_TRY(applySums(ain, ap, RED_OUT_A, rhat, &tmp, &dummy));
+			} else {
+				TE_TRY(te_apply(g, 0, ain, ap));
+				TE_TRY(reduce<RED_DOT>(rhat, ap, &tmp, true));
+			}
+			const double alpha = rho / tmp;
+			const te_vec *sin = o ? ms : s;
+			if (defer) { // s = resid - alpha ap is formed by the first kernel of the cycle that reads it (or just before it)
+				const PendingRhs ps{1, FSrc{resid->d, ap->d, nullptr, s->d, -alpha, 0.0}, n2};
+				TE_TRY(vcycleWith(g, o, s, ms, &ps));
+			} else {
+				if (n2 > 0) {
+					Timed t(g, KC_VECOP, x->n);
+					hipLaunchKernelGGL(k_bicg_s, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) s->d, (const double2 *) resid->d,
+					                   (const double2 *) ap->d, -alpha);
+				}
+				if (o) TE_TRY(te_vcycle(g, o, s, ms));
+			}
+			tmp = tmp2 = 0.0;
+			if (fused) {
+				TE_TRY(applySums(sin, as, RED_OUT_A_OUT, s, &tmp, &tmp2));
+			} else {
+				TE_TRY(te_apply(g, 0, sin, as));
+				if (n2 > 0) {
+					Timed t(g, KC_REDUCE, x->n);
+					hipLaunchKernelGGL(k_bicg_omega, dim3(rb), dim3(256), 0, g->stream, n2, (const double2 *) as->d,
+					                   (const double2 *) s->d, g->partial.p);
+				}
+				if (n2 > 0 || g->nranks > 1) TE_TRY(two(n2 > 0 ? rb : 0, &tmp, &tmp2));
+			}
+			const double   omega = tmp / tmp2;
+			const te_vec *dp = o ? mp : p, *ds = o ? ms : s;
+			double         rho_new = 0.0;
 			if (n2 > 0) {
 				Timed t(g, KC_VECOP, x->n);
-				hipLaunchKernelGGL(k_bicg_s, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) s->d, (const double2 *) resid->d,
-				                   (const double2 *) ap->d, -alpha);
+				hipLaunchKernelGGL(k_bicg_update, dim3(rb), dim3(256), 0, g->stream, n2, (double2 *) x->d, (double2 *) resid->d,
+				                   (const double2 *) dp->d, (const double2 *) ds->d, (const double2 *) ap->d,
+				                   (const double2 *) as->d, (const double2 *) rhat->d, alpha, omega, g->partial.p);
 			}
-			if (o) TE_TRY(te_vcycle(g, o, s, ms));
-		}
-		tmp = tmp2 = 0.0;
-		if (fused) {
-			TE_TRY(applySums(sin, as, RED_OUT_A_OUT, s, &tmp, &tmp2));
-		} else {
-			TE_TRY(te_apply(g, 0, sin, as));
-			if (n2 > 0) {
-				Timed t(g, KC_REDUCE, x->n);
-				hipLaunchKernelGGL(k_bicg_omega, dim3(rb), dim3(256), 0, g->stream, n2, (const double2 *) as->d,
-				                   (const double2 *) s->d, g->partial.p);
+			if (n2 > 0 || g->nranks > 1) TE_TRY(two(n2 > 0 ? rb : 0, &rho_new, &rsq));
+			const double beta = rho_new * alpha / (rho * omega);
+			if (defer) { // p's only reader is the next iteration's cycle (ap and resid stay as they are until then)
+				pend_p      = PendingRhs{2, FSrc{p->d, ap->d, resid->d, p->d, -omega, beta}, n2};
+				have_pend_p = true;
+			} else if (n2 > 0) {
+				Timed t(g, KC_VECOP, x->n);
+				hipLaunchKernelGGL(k_bicg_p, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) p->d, (const double2 *) ap->d,
+				                   (const double2 *) resid->d, -omega, beta);
 			}
-			if (n2 > 0 || g->nranks > 1) TE_TRY(two(n2 > 0 ? rb : 0, &tmp, &tmp2));
+			num_its++;
+			rho = rho_new;
 		}
-		const double   omega = tmp / tmp2;
-		const te_vec *dp = o ? mp : p, *ds = o ? ms : s;
-		double         rho_new = 0.0;
-		if (n2 > 0) {
-			Timed t(g, KC_VECOP, x->n);
-			hipLaunchKernelGGL(k_bicg_update, dim3(rb), dim3(256), 0, g->stream, n2, (double2 *) x->d, (double2 *) resid->d,
-			                   (const double2 *) dp->d, (const double2 *) ds->d, (const double2 *) ap->d,
-			                   (const double2 *) as->d, (const double2 *) rhat->d, alpha, omega, g->partial.p);
-		}
-		if (n2 > 0 || g->nranks > 1) TE_TRY(two(n2 > 0 ? rb : 0, &rho_new, &rsq));
-		const double beta = rho_new * alpha / (rho * omega);
-		if (defer) { // p's only reader is the next iteration's cycle (ap and resid stay as they are until then)
-			pend_p      = PendingRhs{2, FSrc{p->d, ap->d, resid->d, p->d, -omega, beta}, n2};
-			have_pend_p = true;
-		} else if (n2 > 0) {
-			Timed t(g, KC_VECOP, x->n);
-			hipLaunchKernelGGL(k_bicg_p, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) p->d, (const double2 *) ap->d,
-			                   (const double2 *) resid->d, -omega, beta);
-		}
-		num_its++;
-		rho = rho_new;
-	}
 #undef TE_TRY
-	if (iterations) *iterations = num_its;
-	if (rel_resid) *rel_resid = sqrt(rsq) / r0_norm;
-	return done(TE_OK);
+		if (iterations) *iterations = num_its;
+		if (rel_resid) *rel_resid = sqrt(rsq) / r0_norm;
+		return done(TE_OK);
 	});
 }
 
@@ -2984,44 +2984,44 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 int te_init_problem(te_gmg *g, int level, int problem, int neumann, te_vec *f, te_vec *exact)
 {
 	return guarded([&]() -> int {
-	int rc;
-	if ((rc = checkLevelVec(g, level, f, "te_init_problem"))) return rc;
-	if (exact && (rc = checkLevelVec(g, level, exact, "te_init_problem"))) return rc;
-	if (exact == f) return te::fail(TE_EINVAL, "te_init_problem: f and exact must be different vectors");
-	LevelHost &L = *g->levels[level];
-	if (L.xf_valid_for == f->d || (exact && L.xf_valid_for == exact->d)) L.xf_valid_for = nullptr;
-	if (L.P == 0) return TE_OK;
-	InitGeom G;
-	G.dim = L.dim, G.n = L.n, G.P = L.P;
-	G.starts = L.geom_starts.p, G.h = L.geom_h.p, G.face_kind = L.face_kind.p, G.ids = L.node_ids.p;
-	const dim3 grid(gridFor(f->n, 256, 1 << 20)), blk(256);
-	double    *e = exact ? exact->d : nullptr;
-	Timed      t(g, KC_VECOP, f->n);
+		int rc;
+		if ((rc = checkLevelVec(g, level, f, "te_init_problem"))) return rc;
+		if (exact && (rc = checkLevelVec(g, level, exact, "te_init_problem"))) return rc;
+		if (exact == f) return te::fail(TE_EINVAL, "te_init_problem: f and exact must be different vectors");
+		LevelHost &L = *g->levels[level];
+		if (L.xf_valid_for == f->d || (exact && L.xf_valid_for == exact->d)) L.xf_valid_for = nullptr;
+		if (L.P == 0) return TE_OK;
+		InitGeom G;
+		G.dim = L.dim, G.n = L.n, G.P = L.P;
+		G.starts = L.geom_starts.p, G.h = L.geom_h.p, G.face_kind = L.face_kind.p, G.ids = L.node_ids.p;
+		const dim3 grid(gridFor(f->n, 256, 1 << 20)), blk(256);
+		double    *e = exact ? exact->d : nullptr;
+		Timed      t(g, KC_VECOP, f->n);
 #define TE_INIT(K, PROB)                                                                              \
-	if (neumann)                                                                                      \
-		hipLaunchKernelGGL((K<PROB, true>), grid, blk, 0, g->stream, G, f->d, e);                     \
-	else                                                                                              \
-		hipLaunchKernelGGL((K<PROB, false>), grid, blk, 0, g->stream, G, f->d, e);
-	if (problem == PROBLEM_RANDOM) {
-		hipLaunchKernelGGL(k_init_random, grid, blk, 0, g->stream, G, L.nc, (uint64_t) 0x5EED, f->d, e);
-	} else if (problem == PROBLEM_TRIG) {
-		if (L.dim == 3) {
-			TE_INIT(k_init3d, PROBLEM_TRIG)
+		if (neumann)                                                                                      \
+			hipLaunchKernelGGL((K<PROB, true>), grid, blk, 0, g->stream, G, f->d, e);                     \
+		else                                                                                              \
+			hipLaunchKernelGGL((K<PROB, false>), grid, blk, 0, g->stream, G, f->d, e);
+		if (problem == PROBLEM_RANDOM) {
+			hipLaunchKernelGGL(k_init_random, grid, blk, 0, g->stream, G, L.nc, (uint64_t) 0x5EED, f->d, e);
+		} else if (problem == PROBLEM_TRIG) {
+			if (L.dim == 3) {
+				TE_INIT(k_init3d, PROBLEM_TRIG)
+			} else {
+				TE_INIT(k_init2d, PROBLEM_TRIG)
+			}
+		} else if (problem == PROBLEM_GAUSS) {
+			if (L.dim == 3) {
+				TE_INIT(k_init3d, PROBLEM_GAUSS)
+			} else {
+				TE_INIT(k_init2d, PROBLEM_GAUSS)
+			}
 		} else {
-			TE_INIT(k_init2d, PROBLEM_TRIG)
+			return te::fail(TE_EINVAL, "te_init_problem: unknown problem");
 		}
-	} else if (problem == PROBLEM_GAUSS) {
-		if (L.dim == 3) {
-			TE_INIT(k_init3d, PROBLEM_GAUSS)
-		} else {
-			TE_INIT(k_init2d, PROBLEM_GAUSS)
-		}
-	} else {
-		return te::fail(TE_EINVAL, "te_init_problem: unknown problem");
-	}
 #undef TE_INIT
-	HIPCHK(hipGetLastError());
-	return TE_OK;
+		HIPCHK(hipGetLastError());
+		return TE_OK;
 	});
 }
 // StarPatchOp<D>::apply (StarPatchOp.h:204-319; twins SevenPtPatchOperator.cpp:247-409, FivePtPatchOperator.h:172-261):
@@ -3030,14 +3030,14 @@ int te_init_problem(te_gmg *g, int level, int problem, int neumann, te_vec *f, t
 int te_patch_apply(te_gmg *g, int level, const te_vec *u, te_vec *f)
 {
 	return guarded([&]() -> int {
-	int rc;
-	if ((rc = checkLevelVec(g, level, u, "te_patch_apply")) || (rc = checkLevelVec(g, level, f, "te_patch_apply"))) return rc;
-	if (u == f) return te::fail(TE_EINVAL, "te_patch_apply: in-place apply is not supported");
-	LevelHost &L  = *g->levels[level];
-	L.patch_local = true;
-	rc            = launchStencil<MODE_APPLY>(g, L, u->d, nullptr, f->d, 0.0);
-	L.patch_local = false;
-	return rc;
+		int rc;
+		if ((rc = checkLevelVec(g, level, u, "te_patch_apply")) || (rc = checkLevelVec(g, level, f, "te_patch_apply"))) return rc;
+		if (u == f) return te::fail(TE_EINVAL, "te_patch_apply: in-place apply is not supported");
+		LevelHost &L  = *g->levels[level];
+		L.patch_local = true;
+		rc            = launchStencil<MODE_APPLY>(g, L, u->d, nullptr, f->d, 0.0);
+		L.patch_local = false;
+		return rc;
 	});
 }
 // Vector<D>::getLocalData(i) for a run of patches (PetscVector.h:87-98): what Init::initDirichlet, the writers and
@@ -3045,116 +3045,116 @@ int te_patch_apply(te_gmg *g, int level, const te_vec *u, te_vec *f)
 int te_vec_upload_patches(te_vec *v, int first_patch, int npatches, const double *host)
 {
 	return guarded([&]() -> int {
-	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_upload_patches: null");
-	const size_t nc = v->g->levels[v->level]->nc;
-	if (first_patch < 0 || npatches < 0 || ((size_t) first_patch + npatches) * nc > v->n)
-		return te::fail(TE_EINVAL, "te_vec_upload_patches: patch range outside the vector");
-	if (npatches == 0) return TE_OK;
-	LevelHost &L = *v->g->levels[v->level];
-	if (L.xf_valid_for == v->d) L.xf_valid_for = nullptr;
-	HIPCHK(hipMemcpyAsync(v->d + (size_t) first_patch * nc, host, sizeof(double) * nc * npatches, hipMemcpyHostToDevice, v->g->stream));
-	HIPCHK(hipStreamSynchronize(v->g->stream));
-	return TE_OK;
+		if (!v || !host) return te::fail(TE_EINVAL, "te_vec_upload_patches: null");
+		const size_t nc = v->g->levels[v->level]->nc;
+		if (first_patch < 0 || npatches < 0 || ((size_t) first_patch + npatches) * nc > v->n)
+			return te::fail(TE_EINVAL, "te_vec_upload_patches: patch range outside the vector");
+		if (npatches == 0) return TE_OK;
+		LevelHost &L = *v->g->levels[v->level];
+		if (L.xf_valid_for == v->d) L.xf_valid_for = nullptr;
+		HIPCHK(hipMemcpyAsync(v->d + (size_t) first_patch * nc, host, sizeof(double) * nc * npatches, hipMemcpyHostToDevice, v->g->stream));
+		HIPCHK(hipStreamSynchronize(v->g->stream));
+		return TE_OK;
 	});
 }
 int te_vec_download_patches(const te_vec *v, int first_patch, int npatches, double *host)
 {
 	return guarded([&]() -> int {
-	if (!v || !host) return te::fail(TE_EINVAL, "te_vec_download_patches: null");
-	const size_t nc = v->g->levels[v->level]->nc;
-	if (first_patch < 0 || npatches < 0 || ((size_t) first_patch + npatches) * nc > v->n)
-		return te::fail(TE_EINVAL, "te_vec_download_patches: patch range outside the vector");
-	if (npatches == 0) return TE_OK;
-	HIPCHK(hipMemcpyAsync(host, v->d + (size_t) first_patch * nc, sizeof(double) * nc * npatches, hipMemcpyDeviceToHost, v->g->stream));
-	HIPCHK(hipStreamSynchronize(v->g->stream));
-	return TE_OK;
+		if (!v || !host) return te::fail(TE_EINVAL, "te_vec_download_patches: null");
+		const size_t nc = v->g->levels[v->level]->nc;
+		if (first_patch < 0 || npatches < 0 || ((size_t) first_patch + npatches) * nc > v->n)
+			return te::fail(TE_EINVAL, "te_vec_download_patches: patch range outside the vector");
+		if (npatches == 0) return TE_OK;
+		HIPCHK(hipMemcpyAsync(host, v->d + (size_t) first_patch * nc, sizeof(double) * nc * npatches, hipMemcpyDeviceToHost, v->g->stream));
+		HIPCHK(hipStreamSynchronize(v->g->stream));
+		return TE_OK;
 	});
 }
 
 int te_gmg_profile(te_gmg *g, int enable)
 {
 	return guarded([&]() -> int {
-	if (!g) return te::fail(TE_EINVAL, "te_gmg_profile: null");
-	drainEvents(g);
-	g->profiling = enable != 0;
-	return TE_OK;
+		if (!g) return te::fail(TE_EINVAL, "te_gmg_profile: null");
+		drainEvents(g);
+		g->profiling = enable != 0;
+		return TE_OK;
 	});
 }
 int te_integrate(te_gmg *g, int level, const te_vec *v, double *out)
 {
 	return guarded([&]() -> int {
-	int rc;
-	if (!out) return te::fail(TE_EINVAL, "te_integrate: null result");
-	if ((rc = checkLevelVec(g, level, v, "te_integrate"))) return rc;
-	LevelHost &L = *g->levels[level];
-	*out         = 0.0;
-	if (L.P == 0) return TE_OK;
-	DevBuf<double> part;
-	if ((rc = part.alloc(L.P))) return rc;
-	hipLaunchKernelGGL(k_patch_integrals, dim3(L.P), dim3(256), 0, g->stream, (int) L.nc, v->d, L.cellvol.p, part.p);
-	HIPCHK(hipGetLastError());
-	std::vector<double> h(L.P);
-	HIPCHK(hipMemcpyAsync(h.data(), part.p, sizeof(double) * L.P, hipMemcpyDeviceToHost, g->stream));
-	HIPCHK(hipStreamSynchronize(g->stream));
-	double sum = 0.0;
-	for (double x : h) sum += x; // patch order, as the reference's loop over its patch map
-	*out = sum;
-	return TE_OK;
+		int rc;
+		if (!out) return te::fail(TE_EINVAL, "te_integrate: null result");
+		if ((rc = checkLevelVec(g, level, v, "te_integrate"))) return rc;
+		LevelHost &L = *g->levels[level];
+		*out         = 0.0;
+		if (L.P == 0) return TE_OK;
+		DevBuf<double> part;
+		if ((rc = part.alloc(L.P))) return rc;
+		hipLaunchKernelGGL(k_patch_integrals, dim3(L.P), dim3(256), 0, g->stream, (int) L.nc, v->d, L.cellvol.p, part.p);
+		HIPCHK(hipGetLastError());
+		std::vector<double> h(L.P);
+		HIPCHK(hipMemcpyAsync(h.data(), part.p, sizeof(double) * L.P, hipMemcpyDeviceToHost, g->stream));
+		HIPCHK(hipStreamSynchronize(g->stream));
+		double sum = 0.0;
+		for (double x : h) sum += x; // patch order, as the reference's loop over its patch map
+		*out = sum;
+		return TE_OK;
 	});
 }
 int te_volume(te_gmg *g, int level, double *out)
 {
 	return guarded([&]() -> int {
-	if (!g || !out || level < 0 || level >= (int) g->levels.size()) return te::fail(TE_EINVAL, "te_volume: bad argument");
-	double sum = 0.0;
-	for (double x : g->levels[level]->patch_vol) sum += x;
-	*out = sum;
-	return TE_OK;
+		if (!g || !out || level < 0 || level >= (int) g->levels.size()) return te::fail(TE_EINVAL, "te_volume: bad argument");
+		double sum = 0.0;
+		for (double x : g->levels[level]->patch_vol) sum += x;
+		*out = sum;
+		return TE_OK;
 	});
 }
 int te_gmg_profile_select(te_gmg *g, const char *name)
 {
 	return guarded([&]() -> int {
-	if (!g) return te::fail(TE_EINVAL, "te_gmg_profile_select: null");
-	drainEvents(g);
-	g->prof_only = -1;
-	if (!name || !*name) return TE_OK;
-	for (int k = 0; k < KC_COUNT; k++)
-		if (!strcmp(name, kclassName[k])) {
-			g->prof_only = k;
-			return TE_OK;
-		}
-	return te::fail(TE_EINVAL, std::string("te_gmg_profile_select: unknown kernel class ") + name);
+		if (!g) return te::fail(TE_EINVAL, "te_gmg_profile_select: null");
+		drainEvents(g);
+		g->prof_only = -1;
+		if (!name || !*name) return TE_OK;
+		for (int k = 0; k < KC_COUNT; k++)
+			if (!strcmp(name, kclassName[k])) {
+				g->prof_only = k;
+				return TE_OK;
+			}
+		return te::fail(TE_EINVAL, std::string("te_gmg_profile_select: unknown kernel class ") + name);
 	});
 }
 int te_gmg_profile_reset(te_gmg *g)
 {
 	return guarded([&]() -> int {
-	if (!g) return te::fail(TE_EINVAL, "te_gmg_profile_reset: null");
-	drainEvents(g);
-	memset(g->calls, 0, sizeof(g->calls));
-	memset(g->cells, 0, sizeof(g->cells));
-	memset(g->total_ms, 0, sizeof(g->total_ms));
-	return TE_OK;
+		if (!g) return te::fail(TE_EINVAL, "te_gmg_profile_reset: null");
+		drainEvents(g);
+		memset(g->calls, 0, sizeof(g->calls));
+		memset(g->cells, 0, sizeof(g->cells));
+		memset(g->total_ms, 0, sizeof(g->total_ms));
+		return TE_OK;
 	});
 }
 int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *calls, double *total_ms,
                         int64_t *cells)
 {
 	return guarded([&]() -> int {
-	if (!g || !name || !calls || !total_ms || !cells) return te::fail(TE_EINVAL, "te_gmg_profile_rows: null");
-	drainEvents(g);
-	int n = 0;
-	for (int k = 0; k < KC_COUNT && n < max_rows; k++) {
-		if (g->calls[k] == 0) continue;
-		strncpy(name[n], kclassName[k], 63);
-		name[n][63] = 0;
-		calls[n]    = g->calls[k];
-		total_ms[n] = g->total_ms[k];
-		cells[n]    = g->cells[k];
-		n++;
-	}
-	return n;
+		if (!g || !name || !calls || !total_ms || !cells) return te::fail(TE_EINVAL, "te_gmg_profile_rows: null");
+		drainEvents(g);
+		int n = 0;
+		for (int k = 0; k < KC_COUNT && n < max_rows; k++) {
+			if (g->calls[k] == 0) continue;
+			strncpy(name[n], kclassName[k], 63);
+			name[n][63] = 0;
+			calls[n]    = g->calls[k];
+			total_ms[n] = g->total_ms[k];
+			cells[n]    = g->cells[k];
+			n++;
+		}
+		return n;
 	});
 }
 // Diagnostic for the watchdog's bookkeeping: for `seconds` of wall time the host enqueues, WITHOUT ever synchronising, a
@@ -3165,30 +3165,30 @@ int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *call
 int te_gmg_watchdog_selftest(te_gmg *g, double seconds)
 {
 	return guarded([&]() -> int {
-		if (!g || seconds <= 0) return te::fail(TE_EINVAL, "te_gmg_watchdog_selftest: bad argument");
-		watchdogStart(g);
-		LevelHost &L = *g->levels[0];
-		const int  n = 256;
-		if ((size_t) 2 * n > L.r->n) return te::fail(TE_EINVAL, "te_gmg_watchdog_selftest: level 0 too small");
-		double *send = L.r->d, *recv = L.r->d + n;
-		ExPlan  pl;
-		pl.peers    = {g->rank};
-		pl.send_off = {0}, pl.send_cnt = {n}, pl.recv_off = {0}, pl.recv_cnt = {n};
-		const auto t0 = std::chrono::steady_clock::now();
-		int        count = 0;
-		while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
-			int rc = vecop<VOP_SCALE>(L.t.get(), nullptr, nullptr, 1.0, 0, 0);
-			if (rc) return rc;
-			if (g->rccl.comm || g->exchange) {
-				if ((rc = doExchange(g, 9, pl, send, recv))) return rc;
-			} else {
-				WatchdogArm arm(g, g->stream, 9);
-				HIPCHK(hipMemcpyAsync(recv, send, sizeof(double) * n, hipMemcpyDeviceToDevice, g->stream));
+			if (!g || seconds <= 0) return te::fail(TE_EINVAL, "te_gmg_watchdog_selftest: bad argument");
+			watchdogStart(g);
+			LevelHost &L = *g->levels[0];
+			const int  n = 256;
+			if ((size_t) 2 * n > L.r->n) return te::fail(TE_EINVAL, "te_gmg_watchdog_selftest: level 0 too small");
+			double *send = L.r->d, *recv = L.r->d + n;
+			ExPlan  pl;
+			pl.peers    = {g->rank};
+			pl.send_off = {0}, pl.send_cnt = {n}, pl.recv_off = {0}, pl.recv_cnt = {n};
+			const auto t0 = std::chrono::steady_clock::now();
+			int        count = 0;
+			while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < seconds) {
+				int rc = vecop<VOP_SCALE>(L.t.get(), nullptr, nullptr, 1.0, 0, 0);
+				if (rc) return rc;
+				if (g->rccl.comm || g->exchange) {
+					if ((rc = doExchange(g, 9, pl, send, recv))) return rc;
+				} else {
+					WatchdogArm arm(g, g->stream, 9);
+					HIPCHK(hipMemcpyAsync(recv, send, sizeof(double) * n, hipMemcpyDeviceToDevice, g->stream));
+				}
+				count++;
 			}
-			count++;
-		}
-		HIPCHK(hipStreamSynchronize(g->stream));
-		return count;
+			HIPCHK(hipStreamSynchronize(g->stream));
+			return count;
 	});
 }
 // te_bicgstab keeps its eight level-0 work vectors between solves (8 GiB at 512^3); a caller that is done solving hands
@@ -3196,12 +3196,12 @@ int te_gmg_watchdog_selftest(te_gmg *g, double seconds)
 int te_gmg_release_workspace(te_gmg *g)
 {
 	return guarded([&]() -> int {
-		if (!g) return te::fail(TE_EINVAL, "te_gmg_release_workspace: null");
-		for (te_vec *&v : g->bicg_work) {
-			if (v) te_vec_destroy(v);
-			v = nullptr;
-		}
-		return TE_OK;
+			if (!g) return te::fail(TE_EINVAL, "te_gmg_release_workspace: null");
+			for (te_vec *&v : g->bicg_work) {
+				if (v) te_vec_destroy(v);
+				v = nullptr;
+			}
+			return TE_OK;
 	});
 }
 // One TE_* switch of this solver: value == NULL clears it (back to the default). te_gmg_create reads all of
@@ -3210,16 +3210,16 @@ int te_gmg_release_workspace(te_gmg *g)
 int te_gmg_set_option(te_gmg *g, const char *name, const char *value)
 {
 	return guarded([&]() -> int {
-		if (!g || !name) return te::fail(TE_EINVAL, "te_gmg_set_option: null argument");
-		for (int o = 0; o < O_COUNT; o++)
-			if (!strcmp(name, optName[o])) {
-				if (optStructural(o))
-					return te::fail(TE_ESTATE, std::string("te_gmg_set_option: ") + name + " is read when the solver is created; set it in the environment before te_gmg_create");
-				g->cfg.set(o, value);
-				g->verified_opts.clear(); // (an option may change which exchanges a cycle issues)
-				return TE_OK;
-			}
-		return te::fail(TE_EINVAL, std::string("te_gmg_set_option: unknown option ") + name);
+			if (!g || !name) return te::fail(TE_EINVAL, "te_gmg_set_option: null argument");
+			for (int o = 0; o < O_COUNT; o++)
+				if (!strcmp(name, optName[o])) {
+					if (optStructural(o))
+						return te::fail(TE_ESTATE, std::string("te_gmg_set_option: ") + name + " is read when the solver is created; set it in the environment before te_gmg_create");
+					g->cfg.set(o, value);
+					g->verified_opts.clear(); // (an option may change which exchanges a cycle issues)
+					return TE_OK;
+				}
+			return te::fail(TE_EINVAL, std::string("te_gmg_set_option: unknown option ") + name);
 	});
 }
 } // extern "C"
