@@ -1665,8 +1665,14 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 		D.fcorr = fcorr_in;
 		if constexpr (N >= 4) {
 			const dim3  grid(8 * ((D.count + 7) / 8)), blk(Tile3<N>::TPB);
-			const char *ve = g->cfg.str(O_RESWEEP_V); // tuning variants (march3d.hpp), all bit-identical; default 27
-			const int   v  = ve ? atoi(ve) : 27;
+			// tuning variants (march3d.hpp), all bit-identical. Defaults, each measured: the finest level stores u non-temporally
+			// (nobody re-reads it) and loads f non-temporally unless f can still be in the Infinity Cache from the pre-sweep
+			// that read it (19 instead of 27: 256^3, a rank's share at eight ranks; 53.4 -> 49.0 us at 256^3); a coarser
+			// level with exported ghost terms (level 1 of 512^3) keeps ordinary stores as well -- its u is the correction the
+			// finer level's post-sweep reads next (3: 64.5 us, against 68.7 with non-temporal stores)
+			const char *ve    = g->cfg.str(O_RESWEEP_V);
+			const bool  small = (size_t) L.P * L.nc * sizeof(double) <= ((size_t) 160 << 20);
+			const int   v     = ve ? atoi(ve) : (fcorr_in ? 3 : ((small && g->cur_level == 0) ? 19 : 27));
 			if (L.ncf > 0 || L.has_copy) { // refined level: copy-through patches / coarse-fine ghost slots
 				if (v == 3)
 					launchT(t, (k_rbgs_resweep_prolong3d<N, 3, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
@@ -1675,8 +1681,10 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 			} else if (fcorr_in) {
 				if (v == 0)
 					launchT(t, (k_rbgs_resweep_prolong3d<N, 0, true>), grid, blk, 0, g->stream, D, f, out, ps);
-				else if (ve && v == 27) // (measured: on a level whose vectors fit the Infinity Cache the non-temporal form is no faster)
+				else if (v == 27)
 					launchT(t, (k_rbgs_resweep_prolong3d<N, 27, true>), grid, blk, 0, g->stream, D, f, out, ps);
+				else if (v == 19)
+					launchT(t, (k_rbgs_resweep_prolong3d<N, 19, true>), grid, blk, 0, g->stream, D, f, out, ps);
 				else
 					launchT(t, (k_rbgs_resweep_prolong3d<N, 3, true>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 0) {

@@ -410,3 +410,27 @@ def test_fused_sums_of_the_stencil_kernel(case):
         assert abs(a[0] - c[0]) <= (1 if not unprec else max(3, c[0] // 8)), (a[0], c[0])
         # (unpreconditioned: both stop at a relative residual of 1e-8; the solutions agree to that times the condition number)
         assert rel(a[2], c[2]) <= (1e-10 if not unprec else 1e-4)
+
+
+def test_post_sweep_tuning_variants_bit_identical():
+    """k_rbgs_resweep_prolong3d's variants (TE_RESWEEP_V: which black values go back to LDS, when the top neighbour's plane is
+    loaded, non-temporal loads of f / stores of u) and k_rbgs_zero_resid3d's prefetch distance (TE_ZR_AHEAD) change the
+    schedule, not one bit: 256^3 (the default there is 19) and the level-1 variant with exported ghost terms of a 16^3-patch
+    grid of 8^3 patches."""
+    for n, div in ((32, 3), (8, 4)):
+        m, H, levels = util.setup("uniform", n, div)
+        g = capi.GMG(H)
+        f = util.rand_vec(levels[0].size, 88) / levels[0].a["h"].min() ** 2
+        got = {}
+        for v in (None, "0", "3", "19", "27"):
+            g.set_option("TE_RESWEEP_V", v)
+            for ah in (None, "1"):
+                g.set_option("TE_ZR_AHEAD", ah)
+                df, du = g.new_vector(0, f), g.new_vector(0)
+                g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+                got[(v, ah)] = du.download()
+        g.set_option("TE_RESWEEP_V", None)
+        g.set_option("TE_ZR_AHEAD", None)
+        ref = got[(None, None)]
+        for k, x in got.items():
+            assert np.array_equal(x, ref), k
