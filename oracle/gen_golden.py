@@ -55,7 +55,7 @@ def level_case(mesh_file, dim, n, neumann, seed):
     out["apply"] = refslice.apply_with_gamma(L, u, out["gamma"])
     out["patch_apply"] = refslice.patch_apply(L, u)
     out["add_iface_rhs"] = refslice.add_iface_rhs(L, gamma_in, f)
-    if not neumann:
+    if not neumann and "multi_refine_8" not in mesh_file:  # (the unpreconditioned solve does not converge in 1000 iterations on the 9-level trees)
         x, its = refslice.bicgstab(L, f)
         out["bicg_its"] = its
         out["bicg_x"] = x
@@ -81,13 +81,23 @@ def main():
     cases = [("2uni.bin", 3, 4, False), ("2uni.bin", 3, 8, False), ("2refine.bin", 3, 4, False),
              ("2refine.bin", 3, 8, False), ("2refine.bin", 3, 4, True), ("1uni.bin", 3, 8, True),
              ("2d2uni.bin", 2, 8, False), ("2d2ref.bin", 2, 8, False), ("2d2ref.bin", 2, 4, True)]
+    # round 3: deep adaptively refined trees (apps/3d/meshes/multi_refine{,_8}.bin, apps/2d/meshes/multi_refine_8.bin)
+    cases += [("multi_refine.bin", 3, 4, False), ("multi_refine.bin", 3, 4, True), ("multi_refine_8.bin", 3, 4, False),
+              ("2d_multi_refine_8.bin", 2, 4, False), ("2d_multi_refine_8.bin", 2, 8, True)]
+    only = sys.argv[1] if len(sys.argv) > 1 else None  # e.g. "multi_refine": (re)generate the fixtures of matching meshes only
     for i, (mf, dim, n, neu) in enumerate(cases):
+        if only and only not in mf:
+            continue
         d = level_case(mf, dim, n, neu, 1000 + i)
         name = f"ref_{mf.split('.')[0]}_n{n}{'_neumann' if neu else ''}.npz"
         np.savez_compressed(os.path.join(GOLDEN, name), **d)
         print(name, "P", len(d["t_id"]), "ifaces", d["num_ifaces"], "bicg its", d.get("bicg_its"))
-    np.savez_compressed(os.path.join(GOLDEN, "ref_vecops.npz"), **vecop_case(7))
-    for mf, dim, div in [("2uni.bin", 3, 1), ("2refine.bin", 3, 1), ("2refine.bin", 3, 2), ("2d2ref.bin", 2, 2)]:
+    if not only:
+        np.savez_compressed(os.path.join(GOLDEN, "ref_vecops.npz"), **vecop_case(7))
+    for mf, dim, div in [("2uni.bin", 3, 1), ("2refine.bin", 3, 1), ("2refine.bin", 3, 2), ("2d2ref.bin", 2, 2),
+                         ("multi_refine.bin", 3, 0), ("multi_refine.bin", 3, 1), ("2d_multi_refine_8.bin", 2, 1)]:
+        if only and only not in mf:
+            continue
         d = refslice.tree_nodes(os.path.join(GOLDEN, mf), dim, div)
         d.update(mesh=mf, dim=dim, divides=div)
         np.savez_compressed(os.path.join(GOLDEN, f"ref_tree_{mf.split('.')[0]}_div{div}.npz"), **d)

@@ -128,3 +128,23 @@ def test_deep_tree_four_virtual_ranks_equal_one(name, dim, monkeypatch):
         for idx, o in outs:
             got.reshape(P, nc)[idx] = o[k].reshape(len(idx), nc)
         assert np.array_equal(got, want[k]), (k, np.abs(got - want[k]).max())
+
+
+@pytest.mark.parametrize("kw", [dict(cycle_type=1), dict(smoother=capi.SMOOTH_JACOBI, omega=0.8), dict(pre_sweeps=2, post_sweeps=0, coarse_sweeps=3)],
+                         ids=["W-cycle", "jacobi", "V(2,0) coarse 3"])
+def test_other_cycle_shapes_on_deep_tree(kw):
+    """W-cycle (WCycle.h:45-68), the weighted Jacobi smoother and other sweep counts over the nine levels of
+    multi_refine_8.bin, against the oracle on independently extracted tables"""
+    m, H, levels = setup("multi_refine_8.bin", 3)
+    g = capi.GMG(H)
+    f = util.rand_vec(levels[0].size, 97) / levels[0].a["h"].min() ** 2
+    names = dict(pre_sweeps="pre", post_sweeps="post", coarse_sweeps="coarse")
+    okw = {names.get(k, k): v for k, v in kw.items()}
+    okw.setdefault("smoother", capi.SMOOTH_RBGS)
+    want = orc.cycle(levels, orc.cycle_opts(**okw), f)
+    gkw = dict(kw)
+    gkw.setdefault("smoother", capi.SMOOTH_RBGS)
+    for fuse in (0, 3):
+        df, du = g.new_vector(0, f), g.new_vector(0)
+        g.cycle(g.default_opts(fuse=fuse, **gkw), df, du)
+        assert rel(du.download(), want) <= 1e-10, (fuse, rel(du.download(), want))
