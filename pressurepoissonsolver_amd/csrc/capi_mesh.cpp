@@ -125,8 +125,8 @@ int te_hier_level_tables(const te_hier *h, int level, int32_t *id, int32_t *rank
 }
 int te_hier_level_l2g(const te_hier *h, int level, int32_t *l2g)
 {
-	if (!h || level < 0 || level >= (int) h->h.levels.size() || !l2g)
-		return te::fail(TE_EINVAL, "te_hier_level_l2g: bad argument");
+	if (!h || level < 0 || level >= (int) h->h.levels.size() || (!l2g && !h->h.levels[level].l2g.empty()))
+		return te::fail(TE_EINVAL, "te_hier_level_l2g: bad argument"); // (a rank without patches on the level may pass NULL)
 	copyOut(l2g, h->h.levels[level].l2g);
 	return TE_OK;
 }
