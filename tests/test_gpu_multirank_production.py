@@ -95,3 +95,42 @@ def test_production_shape_sharded_cycle_equals_single_rank(name, smoother, monke
     if name.startswith("C5") and smoother == capi.SMOOTH_RBGS:
         for r in rows:
             assert r["rbgs_resweep_prolong"]["calls"] >= 2  # levels 0 and 1 are cut by rank boundaries and stay fused
+
+
+def test_production_shape_sharded_bicgstab_c3():
+    """te_bicgstab at C3's shape on 8 virtual ranks: the level-0 pre-sweeps form the Krylov vectors s and p themselves (FSrc
+    variants of k_rbgs_zero_resid3d), the dot products come out of the stencil kernel, scalars are summed over the ranks.
+    Same iteration count as one rank, same solution to the accuracy of the reordered sums."""
+    c = CONFIGS["C3-512^3-8ranks"]
+    n, nranks = c["n"], c["nranks"]
+    mesh = util.mesh(c["mesh"], c["divides"], 3)
+    nc = n ** 3
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    P = H1.sizes(0)[1]
+    b1, x1 = g1.new_vector(0), g1.new_vector(0)
+    g1.init_problem(b1, None, problem=capi.PROBLEM_TRIG)
+    its1, rr1 = g1.bicgstab(x1, b1, g1.default_opts(smoother=capi.SMOOTH_RBGS))
+    want = x1.download()
+    del b1, x1, g1
+    fab = tedist.LocalFabric(nranks)
+    fab.timeout = 600.0
+    hs = [capi.Hierarchy(mesh, n, rank=r, nranks=nranks) for r in range(nranks)]
+    gs = [capi.GMG(h) for h in hs]
+    for r, g in enumerate(gs):
+        fab.attach(g, r)
+
+    def per_rank(r):
+        g = gs[r]
+        b, x = g.new_vector(0), g.new_vector(0)
+        g.init_problem(b, None, problem=capi.PROBLEM_TRIG)
+        its, rr = g.bicgstab(x, b, g.default_opts(smoother=capi.SMOOTH_RBGS))
+        return hs[r].l2g(0), x.download(), its, rr
+
+    outs = fab.run(per_rank)
+    got = np.zeros(P * nc)
+    for idx, x, _, _ in outs:
+        got.reshape(P, nc)[idx] = x.reshape(len(idx), nc)
+    assert len({o[2] for o in outs}) == 1 and abs(outs[0][2] - its1) <= 1, ([o[2] for o in outs], its1)
+    assert max(o[3] for o in outs) <= 1e-12 and rr1 <= 1e-12
+    assert np.linalg.norm(got - want) <= 1e-9 * np.linalg.norm(want)
