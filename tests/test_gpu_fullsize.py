@@ -107,3 +107,59 @@ def test_solve_to_tolerance(big):
     e.addScaled(-1.0, x)
     # second-order discretisation: error ~ C h^2 with C ~ 3 for the trig problem (7.6e-4 at h = 1/32, n = 16 above)
     assert e.twoNorm() / en <= 4.0 * h ** 2
+
+
+@pytest.fixture(scope="module", params=["C4-2refine-div3", "C5-4096^2"])
+def big_other(request):
+    """the two other full-size configurations of BASELINE.json: the refined octree (7680 patches of 32^3, 252 M cells) and the
+    2D bandwidth case (4096 patches of 64^2)"""
+    if request.param.startswith("C4"):
+        mesh, n, dim = util.mesh("2refine.bin", 3, 3), 32, 3
+    else:
+        mesh, n, dim = util.mesh("uniform", 6, 2), 64, 2
+    H = capi.Hierarchy(mesh, n)
+    g = capi.GMG(H)
+    rng = np.random.default_rng(7)
+    N = H.cells(0)
+    return dict(H=H, g=g, n=n, dim=dim, N=N, u=g.new_vector(0, rng.uniform(-1, 1, N)), v=g.new_vector(0, rng.uniform(-1, 1, N)),
+                hmin=float(H.tables(0)["lengths"].min()) / n)
+
+
+def test_other_configs_linearity_and_definiteness(big_other):
+    g, u, v, h, dim = big_other["g"], big_other["u"], big_other["v"], big_other["hmin"], big_other["dim"]
+    a, b = 0.75, -1.5
+    au, av, w, aw = (g.new_vector(0) for _ in range(4))
+    g.apply(u, au)
+    g.apply(v, av)
+    w.copy(u)
+    w.scaleThenAddScaled(a, b, v)
+    g.apply(w, aw)
+    aw.addScaled(-a, au, -b, av)
+    assert aw.infNorm() <= 64 * util.EPS * 4 * dim / h ** 2 * (abs(a) + abs(b))
+    assert u.dot(au) < 0  # negative definite (Dirichlet; coarse/fine faces included)
+
+
+def test_other_configs_cycle_contraction_and_fusion(big_other):
+    """size-independent properties of the cycle at C4's and C5's full sizes: it contracts the residual, fuse = 1 equals the
+    unfused sequence bit for bit, the default (fuse = 3) equals fuse = 2 bit for bit and fuse = 1 to rounding"""
+    g, H, n, dim = big_other["g"], big_other["H"], big_other["n"], big_other["dim"]
+    f = g.new_vector(0, problems.random_rhs(H.tables(0)["id"], n ** dim))
+    fn = f.twoNorm()
+    for sm, bound in ((capi.SMOOTH_RBGS, 0.35), (capi.SMOOTH_PATCH_SOLVE, 0.15)):
+        xs = {}
+        for fuse in (0, 1, 2, 3):
+            x, r = g.new_vector(0), g.new_vector(0)
+            g.cycle(g.default_opts(smoother=sm, fuse=fuse), f, x)
+            g.residual(x, f, r)
+            assert r.twoNorm() <= bound * fn, (sm, fuse, r.twoNorm() / fn)
+            xs[fuse] = x
+        d = g.new_vector(0)
+        d.copy(xs[1])
+        d.addScaled(-1.0, xs[0])
+        assert d.infNorm() == 0.0
+        d.copy(xs[3])
+        d.addScaled(-1.0, xs[2])
+        assert d.infNorm() == 0.0
+        d.copy(xs[3])
+        d.addScaled(-1.0, xs[1])
+        assert d.twoNorm() <= (1e-12 if sm == capi.SMOOTH_RBGS else 1e-10) * xs[1].twoNorm()
