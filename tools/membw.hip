@@ -189,6 +189,92 @@ __global__ __launch_bounds__(256) void copy_walk_interleaved(size_t nplanes, dou
 		}
 	}
 }
+// WAVE-SPECIALISED walk: waves 0-3 load (AH planes ahead) and hand every plane to LDS; wave 4 alone stores it to global
+// memory. Loads and stores then sit in different waves' vmcnt queues: a wave that waits for a load never waits for a
+// store issued after it (one in-order counter per wave covers both on gfx9). READS = 1 (copy) or 2 (triad).
+template <int CH, int AH, int READS> __global__ __launch_bounds__(320) void walk_ws(size_t nchunks, double *a, const double *b, const double *c)
+{
+	extern __shared__ __attribute__((aligned(16))) double2 wsbuf[]; // [2][512] (+ padding that limits residency)
+	const size_t base = (size_t) blockIdx.x * CH * 512;
+	const int    t    = threadIdx.x;
+	if (t < 256) {
+		double2 x[AH][2], y[AH][2];
+#pragma unroll
+		for (int h = 0; h < AH; h++)
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				x[h][k] = ((const double2 *) b)[base + h * 512 + k * 256 + t];
+				if (READS == 2) y[h][k] = ((const double2 *) c)[base + h * 512 + k * 256 + t];
+			}
+		for (int z0 = 0; z0 < CH; z0 += AH) {
+#pragma unroll
+			for (int h = 0; h < AH; h++) {
+				const int z = z0 + h;
+				if (z >= CH) break;
+				double2   v[2];
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					v[k] = READS == 2 ? double2{x[h][k].x + 0.5 * y[h][k].x, x[h][k].y + 0.5 * y[h][k].y} : double2{x[h][k].x * 0.5, x[h][k].y * 0.5};
+				}
+				const int zn = (z + AH < CH) ? z + AH : z;
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					x[h][k] = ((const double2 *) b)[base + zn * 512 + k * 256 + t];
+					if (READS == 2) y[h][k] = ((const double2 *) c)[base + zn * 512 + k * 256 + t];
+				}
+				wsbuf[(z & 1) * 512 + t]       = v[0];
+				wsbuf[(z & 1) * 512 + 256 + t] = v[1];
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+				__builtin_amdgcn_s_barrier();
+			}
+		}
+	} else {
+		const int l = t - 256;
+		for (int z = 0; z < CH; z++) {
+			__builtin_amdgcn_s_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+			double2 v[8];
+#pragma unroll
+			for (int k = 0; k < 8; k++) v[k] = wsbuf[(z & 1) * 512 + k * 64 + l];
+#pragma unroll
+			for (int k = 0; k < 8; k++) ((double2 *) a)[base + z * 512 + k * 64 + l] = v[k];
+		}
+	}
+}
+// the same walk with the same LDS hop but NO specialisation: every wave loads, passes its values through LDS and stores
+template <int CH, int AH, int READS> __global__ __launch_bounds__(256) void walk_lds_nows(size_t nchunks, double *a, const double *b, const double *c)
+{
+	extern __shared__ __attribute__((aligned(16))) double2 wsbuf[];
+	const size_t base = (size_t) blockIdx.x * CH * 512;
+	const int    t    = threadIdx.x;
+	double2      x[AH][2], y[AH][2];
+#pragma unroll
+	for (int h = 0; h < AH; h++)
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			x[h][k] = ((const double2 *) b)[base + h * 512 + k * 256 + t];
+			if (READS == 2) y[h][k] = ((const double2 *) c)[base + h * 512 + k * 256 + t];
+		}
+	for (int z0 = 0; z0 < CH; z0 += AH) {
+#pragma unroll
+		for (int h = 0; h < AH; h++) {
+			const int z = z0 + h;
+			if (z >= CH) break;
+			double2   v[2];
+#pragma unroll
+			for (int k = 0; k < 2; k++)
+				v[k] = READS == 2 ? double2{x[h][k].x + 0.5 * y[h][k].x, x[h][k].y + 0.5 * y[h][k].y} : double2{x[h][k].x * 0.5, x[h][k].y * 0.5};
+			const int zn = (z + AH < CH) ? z + AH : z;
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				x[h][k] = ((const double2 *) b)[base + zn * 512 + k * 256 + t];
+				if (READS == 2) y[h][k] = ((const double2 *) c)[base + zn * 512 + k * 256 + t];
+			}
+			((double2 *) a)[base + z * 512 + t]       = v[0];
+			((double2 *) a)[base + z * 512 + 256 + t] = v[1];
+		}
+	}
+}
 __global__ __launch_bounds__(256) void copy_flat(size_t n2, double2 *a, const double2 *b)
 {
 	size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
@@ -273,6 +359,23 @@ int main(int argc, char **argv)
 	for (int G : {1024, 2048, 4096}) {
 		snprintf(nm, sizeof nm, "copy_walk_interleaved G=%d", G);
 		timeit(nm, n * 16.0, [&] { hipLaunchKernelGGL(copy_walk_interleaved, dim3(G), dim3(256), 0, 0, n / 1024, a, b); });
+	}
+	// wave-specialised walks: LDS bytes per workgroup set how many are resident per CU (48 KiB: three, as the fused kernels)
+	for (int lds : {16384, 32768, 49152, 65536})
+		for (int rd : {1, 2}) {
+			const double bytes = n * (rd == 2 ? 24.0 : 16.0);
+			snprintf(nm, sizeof nm, "walk_ws AH=3 reads=%d lds=%d", rd, lds);
+			if (rd == 1) timeit(nm, bytes, [&] { hipLaunchKernelGGL((walk_ws<32, 3, 1>), dim3(n / (32 * 1024)), dim3(320), lds, 0, n / (32 * 1024), a, b, c); });
+			else timeit(nm, bytes, [&] { hipLaunchKernelGGL((walk_ws<32, 3, 2>), dim3(n / (32 * 1024)), dim3(320), lds, 0, n / (32 * 1024), a, b, c); });
+			snprintf(nm, sizeof nm, "walk_nows AH=3 reads=%d lds=%d", rd, lds);
+			if (rd == 1) timeit(nm, bytes, [&] { hipLaunchKernelGGL((walk_lds_nows<32, 3, 1>), dim3(n / (32 * 1024)), dim3(256), lds, 0, n / (32 * 1024), a, b, c); });
+			else timeit(nm, bytes, [&] { hipLaunchKernelGGL((walk_lds_nows<32, 3, 2>), dim3(n / (32 * 1024)), dim3(256), lds, 0, n / (32 * 1024), a, b, c); });
+		}
+	for (int lds : {32768, 49152}) {
+		snprintf(nm, sizeof nm, "walk_ws AH=1 reads=1 lds=%d", lds);
+		timeit(nm, n * 16.0, [&] { hipLaunchKernelGGL((walk_ws<32, 1, 1>), dim3(n / (32 * 1024)), dim3(320), lds, 0, n / (32 * 1024), a, b, c); });
+		snprintf(nm, sizeof nm, "walk_ws AH=4 reads=2 lds=%d", lds);
+		timeit(nm, n * 24.0, [&] { hipLaunchKernelGGL((walk_ws<32, 4, 2>), dim3(n / (32 * 1024)), dim3(320), lds, 0, n / (32 * 1024), a, b, c); });
 	}
 	timeit("copy_flat", n * 16.0, [&] { hipLaunchKernelGGL(copy_flat, dim3(n2 / 256), dim3(256), 0, 0, n2, (double2 *) a, (const double2 *) b); });
 	return 0;
