@@ -1584,22 +1584,22 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 			D.f6_out = L.f6buf.p;
 			D.fcorr  = fcorr_in;
 			// TE_ZR_AHEAD = 1: the right-hand side requested one plane ahead only (the form before round 3; bit-identical)
-			const bool ah1 = g->cfg.num(O_ZR_AHEAD, 3) == 1;
+			const bool ah1 = g->cfg.num(O_ZR_AHEAD, 4) == 1;
 #define TE_ZR(EXP, FC)                                                                                                   \
 	if (ah1)                                                                                                             \
 		launchT(t, (k_rbgs_zero_resid3d<N, false, EXP, FC, 1>), grid, blk, 0, g->stream, D, f, out, rd, FSrc());         \
 	else                                                                                                                 \
-		launchT(t, (k_rbgs_zero_resid3d<N, false, EXP, FC, 3>), grid, blk, 0, g->stream, D, f, out, rd, FSrc())
+		launchT(t, (k_rbgs_zero_resid3d<N, false, EXP, FC, 4>), grid, blk, 0, g->stream, D, f, out, rd, FSrc())
 			if (fs) { // the right-hand side is a pending vector statement of te_bicgstab (march3d.hpp FSrc): formed and stored here
 				const FSrc a = fs->args;
 				if (fs->kind == 1 && export_rs6)
-					launchT(t, (k_rbgs_zero_resid3d<N, false, true, false, 3, 1>), grid, blk, 0, g->stream, D, f, out, rd, a);
+					launchT(t, (k_rbgs_zero_resid3d<N, false, true, false, 4, 1>), grid, blk, 0, g->stream, D, f, out, rd, a);
 				else if (fs->kind == 1)
-					launchT(t, (k_rbgs_zero_resid3d<N, false, false, false, 3, 1>), grid, blk, 0, g->stream, D, f, out, rd, a);
+					launchT(t, (k_rbgs_zero_resid3d<N, false, false, false, 4, 1>), grid, blk, 0, g->stream, D, f, out, rd, a);
 				else if (export_rs6)
-					launchT(t, (k_rbgs_zero_resid3d<N, false, true, false, 3, 2>), grid, blk, 0, g->stream, D, f, out, rd, a);
+					launchT(t, (k_rbgs_zero_resid3d<N, false, true, false, 4, 2>), grid, blk, 0, g->stream, D, f, out, rd, a);
 				else
-					launchT(t, (k_rbgs_zero_resid3d<N, false, false, false, 3, 2>), grid, blk, 0, g->stream, D, f, out, rd, a);
+					launchT(t, (k_rbgs_zero_resid3d<N, false, false, false, 4, 2>), grid, blk, 0, g->stream, D, f, out, rd, a);
 			} else if (export_rs6 && fcorr_in) {
 				TE_ZR(true, true);
 			} else if (export_rs6) {
@@ -1695,6 +1695,10 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 				launchT(t, (k_rbgs_resweep_prolong3d<N, 11, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 19) {
 				launchT(t, (k_rbgs_resweep_prolong3d<N, 19, false>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else if (v == 23) {
+				launchT(t, (k_rbgs_resweep_prolong3d<N, 23, false>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else if (v == 31) {
+				launchT(t, (k_rbgs_resweep_prolong3d<N, 31, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 27) {
 				launchT(t, (k_rbgs_resweep_prolong3d<N, 27, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 3) {

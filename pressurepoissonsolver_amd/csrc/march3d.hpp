@@ -952,6 +952,22 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 // in this pass instead of 24 / 32 in a pass of their own plus the 8 this kernel reads anyway. The operands of a plane are
 // requested at the usual distance and combined one step later (not in the step that requests them: that would wait for
 // loads just issued), so they add one raw stage to the ring of planes in flight.
+// A copy the compiler cannot see through: the source registers are dead afterwards, so the load that refills a ring slot can
+// be given the slot's own registers. Without it the register allocator merges the COPY with the slot (the copy is free) and
+// gives every refill fresh registers, which it then moves into the slot's registers at the loop's back edge -- a move that reads
+// the newest loads and makes every iteration wait for them.
+__device__ __forceinline__ double2 takeRegs(const double2 &src)
+{
+	double2 r;
+	asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(r.x), "=&v"(r.y) : "v"(src.x), "v"(src.y));
+	return r;
+}
+__device__ __forceinline__ double takeReg(double src)
+{
+	double r;
+	asm volatile("v_mov_b64 %0, %1" : "=&v"(r) : "v"(src));
+	return r;
+}
 struct FSrc {
 	const double *a, *b, *c; // FS = 1: resid, ap, -; FS = 2: p, ap, resid
 	double       *out;       // s, or p (in place: every thread rewrites exactly the cells it has read)
@@ -963,8 +979,8 @@ template <int FS> __device__ __forceinline__ double2 fsrcCombine(const FSrc &fs,
 	const double tx = __builtin_fma(b.x, fs.s1, a.x), ty = __builtin_fma(b.y, fs.s1, a.y);
 	return double2{__builtin_fma(fs.s2, tx, c.x), __builtin_fma(fs.s2, ty, c.y)};
 }
-template <int N, bool STORE_U, bool EXPORT = false, bool FCORR = false, int AH = 3, int FS = 0>
-__global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L, const double *__restrict__ f,
+template <int N, bool STORE_U, bool EXPORT = false, bool FCORR = false, int AH = 4, int FS = 0>
+__global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_zero_resid3d(LevelDev L, const double *__restrict__ f,
                                                                      double *__restrict__ out, RestrictDst rd, FSrc fs = FSrc())
 {
 	static_assert(FS == 0 || (!FCORR && !STORE_U && AH >= 2), "the fused right-hand sides exist for the level-0 path of te_bicgstab");
@@ -1049,13 +1065,15 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 	double racc = 0.0;
 
 	// new iterate: u3 = plane z-3, u2 = z-2, u1 = z-1, u0 = z (all start from zero); right-hand sides alongside
-	static_assert(AH >= 1 && AH <= 4, "planes of f in flight");
+	static_assert(AH == 1 || AH == 2 || AH == 4, "planes of f in flight: the loop is unrolled over the ring's slots");
 	double2 u3[2], u2[2], u1[2], u0[2], f2[2], f1[2], f0[2];
-	double2 fa[AH][2];                       // planes z+1 .. z+AH, requested AH steps before their first use
+	// planes z .. z+AH-1 at the start of step z, plane p in slot p % AH. A slot is read (into f0) by the step that consumes its
+	// plane and re-requested by the same step; NO register of a plane in flight is ever copied: a ring that rotates through
+	// register moves makes every step wait for its newest load (the move reads it), whatever distance the source asks for.
+	double2 fa[AH][2];
 	const double2 zero2 = double2{0.0, 0.0};
 	FCorrSrc<N>   fc;
-	double2       ccx[FCorrSrc<N>::NX];      // FCORR: the x terms of plane z ...
-	double2       cca[AH][FCorrSrc<N>::NX];  // ... and of the planes in fa (added when a plane becomes f0: the add must not wait for the newest load)
+	double2       cca[AH][FCorrSrc<N>::NX]; // FCORR: the x terms of the planes in fa (added when a plane becomes f0)
 	if (FCORR) fc.init(L.fcorr, pid, X, Yp);
 	// FS: the operands of the plane requested last (plane z + AH - 1 at the start of step z), and where the combined plane goes
 	const double2 *sa2 = FS ? reinterpret_cast<const double2 *>(fs.a + (size_t) pid * NNN) : nullptr;
@@ -1081,43 +1099,48 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
 		u3[k] = u2[k] = u1[k] = u0[k] = zero2;
-		f2[k] = f1[k] = zero2;
-		if (!FS) f0[k] = fp2[q[k]];
+		f2[k] = f1[k] = f0[k] = zero2;
 	}
-	if (FCORR) fc.load(0, ccx);
 	if constexpr (FS != 0) { // planes 0 .. AH-2 combined here (a one-time wait), plane AH-1 left raw for step 0
-		rawLoad(0);
-		rawCombineStore(0, f0);
 #pragma unroll
-		for (int a = 0; a + 2 < AH; a++) {
-			rawLoad(a + 1 < N ? a + 1 : N - 1);
-			rawCombineStore(a + 1, fa[a]);
+		for (int a = 0; a + 1 < AH; a++) {
+			rawLoad(a < N ? a : N - 1);
+			rawCombineStore(a, fa[a]);
 		}
 		rawLoad(AH - 1 < N ? AH - 1 : N - 1);
 	} else {
 #pragma unroll
-		for (int a = 0; a + 1 < AH; a++) { // planes 1 .. AH-1 (the loop requests plane z+AH at step z)
-			const int za = (a + 1 < N) ? a + 1 : N - 1;
+		for (int a = 0; a < AH; a++) { // planes 0 .. AH-1 (step z requests plane z+AH)
+			const int za = (a < N) ? a : N - 1;
 #pragma unroll
 			for (int k = 0; k < 2; k++) fa[a][k] = ldStream<TE_ZR_NT != 0>(fp2 + za * NP + q[k]);
 			if (FCORR) fc.load(za, cca[a]);
+			// in THIS order: the waits of the loop are derived from the oldest state that reaches its head, and a scheduler that
+			// issues slot 0 last here makes every iteration wait for all but the last loads
+			__builtin_amdgcn_sched_barrier(0);
 		}
 	}
-	if (FCORR) fc.apply(f0, ccx);
 	__syncthreads(); // idiag and the zeroed tiles
 
 	int bz = 0; // z % 4
-	auto step = [&](auto zpar, int z) {
-		constexpr int ZPAR = decltype(zpar)::value;
+	auto step = [&](auto zpar, auto slot_, int z) {
+		constexpr int ZPAR = decltype(zpar)::value, SLOT = decltype(slot_)::value; // z % 2, z % AH
 		const int     zc   = (z + AH < N) ? z + AH : N - 1;
-		if constexpr (FS != 0) { // the plane requested in the previous step takes its place in the ring, the next one is requested
-			rawCombineStore(z + AH - 1, fa[AH - 2]);
-			rawLoad(zc);
-		} else {
 #pragma unroll
-			for (int k = 0; k < 2; k++) fa[AH - 1][k] = ldStream<TE_ZR_NT != 0>(fp2 + zc * NP + q[k]);
+		for (int k = 0; k < 2; k++) { // plane z leaves the ring (requested AH steps ago) ...
+			f2[k] = f1[k];
+			f1[k] = f0[k];
+			f0[k] = takeRegs(fa[SLOT][k]);
 		}
-		if (FCORR) fc.load(zc, cca[AH - 1]);
+		if (FCORR) fc.apply(f0, cca[SLOT]);
+		if constexpr (FS != 0) { // ... the plane requested in the previous step takes its slot, the next one is requested
+			rawCombineStore(z + AH - 1, fa[(SLOT + AH - 1) % AH]);
+			rawLoad(zc);
+		} else { // ... and its slot is requested again
+#pragma unroll
+			for (int k = 0; k < 2; k++) fa[SLOT][k] = ldStream<TE_ZR_NT != 0>(fp2 + zc * NP + q[k]);
+		}
+		if (FCORR) fc.load(zc, cca[SLOT]);
 		double *tz = tile[bz];            // plane z
 		double *t1 = tile[(bz + 3) & 3];  // plane z-1
 		double *t2 = tile[(bz + 2) & 3];  // plane z-2
@@ -1148,7 +1171,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 				// per axis serves both sides (value and address chosen per lane) and both jobs -- the kernel is bound by
 				// instruction issue, and eight separately predicated regions per plane were a sixth of its instructions.
 				const int  zz = z - 1, zh = zz >> 1;
-				const bool second = zz & 1;
+				constexpr bool second = !ZPAR; // zz & 1
 				auto       pair = [&](double &e, double a, double b, double w) { // two cells of this plane join the block's sum
                     double t = second ? e : 0.0;
                     t += (w * a) / 8;
@@ -1187,37 +1210,45 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 			}
 		}
 		if (z > 1) { // residual of plane zr = z-2 (needs the black cells of this plane, written one step ago by all
-			// waves, and of plane z-1, just written by this thread's own registers) and its restriction
+			// waves, and of plane z-1, just written by this thread's own registers) and its restriction.
+			// RED cells only: a black cell was relaxed last, from exactly the values its residual is formed with (the red
+			// neighbours of the finished planes; zero ghosts on faces with a neighbour, whose terms come later; physical
+			// faces folded into its diagonal the same way), so its residual is f - (f + diag v - diag v) = 0 up to the rounding
+			// of that one update -- it enters the restriction as exactly 0. Half the stencil work of this block, and red
+			// cells read only their own column of the rows above and below.
 			const int zr = z - 2;
 			// the black values of plane z-2 other waves wrote in the previous step are visible (barrier above)
-			const double2 ylo = ldsLoad2(t2 + ldo[0]);
-			const double2 yhi = ldsLoad2(t2 + ldo[1]);
-			double        a   = (zr & 1) ? racc : 0.0;
-#pragma unroll
-			for (int k = 0; k < 2; k++) {
-				const double *t0 = t2 + lds[k];
-				const double2 c  = u2[k];
-				double2       ym = (k == 0) ? ylo : u2[0];
-				double2       yp = (k == 0) ? u2[1] : yhi;
-				if (k == 0) ym.x += gS * c.x, ym.y += gS * c.y;
-				if (k == 1) yp.x += gN * c.x, yp.y += gN * c.y;
-				const double xl = t0[-1] + gW * c.x, xr = t0[2] + gE * c.y;
-				const double2 below = (zr == 0) ? double2{gB * c.x, gB * c.y} : u3[k];
-				const double2 above = (zr == N - 1) ? double2{gT * c.x, gT * c.y} : u1[k];
-				double2       lap;
-				lap.x = (xl - 2 * c.x + c.y) * rhx;
-				lap.y = (c.x - 2 * c.y + xr) * rhx;
-				lap.x += (ym.x - 2 * c.x + yp.x) * rhy;
-				lap.y += (ym.y - 2 * c.y + yp.y) * rhy;
-				lap.x += (below.x - 2 * c.x + above.x) * rhz;
-				lap.y += (below.y - 2 * c.y + above.y) * rhz;
-				const double2 r = double2{f2[k].x - lap.x, f2[k].y - lap.y};
-				if (rcpy && act) rcpy[zr * NP + q[k]] = r; // (wave-uniform) AvgRstr.h:103-107
-				a += r.x / 8; // AvgRstr.h:95-102 order: x, then y, then z; each /2^D first
-				a += r.y / 8;
-			}
+			double a = ZPAR ? racc : 0.0; // zr and z have the same parity
+			auto redResid = [&](auto kk, auto cr) {
+				constexpr int K = decltype(kk)::value, CR = decltype(cr)::value; // row of the pair; which of its cells is red in plane zr
+				const double *t0 = t2 + lds[K];
+				const double2 c  = u2[K];
+				const double  cc = CR ? c.y : c.x;
+				const double  outer = t2[ldo[K] + CR];                                    // row y-1 (K = 0) / y+2 (K = 1): LDS
+				const double  inner = CR ? u2[1 - K].y : u2[1 - K].x;                     // the other row of the pair: a register
+				double        ym = (K == 0) ? outer : inner, yp = (K == 0) ? inner : outer;
+				if (K == 0) ym += gS * cc;
+				if (K == 1) yp += gN * cc;
+				const double below = (zr == 0) ? gB * cc : (CR ? u3[K].y : u3[K].x);
+				const double above = (zr == N - 1) ? gT * cc : (CR ? u1[K].y : u1[K].x);
+				double       lap;
+				if (CR == 0) {
+					const double xl = t0[-1] + gW * c.x;
+					lap             = (xl - 2 * c.x + c.y) * rhx;
+				} else {
+					const double xr = t0[2] + gE * c.y;
+					lap             = (c.x - 2 * c.y + xr) * rhx;
+				}
+				lap += (ym - 2 * cc + yp) * rhy;
+				lap += (below - 2 * cc + above) * rhz;
+				const double r = (CR ? f2[K].y : f2[K].x) - lap;
+				if (rcpy && act) rcpy[zr * NP + q[K]] = CR ? double2{0.0, r} : double2{r, 0.0}; // (wave-uniform) AvgRstr.h:103-107
+				a += r / 8; // AvgRstr.h:95-102 order: x, then y, then z; each /2^D first (the black cells add exactly 0)
+			};
+			redResid(std::integral_constant<int, 0>{}, std::integral_constant<int, (0 + ZPAR) & 1>{});
+			redResid(std::integral_constant<int, 1>{}, std::integral_constant<int, (1 + ZPAR) & 1>{});
 			racc = a;
-			if (rdst && (zr & 1) && act) rdst[rsz * (zr >> 1)] = a;
+			if (rdst && ZPAR && act) rdst[rsz * (zr >> 1)] = a;
 		}
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
@@ -1225,28 +1256,26 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs_zero_resid3d(LevelDev L,
 			u2[k] = u1[k];
 			u1[k] = u0[k];
 			u0[k] = zero2;
-			f2[k] = f1[k];
-			f1[k] = f0[k];
-			f0[k] = fa[0][k];
-#pragma unroll
-			for (int a = 0; a + 1 < AH; a++) fa[a][k] = fa[a + 1][k];
-		}
-		if (FCORR) {
-			fc.apply(f0, cca[0]);
-#pragma unroll
-			for (int a = 0; a + 1 < AH; a++)
-#pragma unroll
-				for (int c = 0; c < FCorrSrc<N>::NX; c++) cca[a][c] = cca[a + 1][c];
 		}
 		bz = (bz + 1) & 3;
 	};
+	using S0 = std::integral_constant<int, 0>;
+	using S1 = std::integral_constant<int, 1>;
+	using A1 = std::integral_constant<int, 1 % AH>;
+	using A2 = std::integral_constant<int, 2 % AH>;
+	using A3 = std::integral_constant<int, 3 % AH>;
+	static_assert(N % 4 == 0, "the march is unrolled over up to four ring slots");
 #pragma unroll 1
-	for (int z = 0; z < N; z += 2) {
-		step(std::integral_constant<int, 0>{}, z);
-		step(std::integral_constant<int, 1>{}, z + 1);
+	for (int z = 0; z < N; z += (AH == 4 ? 4 : 2)) {
+		step(S0{}, S0{}, z);
+		step(S1{}, A1{}, z + 1);
+		if constexpr (AH == 4) {
+			step(S0{}, A2{}, z + 2);
+			step(S1{}, A3{}, z + 3);
+		}
 	}
-	step(std::integral_constant<int, 0>{}, N);     // black of plane N-1, residual of plane N-2
-	step(std::integral_constant<int, 1>{}, N + 1); // residual of plane N-1
+	step(S0{}, S0{}, N);     // black of plane N-1, residual of plane N-2
+	step(S1{}, A1{}, N + 1); // residual of plane N-1
 }
 
 // Second half of the fusion above: the ghost terms of the residual along patch faces with a neighbour. One
@@ -1542,43 +1571,55 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_resweep_prolong3d(Lev
 	using P0 = std::integral_constant<int, 0>;
 	using P1 = std::integral_constant<int, 1>;
 
-	// right-hand sides of planes z-1 .. z+3 (fn: z+4 in flight), recomputed planes r1 = v(z+1) (red entries are
-	// what is read), r2 = red(z+2) -> v(z+2), r3 = red(z+3); the sweep's planes as in k_rbgs3d
-	double2 fm[2], f0[2], f1[2], f2[2], f3[2], f4[2], fn[2], r1[2], r2[2], r3[2];
+	// right-hand sides: fm, f0, f1, f2 = planes z-1 .. z+2 in registers; planes z+3 .. z+2+RING in the ring fr, plane p in slot
+	// p % RING from its request (step p-2-RING) over its first use (the red values of step p-3, read from the slot itself) to
+	// the top of step p-2, which takes it into f2 (takeRegs: see k_rbgs_zero_resid3d) and requests plane p+RING into the slot:
+	// RING - 1 steps between a request and its first use, and no register of a plane in flight is moved.
+	// Recomputed planes r1 = v(z+1) (red entries are what is read), r2 = red(z+2) -> v(z+2), r3 = red(z+3); the sweep's planes
+	// as in k_rbgs3d
+	constexpr int RING = DEEP ? 3 : 2;
+	double2 fm[2], f0[2], f1[2], f2[2], fr[RING][2], r1[2], r2[2], r3[2];
 	double2 umm[2], um[2], uc[2], un[2], un2[2];
+	FCorrSrc<N> fc;
+	double2     ccr[RING][FCorrSrc<N>::NX]; // FCORR: the x terms of the planes in the ring (added at a plane's first use)
+	if (FCORR) fc.init(L.fcorr, pid, X, Yp);
+	// state "before step 0 shifts": f0 = plane -1 (zero), f1 = plane 0, f2 = plane 1, the ring holds planes 2 .. 1+RING
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
-		fm[k] = zero2;
-		f0[k] = fp2[0 * NP + q[k]];
-		f1[k] = fp2[1 * NP + q[k]];
-		f2[k] = fp2[2 * NP + q[k]];
-		f3[k] = fp2[3 * NP + q[k]];
-		if (DEEP) f4[k] = fp2[(4 < N ? 4 : N - 1) * NP + q[k]];
+		fm[k] = f0[k] = zero2;
+		f1[k] = fp2[0 * NP + q[k]];
+		f2[k] = fp2[1 * NP + q[k]];
 		umm[k] = zero2;
 	}
-	FCorrSrc<N> fc;
-	double2     ccx[FCorrSrc<N>::NX]; // FCORR: the x terms of the plane in fn
 	if (FCORR) {
-		fc.init(L.fcorr, pid, X, Yp);
-		auto fix = [&](int z, double2(&fz)[2]) {
-			fc.load(z, ccx);
-			fc.apply(fz, ccx);
-		};
-		fix(0, f0), fix(1, f1), fix(2, f2), fix(3, f3);
-		if (DEEP) fix(4 < N ? 4 : N - 1, f4);
+		double2 c0[FCorrSrc<N>::NX], c1[FCorrSrc<N>::NX];
+		fc.load(0, c0);
+		fc.load(1, c1);
+		fc.apply(f1, c0);
+		fc.apply(f2, c1);
 	}
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int a = 0; a < RING; a++) { // planes 2 .. 1+RING, oldest first (the loop's waits assume this order)
+		const int p = 2 + a, zp = p < N ? p : N - 1;
+#pragma unroll
+		for (int k = 0; k < 2; k++) fr[p % RING][k] = ldStream<NTL>(fp2 + zp * NP + q[k]);
+		if (FCORR) fc.load(zp, ccr[p % RING]);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	if (FCORR) fc.apply(fr[2 % RING], ccr[2 % RING]); // plane 2 is read below
 	__syncthreads(); // idiag, zeroed tileV
 	{ // prologue: v(0), v(1)
 		double2 v0[2], v1[2];
-		redOf(P0{}, 0, f0, v0);
-		redOf(P1{}, 1, f1, v1);
-		redOf(P0{}, 2, f2, r2);
+		redOf(P0{}, 0, f1, v0);
+		redOf(P1{}, 1, f2, v1);
+		redOf(P0{}, 2, fr[2 % RING], r2);
 		putRed(P0{}, tileV[0], v0);
 		putRed(P1{}, tileV[1], v1);
 		ldsBarrier();
 		const double2 none[2] = {zero2, zero2};
-		fillBlack(P0{}, 0, tileV[0], v0, none, v1, f0);
-		fillBlack(P1{}, 1, tileV[1], v1, v0, r2, f1);
+		fillBlack(P0{}, 0, tileV[0], v0, none, v1, f1);
+		fillBlack(P1{}, 1, tileV[1], v1, v0, r2, f2);
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
 			if (!CFP) {
@@ -1600,41 +1641,69 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_resweep_prolong3d(Lev
 		}
 		ldsBarrier(); // both red planes have been read: step 0 rewrites the first one
 	}
-	double hv = hs.s * (hs.p[0] + shalo * chalo[0]);
+	// Nothing a step loads is consumed by the same step: loads return in order, so one load that is waited for in the step that
+	// issues it drags every older request (the ring's) to completion with it. The halo value of plane z+1 is requested as its two
+	// raw operands and combined at the top of step z+1; the coarse value of planes z+4, z+5 is requested at even z, two steps
+	// before its first use (one load per coarse plane instead of one per fine plane).
+	double hA = hs.p[0], hB = chalo[0];
+	double cnx = CFP ? 0.0 : cown[NN * 1 + cq], ccur = 0.0; // N >= 4: planes 2 and 3 share coarse plane 1
 
 	int bz = 0; // z % 3
-	auto step = [&](auto zpar, int z) {
-		constexpr int ZPAR = decltype(zpar)::value;
+	// LAST: the three steps z = N-2, N-1, N, whose plane z+2 is the top neighbour's: code of their own, so that the loads they
+	// alone issue (that plane, used at once) exist nowhere in the loop -- a load inside a branch makes the compiler wait for
+	// everything where the branch rejoins, on every step (it cannot know the branch was not taken).
+	auto step = [&](auto zpar, auto slot_, auto last_, int z) {
+		constexpr int  ZPAR = decltype(zpar)::value, SLOT = decltype(slot_)::value; // z % 2, z % RING
+		constexpr bool LAST = decltype(last_)::value;                               // z + 2 >= N
+		constexpr int S2 = (SLOT + 2) % RING, S3 = (SLOT + 3) % RING;               // the slots of planes z+2 and z+3
 		using ZQ          = std::integral_constant<int, 1 - ZPAR>;
 		double2 c2v[2]; // CFP: the correction of plane z+2 (or of the top neighbour's plane), per row
-		// loads for the coming steps
-		constexpr int AHEAD = DEEP ? 5 : 4;
-		const int     zf = (z + AHEAD < N) ? z + AHEAD : N - 1, zc = (z + 1 < N) ? z + 1 : N - 1;
+		// Order of the requests: the operands that are consumed ONE step later (halo, coarse value) first, then the ring's slot,
+		// whose first use is RING - 1 steps away -- loads return in order, so waiting for a load completes everything requested
+		// before it, and nothing more.
+		const int zf = (z + 2 + RING < N) ? z + 2 + RING : N - 1, zc = (z + 1 < N) ? z + 1 : N - 1;
+		const double hv = hs.s * (takeReg(hA) + shalo * takeReg(hB)); // plane z's
+		hA              = hs.p[zc * hs.stride];
+		hB              = chalo[NN * (zc >> hsh)];
+		if constexpr (ZPAR == 0 && !CFP) {
+			ccur = takeReg(cnx);
+			cnx  = (z + 4 < N) ? cown[NN * ((z + 4) >> 1) + cq] : ctop[cq];
+		}
+		__builtin_amdgcn_sched_barrier(0);
+		// the right-hand sides move down one plane; plane z+2 leaves the ring and its slot is requested again
 #pragma unroll
-		for (int k = 0; k < 2; k++) fn[k] = ldStream<NTL>(fp2 + zf * NP + q[k]);
-		if (FCORR) fc.load(zf, ccx);
-		const double hvn = hs.s * (hs.p[zc * hs.stride] + shalo * chalo[NN * (zc >> hsh)]);
-		const double c2  = CFP ? 0.0 : ((z + 2 < N) ? cown[NN * ((z + 2) >> 1) + cq] : stop * ctop[cq]);
+		for (int k = 0; k < 2; k++) {
+			fm[k] = f0[k];
+			f0[k] = f1[k];
+			f1[k] = f2[k];
+			f2[k] = takeRegs(fr[S2][k]);
+			fr[S2][k] = ldStream<NTL>(fp2 + zf * NP + q[k]);
+		}
+		if (FCORR) {
+			fc.load(zf, ccr[S2]);
+			fc.apply(fr[S3], ccr[S3]); // plane z+3: first read below
+		}
+		const double c2 = CFP ? 0.0 : (!LAST ? ccur : stop * ccur);
 		if (CFP) {
 #pragma unroll
 			for (int k = 0; k < 2; k++) {
-				const double2 c  = (z + 2 < N) ? ownC(k, z + 2) : topC(k);
-				const double  cs = (z + 2 < N) ? 1.0 : stop;
+				const double2 c  = !LAST ? ownC(k, z + 2) : topC(k);
+				const double  cs = !LAST ? 1.0 : stop;
 				c2v[k]           = double2{cs * c.x, cs * c.y};
 			}
 		}
 		double2      tg[2];
-		if (TG_ALWAYS || z + 2 >= N) { // the top neighbour's plane (used on the last steps only)
+		if constexpr (TG_ALWAYS || LAST) { // the top neighbour's plane (used on the last steps only)
 #pragma unroll
 			for (int k = 0; k < 2; k++) tg[k] = top.p[q[k]];
 		}
 		// before the barrier: red values two and three planes ahead, this plane of the iterate into LDS
 		double *tvz = tileV[z & 1];
 		if (z + 3 < N)
-			redOf(ZQ{}, z + 3, f3, r3);
+			redOf(ZQ{}, z + 3, fr[S3], r3);
 		else
 			r3[0] = r3[1] = zero2;
-		if (z + 2 < N) putRed(zpar, tvz, r2);
+		if constexpr (!LAST) putRed(zpar, tvz, r2);
 		double *tz = tileS[bz];
 		double *tm = tileS[bz == 0 ? 2 : bz - 1];
 		if (z < N) {
@@ -1646,7 +1715,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_resweep_prolong3d(Lev
 		}
 		ldsBarrier();
 		// the iterate two planes ahead: black values of the recomputed plane, plus the coarse correction
-		if (z + 2 < N) {
+		if constexpr (!LAST) {
 			fillBlack(zpar, z + 2, tvz, r2, r1, r3, f2);
 #pragma unroll
 			for (int k = 0; k < 2; k++) un2[k] = CFP ? double2{r2[k].x + c2v[k].x, r2[k].y + c2v[k].y} : double2{r2[k].x + c2, r2[k].y + c2};
@@ -1682,28 +1751,43 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_resweep_prolong3d(Lev
 			um[k]  = uc[k];
 			uc[k]  = un[k];
 			un[k]  = un2[k];
-			fm[k]  = f0[k];
-			f0[k]  = f1[k];
-			f1[k]  = f2[k];
-			f2[k]  = f3[k];
-			if (DEEP) {
-				f3[k] = f4[k];
-				f4[k] = fn[k];
-			} else {
-				f3[k] = fn[k];
-			}
 			r1[k]  = r2[k];
 			r2[k]  = r3[k];
 		}
-		if (FCORR) fc.apply(DEEP ? f4 : f3, ccx);
-		hv = hvn;
 		bz = (bz == 2) ? 0 : bz + 1;
 	};
+	// unrolled over parity and ring slots: U = lcm(2, RING) steps per iteration over z < N-2, then the (N-2) % U steps left, then
+	// the three LAST steps
+	constexpr int U = (RING == 3) ? 6 : 2;
+	using NotLast = std::integral_constant<bool, false>;
+	using Last    = std::integral_constant<bool, true>;
+	auto run = [&](auto ic, int z) {
+		constexpr int I = decltype(ic)::value;
+		step(std::integral_constant<int, I & 1>{}, std::integral_constant<int, I % RING>{}, NotLast{}, z);
+	};
+	// every request of the prologue has arrived before the loop starts (planes 0..2 were waited for above anyway): the waits
+	// inside the loop are derived from the worst state that reaches its head, and the prologue's request order is not the loop's
+	__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+	int z = 0;
 #pragma unroll 1
-	for (int z = 0; z < N; z += 2) {
-		step(P0{}, z);
-		step(P1{}, z + 1);
+	for (; z + U <= N - 2; z += U) {
+		run(std::integral_constant<int, 0>{}, z);
+		run(std::integral_constant<int, 1>{}, z + 1);
+		if constexpr (U == 6) {
+			run(std::integral_constant<int, 2>{}, z + 2);
+			run(std::integral_constant<int, 3>{}, z + 3);
+			run(std::integral_constant<int, 4>{}, z + 4);
+			run(std::integral_constant<int, 5>{}, z + 5);
+		}
 	}
-	step(P0{}, N);
+	constexpr int REM = (N - 2) % U; // (z is a multiple of U here)
+	if constexpr (REM > 0) run(std::integral_constant<int, 0>{}, z);
+	if constexpr (REM > 1) run(std::integral_constant<int, 1>{}, z + 1);
+	if constexpr (REM > 2) run(std::integral_constant<int, 2>{}, z + 2);
+	if constexpr (REM > 3) run(std::integral_constant<int, 3>{}, z + 3);
+	if constexpr (REM > 4) run(std::integral_constant<int, 4>{}, z + 4);
+	step(std::integral_constant<int, 0>{}, std::integral_constant<int, (N - 2) % RING>{}, Last{}, N - 2);
+	step(std::integral_constant<int, 1>{}, std::integral_constant<int, (N - 1) % RING>{}, Last{}, N - 1);
+	step(std::integral_constant<int, 0>{}, std::integral_constant<int, N % RING>{}, Last{}, N);
 }
 } // namespace te
