@@ -1667,12 +1667,14 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 			const dim3  grid(8 * ((D.count + 7) / 8)), blk(Tile3<N>::TPB);
 			// tuning variants (march3d.hpp), all bit-identical. Defaults, each measured: the finest level stores u non-temporally
 			// (nobody re-reads it) and loads f non-temporally unless f can still be in the Infinity Cache from the pre-sweep
-			// that read it (19 instead of 27: 256^3, a rank's share at eight ranks; 53.4 -> 49.0 us at 256^3); a coarser
-			// level with exported ghost terms (level 1 of 512^3) keeps ordinary stores as well -- its u is the correction the
-			// finer level's post-sweep reads next (3: 64.5 us, against 68.7 with non-temporal stores)
+			// that read it (19 instead of 27: 256^3, a rank's share at eight ranks; 53.4 -> 49.0 us at 256^3); a large finest
+			// level runs two workgroups per CU with four planes of f in flight each instead of three with two (59: 450 -> 443 us
+			// at 512^3, same box; slower at 256^3); a coarser level with exported ghost terms (level 1 of 512^3) keeps ordinary
+			// stores as well -- its u is the correction the finer level's post-sweep reads next (3: 64.5 us, against 68.7 with
+			// non-temporal stores)
 			const char *ve    = g->cfg.str(O_RESWEEP_V);
 			const bool  small = (size_t) L.P * L.nc * sizeof(double) <= ((size_t) 160 << 20);
-			const int   v     = ve ? atoi(ve) : (fcorr_in ? 3 : ((small && g->cur_level == 0) ? 19 : 27));
+			const int   v     = ve ? atoi(ve) : (fcorr_in ? 3 : (g->cur_level != 0 ? 27 : (small ? 19 : 59)));
 			if (L.ncf > 0 || L.has_copy) { // refined level: copy-through patches / coarse-fine ghost slots
 				if (v == 3)
 					launchT(t, (k_rbgs_resweep_prolong3d<N, 3, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
@@ -1695,6 +1697,10 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 				launchT(t, (k_rbgs_resweep_prolong3d<N, 11, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 19) {
 				launchT(t, (k_rbgs_resweep_prolong3d<N, 19, false>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else if (v == 59) {
+				launchT(t, (k_rbgs_resweep_prolong3d<N, 59, false>), grid, blk, 0, g->stream, D, f, out, ps);
+			} else if (v == 63) {
+				launchT(t, (k_rbgs_resweep_prolong3d<N, 63, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 23) {
 				launchT(t, (k_rbgs_resweep_prolong3d<N, 23, false>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (v == 31) {

@@ -39,6 +39,22 @@ template <bool NT> __device__ __forceinline__ void stStream(double2 *p, double2 
 	} else
 		*p = v;
 }
+// A copy the compiler cannot see through: the source registers are dead afterwards, so the load that refills a ring slot can
+// be given the slot's own registers. Without it the register allocator merges the COPY with the slot (the copy is free) and
+// gives every refill fresh registers, which it then moves into the slot's registers at the loop's back edge -- a move that reads
+// the newest loads and makes every iteration wait for them.
+__device__ __forceinline__ double2 takeRegs(const double2 &src)
+{
+	double2 r;
+	asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(r.x), "=&v"(r.y) : "v"(src.x), "v"(src.y));
+	return r;
+}
+__device__ __forceinline__ double takeReg(double src)
+{
+	double r;
+	asm volatile("v_mov_b64 %0, %1" : "=&v"(r) : "v"(src));
+	return r;
+}
 template <int N> struct Tile3 {
 	static constexpr int H   = N / 2;
 	static constexpr int NT  = H * H;               // threads that own cells
@@ -149,47 +165,67 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 	const PlaneSrc top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, -1.0, 1.0);
 
 	// ---- register pipeline over z ------------------------------------------------------------
-	double2        um[2], uc[2], un[2], un2[2], fc[2], fn[2];
-	const double2 *pm  = (z0 > 0) ? up2 + (z0 - 1) * NP : bot.p;
-	const double   sm  = (z0 > 0) ? 1.0 : bot.s;
-	const double2 *pn1 = (z0 + 1 < N) ? up2 + (z0 + 1) * NP : top.p;
-	const double   sn1 = (z0 + 1 < N) ? 1.0 : top.s;
+	// um, uc, un = planes z-1, z, z+1 of u (ghost planes scaled). Planes z+2, z+3 of u, z+1, z+2 of the right-hand side (and of
+	// the fused sums' second operand) are in flight in two-slot rings, plane p in slot p & 1, raw: a slot is taken (takeRegs,
+	// see k_rbgs_zero_resid3d) by the step that first needs its plane and requested again in place, two steps before its next
+	// use; nothing a step requests is touched by the same step (a load consumed in the step that issues it makes the step wait
+	// for it and, loads returning in order, for everything requested before it). The halo value of the next plane is requested
+	// first in every step: it is what the next step waits for.
+	constexpr bool HAS_F = MODE != MODE_APPLY, HAS_A = RED == RED_OUT_A || RED == RED_OUT_A_OUT;
+	const double2 *ap2 = HAS_A ? reinterpret_cast<const double2 *>(red.a + (size_t) pid * NNN) : nullptr;
+	double2        um[2], uc[2], un[2], fc[2], ac[2];
+	double2        ur[2][2], fr[2][2], ar[2][2];
+	double         acc0 = 0.0, acc1 = 0.0;
+	auto uPlane = [&](int p) { return (p < 0) ? bot.p : (p < N ? up2 + p * NP : top.p); };   // p = z0 - 1 .. N
+	auto uScale = [&](int p) { return (p < 0) ? bot.s : (p < N ? 1.0 : top.s); };
+	auto clampP = [&](int p) { return p < N ? p : N - 1; };
+	// state before step 0 shifts: uc = plane z0-1 (-> um), un = plane z0 (-> uc); the rings hold planes z0+1, z0+2 of u and
+	// z0, z0+1 of the right-hand side
 #pragma unroll
 	for (int k = 0; k < 2; k++) {
-		uc[k]     = up2[z0 * NP + q[k]];
-		double2 a = pm[q[k]], b = pn1[q[k]];
-		um[k]     = double2{sm * a.x, sm * a.y};
-		un[k]     = double2{sn1 * b.x, sn1 * b.y};
-		if (MODE != MODE_APPLY) fc[k] = fp2[z0 * NP + q[k]];
+		const double2 a = uPlane(z0 - 1)[q[k]];
+		const double  sm = uScale(z0 - 1);
+		uc[k] = double2{sm * a.x, sm * a.y};
+		un[k] = up2[z0 * NP + q[k]];
 	}
-	double hv = hs.s * hs.p[z0 * hs.stride];
-	// fused sums: the second operand travels one plane ahead, like f
-	const double2 *ap2 = (RED == RED_OUT_A || RED == RED_OUT_A_OUT) ? reinterpret_cast<const double2 *>(red.a + (size_t) pid * NNN) : nullptr;
-	double2        ac[2], an[2];
-	double         acc0 = 0.0, acc1 = 0.0;
-	if (RED == RED_OUT_A || RED == RED_OUT_A_OUT) {
+	double hraw = hs.p[z0 * hs.stride];
+	__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-		for (int k = 0; k < 2; k++) ac[k] = ap2[z0 * NP + q[k]];
-	}
-
-#pragma unroll 1
-	for (int zz = 0; zz < ZL; zz++) {
-		const int z = z0 + zz;
-		// issue everything the NEXT iteration needs: plane z+2 (or the top ghost), rhs plane z+1,
-		// halo of plane z+1 (indices clamped on the last iterations: harmless re-reads)
-		const double2 *pn = (z + 2 < N) ? up2 + (z + 2) * NP : top.p;
-		const double   sn = (z + 2 < N) ? 1.0 : top.s;
-		const int      zc = (z + 1 < N) ? z + 1 : N - 1;
+	for (int i = 0; i < 2; i++) { // oldest first: the loop's waits assume the order of its own requests
 #pragma unroll
 		for (int k = 0; k < 2; k++) {
-			double2 a = pn[q[k]];
-			un2[k]    = double2{sn * a.x, sn * a.y};
-			if (MODE != MODE_APPLY) fn[k] = fp2[zc * NP + q[k]];
-			if (RED == RED_OUT_A || RED == RED_OUT_A_OUT) an[k] = ap2[zc * NP + q[k]];
+			ur[(i + 1) & 1][k] = uPlane(z0 + 1 + i)[q[k]];
+			if (HAS_F) fr[i][k] = fp2[clampP(z0 + i) * NP + q[k]];
+			if (HAS_A) ar[i][k] = ap2[clampP(z0 + i) * NP + q[k]];
 		}
-		const double hvn = hs.s * hs.p[zc * hs.stride];
+		__builtin_amdgcn_sched_barrier(0);
+	}
 
-		double *tl = tile[zz & 1];
+	// REFILL = false: the last two steps of a slab, which request nothing (their planes would never be used)
+	auto step = [&](auto par, auto refill, int zz) {
+		constexpr int  PAR = decltype(par)::value; // zz & 1
+		constexpr bool REFILL = decltype(refill)::value;
+		const int      z = z0 + zz;
+		const double   hv = hs.s * takeReg(hraw);
+		if (REFILL || PAR == 0) hraw = hs.p[clampP(z + 1) * hs.stride]; // (the last step has no successor)
+		__builtin_amdgcn_sched_barrier(0);
+		const double sn = uScale(z + 1);
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			um[k] = uc[k];
+			uc[k] = un[k];
+			const double2 a = takeRegs(ur[1 - PAR][k]); // plane z+1
+			un[k]           = double2{sn * a.x, sn * a.y};
+			if (HAS_F) fc[k] = takeRegs(fr[PAR][k]);
+			if (HAS_A) ac[k] = takeRegs(ar[PAR][k]);
+			if (REFILL) {
+				ur[1 - PAR][k] = uPlane(z + 3)[q[k]];
+				if (HAS_F) fr[PAR][k] = fp2[clampP(z + 2) * NP + q[k]];
+				if (HAS_A) ar[PAR][k] = ap2[clampP(z + 2) * NP + q[k]];
+			}
+		}
+
+		double *tl = tile[PAR];
 		if (act) {
 			ldsStore2(tl + lds[0], uc[0]);
 			ldsStore2(tl + lds[1], uc[1]);
@@ -227,13 +263,13 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 			}
 		}
 		if (MODE == MODE_RESID_RESTRICT && rorth >= 0) {
-			double a = (z & 1) ? racc : 0.0; // AvgRstr.h:95-102 order: x, then y, then z; each /2^D first
+			double a = PAR ? racc : 0.0; // (z0 is even) AvgRstr.h:95-102 order: x, then y, then z; each /2^D first
 			a += r[0].x / 8;
 			a += r[0].y / 8;
 			a += r[1].x / 8;
 			a += r[1].y / 8;
 			racc = a;
-			if ((z & 1) && act) rdst[rsz * (z >> 1)] = a;
+			if (PAR && act) rdst[rsz * (z >> 1)] = a;
 		} else if (act) {
 			op2[z * NP + q[0]] = r[0];
 			op2[z * NP + q[1]] = r[1];
@@ -255,16 +291,17 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 				}
 			}
 		}
-#pragma unroll
-		for (int k = 0; k < 2; k++) {
-			um[k] = uc[k];
-			uc[k] = un[k];
-			un[k] = un2[k];
-			if (MODE != MODE_APPLY) fc[k] = fn[k];
-			if (RED == RED_OUT_A || RED == RED_OUT_A_OUT) ac[k] = an[k];
-		}
-		hv = hvn;
+	};
+	using B0 = std::integral_constant<int, 0>;
+	using B1 = std::integral_constant<int, 1>;
+	static_assert(ZL % 2 == 0 && ZL >= 4, "the march is unrolled over the two ring slots and ends with two steps of its own");
+#pragma unroll 1
+	for (int zz = 0; zz < ZL - 2; zz += 2) {
+		step(B0{}, std::true_type{}, zz);
+		step(B1{}, std::true_type{}, zz + 1);
 	}
+	step(B0{}, std::false_type{}, ZL - 2);
+	step(B1{}, std::false_type{}, ZL - 1);
 	if (RED != RED_NONE) {
 		__syncthreads(); // (the LDS of blockReduce2 is its own, but every wave must have left the plane loop's barriers)
 		blockReduce2(acc0, acc1);
@@ -952,22 +989,6 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 // in this pass instead of 24 / 32 in a pass of their own plus the 8 this kernel reads anyway. The operands of a plane are
 // requested at the usual distance and combined one step later (not in the step that requests them: that would wait for
 // loads just issued), so they add one raw stage to the ring of planes in flight.
-// A copy the compiler cannot see through: the source registers are dead afterwards, so the load that refills a ring slot can
-// be given the slot's own registers. Without it the register allocator merges the COPY with the slot (the copy is free) and
-// gives every refill fresh registers, which it then moves into the slot's registers at the loop's back edge -- a move that reads
-// the newest loads and makes every iteration wait for them.
-__device__ __forceinline__ double2 takeRegs(const double2 &src)
-{
-	double2 r;
-	asm volatile("v_mov_b64 %0, %2\n\tv_mov_b64 %1, %3" : "=&v"(r.x), "=&v"(r.y) : "v"(src.x), "v"(src.y));
-	return r;
-}
-__device__ __forceinline__ double takeReg(double src)
-{
-	double r;
-	asm volatile("v_mov_b64 %0, %1" : "=&v"(r) : "v"(src));
-	return r;
-}
 struct FSrc {
 	const double *a, *b, *c; // FS = 1: resid, ap, -; FS = 2: p, ap, resid
 	double       *out;       // s, or p (in place: every thread rewrites exactly the cells it has read)
@@ -1417,14 +1438,15 @@ __global__ void k_pack_faces6_3d(const int32_t *__restrict__ faces, const double
 
 // V (tuning variants, all bit-identical): bit 0: the black values of the recomputed plane and of the sweep's plane z-1 are
 // not written back to LDS (nobody reads them: their x/y neighbours are red); bit 1: the top neighbour's plane is loaded on
-// the last steps only; bit 2: right-hand sides are requested five planes ahead instead of four (two steps before their
-// first use instead of one: measured, no effect); bit 3 / bit 4: non-temporal loads of f / stores of u (a level's vectors
-// are not re-read before they have left the caches: +1.4 % at 512^3, +10 % at 256^3). Default 27.
+// the last steps only; bit 2: three ring slots for the planes of f in flight instead of two (a request is two steps ahead
+// of its first use instead of one; costs 8 registers: spills at three workgroups per CU); bit 3 / bit 4: non-temporal loads
+// of f / stores of u (a level's vectors are not re-read before they have left the caches: +1.4 % at 512^3, +10 % at 256^3);
+// bit 5: two workgroups per CU (256 registers) with four ring slots (with bit 2: three). Defaults: see resweepProlongN.
 // FCORR: this level's right-hand side carries ghost terms in L.fcorr (see FCorrSrc)
 // CFP: a refined level, as k_rbgs3d<..., CFP>: patches that copy through take their correction cell by cell from the
 // same-size coarse patch, coarse/fine ghost slots hold u + P e already (k_cf_ghost6_3d<N, true>)
 template <int N, int V = 0, bool FCORR = false, bool CFP = false>
-__global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_resweep_prolong3d(LevelDev L, const double *__restrict__ f,
+__global__ __launch_bounds__(Tile3<N>::TPB, (V & 32) ? 2 : 3) void k_rbgs_resweep_prolong3d(LevelDev L, const double *__restrict__ f,
                                                                           double *__restrict__ out, ProlongSrc ps)
 {
 	constexpr bool LDS_ALL = !(V & 1), TG_ALWAYS = !(V & 2), DEEP = (V & 4) != 0, NTL = (V & 8) != 0, NTS = (V & 16) != 0;
@@ -1577,7 +1599,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_resweep_prolong3d(Lev
 	// RING - 1 steps between a request and its first use, and no register of a plane in flight is moved.
 	// Recomputed planes r1 = v(z+1) (red entries are what is read), r2 = red(z+2) -> v(z+2), r3 = red(z+3); the sweep's planes
 	// as in k_rbgs3d
-	constexpr int RING = DEEP ? 3 : 2;
+	constexpr int RING = (V & 32) ? (DEEP ? 3 : 4) : (DEEP ? 3 : 2);
 	double2 fm[2], f0[2], f1[2], f2[2], fr[RING][2], r1[2], r2[2], r3[2];
 	double2 umm[2], um[2], uc[2], un[2], un2[2];
 	FCorrSrc<N> fc;
@@ -1758,7 +1780,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_resweep_prolong3d(Lev
 	};
 	// unrolled over parity and ring slots: U = lcm(2, RING) steps per iteration over z < N-2, then the (N-2) % U steps left, then
 	// the three LAST steps
-	constexpr int U = (RING == 3) ? 6 : 2;
+	constexpr int U = (RING == 3) ? 6 : (RING == 4 ? 4 : 2);
 	using NotLast = std::integral_constant<bool, false>;
 	using Last    = std::integral_constant<bool, true>;
 	auto run = [&](auto ic, int z) {
@@ -1773,9 +1795,11 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_resweep_prolong3d(Lev
 	for (; z + U <= N - 2; z += U) {
 		run(std::integral_constant<int, 0>{}, z);
 		run(std::integral_constant<int, 1>{}, z + 1);
-		if constexpr (U == 6) {
+		if constexpr (U >= 4) {
 			run(std::integral_constant<int, 2>{}, z + 2);
 			run(std::integral_constant<int, 3>{}, z + 3);
+		}
+		if constexpr (U == 6) {
 			run(std::integral_constant<int, 4>{}, z + 4);
 			run(std::integral_constant<int, 5>{}, z + 5);
 		}

@@ -414,7 +414,7 @@ def test_fused_sums_of_the_stencil_kernel(case):
 
 def test_post_sweep_tuning_variants_bit_identical():
     """k_rbgs_resweep_prolong3d's variants (TE_RESWEEP_V: which black values go back to LDS, when the top neighbour's plane is
-    loaded, non-temporal loads of f / stores of u) and k_rbgs_zero_resid3d's prefetch distance (TE_ZR_AHEAD) change the
+    loaded, non-temporal loads of f / stores of u, two / three / four ring slots for the planes of f in flight) and k_rbgs_zero_resid3d's prefetch distance (TE_ZR_AHEAD) change the
     schedule, not one bit: 256^3 (the default there is 19) and the level-1 variant with exported ghost terms of a 16^3-patch
     grid of 8^3 patches."""
     for n, div in ((32, 3), (8, 4)):
@@ -422,7 +422,7 @@ def test_post_sweep_tuning_variants_bit_identical():
         g = capi.GMG(H)
         f = util.rand_vec(levels[0].size, 88) / levels[0].a["h"].min() ** 2
         got = {}
-        for v in (None, "0", "3", "19", "27"):
+        for v in (None, "0", "3", "19", "27", "31", "59"):
             g.set_option("TE_RESWEEP_V", v)
             for ah in (None, "1"):
                 g.set_option("TE_ZR_AHEAD", ah)

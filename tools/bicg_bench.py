@@ -1,7 +1,9 @@
-import sys, time
-sys.path.insert(0, '/root/repo')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pressurepoissonsolver_amd import capi, problems
+if len(sys.argv) > 2 and sys.argv[1] == '--lib':  # another build of the library (same-box comparisons)
+    capi.LIB_PATH = os.path.abspath(sys.argv[2])
 n=32
 mesh = capi.Mesh.uniform(3, 4)
 H = capi.Hierarchy(mesh, n)
