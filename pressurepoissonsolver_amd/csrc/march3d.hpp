@@ -55,6 +55,35 @@ __device__ __forceinline__ double takeReg(double src)
 	asm volatile("v_mov_b64 %0, %1" : "=&v"(r) : "v"(src));
 	return r;
 }
+// The six face kinds of a patch, requested together: read one by one under conditions (position class != interior) they
+// are three dependent waits at the start of every workgroup, and a slab kernel is six plane steps long.
+struct FaceKinds {
+	int32_t k[6];
+	__device__ __forceinline__ explicit FaceKinds(const int32_t *fk)
+	{
+#pragma unroll
+		for (int s = 0; s < 6; s++) k[s] = fk[s];
+	}
+	// ghost of the residual's stencil as a multiple of the cell just inside: -1 Dirichlet, +1 Neumann, 0 on a face with a neighbour
+	__device__ __forceinline__ double phys(int s) const { return k[s] == FACE_DIRICHLET ? -1.0 : (k[s] == FACE_NEUMANN ? 1.0 : 0.0); }
+};
+// 1/diag of the patch-local relaxation per (x, y, z) position class (low face, interior, high face): physical faces are folded
+// into the diagonal, k = 3 Dirichlet, 1 Neumann (StarPatchOp.h:39-65)
+__device__ __forceinline__ void idiagTable(double *idiag, int tid, const FaceKinds &kinds, double rhx, double rhy, double rhz)
+{
+	if (tid < 27) {
+		double    kf[3];
+		const int cls[3] = {tid % 3, (tid / 3) % 3, tid / 9};
+#pragma unroll
+		for (int ax = 0; ax < 3; ax++) {
+			const int kind = cls[ax] == 2 ? kinds.k[2 * ax + 1] : kinds.k[2 * ax];
+			kf[ax]         = 2.0;
+			if (cls[ax] != 1 && kind == FACE_DIRICHLET) kf[ax] = 3.0;
+			if (cls[ax] != 1 && kind == FACE_NEUMANN) kf[ax] = 1.0;
+		}
+		idiag[tid] = 1.0 / (kf[0] * rhx + kf[1] * rhy + kf[2] * rhz);
+	}
+}
 template <int N> struct Tile3 {
 	static constexpr int H   = N / 2;
 	static constexpr int NT  = H * H;               // threads that own cells
@@ -147,13 +176,16 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 
 	int dix[2][2] = {{0, 0}, {0, 0}}; // cx + 3 cy of (row k, cell)
 	if (MODE == MODE_JACOBI) {
+		const double *kp = L.face_kadj + (size_t) pid * 6;
+		double        ka[6]; // (all six together: one wait instead of three)
+#pragma unroll
+		for (int s6 = 0; s6 < 6; s6++) ka[s6] = kp[s6];
 		if (tid < 27) {
-			const double *ka = L.face_kadj + (size_t) pid * 6;
-			int           cx = tid % 3, cy = (tid / 3) % 3, cz = tid / 9;
-			double        kx = 2.0 + (cx == 0 ? ka[0] : 0.0) + (cx == 2 ? ka[1] : 0.0);
-			double        ky = 2.0 + (cy == 0 ? ka[2] : 0.0) + (cy == 2 ? ka[3] : 0.0);
-			double        kz = 2.0 + (cz == 0 ? ka[4] : 0.0) + (cz == 2 ? ka[5] : 0.0);
-			idiag[tid]       = -1.0 / (kx * rhx + ky * rhy + kz * rhz);
+			int    cx = tid % 3, cy = (tid / 3) % 3, cz = tid / 9;
+			double kx = 2.0 + (cx == 0 ? ka[0] : 0.0) + (cx == 2 ? ka[1] : 0.0);
+			double ky = 2.0 + (cy == 0 ? ka[2] : 0.0) + (cy == 2 ? ka[3] : 0.0);
+			double kz = 2.0 + (cz == 0 ? ka[4] : 0.0) + (cz == 2 ? ka[5] : 0.0);
+			idiag[tid] = -1.0 / (kx * rhx + ky * rhy + kz * rhz);
 		}
 		const int cy0 = (Yp == 0) ? 0 : 1, cy1 = (Yp == H - 1) ? 2 : 1;
 		const int cx0 = (X == 0) ? 0 : 1, cx1 = (X == H - 1) ? 2 : 1;
@@ -540,20 +572,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	const double2 *fp2 = reinterpret_cast<const double2 *>(f + (size_t) pid * NNN);
 	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
 
-	if (tid < 27) {
-		double kf[3];
-		int    cls[3] = {tid % 3, (tid / 3) % 3, tid / 9};
-#pragma unroll
-		for (int ax = 0; ax < 3; ax++) {
-			kf[ax] = 2.0;
-			if (cls[ax] != 1) {
-				int kind = fk[2 * ax + (cls[ax] == 2)];
-				if (kind == FACE_DIRICHLET) kf[ax] = 3.0;
-				if (kind == FACE_NEUMANN) kf[ax] = 1.0;
-			}
-		}
-		idiag[tid] = 1.0 / (kf[0] * rhx + kf[1] * rhy + kf[2] * rhz);
-	}
+	FaceKinds kinds(fk);
+	idiagTable(idiag, tid, kinds, rhx, rhy, rhz);
 
 	HaloSrc  hs;
 	PlaneSrc bot, top;
@@ -877,24 +897,49 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 	constexpr int QN = (NN + 255) / 256;
 	const int     pc = blockIdx.x / 12, blk = blockIdx.x % 12; // 0..3: the x planes; 4..7: the y planes; 8..11: the z planes
 	const bool    cp = copy && copy[pc];
-	// the term of entry (a, b) of plane j of axis ax of this coarse patch
-	auto term = [&](int ax, int j, int a, int b) -> double {
-		if (rs6 && gtab) { // (a uniformly refined fine level: the finished sums of the neighbours)
-			const int oa = a >= H, ob = b >= H;
-			const int t  = gtab[(size_t) pc * 48 + ax * 16 + j * 4 + oa + 2 * ob];
-			if (t >= 0) return rs6[(size_t) t + (a - oa * H) + H * (b - ob * H)];
-			if (t == -1) return 0.0;
+	// The term of entry (a, b) of plane j of axis ax of this coarse patch, in two stages so that a thread's entries overlap:
+	// where (tabIndex: one cached table read per entry, all of a thread's entries requested together), then the value
+	// (fastValue: again all together, from a harmless address where there is nothing to read), and only for entries the table
+	// does not cover (-2: neighbour on another rank, copy-through patch, no table) the general chain child -> face kind /
+	// source -> values (slowTerm). Read one after the other under their conditions, a thread's four entries were eight
+	// dependent waits.
+	const bool tab = rs6 && gtab;
+	// A coarse patch that IS a fine patch that does not coarsen (cp, uniform over the workgroup): its own two faces of each axis,
+	// cell by cell (w g), as the copy-through branch of k_restrict_fixup3d adds them. Where g comes from and w are facts of the
+	// patch and the face: read once per workgroup (cpG / cpW [axis][low, high face]; null: no term), so that an entry is one load.
+	const double *cpG[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+	double        cpW[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+	if (cp) {
+		const int p = child[(size_t) pc * 8];
+		if (p >= 0) {
+			const int axb = blk >> 2; // this workgroup's axis; a z plane also adds the y terms of its first and last row
+#pragma unroll
+			for (int ax = 0; ax < 3; ax++) {
+				if (ax != axb && !(axb == 2 && ax == 1)) continue;
+#pragma unroll
+				for (int hi = 0; hi < 2; hi++) {
+					const int sp = 2 * ax + hi;
+					const int kind = L.face_kind[(size_t) p * 6 + sp], src = L.face_src[(size_t) p * 6 + sp];
+					if (kind < FACE_LOCAL) continue;
+					cpG[ax][hi] = kind == FACE_GHOST ? L.ghost + (size_t) src * NN : f6 + ((size_t) src * 6 + (sp ^ 1)) * NN;
+					cpW[ax][hi] = -L.rh2[(size_t) p * 3 + ax];
+				}
+			}
 		}
+	}
+	auto tabIndex = [&](int ax, int j, int a, int b) -> int { // >= 0: offset of the 16x16 block in rs6; -1: zero; -2: slowTerm; -3: cp
+		if (cp) return (j == 0 || j == 3) && cpG[ax][j == 3] ? -3 : -1;
+		if (!tab) return -2;
+		const int oa = a >= H, ob = b >= H;
+		return gtab[(size_t) pc * 48 + ax * 16 + j * 4 + oa + 2 * ob];
+	};
+	auto fastAddr = [&](int t, int ax, int j, int a, int b) -> const double * {
+		const int oa = a >= H, ob = b >= H;
+		if (t == -3) return cpG[ax][j == 3] + a + N * b;
+		return t >= 0 ? rs6 + (size_t) t + (a - oa * H) + H * (b - ob * H) : coarse; // (coarse: any valid address)
+	};
+	auto slowTerm = [&](int ax, int j, int a, int b) -> double {
 		const int a0 = (ax == 0) ? 1 : 0, a1 = (ax == 2) ? 1 : 2; // the two other axes in order
-		if (cp) { // the coarse patch IS a fine patch that does not coarsen: its own two faces of the axis, cell by cell (w g)
-			if (j == 1 || j == 2) return 0.0;
-			const int p = child[(size_t) pc * 8], sp = 2 * ax + (j == 3);
-			if (p < 0) return 0.0;
-			const int kind = L.face_kind[(size_t) p * 6 + sp], src = L.face_src[(size_t) p * 6 + sp];
-			if (kind < FACE_LOCAL) return 0.0;
-			const double g = kind == FACE_GHOST ? L.ghost[(size_t) src * NN + a + N * b] : f6[((size_t) src * 6 + (sp ^ 1)) * NN + a + N * b];
-			return -L.rh2[(size_t) p * 3 + ax] * g;
-		}
 		const int s = 2 * ax + (j & 1), hi = j >> 1; // j = 0: low face of the low child, 1: its high face, 2, 3: the high child's
 		const int oa = a >= H, ob = b >= H, ha = a - oa * H, hb = b - ob * H;
 		const int p = child[(size_t) pc * 8 + ((hi << ax) | (oa << a0) | (ob << a1))];
@@ -912,15 +957,33 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 			for (int da = 0; da < 2; da++) v += (w * gp[(2 * ha + da) + N * (2 * hb + db)]) / 8;
 		return v;
 	};
+	// stage 3 of an entry: the value behind table index t
+	auto finish = [&](int t, double fast, int ax, int j, int a, int b) -> double {
+		if (t >= 0) return fast;
+		if (t == -1) return 0.0;
+		if (t == -3) return cpW[ax][j == 3] * fast;
+		return slowTerm(ax, j, a, b);
+	};
 	constexpr int coord[4] = {0, H - 1, H, N - 1};
 	double       *cv       = coarse + (size_t) pc * NNN;
 	const int     j        = blk & 3;
-	double        v[QN], vy[QN], f[QN];
+	double        v[QN], vy[QN], f[QN], fast[QN], fasty[QN];
+	int           t[QN], ty[QN];
 	if (blk < 4) { // an x plane: into the side array
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
 			const int i = threadIdx.x + 256 * k;
-			v[k]        = i < NN ? term(0, j, i % N, i / N) : 0.0;
+			t[k]        = i < NN ? tabIndex(0, j, i % N, i / N) : -1;
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k;
+			fast[k]     = *fastAddr(t[k], 0, j, i % N, i / N);
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k;
+			v[k]        = finish(t[k], fast[k], 0, j, i % N, i / N);
 		}
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
@@ -931,30 +994,57 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
 			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N;
-			v[k]        = (i < NN && octPlane<N>(b) < 0) ? term(1, j, a, b) : 0.0;
+			t[k]        = (i < NN && octPlane<N>(b) < 0) ? tabIndex(1, j, a, b) : -1;
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k;
+			fast[k]     = *fastAddr(t[k], 1, j, i % N, i / N);
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k;
+			v[k]        = finish(t[k], fast[k], 1, j, i % N, i / N);
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) { // (old values first, all of them: a store between two loads of the same array orders them)
+			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N;
+			f[k]        = v[k] != 0.0 ? cv[a + N * coord[j] + NN * b] : 0.0;
 		}
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
 			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N;
-			if (v[k] != 0.0) cv[a + N * coord[j] + NN * b] += v[k];
+			if (v[k] != 0.0) cv[a + N * coord[j] + NN * b] = f[k] + v[k];
 		}
 	} else { // a z plane: entry (x, y) -> cell (x, y, coord[j]); a cell that lies on a y plane too takes its y term first
 #pragma clang fp contract(off)
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
-			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N, jy = octPlane<N>(b);
+			const int  i = threadIdx.x + 256 * k, a = i % N, b = i / N, jy = octPlane<N>(b);
 			const bool in = i < NN;
 			f[k]          = in ? cv[a + N * b + NN * coord[j]] : 0.0;
-			vy[k]         = (in && jy >= 0) ? term(1, jy, a, coord[j]) : 0.0;
-			v[k]          = in ? term(2, j, a, b) : 0.0;
+			ty[k]         = (in && jy >= 0) ? tabIndex(1, jy, a, coord[j]) : -1;
+			t[k]          = in ? tabIndex(2, j, a, b) : -1;
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N, jy = octPlane<N>(b);
+			fasty[k]    = *fastAddr(ty[k], 1, jy, a, coord[j]);
+			fast[k]     = *fastAddr(t[k], 2, j, a, b);
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N, jy = octPlane<N>(b);
+			vy[k]       = finish(ty[k], fasty[k], 1, jy, a, coord[j]);
+			v[k]        = finish(t[k], fast[k], 2, j, a, b);
 		}
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
 			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N;
-			double    t = f[k];
-			if (vy[k] != 0.0) t = t + vy[k];
-			if (v[k] != 0.0) t = t + v[k];
-			if (vy[k] != 0.0 || v[k] != 0.0) cv[a + N * b + NN * coord[j]] = t;
+			double    tt = f[k];
+			if (vy[k] != 0.0) tt = tt + vy[k];
+			if (v[k] != 0.0) tt = tt + v[k];
+			if (vy[k] != 0.0 || v[k] != 0.0) cv[a + N * b + NN * coord[j]] = tt;
 		}
 	}
 }
@@ -1021,20 +1111,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_zero_resid3d(LevelDev
 	const double2 *fp2 = reinterpret_cast<const double2 *>(f + (size_t) pid * NNN);
 	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
 
-	if (tid < 27) {
-		double kf[3];
-		int    cls[3] = {tid % 3, (tid / 3) % 3, tid / 9};
-#pragma unroll
-		for (int ax = 0; ax < 3; ax++) {
-			kf[ax] = 2.0;
-			if (cls[ax] != 1) {
-				int kind = fk[2 * ax + (cls[ax] == 2)];
-				if (kind == FACE_DIRICHLET) kf[ax] = 3.0;
-				if (kind == FACE_NEUMANN) kf[ax] = 1.0;
-			}
-		}
-		idiag[tid] = 1.0 / (kf[0] * rhx + kf[1] * rhy + kf[2] * rhz);
-	}
+	FaceKinds kinds(fk);
+	idiagTable(idiag, tid, kinds, rhx, rhy, rhz);
 	for (int i = tid; i < 4 * T::LSZ; i += TPB) (&tile[0][0])[i] = 0.0; // halo ring stays zero: ghosts of a zero iterate
 	// EXPORT: the 2x2 sums of this patch's six face layers, [6][H*H] next to the patch's other face data
 	double *const rs = EXPORT ? rd.rs6 + (size_t) pid * 6 * (H * H) : nullptr;
@@ -1063,10 +1141,9 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_zero_resid3d(LevelDev
 	double *const yrs = EXPORT ? rs + (2 + (ys > 0 ? 1 : 0)) * (H * H) + X : nullptr;
 	// ghost of the residual's stencil on each side, as a multiple of the cell just inside: -1 Dirichlet, +1 Neumann
 	// (StarPatchOp.h:39-65); 0 on faces with a neighbour (that term is k_restrict_fixup3d's)
-	auto phys = [&](int s) { return fk[s] == FACE_DIRICHLET ? -1.0 : (fk[s] == FACE_NEUMANN ? 1.0 : 0.0); };
-	const double gW = (X == 0) ? phys(0) : 0.0, gE = (X == H - 1) ? phys(1) : 0.0;
-	const double gS = (Yp == 0) ? phys(2) : 0.0, gN = (Yp == H - 1) ? phys(3) : 0.0;
-	const double gB = phys(4), gT = phys(5);
+	const double gW = (X == 0) ? kinds.phys(0) : 0.0, gE = (X == H - 1) ? kinds.phys(1) : 0.0;
+	const double gS = (Yp == 0) ? kinds.phys(2) : 0.0, gN = (Yp == H - 1) ? kinds.phys(3) : 0.0;
+	const double gB = kinds.phys(4), gT = kinds.phys(5);
 
 	// fused restriction target (see k_stencil3d<MODE_RESID_RESTRICT>): the parent's octant, or the block this rank
 	// ships to the parent's rank; no copy-through patches on these levels
@@ -1469,20 +1546,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB, (V & 32) ? 2 : 3) void k_rbgs_reswee
 	const double2 *fp2 = reinterpret_cast<const double2 *>(f + (size_t) pid * NNN);
 	double2       *op2 = reinterpret_cast<double2 *>(out + (size_t) pid * NNN);
 
-	if (tid < 27) {
-		double kf[3];
-		int    cls[3] = {tid % 3, (tid / 3) % 3, tid / 9};
-#pragma unroll
-		for (int ax = 0; ax < 3; ax++) {
-			kf[ax] = 2.0;
-			if (cls[ax] != 1) {
-				int kind = fk[2 * ax + (cls[ax] == 2)];
-				if (kind == FACE_DIRICHLET) kf[ax] = 3.0;
-				if (kind == FACE_NEUMANN) kf[ax] = 1.0;
-			}
-		}
-		idiag[tid] = 1.0 / (kf[0] * rhx + kf[1] * rhy + kf[2] * rhz);
-	}
+	FaceKinds kinds(fk);
+	idiagTable(idiag, tid, kinds, rhx, rhy, rhz);
 	for (int i = tid; i < 2 * T::LSZ; i += TPB) (&tileV[0][0])[i] = 0.0; // its halo ring stays zero: ghosts of a zero iterate
 
 	const HaloSrc  hs  = haloSrc6<N>(tid, fk, fs, L.f6, L.ghost);
