@@ -861,7 +861,9 @@ template <int N> struct FCorrSrc {
 // gtab [coarse patch][axis][plane j][quadrant oa + 2 ob] (built once per level by k_gather_table3d): where in rs6 the 16x16
 // block of finished terms of that quarter plane starts; -1: the terms are zero (physical face, no such child); -2: take the
 // general path (neighbour on another rank, copy-through patch). One cached table read instead of the dependent chain
-// child -> face kind / source -> value (the kernel is all latency: 90 % of its wave cycles wait).
+// child -> face kind / source -> value (the kernel is all latency: 90 % of its wave cycles wait). Tried and dropped: a thread's
+// four entries in stages (indices together, then values together from a harmless address where there is nothing to read, the
+// general chain only where the table has no answer): 36 -> 52-59 us on the same box.
 template <int N>
 __global__ void k_gather_table3d(LevelDev L, const int32_t *__restrict__ child, const int32_t *__restrict__ copy, int32_t *__restrict__ gtab)
 {
@@ -897,49 +899,24 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 	constexpr int QN = (NN + 255) / 256;
 	const int     pc = blockIdx.x / 12, blk = blockIdx.x % 12; // 0..3: the x planes; 4..7: the y planes; 8..11: the z planes
 	const bool    cp = copy && copy[pc];
-	// The term of entry (a, b) of plane j of axis ax of this coarse patch, in two stages so that a thread's entries overlap:
-	// where (tabIndex: one cached table read per entry, all of a thread's entries requested together), then the value
-	// (fastValue: again all together, from a harmless address where there is nothing to read), and only for entries the table
-	// does not cover (-2: neighbour on another rank, copy-through patch, no table) the general chain child -> face kind /
-	// source -> values (slowTerm). Read one after the other under their conditions, a thread's four entries were eight
-	// dependent waits.
-	const bool tab = rs6 && gtab;
-	// A coarse patch that IS a fine patch that does not coarsen (cp, uniform over the workgroup): its own two faces of each axis,
-	// cell by cell (w g), as the copy-through branch of k_restrict_fixup3d adds them. Where g comes from and w are facts of the
-	// patch and the face: read once per workgroup (cpG / cpW [axis][low, high face]; null: no term), so that an entry is one load.
-	const double *cpG[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-	double        cpW[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
-	if (cp) {
-		const int p = child[(size_t) pc * 8];
-		if (p >= 0) {
-			const int axb = blk >> 2; // this workgroup's axis; a z plane also adds the y terms of its first and last row
-#pragma unroll
-			for (int ax = 0; ax < 3; ax++) {
-				if (ax != axb && !(axb == 2 && ax == 1)) continue;
-#pragma unroll
-				for (int hi = 0; hi < 2; hi++) {
-					const int sp = 2 * ax + hi;
-					const int kind = L.face_kind[(size_t) p * 6 + sp], src = L.face_src[(size_t) p * 6 + sp];
-					if (kind < FACE_LOCAL) continue;
-					cpG[ax][hi] = kind == FACE_GHOST ? L.ghost + (size_t) src * NN : f6 + ((size_t) src * 6 + (sp ^ 1)) * NN;
-					cpW[ax][hi] = -L.rh2[(size_t) p * 3 + ax];
-				}
-			}
+	// the term of entry (a, b) of plane j of axis ax of this coarse patch
+	auto term = [&](int ax, int j, int a, int b) -> double {
+		if (rs6 && gtab) { // (a uniformly refined fine level: the finished sums of the neighbours)
+			const int oa = a >= H, ob = b >= H;
+			const int t  = gtab[(size_t) pc * 48 + ax * 16 + j * 4 + oa + 2 * ob];
+			if (t >= 0) return rs6[(size_t) t + (a - oa * H) + H * (b - ob * H)];
+			if (t == -1) return 0.0;
 		}
-	}
-	auto tabIndex = [&](int ax, int j, int a, int b) -> int { // >= 0: offset of the 16x16 block in rs6; -1: zero; -2: slowTerm; -3: cp
-		if (cp) return (j == 0 || j == 3) && cpG[ax][j == 3] ? -3 : -1;
-		if (!tab) return -2;
-		const int oa = a >= H, ob = b >= H;
-		return gtab[(size_t) pc * 48 + ax * 16 + j * 4 + oa + 2 * ob];
-	};
-	auto fastAddr = [&](int t, int ax, int j, int a, int b) -> const double * {
-		const int oa = a >= H, ob = b >= H;
-		if (t == -3) return cpG[ax][j == 3] + a + N * b;
-		return t >= 0 ? rs6 + (size_t) t + (a - oa * H) + H * (b - ob * H) : coarse; // (coarse: any valid address)
-	};
-	auto slowTerm = [&](int ax, int j, int a, int b) -> double {
 		const int a0 = (ax == 0) ? 1 : 0, a1 = (ax == 2) ? 1 : 2; // the two other axes in order
+		if (cp) { // the coarse patch IS a fine patch that does not coarsen: its own two faces of the axis, cell by cell (w g)
+			if (j == 1 || j == 2) return 0.0;
+			const int p = child[(size_t) pc * 8], sp = 2 * ax + (j == 3);
+			if (p < 0) return 0.0;
+			const int kind = L.face_kind[(size_t) p * 6 + sp], src = L.face_src[(size_t) p * 6 + sp];
+			if (kind < FACE_LOCAL) return 0.0;
+			const double g = kind == FACE_GHOST ? L.ghost[(size_t) src * NN + a + N * b] : f6[((size_t) src * 6 + (sp ^ 1)) * NN + a + N * b];
+			return -L.rh2[(size_t) p * 3 + ax] * g;
+		}
 		const int s = 2 * ax + (j & 1), hi = j >> 1; // j = 0: low face of the low child, 1: its high face, 2, 3: the high child's
 		const int oa = a >= H, ob = b >= H, ha = a - oa * H, hb = b - ob * H;
 		const int p = child[(size_t) pc * 8 + ((hi << ax) | (oa << a0) | (ob << a1))];
@@ -957,33 +934,15 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 			for (int da = 0; da < 2; da++) v += (w * gp[(2 * ha + da) + N * (2 * hb + db)]) / 8;
 		return v;
 	};
-	// stage 3 of an entry: the value behind table index t
-	auto finish = [&](int t, double fast, int ax, int j, int a, int b) -> double {
-		if (t >= 0) return fast;
-		if (t == -1) return 0.0;
-		if (t == -3) return cpW[ax][j == 3] * fast;
-		return slowTerm(ax, j, a, b);
-	};
 	constexpr int coord[4] = {0, H - 1, H, N - 1};
 	double       *cv       = coarse + (size_t) pc * NNN;
 	const int     j        = blk & 3;
-	double        v[QN], vy[QN], f[QN], fast[QN], fasty[QN];
-	int           t[QN], ty[QN];
+	double        v[QN], vy[QN], f[QN];
 	if (blk < 4) { // an x plane: into the side array
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
 			const int i = threadIdx.x + 256 * k;
-			t[k]        = i < NN ? tabIndex(0, j, i % N, i / N) : -1;
-		}
-#pragma unroll
-		for (int k = 0; k < QN; k++) {
-			const int i = threadIdx.x + 256 * k;
-			fast[k]     = *fastAddr(t[k], 0, j, i % N, i / N);
-		}
-#pragma unroll
-		for (int k = 0; k < QN; k++) {
-			const int i = threadIdx.x + 256 * k;
-			v[k]        = finish(t[k], fast[k], 0, j, i % N, i / N);
+			v[k]        = i < NN ? term(0, j, i % N, i / N) : 0.0;
 		}
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
@@ -994,57 +953,30 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
 			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N;
-			t[k]        = (i < NN && octPlane<N>(b) < 0) ? tabIndex(1, j, a, b) : -1;
-		}
-#pragma unroll
-		for (int k = 0; k < QN; k++) {
-			const int i = threadIdx.x + 256 * k;
-			fast[k]     = *fastAddr(t[k], 1, j, i % N, i / N);
-		}
-#pragma unroll
-		for (int k = 0; k < QN; k++) {
-			const int i = threadIdx.x + 256 * k;
-			v[k]        = finish(t[k], fast[k], 1, j, i % N, i / N);
-		}
-#pragma unroll
-		for (int k = 0; k < QN; k++) { // (old values first, all of them: a store between two loads of the same array orders them)
-			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N;
-			f[k]        = v[k] != 0.0 ? cv[a + N * coord[j] + NN * b] : 0.0;
+			v[k]        = (i < NN && octPlane<N>(b) < 0) ? term(1, j, a, b) : 0.0;
 		}
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
 			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N;
-			if (v[k] != 0.0) cv[a + N * coord[j] + NN * b] = f[k] + v[k];
+			if (v[k] != 0.0) cv[a + N * coord[j] + NN * b] += v[k];
 		}
 	} else { // a z plane: entry (x, y) -> cell (x, y, coord[j]); a cell that lies on a y plane too takes its y term first
 #pragma clang fp contract(off)
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
-			const int  i = threadIdx.x + 256 * k, a = i % N, b = i / N, jy = octPlane<N>(b);
+			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N, jy = octPlane<N>(b);
 			const bool in = i < NN;
 			f[k]          = in ? cv[a + N * b + NN * coord[j]] : 0.0;
-			ty[k]         = (in && jy >= 0) ? tabIndex(1, jy, a, coord[j]) : -1;
-			t[k]          = in ? tabIndex(2, j, a, b) : -1;
-		}
-#pragma unroll
-		for (int k = 0; k < QN; k++) {
-			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N, jy = octPlane<N>(b);
-			fasty[k]    = *fastAddr(ty[k], 1, jy, a, coord[j]);
-			fast[k]     = *fastAddr(t[k], 2, j, a, b);
-		}
-#pragma unroll
-		for (int k = 0; k < QN; k++) {
-			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N, jy = octPlane<N>(b);
-			vy[k]       = finish(ty[k], fasty[k], 1, jy, a, coord[j]);
-			v[k]        = finish(t[k], fast[k], 2, j, a, b);
+			vy[k]         = (in && jy >= 0) ? term(1, jy, a, coord[j]) : 0.0;
+			v[k]          = in ? term(2, j, a, b) : 0.0;
 		}
 #pragma unroll
 		for (int k = 0; k < QN; k++) {
 			const int i = threadIdx.x + 256 * k, a = i % N, b = i / N;
-			double    tt = f[k];
-			if (vy[k] != 0.0) tt = tt + vy[k];
-			if (v[k] != 0.0) tt = tt + v[k];
-			if (vy[k] != 0.0 || v[k] != 0.0) cv[a + N * b + NN * coord[j]] = tt;
+			double    t = f[k];
+			if (vy[k] != 0.0) t = t + vy[k];
+			if (v[k] != 0.0) t = t + v[k];
+			if (vy[k] != 0.0 || v[k] != 0.0) cv[a + N * b + NN * coord[j]] = t;
 		}
 	}
 }

@@ -61,7 +61,7 @@ for var in a.variants:
     rows = g.profile_rows()
     g.profile(False)
     digest = hashlib.sha1(u.download().tobytes()).hexdigest()[:12]
-    top = sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:6]
+    top = sorted(rows.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get("VB_TOP", "6"))]
     print(f"[{var or 'default':28s}] {ms:.4f} ms/cycle  {cells / ms / 1e6:.1f} G updates/s  sha {digest}  | "
           + "  ".join(f"{k} {v['ms'] / v['calls'] * 1e3:.1f}us x{v['calls'] // 5}" for k, v in top), flush=True)
     for k in keys:
