@@ -808,7 +808,8 @@ template <int N> __device__ __forceinline__ int octPlane(int c) // 0, H-1, H, N-
 template <int N> struct FCorrSrc {
 	// N >= 8: at most one of a thread's two cells lies on an octant face (one pointer, one pair of values); N = 4: both may
 	static constexpr int NX = (N >= 8) ? 1 : 2;
-	const double        *x[NX]; // that cell's x plane at row 2Yp, or null
+	const double        *x[NX]; // that cell's x plane at row 2Yp (a harmless valid address where has[c] is false)
+	bool                 has[NX];
 	int                  xc;    // N >= 8: which cell of the pair it is
 	__device__ __forceinline__ void init(const double *fcorr, int pid, int X, int Yp)
 	{
@@ -816,36 +817,40 @@ template <int N> struct FCorrSrc {
 		const double *b  = fcorr + (size_t) pid * 4 * NN;
 		if (NX == 1) {
 			const int j0 = octPlane<N>(2 * X), j1 = octPlane<N>(2 * X + 1), j = j0 >= 0 ? j0 : j1;
-			xc   = j0 >= 0 ? 0 : 1;
-			x[0] = j >= 0 ? b + (size_t) j * NN + 2 * Yp : nullptr;
+			xc     = j0 >= 0 ? 0 : 1;
+			has[0] = j >= 0;
+			x[0]   = b + (size_t) (j >= 0 ? j : 0) * NN + 2 * Yp;
 		} else {
 			xc = 0;
 #pragma unroll
 			for (int c = 0; c < NX; c++) {
 				const int j = octPlane<N>(2 * X + c);
-				x[c]        = j >= 0 ? b + (size_t) j * NN + 2 * Yp : nullptr;
+				has[c]      = j >= 0;
+				x[c]        = b + (size_t) (j >= 0 ? j : 0) * NN + 2 * Yp;
 			}
 		}
 	}
-	// issue the loads for plane z: cx[c] = {row 0, row 1} of that cell
+	// issue the loads for plane z: cx[c] = {row 0, row 1} of that cell. Unconditional: a load under a per-lane condition is
+	// merged with its default right behind it, and that merge waits for the load in the step that issued it.
 	__device__ __forceinline__ void load(int z, double2 (&cx)[NX]) const
 	{
 #pragma unroll
-		for (int c = 0; c < NX; c++) cx[c] = x[c] ? *reinterpret_cast<const double2 *>(x[c] + N * z) : double2{0.0, 0.0};
+		for (int c = 0; c < NX; c++) cx[c] = *reinterpret_cast<const double2 *>(x[c] + N * z);
 	}
 	__device__ __forceinline__ void apply(double2 (&f)[2], const double2 (&cx)[NX]) const
 	{
 #pragma clang fp contract(off)
-		if (NX == 1) { // (the other cell takes + 0)
-			const double a0 = xc == 0 ? cx[0].x : 0.0, a1 = xc == 0 ? 0.0 : cx[0].x;
-			const double b0 = xc == 0 ? cx[0].y : 0.0, b1 = xc == 0 ? 0.0 : cx[0].y;
+		if (NX == 1) { // (the other cell, and both where no cell lies on an octant face, take + 0)
+			const bool   h0 = has[0] && xc == 0, h1 = has[0] && xc != 0;
+			const double a0 = h0 ? cx[0].x : 0.0, a1 = h1 ? cx[0].x : 0.0;
+			const double b0 = h0 ? cx[0].y : 0.0, b1 = h1 ? cx[0].y : 0.0;
 			f[0].x = f[0].x + a0, f[0].y = f[0].y + a1;
 			f[1].x = f[1].x + b0, f[1].y = f[1].y + b1;
 		} else {
-			f[0].x = f[0].x + cx[0].x;
-			f[0].y = f[0].y + cx[NX - 1].x;
-			f[1].x = f[1].x + cx[0].y;
-			f[1].y = f[1].y + cx[NX - 1].y;
+			f[0].x = f[0].x + (has[0] ? cx[0].x : 0.0);
+			f[0].y = f[0].y + (has[NX - 1] ? cx[NX - 1].x : 0.0);
+			f[1].x = f[1].x + (has[0] ? cx[0].y : 0.0);
+			f[1].y = f[1].y + (has[NX - 1] ? cx[NX - 1].y : 0.0);
 		}
 	}
 };
