@@ -1098,8 +1098,12 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 	};
 	// (levels with few local patches: nothing worth hiding under the exchange, and the second stream and its two
 	// events only add host calls and latency)
-	// (TE_OVERLAP_MIN: tests set 0 so that their small levels take the overlapped path)
-	if (L.patch_local || g->recording || L.nremote == 0 || !g->overlap || L.n_int == 0 || L.P < g->cfg.num(O_OVERLAP_MIN, 128)) {
+	// TE_OVERLAP_MIN (tests set 0 so that their small levels take the overlapped path). The split costs a second launch -- no
+	// launch is shorter than one patch march, about 30 us -- and two cross-stream event hand-overs of about 20 us each, so it
+	// pays only where the interior launch is much longer than that: more local patches than the chip holds workgroups at once
+	// (3 x 256). Measured per rank with the exchanges in loop-back (tools/mr8_budget.py): at 512 local patches (512^3 on eight
+	// ranks) the cycle is 525 us with the split and 475 us without it.
+	if (L.patch_local || g->recording || L.nremote == 0 || !g->overlap || L.n_int == 0 || L.P < g->cfg.num(O_OVERLAP_MIN, 768)) {
 		int rc = prepareGhosts<N>(g, L, u, ps);
 		if (rc) return rc;
 		launch(L.dev());

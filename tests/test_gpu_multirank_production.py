@@ -1,5 +1,6 @@
-"""-m gpu: the sharded path at BASELINE.json's PRODUCTION shapes, default options, default switches (overlap path on,
-default TE_OVERLAP_MIN / TE_AGGLOMERATE), both smoothers, against the single-rank run BIT FOR BIT:
+"""-m gpu: the sharded path at BASELINE.json's PRODUCTION shapes, default options, default switches (default
+TE_OVERLAP_MIN / TE_AGGLOMERATE; C3 also with the overlap path forced on at its 512 local patches), both smoothers, against
+the single-rank run BIT FOR BIT:
 
   C3  512^3 uniform, 4096 patches of 32^3, 8 ranks (2x2x2 octants of 8^3 patches)
   C4  2refine.bin --divide 2 (960 patches of 32^3, coarse/fine faces cut by rank boundaries), 4 ranks
@@ -40,11 +41,16 @@ def cycle_single(mesh, n, sm, f):
     return want, rows
 
 
+CASES = [(name, None) for name in CONFIGS] + [("C3-512^3-8ranks", "128")]
+
+
 @pytest.mark.parametrize("smoother", [capi.SMOOTH_RBGS, capi.SMOOTH_PATCH_SOLVE], ids=["rbgs", "patch_solve"])
-@pytest.mark.parametrize("name", list(CONFIGS))
-def test_production_shape_sharded_cycle_equals_single_rank(name, smoother, monkeypatch):
+@pytest.mark.parametrize("name,overlap_min", CASES, ids=[n + ("" if o is None else "-overlap-forced") for n, o in CASES])
+def test_production_shape_sharded_cycle_equals_single_rank(name, overlap_min, smoother, monkeypatch):
     for k in ("TE_OVERLAP_MIN", "TE_AGGLOMERATE", "TE_AGGLOMERATE_MAX", "TE_NO_OVERLAP"):
         monkeypatch.delenv(k, raising=False)  # the defaults are what is under test
+    if overlap_min is not None:  # the interior/boundary split at a shape where the default (768 local patches) leaves it off
+        monkeypatch.setenv("TE_OVERLAP_MIN", overlap_min)
     c = CONFIGS[name]
     n, dim, nranks = c["n"], c["dim"], c["nranks"]
     mesh = util.mesh(c["mesh"], c["divides"], dim)
@@ -83,10 +89,11 @@ def test_production_shape_sharded_cycle_equals_single_rank(name, smoother, monke
 
     rows = [o[2] for o in outs]
     if name.startswith("C3") and smoother == capi.SMOOTH_RBGS:
-        # 512 local patches on level 0 >= TE_OVERLAP_MIN (128): interior (343) and boundary (169) patches of the post-sweep are
-        # two launches with the exchange under the first; level 1 (64 local patches) runs in one launch of the FCORR symbol
+        # forced: interior (343) and boundary (169) patches of the level-0 post-sweep are two launches with the exchange under the
+        # first; default: 512 local patches < TE_OVERLAP_MIN (768), one launch behind the exchange. Level 1 (64 local patches)
+        # runs in one launch of the FCORR symbol either way
         for r in rows:
-            assert r["rbgs_resweep_prolong"]["calls"] == 2, r["rbgs_resweep_prolong"]
+            assert r["rbgs_resweep_prolong"]["calls"] == (2 if overlap_min is not None else 1), r["rbgs_resweep_prolong"]
             assert r["rbgs_zero_resid_restrict_faces"]["calls"] == 1
             assert r["pack"]["calls"] >= 2 and r["exchange"]["calls"] >= 1
     if name.startswith("C3"):
