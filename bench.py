@@ -338,7 +338,9 @@ def main():
     g.init_problem(f, None, problem=capi.PROBLEM_RANDOM)  # U(-1,1) splitmix64(0x5EED + patch id), generated on the device
     u = g.new_vector(0)
     cells_global = [H.sizes(l)[1] * n ** a.dim for l in range(H.num_levels)]
-    placement = [[int(c) for c in np.bincount(H.tables(l)["rank"], minlength=world)] for l in range(H.num_levels)] if world > 1 else None
+    # patches per rank and level; a gathered level that every rank holds and computes itself (TE_REPLICATE) is "replicated"
+    placement = [("replicated" if H.replicated(l) else [int(c) for c in np.bincount(H.tables(l)["rank"], minlength=world)])
+                 for l in range(H.num_levels)] if world > 1 else None
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():

@@ -62,6 +62,10 @@ int te_hier_dim(const te_hier *h);
 int te_hier_n(const te_hier *h);
 /* level 0 = finest. P_local = this rank's patches, P_global = all ranks'. */
 int te_hier_level_sizes(const te_hier *h, int level, int *P_local, int *P_global);
+/* 1: the level lives on EVERY rank (a gathered coarse level of a 3D hierarchy, TE_REPLICATE: each rank holds and computes all
+ * of it, P_local == P_global, and the `rank` column of te_hier_level_tables names the calling rank for every patch); 0: every
+ * patch has one owner; < 0: error. Replaces nothing in the reference (CycleFactory3d.cpp:104 cuts the hierarchy instead). */
+int te_hier_level_replicated(const te_hier *h, int level);
 /* Global tables of one level (Morton order); any pointer may be NULL.
  * id[P] rank[P] local[P] starts[P][dim] lengths[P][dim] nbr_kind[P][2dim] (0 none, 1 normal,
  * 2 coarse, 3 fine) nbr[P][2dim][4] nbr_orth[P][2dim] parent[P] orth_on_parent[P] */

@@ -66,6 +66,7 @@ SYMBOLS = {
     "te_hier_dim": (_I, [_P]),
     "te_hier_n": (_I, [_P]),
     "te_hier_level_sizes": (_I, [_P, _I, C.POINTER(_I), C.POINTER(_I)]),
+    "te_hier_level_replicated": (_I, [_P, _I]),
     "te_hier_level_tables": (_I, [_P, _I] + [_P] * 10),
     "te_hier_level_l2g": (_I, [_P, _I, _P]),
     "te_hier_destroy": (None, [_P]),
@@ -232,6 +233,13 @@ class Hierarchy:
         a, b = C.c_int(), C.c_int()
         check(lib().te_hier_level_sizes(self.h, level, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def replicated(self, level):
+        """the level lives on every rank (a gathered coarse level, TE_REPLICATE): each rank holds and computes all of it"""
+        r = lib().te_hier_level_replicated(self.h, level)
+        if r < 0:
+            check(r)
+        return bool(r)
 
     def tables(self, level):
         P = self.sizes(level)[1]

@@ -104,6 +104,12 @@ int te_hier_level_sizes(const te_hier *h, int level, int *P_local, int *P_global
 	if (P_global) *P_global = h->h.levels[level].P_global;
 	return TE_OK;
 }
+int te_hier_level_replicated(const te_hier *h, int level)
+{
+	if (!h || level < 0 || level >= (int) h->h.levels.size())
+		return te::fail(TE_EINVAL, "te_hier_level_replicated: bad level");
+	return h->h.levels[level].replicated ? 1 : 0;
+}
 int te_hier_level_tables(const te_hier *h, int level, int32_t *id, int32_t *rank, int32_t *local,
                          double *starts, double *lengths, int32_t *nbr_kind, int32_t *nbr,
                          int32_t *nbr_orth, int32_t *parent, int32_t *orth_on_parent)

@@ -163,6 +163,11 @@ struct LevelHost {
 	// children / parents that live on another rank: blocks of nc/8 (or nc, copy-through) doubles
 	ExPlan          tx_up, tx_down; // child side (sends in restrict), parent side (sends in prolong)
 	int             n_up = 0, n_down = 0;
+	// the coarser level is replicated on every rank (mesh.cpp TE_REPLICATE) and this one is not: every local patch's restricted
+	// block goes to every other rank (n_up blocks, one copy in upbuf, the same range sent to each peer; bc_desc = (local coarse
+	// patch, orthant) of each block for the paths that have written the coarse octants already); nothing comes back up
+	bool            repl_up = false;
+	DevBuf<int32_t> bc_desc;
 	DevBuf<int32_t> up_desc, down_desc; // [n][2] (patch, orthant)
 	DevBuf<int64_t> up_off, down_off;   // block offsets inside upbuf / downbuf
 	DevBuf<double>  upbuf, downbuf;
@@ -755,6 +760,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 			bool    operator<(const Blk &b) const { return std::tie(peer, gpar, o) < std::tie(b.peer, b.gpar, b.o); }
 		};
 		std::vector<Blk> up, down;
+		const bool       repl = cv.replicated && !lv.replicated;
 		for (int p = 0; p < P; p++) {
 			const int gp = lv.l2g[p], gpar = lv.g_parent[gp];
 			orth[p]      = lv.g_orth_on_parent[gp];
@@ -793,6 +799,21 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 			parent[up[i].patch] = -((int) i + 2); // prolong reads block i of upbuf
 			pos += up[i].size;
 		}
+		std::vector<int32_t> bcd;
+		if (repl) { // (up is empty: every parent is local) one block per local patch, in the order the receivers expect: (parent, orthant)
+			std::vector<Blk> bc;
+			for (int p = 0; p < P; p++)
+				bc.push_back({0, lv.g_parent[lv.l2g[p]], orth[p] < 0 ? 0 : orth[p], p, (int64_t) (orth[p] < 0 ? L->nc : L->nc / NCH)});
+			std::sort(bc.begin(), bc.end());
+			for (size_t i = 0; i < bc.size(); i++) {
+				upd.push_back(bc[i].patch); // (fine patch, orthant): k_restrict_pack restricts it into its block
+				upd.push_back(orth[bc[i].patch]);
+				bcd.push_back(parent[bc[i].patch]); // (coarse patch, orthant or -1): k_prolong_pack copies the finished octant out
+				bcd.push_back(orth[bc[i].patch] < 0 ? -1 : bc[i].o);
+				upo.push_back(pos);
+				pos += bc[i].size;
+			}
+		}
 		const int64_t up_total = pos;
 		pos                    = 0;
 		for (size_t i = 0; i < down.size(); i++) {
@@ -813,10 +834,12 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 					return te::fail(TE_EINVAL, "te_gmg_create: coarse patch with a missing child");
 		}
 		L->Pc      = cv.P;
-		L->prolong_fusable = (D == 3 && L->ncf == 0 && up.empty() && down.empty()
+		// (repl: the blocks in `down` are received for the restriction only; every parent is local)
+		const bool parents_local = up.empty() && (down.empty() || repl);
+		L->prolong_fusable = (D == 3 && L->ncf == 0 && parents_local
 		                      && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
 		L->has_copy           = std::any_of(orth.begin(), orth.end(), [](int32_t o) { return o < 0; });
-		L->prolong_fusable_cf = (D == 3 && up.empty() && down.empty() && !g->cfg.has(O_NO_CFP));
+		L->prolong_fusable_cf = (D == 3 && parents_local && !g->cfg.has(O_NO_CFP));
 		if (D == 2 && L->lds2d && up.empty() && down.empty()) {
 			L->fuse2d          = true;
 			// (faces on other ranks are fine: their values of u + P e arrive in ghost slots, packProlongFaces2d)
@@ -834,10 +857,35 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 			L->fuse2_ok = uniform;
 			if (uniform && (rc = L->e4buf.alloc((size_t) std::max(P, 1) * 4 * n))) return rc;
 		}
-		L->n_up    = (int) up.size();
+		L->n_up    = (int) (upd.size() / 2);
 		L->n_down  = (int) down.size();
-		L->tx_up   = mergePlan(ups, downs);   // restrict: send child blocks, receive into downbuf
-		L->tx_down = mergePlan(downs, ups);   // prolong: send octants, receive into upbuf
+		L->repl_up = repl;
+		if (repl) {
+			// restrict: the same range of upbuf to every other rank (if this rank has patches here at all), and from every rank
+			// that has patches here its blocks; prolong: nothing
+			L->tx_up = mergePlan({}, downs);
+			ExPlan &pl = L->tx_up;
+			if (up_total > 0) {
+				ExPlan full;
+				size_t k = 0;
+				for (int r = 0; r < H.nranks; r++) {
+					if (r == me) continue;
+					while (k < pl.peers.size() && pl.peers[k] < r) k++;
+					const bool have = k < pl.peers.size() && pl.peers[k] == r;
+					full.peers.push_back(r);
+					full.send_off.push_back(0);
+					full.send_cnt.push_back(up_total);
+					full.recv_off.push_back(have ? pl.recv_off[k] : 0);
+					full.recv_cnt.push_back(have ? pl.recv_cnt[k] : 0);
+				}
+				pl = full;
+			}
+			L->tx_down = ExPlan();
+			if ((rc = L->bc_desc.upload(bcd))) return rc;
+		} else {
+			L->tx_up   = mergePlan(ups, downs);   // restrict: send child blocks, receive into downbuf
+			L->tx_down = mergePlan(downs, ups);   // prolong: send octants, receive into upbuf
+		}
 		if ((rc = L->parent.upload(parent)) || (rc = L->orth.upload(orth)) || (rc = L->child.upload(child))
 		    || (rc = L->copy.upload(copy)) || (rc = L->up_desc.upload(upd)) || (rc = L->down_desc.upload(downd))
 		    || (rc = L->up_off.upload(upo)) || (rc = L->down_off.upload(downo))
@@ -1559,6 +1607,24 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
+// The restricted blocks of this rank's patches to the other ranks (the kernels before this have written them into the local
+// coarse patches or into upbuf), the other ranks' blocks into the local coarse patches. repl_up (the coarse level lives on
+// every rank): the finished octants are copied out of the coarse patches first -- one copy, sent to everybody.
+template <int N> int shipRestricted(te_gmg *g, LevelHost &L, double *coarse)
+{
+	if (L.repl_up && L.n_up > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_up * L.nc / 8);
+		hipLaunchKernelGGL(k_prolong_pack3d<N>, dim3(L.n_up), dim3(256), 0, g->stream, L.bc_desc.p, L.up_off.p, coarse, L.upbuf.p);
+	}
+	int rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p);
+	if (rc) return rc;
+	if (L.n_down > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 8);
+		hipLaunchKernelGGL(k_restrict_unpack3d<N>, dim3(L.n_down), dim3(256), 0, g->stream, L.down_desc.p, L.down_off.p,
+		                   L.downbuf.p, coarse);
+	}
+	return TE_OK;
+}
 // opts.fuse = 2: first pre-smoothing sweep from a zero iterate + residual + restriction (march3d.hpp,
 // k_rbgs_zero_resid3d / k_restrict_fixup3d). out = S(0, f) with its x faces in xf_out, coarse = AvgRstr(f - A out).
 // store_u = false (opts.fuse = 3): the new iterate is left in L.f6buf as its six face layers only
@@ -1645,12 +1711,7 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 		hipLaunchKernelGGL((k_restrict_fixup3d<N, false>), dim3(L.P), dim3(256), 0, g->stream, D, out, rd);
 	}
 	// children whose parent lives on another rank: ship the finished blocks (as residRestrictN)
-	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
-	if (L.n_down > 0) {
-		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 8);
-		hipLaunchKernelGGL(k_restrict_unpack3d<N>, dim3(L.n_down), dim3(256), 0, g->stream, L.down_desc.p, L.down_off.p,
-		                   L.downbuf.p, coarse);
-	}
+	if ((rc = shipRestricted<N>(g, L, coarse))) return rc;
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
@@ -1767,12 +1828,7 @@ template <int N> int interfaceResidRestrictN(te_gmg *g, LevelHost &L, const doub
 		D.f6       = L.ps_faces ? L.f6buf.p : nullptr;
 		hipLaunchKernelGGL((k_restrict_fixup3d<N, true>), dim3(L.P), dim3(256), 0, g->stream, D, u, rd);
 	}
-	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
-	if (L.n_down > 0) {
-		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 8);
-		hipLaunchKernelGGL(k_restrict_unpack3d<N>, dim3(L.n_down), dim3(256), 0, g->stream, L.down_desc.p, L.down_off.p,
-		                   L.downbuf.p, coarse);
-	}
+	if ((rc = shipRestricted<N>(g, L, coarse))) return rc;
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
@@ -1821,12 +1877,7 @@ template <int N> int residRestrictN(te_gmg *g, LevelHost &L, const double *u, co
 	int rc        = TE_OK;
 	if (L.P > 0) rc = launchStencilN<N, MODE_RESID_RESTRICT>(g, L, u, f, L.r->d, 0.0, rd, xf_in);
 	if (rc) return rc;
-	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
-	if (L.n_down > 0) {
-		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 8);
-		hipLaunchKernelGGL(k_restrict_unpack3d<N>, dim3(L.n_down), dim3(256), 0, g->stream, L.down_desc.p, L.down_off.p,
-		                   L.downbuf.p, coarse);
-	}
+	if ((rc = shipRestricted<N>(g, L, coarse))) return rc;
 	HIPCHK(hipGetLastError());
 	return TE_OK;
 }
@@ -2058,7 +2109,7 @@ template <int N> int restrictN(te_gmg *g, LevelHost &L, const double *fine, doub
 }
 template <int N> int prolongN(te_gmg *g, LevelHost &L, const double *coarse, double *fine)
 {
-	if (L.n_down > 0) {
+	if (L.n_down > 0 && !L.repl_up) { // (repl_up: those blocks were received for the restriction; every parent is local)
 		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 8);
 		hipLaunchKernelGGL(k_prolong_pack3d<N>, dim3(L.n_down), dim3(256), 0, g->stream, L.down_desc.p, L.down_off.p,
 		                   coarse, L.downbuf.p);
@@ -2308,10 +2359,11 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		u_unstored = unstoredAt(L, true);
 		// ... and if the next level takes the same path, its two kernels are the only readers of its right-hand side: the
 		// ghost terms of the restricted residual go to its side array instead of a fix-up pass (bit-identical; rank-local)
-		double *fcorr_out = (u_unstored && L.dim == 3 && (L.prolong_fusable || !g->cfg.has(O_NO_FCORR_CF)) && C.fcorr.p && C.prolong_fusable
+		double *fcorr_out = (u_unstored && L.dim == 3 && !L.repl_up && (L.prolong_fusable || !g->cfg.has(O_NO_FCORR_CF)) && C.fcorr.p && C.prolong_fusable
 		                     && unstoredAt(C, l + 2 < nl) && !g->cfg.has(O_NO_FCORR))
 		                        ? C.fcorr.p
-		                        : nullptr; // (the next level uniformly refined; this one may be refined: the gather forms the terms)
+		                        : nullptr; // (the next level uniformly refined; this one may be refined: the gather forms the terms;
+		                                   //  not into a replicated level: its x terms would have to travel with the blocks)
 		if (fcorr_in && !u_unstored) return te::fail(TE_ESTATE, "te_vcycle: exported ghost terms without a reader");
 		// (the kernel variants that form a pending right-hand side exist for the 3D path that does not store the iterate)
 		const PendingRhs *fs = (pend && u_unstored && L.dim == 3 && !fcorr_in && L.P > 0 && !g->recording) ? pend : nullptr;

@@ -322,15 +322,24 @@ Hierarchy Hierarchy::build(const Tree &t, int n, bool neumann, int max_levels,
 		// The per-rank threshold alone grows with the number of ranks (at 64 ranks a 512-patch level of 32^3 patches would land
 		// on one GPU): the first gathered level also has at most TE_AGGLOMERATE_MAX patches in total (default 64 -- the size
 		// below which one GPU runs a level in the same ~20 us however many patches it has).
+		// TE_REPLICATE (default on, 3D): a gathered level is not rank 0's but EVERY rank's -- each rank receives the restricted
+		// blocks of all children of the first gathered level (the transfer rank 0 alone received before, now to everybody: the
+		// same bytes per link) and runs the small levels itself, redundantly and bit for bit the same; the way back up then needs
+		// no transfer at all, every parent being local. One exchange per cycle less on the critical path, and the level above
+		// keeps its fused post-sweep (its parents are local). 0: rank 0 alone, as before.
 		if (nranks > 1) {
-			const char  *e   = getenv("TE_AGGLOMERATE"), *em = getenv("TE_AGGLOMERATE_MAX");
+			const char  *e   = getenv("TE_AGGLOMERATE"), *em = getenv("TE_AGGLOMERATE_MAX"), *er = getenv("TE_REPLICATE");
 			const double agg = e ? atof(e) : 16.0;
 			const int    cap = em ? atoi(em) : 64;
+			const bool   rep = h.dim == 3 && (er ? atoi(er) != 0 : true);
 			bool         gathered = false;
 			for (size_t li = 1; li < h.levels.size(); li++) {
 				Level &lv = h.levels[li];
 				if (!gathered && lv.P_global < agg * nranks && lv.P_global <= cap) gathered = true;
-				if (gathered) std::fill(lv.g_rank.begin(), lv.g_rank.end(), 0);
+				if (gathered) {
+					lv.replicated = rep;
+					std::fill(lv.g_rank.begin(), lv.g_rank.end(), rep ? rank : 0);
+				}
 			}
 		}
 		for (auto &lv : h.levels) {

@@ -82,6 +82,8 @@ struct Level {
 
 	// ---- local --------------------------------------------------------------------------
 	int                  P = 0;   ///< patches owned by this rank
+	/// every rank holds (and computes) the whole level: g_rank is this rank's number for every patch, P == P_global
+	bool                 replicated = false;
 	std::vector<int32_t> l2g;     ///< [P] local -> global index
 };
 

@@ -49,13 +49,15 @@ def shard_run(mesh, n, nranks, fn, dim=3):
                                                 # (copy-through patches and coarse/fine faces with neighbours on other ranks)
                                                 ("2refine.bin", 2, 4, 3)])
 def test_sharded_ops_equal_single_rank(nranks, name, divides, n, dim, monkeypatch):
-    # levels with fewer than 128 local patches skip the interior/boundary overlap by default: these small meshes must
+    # levels with fewer than 768 local patches skip the interior/boundary overlap by default: these small meshes must
     # exercise it (the 8-rank run keeps the default, i.e. covers the non-overlapped path too)
     if nranks != 8:
         monkeypatch.setenv("TE_OVERLAP_MIN", "0")
-    # coarse levels with few patches per rank are gathered on rank 0 by default (TE_AGGLOMERATE = 16 per rank); the
-    # 4-rank runs keep every level spread out, so both placements are compared with the single-rank result
+    # coarse levels with few patches per rank are gathered by default (TE_AGGLOMERATE = 16 per rank) -- on every rank in 3D
+    # (TE_REPLICATE, the default: 2 and 8 ranks here), on rank 0 alone otherwise (3 ranks here); the 4-rank runs keep every
+    # level spread out: all three placements are compared with the single-rank result
     monkeypatch.setenv("TE_AGGLOMERATE", "0" if nranks == 4 else "16")
+    monkeypatch.setenv("TE_REPLICATE", "0" if nranks == 3 else "1")
     mesh = util.mesh(name, divides, dim)
     H1 = capi.Hierarchy(mesh, n)
     g1 = capi.GMG(H1)

@@ -41,16 +41,24 @@ def cycle_single(mesh, n, sm, f):
     return want, rows
 
 
-CASES = [(name, None) for name in CONFIGS] + [("C3-512^3-8ranks", "128")]
+# (name, TE_OVERLAP_MIN, TE_REPLICATE); None = the default
+CASES = [(name, None, None) for name in CONFIGS] + [("C3-512^3-8ranks", "128", None), ("C3-512^3-8ranks", None, "0"),
+                                                      ("C4-2refine-div2-4ranks", None, "0")]
+
+
+def case_id(c):
+    return c[0] + ("" if c[1] is None else "-overlap-forced") + ("" if c[2] is None else "-gathered-on-rank0")
 
 
 @pytest.mark.parametrize("smoother", [capi.SMOOTH_RBGS, capi.SMOOTH_PATCH_SOLVE], ids=["rbgs", "patch_solve"])
-@pytest.mark.parametrize("name,overlap_min", CASES, ids=[n + ("" if o is None else "-overlap-forced") for n, o in CASES])
-def test_production_shape_sharded_cycle_equals_single_rank(name, overlap_min, smoother, monkeypatch):
-    for k in ("TE_OVERLAP_MIN", "TE_AGGLOMERATE", "TE_AGGLOMERATE_MAX", "TE_NO_OVERLAP"):
+@pytest.mark.parametrize("name,overlap_min,replicate", CASES, ids=[case_id(c) for c in CASES])
+def test_production_shape_sharded_cycle_equals_single_rank(name, overlap_min, replicate, smoother, monkeypatch):
+    for k in ("TE_OVERLAP_MIN", "TE_AGGLOMERATE", "TE_AGGLOMERATE_MAX", "TE_NO_OVERLAP", "TE_REPLICATE"):
         monkeypatch.delenv(k, raising=False)  # the defaults are what is under test
     if overlap_min is not None:  # the interior/boundary split at a shape where the default (768 local patches) leaves it off
         monkeypatch.setenv("TE_OVERLAP_MIN", overlap_min)
+    if replicate is not None:  # the gathered levels on rank 0 alone (round 2's form) instead of on every rank
+        monkeypatch.setenv("TE_REPLICATE", replicate)
     c = CONFIGS[name]
     n, dim, nranks = c["n"], c["dim"], c["nranks"]
     mesh = util.mesh(c["mesh"], c["divides"], dim)
@@ -97,8 +105,11 @@ def test_production_shape_sharded_cycle_equals_single_rank(name, overlap_min, sm
             assert r["rbgs_zero_resid_restrict_faces"]["calls"] == 1
             assert r["pack"]["calls"] >= 2 and r["exchange"]["calls"] >= 1
     if name.startswith("C3"):
-        # levels with 64, 8 and 1 patches live on rank 0 (agglomeration): the other ranks launch nothing there
-        assert hs[1].sizes(2)[0] == 0 and hs[0].sizes(2)[0] == 64
+        # levels with 64, 8 and 1 patches are gathered: on every rank (each computes them itself; nothing travels back up), or on
+        # rank 0 alone (the other ranks launch nothing there)
+        assert hs[0].sizes(2)[0] == 64 and hs[1].sizes(2)[0] == (0 if replicate == "0" else 64)
+        up = [r.get("exchange", {"calls": 0})["calls"] for r in rows]
+        assert len(set(up)) == 1 or replicate == "0", up  # replicated: every rank issues the same exchanges
     if name.startswith("C5") and smoother == capi.SMOOTH_RBGS:
         for r in rows:
             assert r["rbgs_resweep_prolong"]["calls"] >= 2  # levels 0 and 1 are cut by rank boundaries and stay fused

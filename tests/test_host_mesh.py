@@ -105,15 +105,17 @@ def test_parent_links(name, dim, div):
                 assert np.allclose(2 * f["lengths"][p], c["lengths"][par])
 
 
+@pytest.mark.parametrize("replicate", [1, 0], ids=["replicated", "rank0"])
 @pytest.mark.parametrize("agg,cap", [(0, 64), (16, 64), (16, 8)])
 @pytest.mark.parametrize("nranks", [2, 4, 8])
-def test_morton_partition(nranks, agg, cap, monkeypatch):
-    """agg = patches per rank below which a level (and every coarser one) is gathered on rank 0
-    (TE_AGGLOMERATE, default 16; SURVEY 8(e), CycleFactory3d.cpp:104 semantics); 0 = never. cap = the largest level (patches
-    in total) that may be the first gathered one (TE_AGGLOMERATE_MAX, default 64): the per-rank threshold alone grows with
-    the number of ranks."""
+def test_morton_partition(nranks, agg, cap, replicate, monkeypatch):
+    """agg = patches per rank below which a level (and every coarser one) is gathered (TE_AGGLOMERATE, default 16; SURVEY
+    8(e), CycleFactory3d.cpp:104 semantics); 0 = never. cap = the largest level (patches in total) that may be the first
+    gathered one (TE_AGGLOMERATE_MAX, default 64): the per-rank threshold alone grows with the number of ranks. Gathered =
+    on EVERY rank (TE_REPLICATE, the default in 3D: each rank holds and computes the whole level) or on rank 0 alone."""
     monkeypatch.setenv("TE_AGGLOMERATE", str(agg))
     monkeypatch.setenv("TE_AGGLOMERATE_MAX", str(cap))
+    monkeypatch.setenv("TE_REPLICATE", str(replicate))
     m = util.mesh("uniform", 3)  # 8^3 patches
     hs = [capi.Hierarchy(m, 4, rank=r, nranks=nranks) for r in range(nranks)]
     gathered = False
@@ -122,6 +124,13 @@ def test_morton_partition(nranks, agg, cap, monkeypatch):
         P = len(t["id"])
         counts = np.bincount(t["rank"], minlength=nranks)
         gathered = gathered or (lvl > 0 and P < agg * nranks and P <= cap)
+        if gathered and replicate:
+            for r, h in enumerate(hs):  # the whole level on every rank, in global order, and each rank's tables say "mine"
+                assert h.replicated(lvl) and not h.replicated(0)
+                assert np.array_equal(h.l2g(lvl), np.arange(P))
+                tr = h.tables(lvl)
+                assert np.all(tr["rank"] == r) and np.array_equal(tr["local"], np.arange(P))
+            continue
         if gathered:
             assert counts[0] == P  # the whole level on rank 0
         elif P >= nranks:
