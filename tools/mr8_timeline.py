@@ -21,7 +21,9 @@ def short(n):
 
 names = [short(r[0]) for r in rows]
 # a cycle starts with the level-0 pre-sweep; rank 0's unprofiled back-to-back section is cycles 45..85 of its run
-starts = [i for i, n in enumerate(names) if n.startswith("k_rbgs_zero_resid3d<32, false")]
+# (the level-0 pre-sweep: the pre-sweep that follows a post-sweep -- coarser levels may run the same symbols)
+starts = [i for i, n in enumerate(names)
+          if n.startswith("k_rbgs_zero_resid3d<32, false") and (i == 0 or names[i - 1].startswith("k_rbgs_resweep_prolong3d"))]
 i0, i1 = starts[60], starts[61]
 t0 = rows[i0][1]
 print(f"# commit {commit}; rocprofv3 --kernel-trace -- python3 tools/mr8_budget.py --ranks 8 --agg 16: one cycle of rank 0 of 8 (512^3, RB-GS,", file=out)
