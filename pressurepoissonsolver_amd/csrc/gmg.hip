@@ -316,6 +316,7 @@ struct te_gmg {
 		std::atomic<bool> stop{false};
 		Slot              slot[RING];
 		uint64_t          head = 0, tail = 0; // [head, tail) outstanding
+		int64_t           batch = -1;         // >= 0: inside WatchdogBatch, the slot that stands for the whole call
 		double            timeout_s = 300.0;
 	} wd;
 	// optional: RCCL point-to-point called straight from this library (no host callback per exchange)
@@ -985,6 +986,13 @@ struct WatchdogArm { // around the issue of one exchange: takes a ring slot (iss
 		auto &w = g->wd;
 		if (!w.th.joinable()) return;
 		std::lock_guard<std::mutex> lk(w.mu);
+		if (w.batch >= 0) { // inside a V-cycle or a Krylov solve: the call's one slot stands for this exchange too
+			auto &sl = w.slot[w.batch % te_gmg::Watchdog::RING];
+			sl.since = std::chrono::steady_clock::now(); // (the host got this far: the deadline runs from the newest issue)
+			sl.tag   = tag;
+			sl.level = g->cur_level;
+			return;
+		}
 		watchdogRetire(w);
 		if (w.tail - w.head == te_gmg::Watchdog::RING) {
 			// ring full (the host is more than RING exchanges ahead of the GPU): the newest slot is reused -- it keeps its
@@ -1006,6 +1014,41 @@ struct WatchdogArm { // around the issue of one exchange: takes a ring slot (iss
 		std::lock_guard<std::mutex> lk(w.mu);
 		auto &sl    = w.slot[idx % te_gmg::Watchdog::RING];
 		sl.recorded = (hipEventRecord(sl.ev, stream) == hipSuccess);
+	}
+};
+
+// Around one call that issues several exchanges (a V-cycle, a Krylov solve): ONE ring slot and ONE event, recorded on the solver
+// stream when the call has enqueued everything -- an event behind every exchange costs about 5 us of stream time each (the
+// kernel behind it waits for the marker to retire: 27 us of a 428 us cycle at eight ranks). What is watched does not change:
+// the slot's deadline restarts whenever the host issues the next exchange of the call (a host that still issues is not stuck;
+// one that blocks in a callback or a synchronisation stops issuing), and the event at the end cannot complete before every
+// exchange of the call has -- a peer that never posts its half is found TE_EXCHANGE_TIMEOUT after the last issue, as before.
+struct WatchdogBatch {
+	te_gmg *g;
+	int64_t idx = -1;
+	explicit WatchdogBatch(te_gmg *g_) : g(g_)
+	{
+		auto &w = g->wd;
+		if (!w.th.joinable()) return;
+		std::lock_guard<std::mutex> lk(w.mu);
+		if (w.batch >= 0) return; // (nested: the outer call's slot)
+		watchdogRetire(w);
+		if (w.tail - w.head == te_gmg::Watchdog::RING) return; // ring full: this call's exchanges take slots of their own
+		idx      = (int64_t) w.tail++;
+		auto &sl = w.slot[idx % te_gmg::Watchdog::RING];
+		sl.since = std::chrono::steady_clock::now();
+		sl.tag = 0, sl.level = 0;
+		sl.recorded = false;
+		w.batch     = idx;
+	}
+	~WatchdogBatch()
+	{
+		if (idx < 0) return;
+		auto &w = g->wd;
+		std::lock_guard<std::mutex> lk(w.mu);
+		w.batch     = -1;
+		auto &sl    = w.slot[idx % te_gmg::Watchdog::RING];
+		sl.recorded = (hipEventRecord(sl.ev, g->stream) == hipSuccess);
 	}
 };
 
@@ -2887,7 +2930,11 @@ int te_gmg_verify_schedule(te_gmg *g, const te_cycle_opts *o)
 static int vcycleWith(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u, const PendingRhs *pending);
 int te_vcycle(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u)
 {
-	return guarded([&]() -> int { return vcycleWith(g, o, f, u, nullptr); });
+	return guarded([&]() -> int {
+		if (!g) return te::fail(TE_EINVAL, "te_vcycle: null solver");
+		WatchdogBatch batch(g);
+		return vcycleWith(g, o, f, u, nullptr);
+	});
 }
 // te_vcycle; `pending`: f is still to be formed (te_bicgstab; consumed by level 0's first reader, visit())
 static int vcycleWith(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec *u, const PendingRhs *pending)
@@ -2924,6 +2971,7 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 	return guarded([&]() -> int {
 		int rc;
 		if ((rc = checkLevelVec(g, 0, x, "te_bicgstab")) || (rc = checkLevelVec(g, 0, b, "te_bicgstab"))) return rc;
+		WatchdogBatch batch(g);
 		if (g->nranks > 1 && !g->rccl.comm && !g->allreduce)
 			return te::fail(TE_ESTATE, "te_bicgstab on a sharded hierarchy needs te_gmg_use_rccl or te_gmg_set_allreduce");
 		// the eight work vectors stay with the solver (a driver solves again and again: allocating and freeing 8 GiB at 512^3
