@@ -28,13 +28,15 @@ ap.add_argument("--smoother", default="rbgs")
 ap.add_argument("--out", default=None)
 ap.add_argument("--ranks", default="1,2,4,8")
 ap.add_argument("--agg", default="16,4,0")
+ap.add_argument("--dim", type=int, default=3)
+ap.add_argument("--patch", type=int, default=None, help="cells per patch axis (default 32 in 3D, 64 in 2D)")
 a = ap.parse_args()
 
 os.environ["TE_RCCL_LOOPBACK"] = "1"
 os.environ["TE_NO_VERIFY"] = "1"
 from pressurepoissonsolver_amd import capi, dist as tedist  # noqa: E402
 
-n = 32
+n = a.patch or (32 if a.dim == 3 else 64)
 div = int(round(np.log2(a.size // n)))
 sm = {"rbgs": capi.SMOOTH_RBGS, "patch_solve": capi.SMOOTH_PATCH_SOLVE}[a.smoother]
 lines = []
@@ -47,7 +49,7 @@ def emit(s=""):
 
 def run(nranks, rank, agg):
     os.environ["TE_AGGLOMERATE"] = str(agg)
-    mesh = capi.Mesh.uniform(3, div)
+    mesh = capi.Mesh.uniform(a.dim, div)
     H = capi.Hierarchy(mesh, n, rank=rank, nranks=nranks)
     g = capi.GMG(H)
     if nranks > 1:
