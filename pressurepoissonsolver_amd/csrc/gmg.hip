@@ -70,12 +70,12 @@ const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_j
 enum Opt : int {
 	O_2D_SIMPLE, O_2D_NO_MFMA, O_2D_NO_PF, O_2D_NO_MR_FUSE, O_2D_TPB, O_NO_FUSE2, O_NO_FUSE3, O_NO_FUSE3_CF, O_NO_CFP, O_NO_XF,
 	O_NO_FCORR, O_NO_FCORR_CF, O_NO_GTAB, O_NO_OVERLAP, O_OVERLAP_MIN, O_NO_PS_FACES, O_PS_MODE, O_PS_SLOW, O_RBGS_NOSLAB,
-	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_COUNT
+	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_COUNT
 };
 const char *optName[O_COUNT] = {"TE_2D_SIMPLE", "TE_2D_NO_MFMA", "TE_2D_NO_PF", "TE_2D_NO_MR_FUSE", "TE_2D_TPB", "TE_NO_FUSE2", "TE_NO_FUSE3",
                                 "TE_NO_FUSE3_CF", "TE_NO_CFP", "TE_NO_XF", "TE_NO_FCORR", "TE_NO_FCORR_CF", "TE_NO_GTAB", "TE_NO_OVERLAP",
                                 "TE_OVERLAP_MIN", "TE_NO_PS_FACES", "TE_PS_MODE", "TE_PS_SLOW", "TE_RBGS_NOSLAB", "TE_ZS_FORCE", "TE_NO_ZS8",
-                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE"};
+                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS"};
 // options that shape the level tables te_gmg_create builds: fixed for the solver's lifetime
 inline bool optStructural(int o) { return o == O_2D_SIMPLE || o == O_NO_CFP || o == O_2D_NO_MR_FUSE || o == O_NO_OVERLAP || o == O_EXCHANGE_TIMEOUT; }
 struct Cfg {
@@ -210,6 +210,7 @@ struct LevelHost {
 		L.xf_out    = nullptr;
 		L.f6        = nullptr;
 		L.f6_out    = nullptr;
+		L.f6off     = f6Off();
 		L.fcorr     = nullptr;
 		return L;
 	}
@@ -220,6 +221,23 @@ struct LevelHost {
 	DevBuf<double> cellvol;          // [P] product of the spacings (te_integrate)
 	std::vector<double> patch_vol;   // [P] product of the patch lengths (te_volume)
 	DevBuf<double> f6buf;            // [P][6][n^2]: the six face layers of an iterate that is never stored (opts.fuse = 3)
+	// Where the RB-GS kernels keep face layer (p, s) inside f6buf (LevelDev.f6off): the layers that travel to other ranks
+	// first, in the order of the level's face exchange, so that the exchange after the pre-sweep sends them from where they
+	// are -- no pack kernel. Empty when a layer travels more than once (a refined level cut by rank boundaries: the pack kernel
+	// stays). f6_tab: the face layers in f6buf were written through the table (the patch solve writes [p][6]).
+	DevBuf<int32_t> f6off;
+	bool            f6_tab = false;
+	const int32_t  *f6Off() const { return f6_tab ? f6off.p : nullptr; }
+	// The coarser level lives on every rank and this level is uniformly refined everywhere (global facts): the parent of a
+	// neighbour on another rank is local, so the post-sweep on v + P e forms that neighbour's correction itself
+	// (ProlongSrc::gparent) from the face layers of v its ghost slots still hold from the pre-sweep's exchange
+	// (ghost_has_v) -- the second face exchange of the level and its pack kernel do not exist.
+	bool            post_exchange_free = false, ghost_has_v = false;
+	DevBuf<int32_t> slot_parent, slot_orth; // [nremote]
+	// repl_up and every rank's patches restrict into whole coarse patches that are a contiguous run of the coarse level:
+	// the restricted blocks are exchanged in place (run to run inside the coarse vector), no pack / unpack kernel
+	bool   repl_direct = false;
+	ExPlan tx_direct;
 	// [P][4][n^2]: the x-face ghost terms of this level's right-hand side that the finer level's pre-sweep exported instead of
 	// adding them in a fix-up pass (march3d.hpp FCorrSrc); f_has_corr: they belong to the current L.f (inside te_vcycle)
 	DevBuf<double> fcorr;
@@ -503,7 +521,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	// themselves on a same-level face, raw neighbour cells for k_cf_ghost on a coarse/fine face (q = which
 	// of the finer neighbours; the coarse side of a coarse/fine face receives one slot per fine neighbour).
 	struct RFace {
-		int peer, key_patch, key_side, key_q, p, s;
+		int peer, key_patch, key_side, key_q, p, s, nb;
 		bool operator<(const RFace &o) const
 		{
 			return std::tie(peer, key_patch, key_side, key_q) < std::tie(o.peer, o.key_patch, o.key_side, o.key_q);
@@ -519,11 +537,11 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 			for (int q = 0; q < NQ; q++) {
 				const int nb = lv.g_nbr[gf * 4 + q];
 				if (nb < 0 || lv.g_rank[nb] == me) continue;
-				recvs.push_back({lv.g_rank[nb], gp, s, q, p, s});
+				recvs.push_back({lv.g_rank[nb], gp, s, q, p, s, nb});
 				// what the neighbour files my layer under: its own (patch, side) and, when it is the coarse
 				// side, my position among its fine neighbours = my quadrant on its face
 				const int their_q = (kind == NBR_COARSE) ? lv.g_nbr_orth[gf] : 0;
-				sends.push_back({lv.g_rank[nb], nb, s ^ 1, their_q, p, s});
+				sends.push_back({lv.g_rank[nb], nb, s ^ 1, their_q, p, s, nb});
 			}
 		}
 	}
@@ -545,6 +563,21 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		L->nremote = nremote;
 		int rc0;
 		if ((rc0 = L->send_faces.upload(sf)) || (rc0 = L->sendbuf.alloc((size_t) std::max(nremote, 1) * L->nf))) return rc0;
+		if (D == 3 && nremote > 0) { // the place of every face layer in f6buf: sent layers first, in send order (see LevelHost::f6off)
+			std::vector<int32_t> off((size_t) P * NS, -1);
+			bool                 once = true;
+			for (size_t i = 0; i < sends.size() && once; i++) {
+				int32_t &o = off[(size_t) sends[i].p * NS + sends[i].s];
+				once       = (o < 0);
+				o          = (int32_t) i;
+			}
+			if (once) {
+				int32_t next = (int32_t) sends.size();
+				for (auto &o : off)
+					if (o < 0) o = next++;
+				if ((rc0 = L->f6off.upload(off))) return rc0;
+			}
+		}
 	}
 
 	std::vector<int32_t> fk(P * NS), fs(P * NS, -1), cfd, cfs, plan(P, 0);
@@ -861,6 +894,50 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		L->n_up    = (int) (upd.size() / 2);
 		L->n_down  = (int) down.size();
 		L->repl_up = repl;
+		if (D == 3 && repl) {
+			bool uniform = true;
+			for (int gp = 0; gp < lv.P_global && uniform; gp++) {
+				uniform = lv.g_orth_on_parent[gp] >= 0;
+				for (int s2 = 0; s2 < NS && uniform; s2++) uniform = lv.g_nbr_kind[(size_t) gp * NS + s2] <= NBR_NORMAL;
+			}
+			L->post_exchange_free = uniform;
+			if (uniform && nremote > 0) {
+				std::vector<int32_t> sp(nremote), so(nremote);
+				for (int i = 0; i < nremote; i++) {
+					sp[i] = cv.g_local[lv.g_parent[recvs[i].nb]];
+					so[i] = lv.g_orth_on_parent[recvs[i].nb];
+				}
+				if ((rc = L->slot_parent.upload(sp)) || (rc = L->slot_orth.upload(so))) return rc;
+			}
+			// in-place exchange of the restricted blocks: who fills which coarse patches
+			std::vector<int> owner(cv.P_global, -1), lo(H.nranks, cv.P_global), hi(H.nranks, -1), cnt(H.nranks, 0);
+			bool             direct = true;
+			for (int gf = 0; gf < lv.P_global && direct; gf++) {
+				int &o = owner[lv.g_parent[gf]];
+				if (o >= 0 && o != lv.g_rank[gf]) direct = false;
+				o = lv.g_rank[gf];
+			}
+			for (int pc = 0; pc < cv.P_global && direct; pc++) {
+				const int r = owner[pc], lc = cv.g_local[pc];
+				if (r < 0) {
+					direct = false;
+					break;
+				}
+				lo[r] = std::min(lo[r], lc), hi[r] = std::max(hi[r], lc), cnt[r]++;
+			}
+			for (int r = 0; r < H.nranks && direct; r++) direct = (cnt[r] == 0 || cnt[r] == hi[r] - lo[r] + 1);
+			if (direct) {
+				for (int r = 0; r < H.nranks; r++) {
+					if (r == me || (cnt[r] == 0 && cnt[me] == 0)) continue;
+					L->tx_direct.peers.push_back(r);
+					L->tx_direct.send_off.push_back(cnt[me] ? (int64_t) lo[me] * (int64_t) L->nc : 0);
+					L->tx_direct.send_cnt.push_back((int64_t) cnt[me] * (int64_t) L->nc);
+					L->tx_direct.recv_off.push_back(cnt[r] ? (int64_t) lo[r] * (int64_t) L->nc : 0);
+					L->tx_direct.recv_cnt.push_back((int64_t) cnt[r] * (int64_t) L->nc);
+				}
+				L->repl_direct = true;
+			}
+		}
 		if (repl) {
 			// restrict: the same range of upbuf to every other rank (if this rank has patches here at all), and from every rank
 			// that has patches here its blocks; prolong: nothing
@@ -1142,7 +1219,7 @@ template <int N> void packFaces(te_gmg *g, LevelHost &L, const double *u, const 
 	const dim3 grid(L.nremote), blk(N * N < 256 ? N * N : 256);
 	if (L.pack_f6) { // the iterate exists only as its face layers
 		ProlongSrc none{nullptr, nullptr, nullptr};
-		hipLaunchKernelGGL(k_pack_faces6_3d<N>, grid, blk, 0, g->stream, L.send_faces.p, L.pack_f6, ps ? *ps : none, L.sendbuf.p);
+		hipLaunchKernelGGL(k_pack_faces6_3d<N>, grid, blk, 0, g->stream, L.send_faces.p, L.pack_f6, ps ? *ps : none, L.sendbuf.p, L.f6Off());
 	} else if (ps)
 		hipLaunchKernelGGL(k_pack_faces_prolong3d<N>, grid, blk, 0, g->stream, L.send_faces.p, u, *ps, L.sendbuf.p);
 	else
@@ -1155,9 +1232,9 @@ template <int N> void cfGhosts(te_gmg *g, LevelHost &L, const double *u, const P
 	const dim3 grid(L.ncf), blk(N * N < 256 ? N * N : 256);
 	if (L.pack_f6) {
 		if (ps)
-			hipLaunchKernelGGL((k_cf_ghost6_3d<N, true>), grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, L.pack_f6, *ps, L.ghost.p);
+			hipLaunchKernelGGL((k_cf_ghost6_3d<N, true>), grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, L.pack_f6, *ps, L.ghost.p, L.f6Off());
 		else
-			hipLaunchKernelGGL((k_cf_ghost6_3d<N, false>), grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, L.pack_f6, ProlongSrc(), L.ghost.p);
+			hipLaunchKernelGGL((k_cf_ghost6_3d<N, false>), grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, L.pack_f6, ProlongSrc(), L.ghost.p, L.f6Off());
 	} else if (ps)
 		hipLaunchKernelGGL(k_cf_ghost_prolong3d<N>, grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, u, *ps, L.ghost.p);
 	else
@@ -1166,9 +1243,12 @@ template <int N> void cfGhosts(te_gmg *g, LevelHost &L, const double *u, const P
 template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u, const ProlongSrc *ps = nullptr)
 {
 	if (L.patch_local) return TE_OK; // the patch operator reads no neighbour
+	L.ghost_has_v = false;
 	if (L.nremote > 0) {
-		packFaces<N>(g, L, u, ps);
-		int rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p);
+		// the face layers of an iterate that exists only as such already sit in send order (LevelHost::f6off): sent from there
+		const bool direct = L.pack_f6 && !ps && L.f6Off();
+		if (!direct) packFaces<N>(g, L, u, ps);
+		int rc = doExchange(g, 1, L.fx, direct ? L.pack_f6 : L.sendbuf.p, L.ghost.p);
 		if (rc) return rc;
 	}
 	if (L.ncf == 0) return TE_OK;
@@ -1194,6 +1274,7 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 	// pays only where the interior launch is much longer than that: more local patches than the chip holds workgroups at once
 	// (3 x 256). Measured per rank with the exchanges in loop-back (tools/mr8_budget.py): at 512 local patches (512^3 on eight
 	// ranks) the cycle is 525 us with the split and 475 us without it.
+	L.ghost_has_v = false;
 	if (L.patch_local || g->recording || L.nremote == 0 || !g->overlap || L.n_int == 0 || L.P < g->cfg.num(O_OVERLAP_MIN, 768)) {
 		int rc = prepareGhosts<N>(g, L, u, ps);
 		if (rc) return rc;
@@ -1655,6 +1736,8 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 // every rank): the finished octants are copied out of the coarse patches first -- one copy, sent to everybody.
 template <int N> int shipRestricted(te_gmg *g, LevelHost &L, double *coarse)
 {
+	// every rank's blocks are whole coarse patches in one run of the coarse vector: run to run, in place
+	if (L.repl_up && L.repl_direct && !g->cfg.has(O_REPL_BLOCKS)) return doExchange(g, 2, L.tx_direct, coarse, coarse);
 	if (L.repl_up && L.n_up > 0) {
 		Timed t(g, KC_PACK, (size_t) L.n_up * L.nc / 8);
 		hipLaunchKernelGGL(k_prolong_pack3d<N>, dim3(L.n_up), dim3(256), 0, g->stream, L.bc_desc.p, L.up_off.p, coarse, L.upbuf.p);
@@ -1688,6 +1771,7 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	int rc;
 	if (L.P > 0) {
 		Timed      t(g, store_u ? KC_ZERO_RESID : (fcorr_in ? KC_ZERO_RESID_FACES_FCORR : KC_ZERO_RESID_FACES), (size_t) L.P * L.nc, true);
+		if (!store_u) L.f6_tab = L.f6off.p != nullptr; // the face layers go where the level's table puts them
 		LevelDev   D = L.dev();
 		const dim3 grid(8 * ((L.P + 7) / 8)), blk(Tile3<N>::TPB);
 		if (store_u) {
@@ -1730,6 +1814,7 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	rc        = prepareGhosts<N>(g, L, out);
 	L.pack_f6 = nullptr;
 	if (rc) return rc;
+	L.ghost_has_v = !store_u; // (the slots of neighbours on other ranks hold their face layers of v until the next exchange of the level)
 	if (fcorr_out) { // the ghost terms were formed by the patches that own the face values: sort them into the coarse
 		// level's side array (a permutation copy of 6/128 of a vector instead of the fix-up pass)
 		if (L.Pc > 0) {
@@ -1822,6 +1907,19 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 			}
 		}
 	};
+	if (L.post_exchange_free && L.ghost_has_v && L.ncf == 0 && !L.has_copy && !g->cfg.has(O_POST_EXCHANGE)) {
+		// every neighbour's parent is local (the coarser level lives on every rank) and the ghost slots still hold the neighbours'
+		// face layers of v: the kernel forms v + P e for them as for local neighbours; nothing travels (a global decision: all
+		// ranks of the level take it together)
+		ps.gparent    = L.slot_parent.p;
+		ps.gorth      = L.slot_orth.p;
+		L.ghost_has_v = false;
+		LevelDev D    = L.dev();
+		D.xf_out      = xf_out;
+		launch(D);
+		HIPCHK(hipGetLastError());
+		return TE_OK;
+	}
 	L.pack_f6 = L.f6buf.p; // neighbours on other ranks receive the face layers of v + P(coarse)
 	int rc    = withGhosts<N>(g, L, out /* unused: the faces come from pack_f6 */, launch, nullptr, xf_out, &ps);
 	L.pack_f6 = nullptr;
@@ -2042,6 +2140,7 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 				double    *xo = (g->in_cycle && n_mix == 0 && !g->no_xf_export) ? L.xfbuf[L.xf_cur ^ 1].p : nullptr; // (k_ps_fused does not export)
 				const bool faces = faces_req && n_mix == 0 && L.f6buf.p;
 				if (faces) { // only the face layers of the result: see k_ps_sym<CORR, FACES>
+					L.f6_tab = false; // (written as [p][6])
 					launchT(t, (k_ps_sym<false, true>), gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
 					        L.zero_mode.p, L.rh2.p, f, cp, u, (double *) nullptr, lst_sym, L.f6buf.p);
 					L.ps_faces = true;

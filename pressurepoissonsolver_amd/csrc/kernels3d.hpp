@@ -51,9 +51,18 @@ struct LevelDev {
 	// a + N b with (a, b) the two other axes in order (the ghost-slot layout). f6 belongs to the input, f6_out is filled.
 	const double *f6;
 	double       *f6_out;
+	// where face layer (p, s) sits inside f6 / f6_out, in units of N*N doubles (null: at p * 6 + s). A level cut by rank
+	// boundaries keeps the layers that travel to other ranks first, in send order: the exchange sends them from where
+	// they are and no pack kernel runs (gmg.hip buildLevel)
+	const int32_t *f6off;
 	// ghost terms that still belong to this level's right-hand side (march3d.hpp FCorrSrc), or null
 	const double *fcorr;
 };
+
+template <int N> __device__ __forceinline__ size_t f6Face(const int32_t *f6off, int p, int s)
+{
+	return (size_t) (f6off ? f6off[(size_t) p * 6 + s] : p * 6 + s) * (N * N);
+}
 
 // Blocks b, b+8, b+16, ... share an XCD (observed round-robin dispatch); give every XCD one
 // contiguous run of patches so that x/y/z-neighbour faces are mostly served from that XCD's
@@ -186,19 +195,20 @@ __device__ __forceinline__ HaloSrc haloSrc(int tid, const int32_t *fk, const int
 // The same two helpers for an iterate that exists only as its six face layers (LevelDev.f6) -- the relaxation kernels
 // fold physical faces into the diagonal, so those contribute 0.
 template <int N>
-__device__ __forceinline__ PlaneSrc zPlaneSrc6(int kind, int src, bool top, const double *f6, const double *ghost)
+__device__ __forceinline__ PlaneSrc zPlaneSrc6(int kind, int src, bool top, const double *f6, const double *ghost, const int32_t *f6off)
 {
 	constexpr int NN = N * N;
 	PlaneSrc      r;
 	const double *p = f6; // harmless valid address where nothing applies (scale 0)
 	r.s             = 0.0;
-	if (kind == FACE_LOCAL) p = f6 + ((size_t) src * 6 + (top ? 4 : 5)) * NN, r.s = 1.0;
+	if (kind == FACE_LOCAL) p = f6 + f6Face<N>(f6off, src, top ? 4 : 5), r.s = 1.0;
 	if (kind == FACE_GHOST) p = ghost + (size_t) src * NN, r.s = 1.0;
 	r.p = reinterpret_cast<const double2 *>(p);
 	return r;
 }
 template <int N>
-__device__ __forceinline__ HaloSrc haloSrc6(int tid, const int32_t *fk, const int32_t *fs, const double *f6, const double *ghost)
+__device__ __forceinline__ HaloSrc haloSrc6(int tid, const int32_t *fk, const int32_t *fs, const double *f6, const double *ghost,
+                                            const int32_t *f6off)
 {
 	constexpr int NN = N * N;
 	using T2 = Tile2<N>;
@@ -211,7 +221,7 @@ __device__ __forceinline__ HaloSrc haloSrc6(int tid, const int32_t *fk, const in
 		const int side = tid / N, t = tid % N;
 		const int kind = fk[side], src = fs[side];
 		h.lds = (side == 0) ? T2::row(t + 1) + 1 : (side == 1) ? T2::row(t + 1) + N + 2 : (side == 2) ? T2::row(0) + t + 2 : T2::row(N + 1) + t + 2;
-		if (kind == FACE_LOCAL) h.p = f6 + ((size_t) src * 6 + (side ^ 1)) * NN + t, h.stride = N, h.s = 1.0;
+		if (kind == FACE_LOCAL) h.p = f6 + f6Face<N>(f6off, src, side ^ 1) + t, h.stride = N, h.s = 1.0;
 		if (kind == FACE_GHOST) h.p = ghost + (size_t) src * NN + t, h.stride = N, h.s = 1.0;
 	}
 	return h;

@@ -353,7 +353,20 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 struct ProlongSrc {
 	const int32_t *parent, *orth;
 	const double  *coarse;
+	// k_rbgs_resweep_prolong3d on a level whose coarser level lives on every rank (a replicated level): the parent of a
+	// neighbour on ANOTHER rank is a local coarse patch too, so the correction of a ghost slot's values is formed here
+	// as for a local neighbour -- the slot still holds the neighbour's face layer of v from the pre-sweep's exchange, and
+	// no second exchange (nor its pack kernel) runs. gparent / gorth [ghost slot]: that coarse patch and orthant; null
+	// when the slots hold v + P e already (sent that way: k_pack_faces6_3d)
+	const int32_t *gparent = nullptr, *gorth = nullptr;
 };
+// coarseOctant for the patch behind ghost slot `slot` (see ProlongSrc::gparent)
+template <int N> __device__ __forceinline__ const double *coarseOctantSlot(const ProlongSrc &ps, int slot)
+{
+	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
+	const int     o = ps.gorth[slot];
+	return ps.coarse + (size_t) ps.gparent[slot] * NNN + ((o & 1) ? H : 0) + N * ((o & 2) ? H : 0) + NN * ((o & 4) ? H : 0);
+}
 // base of the coarse octant that fine patch p maps onto: coarse cell of fine (x,y,z) = base[x/2 + N (y/2) + N^2 (z/2)]
 template <int N> __device__ __forceinline__ const double *coarseOctant(const ProlongSrc &ps, int p)
 {
@@ -424,7 +437,7 @@ __global__ void k_cf_ghost_prolong3d(const int32_t *__restrict__ desc, const int
 // PROLONG: the iterate is that + P(coarse), formed value by value as k_cf_ghost_prolong3d does.
 template <int N, bool PROLONG>
 __global__ void k_cf_ghost6_3d(const int32_t *__restrict__ desc, const int32_t *__restrict__ slots, const double *__restrict__ f6,
-                               ProlongSrc ps, double *__restrict__ ghost)
+                               ProlongSrc ps, double *__restrict__ ghost, const int32_t *__restrict__ f6off)
 {
 	constexpr int  NN = N * N;
 	const int32_t *d  = desc + (size_t) blockIdx.x * 8;
@@ -438,7 +451,7 @@ __global__ void k_cf_ghost6_3d(const int32_t *__restrict__ desc, const int32_t *
 	double        *g    = ghost + (size_t) slots[blockIdx.x] * NN;
 	// value at face cell (a, b) of `patch` on its side `side` (cell index base + a sa + b sb inside the patch)
 	auto U = [&](int patch, int side, int base, int a, int b) {
-		double v = f6[((size_t) patch * 6 + side) * NN + a + N * b];
+		double v = f6[f6Face<N>(f6off, patch, side) + a + N * b];
 		if (PROLONG) v += coarseAtCell<N>(ps, patch, base + a * sa + b * sb);
 		return v;
 	};
@@ -919,7 +932,7 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 			if (p < 0) return 0.0;
 			const int kind = L.face_kind[(size_t) p * 6 + sp], src = L.face_src[(size_t) p * 6 + sp];
 			if (kind < FACE_LOCAL) return 0.0;
-			const double g = kind == FACE_GHOST ? L.ghost[(size_t) src * NN + a + N * b] : f6[((size_t) src * 6 + (sp ^ 1)) * NN + a + N * b];
+			const double g = kind == FACE_GHOST ? L.ghost[(size_t) src * NN + a + N * b] : f6[f6Face<N>(L.f6off, src, sp ^ 1) + a + N * b];
 			return -L.rh2[(size_t) p * 3 + ax] * g;
 		}
 		const int s = 2 * ax + (j & 1), hi = j >> 1; // j = 0: low face of the low child, 1: its high face, 2, 3: the high child's
@@ -931,7 +944,7 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 		if (kind == FACE_LOCAL && rs6) return rs6[((size_t) src * 6 + (s ^ 1)) * HH + ha + H * hb];
 		// the sum of k_restrict_fixup3d over the 2x2 block, first face coordinate fastest
 		const double  w  = -L.rh2[(size_t) p * 3 + ax];
-		const double *gp = kind == FACE_GHOST ? L.ghost + (size_t) src * NN : f6 + ((size_t) src * 6 + (s ^ 1)) * NN;
+		const double *gp = kind == FACE_GHOST ? L.ghost + (size_t) src * NN : f6 + f6Face<N>(L.f6off, src, s ^ 1);
 		double        v  = 0.0;
 #pragma unroll
 		for (int db = 0; db < 2; db++)
@@ -1072,8 +1085,13 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_zero_resid3d(LevelDev
 	// which x face (0 W, 1 E) and which y face (0 S, 1 N) this thread's cells lie on, or -1 (at most one of each: H >= 2),
 	// and where its entries of plane 0 go in the face layers / in the 2x2 sums
 	const int     xs  = !act ? -1 : (X == 0 ? 0 : (X == H - 1 ? 1 : -1)), ys = !act ? -1 : (Yp == 0 ? 0 : (Yp == H - 1 ? 1 : -1));
-	double *const xfo = STORE_U ? nullptr : L.f6_out + (size_t) pid * 6 * NN + (xs > 0 ? NN : 0) + 2 * Yp;
-	double *const yfo = STORE_U ? nullptr : L.f6_out + (size_t) pid * 6 * NN + (2 + (ys > 0 ? 1 : 0)) * NN + 2 * X;
+	// (the face layers' places come from a table: the ones other ranks need sit in send order, LevelDev.f6off; the two z
+	// layers' places are fetched here, not in the step that stores them -- a load under a branch inside the march makes every
+	// step wait where the branch rejoins)
+	double *const xfo = STORE_U ? nullptr : L.f6_out + f6Face<N>(L.f6off, pid, xs > 0 ? 1 : 0) + 2 * Yp;
+	double *const yfo = STORE_U ? nullptr : L.f6_out + f6Face<N>(L.f6off, pid, 2 + (ys > 0 ? 1 : 0)) + 2 * X;
+	double *const zfo[2] = {STORE_U ? nullptr : L.f6_out + f6Face<N>(L.f6off, pid, 4) + 2 * X + N * (2 * Yp),
+	                        STORE_U ? nullptr : L.f6_out + f6Face<N>(L.f6off, pid, 5) + 2 * X + N * (2 * Yp)};
 	double *const xrs = EXPORT ? rs + (xs > 0 ? H * H : 0) + Yp : nullptr;
 	double *const yrs = EXPORT ? rs + (2 + (ys > 0 ? 1 : 0)) * (H * H) + X : nullptr;
 	// ghost of the residual's stencil on each side, as a multiple of the cell just inside: -1 Dirichlet, +1 Neumann
@@ -1232,9 +1250,9 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_zero_resid3d(LevelDev
 				}
 				if (act && (zz == 0 || zz == N - 1)) { // z faces: the whole 2x2 block is in this thread; entry (x, y)
 					if (!STORE_U) {
-						double *zo = L.f6_out + (size_t) pid * 6 * NN + (zz == 0 ? 4 : 5) * NN + 2 * X;
-						*reinterpret_cast<double2 *>(zo + N * (2 * Yp))     = u1[0];
-						*reinterpret_cast<double2 *>(zo + N * (2 * Yp + 1)) = u1[1];
+						double *zo = zfo[zz == 0 ? 0 : 1];
+						*reinterpret_cast<double2 *>(zo)     = u1[0];
+						*reinterpret_cast<double2 *>(zo + N) = u1[1];
 					}
 					if (EXPORT) {
 						double t = 0.0;
@@ -1355,13 +1373,13 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 					if (kind == FACE_GHOST)
 						g = L.ghost[(size_t) src * NN + i];
 					else if (L.f6) // the iterate exists only as its face layers
-						g = L.f6[((size_t) src * 6 + (s ^ 1)) * NN + i];
+						g = L.f6[f6Face<N>(L.f6off, src, s ^ 1) + i];
 					else if (ax == 0 && L.xf) // compact x-face columns instead of a stride-N gather
 						g = L.xf[((size_t) src * 2 + ((s & 1) ^ 1)) * NN + i];
 					else
 						g = u[(size_t) src * NNN + oth + cell];
 					if (OWN)
-						g += L.f6 ? L.f6[((size_t) p * 6 + s) * NN + i]
+						g += L.f6 ? L.f6[f6Face<N>(L.f6off, p, s) + i]
 						          : ((ax == 0 && L.xf) ? L.xf[((size_t) p * 2 + (s & 1)) * NN + i] : u[(size_t) p * NNN + mine + cell]);
 					cc[mine + cell] += w * g;
 				}
@@ -1390,14 +1408,14 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 						if (kind == FACE_GHOST)
 							g = L.ghost[(size_t) src * NN + a + N * b];
 						else if (L.f6)
-							g = L.f6[((size_t) src * 6 + (s ^ 1)) * NN + a + N * b];
+							g = L.f6[f6Face<N>(L.f6off, src, s ^ 1) + a + N * b];
 						else if (ax == 0 && L.xf)
 							g = L.xf[((size_t) src * 2 + ((s & 1) ^ 1)) * NN + a + N * b];
 						else
 							g = u[(size_t) src * NNN + oth + a * sa + b * sb];
 						if (OWN) {
 							if (L.f6)
-								g += L.f6[((size_t) p * 6 + s) * NN + a + N * b];
+								g += L.f6[f6Face<N>(L.f6off, p, s) + a + N * b];
 							else if (ax == 0 && L.xf)
 								g += L.xf[((size_t) p * 2 + (s & 1)) * NN + a + N * b];
 							else
@@ -1429,13 +1447,13 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 // red update of plane z and black update of plane z-1 exactly as in k_rbgs3d.
 template <int N>
 __global__ void k_pack_faces6_3d(const int32_t *__restrict__ faces, const double *__restrict__ f6, ProlongSrc ps,
-                                 double *__restrict__ sendbuf)
+                                 double *__restrict__ sendbuf, const int32_t *__restrict__ f6off)
 {
 	constexpr int NN = N * N, H = N / 2;
 	const int     p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
 	const int     ax = s >> 1;
 	const int     sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
-	const double *fp = f6 + ((size_t) p * 6 + s) * NN;
+	const double *fp = f6 + f6Face<N>(f6off, p, s);
 	double       *o  = sendbuf + (size_t) blockIdx.x * NN;
 	if (ps.coarse && ps.orth[p] < 0) { // a patch that copies through (refined level): its correction is the same-size coarse
 		// patch, cell by cell -- as k_pack_faces_prolong3d and k_cf_ghost6_3d<N, true> form it for local readers
@@ -1487,9 +1505,9 @@ __global__ __launch_bounds__(Tile3<N>::TPB, (V & 32) ? 2 : 3) void k_rbgs_reswee
 	idiagTable(idiag, tid, kinds, rhx, rhy, rhz);
 	for (int i = tid; i < 2 * T::LSZ; i += TPB) (&tileV[0][0])[i] = 0.0; // its halo ring stays zero: ghosts of a zero iterate
 
-	const HaloSrc  hs  = haloSrc6<N>(tid, fk, fs, L.f6, L.ghost);
-	const PlaneSrc bot = zPlaneSrc6<N>(fk[4], fs[4], false, L.f6, L.ghost);
-	const PlaneSrc top = zPlaneSrc6<N>(fk[5], fs[5], true, L.f6, L.ghost);
+	const HaloSrc  hs  = haloSrc6<N>(tid, fk, fs, L.f6, L.ghost, L.f6off);
+	const PlaneSrc bot = zPlaneSrc6<N>(fk[4], fs[4], false, L.f6, L.ghost, L.f6off);
+	const PlaneSrc top = zPlaneSrc6<N>(fk[5], fs[5], true, L.f6, L.ghost, L.f6off);
 
 	const bool act = (T::NT == TPB) || tid < T::NT;
 	const int  X = act ? tid % H : 0, Yp = act ? tid / H : 0;
@@ -1530,6 +1548,12 @@ __global__ __launch_bounds__(Tile3<N>::TPB, (V & 32) ? 2 : 3) void k_rbgs_reswee
 				chalo = cn + cx + N * cy;
 			}
 			shalo = 1.0;
+		} else if (!CFP && fk[side] == FACE_GHOST && ps.gparent) { // a neighbour on another rank whose parent is local
+			const double *cn = coarseOctantSlot<N>(ps, fs[side]);
+			const int     cx = (side == 0) ? H - 1 : (side == 1 ? 0 : t / 2);
+			const int     cy = (side == 2) ? H - 1 : (side == 3 ? 0 : t / 2);
+			chalo = cn + cx + N * cy;
+			shalo = 1.0;
 		}
 	}
 	if (fk[4] == FACE_LOCAL) {
@@ -1538,12 +1562,18 @@ __global__ __launch_bounds__(Tile3<N>::TPB, (V & 32) ? 2 : 3) void k_rbgs_reswee
 		else
 			cbot = coarseOctant<N>(ps, fs[4]) + NN * (H - 1);
 		sbot = 1.0;
+	} else if (!CFP && fk[4] == FACE_GHOST && ps.gparent) {
+		cbot = coarseOctantSlot<N>(ps, fs[4]) + NN * (H - 1);
+		sbot = 1.0;
 	}
 	if (fk[5] == FACE_LOCAL) {
 		if (CFP && ps.orth[fs[5]] < 0)
 			cpt = true, ytop = ps.coarse + (size_t) ps.parent[fs[5]] * NNN;
 		else
 			ctop = coarseOctant<N>(ps, fs[5]);
+		stop = 1.0;
+	} else if (!CFP && fk[5] == FACE_GHOST && ps.gparent) {
+		ctop = coarseOctantSlot<N>(ps, fs[5]);
 		stop = 1.0;
 	}
 	// the correction of this thread's two cells of row k: plane z of the own patch / the bottom / top neighbour's facing plane
