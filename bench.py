@@ -306,32 +306,63 @@ def main():
         assert a.size % n == 0 and (a.size // n) & (a.size // n - 1) == 0, "--size must be patch * 2^k"
         mesh = capi.Mesh.uniform(a.dim, int(round(np.log2(a.size // n))))
     t_setup1 = time.perf_counter()
-    H = capi.Hierarchy(mesh, n, rank=rank, nranks=world)   # te_hier_build: level extraction + partition
-    t_setup2 = time.perf_counter()
-    g = capi.GMG(H, device=local_rank)                     # te_gmg_create: tables, plans, scratch (synchronised on return)
-    t_setup3 = time.perf_counter()
-    setup_ms = {"mesh": (t_setup1 - t_setup0) * 1e3, "te_hier_build": (t_setup2 - t_setup1) * 1e3,
-                "te_gmg_create": (t_setup3 - t_setup2) * 1e3}
-    exchange_backend = "none"
-    if world > 1:
-        # RCCL point-to-point issued by the native library itself (no Python per exchange); the
-        # torch.distributed callback is the fallback (and the only choice for the gloo rehearsal)
-        exchange_backend = "torch.distributed"
-        want = os.environ.get("TE_EXCHANGE", "rccl" if backend == "nccl" else "torch")
-        ok = 0
-        if want == "rccl":
-            try:
-                tedist.attach_rccl(g, dist, rank, world)
-                ok = 1
-            except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks must use the same back-end
-        if int(flag.item()) == 1:
-            exchange_backend = "rccl (native ncclSend/ncclRecv groups)"
-        else:
-            tedist.attach(g, dist)
+    setup_ms = {"mesh": (t_setup1 - t_setup0) * 1e3}
     smoothers = {"rbgs": capi.SMOOTH_RBGS, "jacobi": capi.SMOOTH_JACOBI, "patch_solve": capi.SMOOTH_PATCH_SOLVE}
+
+    def make(placement):
+        """hierarchy + solver + transport for one placement of the small levels ((agglomerate, agglomerate_max, replicate),
+        None = the environment's / the defaults)"""
+        t0 = time.perf_counter()
+        H = capi.Hierarchy(mesh, n, rank=rank, nranks=world, placement=placement)  # te_hier_build: level extraction + partition
+        t1 = time.perf_counter()
+        g = capi.GMG(H, device=local_rank)                  # te_gmg_create: tables, plans, scratch (synchronised on return)
+        t2 = time.perf_counter()
+        setup_ms.update({"te_hier_build": (t1 - t0) * 1e3, "te_gmg_create": (t2 - t1) * 1e3})
+        name = "none"
+        if world > 1:
+            # RCCL point-to-point issued by the native library itself (no Python per exchange); the
+            # torch.distributed callback is the fallback (and the only choice for the gloo rehearsal)
+            name = "torch.distributed"
+            want = os.environ.get("TE_EXCHANGE", "rccl" if backend == "nccl" else "torch")
+            ok = 0
+            if want == "rccl":
+                try:
+                    tedist.attach_rccl(g, dist, rank, world)
+                    ok = 1
+                except Exception as e:  # noqa: BLE001
+                    print(f"[rank {rank}] native RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # all ranks must use the same back-end
+            if int(flag.item()) == 1:
+                name = "rccl (native ncclSend/ncclRecv groups)"
+            else:
+                tedist.attach(g, dist)
+        return H, g, name
+
+    # N > 1: the switches that decide a sharded cycle's fixed cost -- where the small levels live (te_hier_build_placed) and
+    # how the sweeps meet their face exchanges (te_gmg_autotune) -- are chosen HERE, on the communicator the job runs on:
+    # every candidate is timed for a few cycles, the maximum over the ranks decides, the fastest is kept. All candidates give
+    # the same results (bit for bit; tests/test_gpu_multirank*.py), so the choice changes no number but the time.
+    autotune = None
+    if world > 1 and os.environ.get("TE_BENCH_NO_AUTOTUNE") is None:
+        pinned = any(os.environ.get(k) is not None for k in ("TE_AGGLOMERATE", "TE_AGGLOMERATE_MAX", "TE_REPLICATE"))
+        cands = [("environment", None)] if pinned else (
+            [("gathered-on-every-rank", (16, 64, 1)), ("gathered-on-rank-0", (16, 64, 0)), ("never-gathered", (0, 64, 0))] if a.dim == 3
+            else [("gathered-on-rank-0", (16, 64, 0)), ("never-gathered", (0, 64, 0))])
+        tried, best = [], None
+        for cname, pl in cands:
+            Hc, gc, bname = make(pl)
+            ms, rep = gc.autotune(gc.default_opts(smoother=smoothers[a.smoother]), reps=10)
+            tried.append({"placement": cname, "agglomerate/max/replicate": list(Hc.placement()), "ms_per_cycle_max_over_ranks": ms, "overlap": rep})
+            if best is None or ms < best[0]:
+                best = (ms, Hc, gc, bname, cname)
+            else:
+                del gc, Hc
+        _, H, g, exchange_backend, chosen = best
+        autotune = {"chosen_placement": chosen, "candidates": tried, "reps": 10,
+                    "note": "timed on this run's communicator before the measured region; maximum over the ranks; identical results for every candidate"}
+    else:
+        H, g, exchange_backend = make(None)
     opts = g.default_opts(smoother=smoothers[a.smoother])
 
     f = g.new_vector(0)
@@ -420,6 +451,33 @@ def main():
     barrier()
     ms_median = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs]))
 
+    # N > 1: what makes a SCALE record diagnosable -- per rank and cycle, the time inside the exchanges as the solver stream
+    # sees it (RCCL's kernels plus the wait for the peers), the pack / unpack launches, the kernels, and the host time to
+    # enqueue one cycle; minimum and maximum over the ranks. And the rank count RCCL itself reports for the communicator.
+    sharded = None
+    if world > 1:
+        tq = []
+        for _ in range(10):
+            g.sync()
+            t0h = time.perf_counter()
+            g.cycle(opts, f, u)
+            tq.append(time.perf_counter() - t0h)
+        g.sync()
+        pw = max(1, m["profiled_warm"])
+        per = lambda k: rows_all.get(k, {"ms": 0.0})["ms"] / pw * 1e3  # noqa: E731
+        kern = sum(v["ms"] for k, v in rows_all.items() if k not in ("exchange", "pack")) / pw * 1e3
+        mine = [per("exchange"), per("pack"), kern, float(np.median(tq)) * 1e6,
+                rows_all.get("exchange", {"calls": 0})["calls"] / pw, sum(v["calls"] for v in rows_all.values()) / pw]
+        lo = torch.tensor(mine, dtype=torch.float64, device=red_dev)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        names_ = ["exchange_us", "pack_us", "kernels_us", "host_enqueue_us", "exchanges", "launches_plus_exchanges"]
+        rn, rr_ = g.comm_info()
+        sharded = {"rccl_nranks": rn, "rccl_rank_of_rank0": rr_, "per_cycle_min_max_over_ranks": {k: [float(lo[i]), float(hi[i])] for i, k in enumerate(names_)},
+                   "note": "from the warm-up cycles, every class timed (event pairs cost a few us per launch: the sum exceeds ms_per_step); "
+                           "exchange_us includes waiting for the peers"}
+
     # measured ceiling taken in the same run: a bare 2-read + 1-write fp64 stream over the
     # finest-level vectors, one 16-B element per thread (te_vec_scale_then_add_scaled: y = a y + b x)
     r = g.new_vector(0)
@@ -484,8 +542,8 @@ def main():
                        "patches_per_level": [c // n ** a.dim for c in cells_global],
                        # where every level lives (patches per rank): coarse levels gathered on rank 0 show up here
                        "placement_patches_per_rank": placement,
-                       "agglomerate": {"TE_AGGLOMERATE": os.environ.get("TE_AGGLOMERATE", "16 (default)"),
-                                       "TE_AGGLOMERATE_MAX": os.environ.get("TE_AGGLOMERATE_MAX", "64 (default)")} if world > 1 else None,
+                       "agglomerate/max/replicate": list(H.placement()) if world > 1 else None,
+                       "autotune": autotune, "sharded": sharded,
                        "smoother": a.smoother, "residual_reduction_per_cycle": reduction},
             "roofline": roof,
             # whole cycle: (i) against the bytes its fused kernels must move (a roofline fraction); (ii) SURVEY 8(d)'s

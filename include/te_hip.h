@@ -57,6 +57,16 @@ void te_mesh_destroy(te_mesh *m);
  * The Zoltan partition is replaced by contiguous Morton ranges over `nranks`. */
 int te_hier_build(const te_mesh *m, int n, int neumann, int max_levels, double patches_per_proc,
                   int rank, int nranks, te_hier **out);
+/* The same with the placement of the small levels over the ranks spelled out instead of taken from the environment
+ * (te_hier_build reads TE_AGGLOMERATE, TE_AGGLOMERATE_MAX, TE_REPLICATE once per call and comes here): a level with fewer
+ * than `agglomerate` patches per rank and at most `agglomerate_max` patches in total, and every level below it, is gathered --
+ * on every rank (`replicate` != 0, 3D only) or on rank 0. A negative value = the default (16, 64, 1); agglomerate = 0 never
+ * gathers. What the reference does instead is cut the hierarchy (patches_per_proc, CycleFactory3d.cpp:104). Every rank must
+ * pass the same values: te_vcycle / te_bicgstab compare them across the ranks before the first cycle (TE_ESTATE, by name). */
+int te_hier_build_placed(const te_mesh *m, int n, int neumann, int max_levels, double patches_per_proc,
+                         int rank, int nranks, double agglomerate, int agglomerate_max, int replicate, te_hier **out);
+/* the placement this hierarchy was built with (any pointer may be NULL) */
+int te_hier_placement(const te_hier *h, double *agglomerate, int *agglomerate_max, int *replicate);
 int te_hier_num_levels(const te_hier *h);
 int te_hier_dim(const te_hier *h);
 int te_hier_n(const te_hier *h);
@@ -88,7 +98,11 @@ typedef struct {
 	                            (residual+restrict, zero-guess first sweep, sweep on u + P e);
 	                         3 (default): 2, and with exactly one RB-GS pre-sweep and a post-sweep in a V-cycle the
 	                            iterate between them is never stored: the post-sweep kernel recomputes it from f
-	                            (bit-identical to 2);
+	                            (bit-identical to 2). In 2 and 3 the fused pre-sweep forms the residual it restricts on RED
+	                            cells only and takes the black cells' residual as exactly 0: a black cell was relaxed last,
+	                            from the very values its residual is formed with, so what is dropped is the rounding of that
+	                            one update (~1e-16 relative in the coarse right-hand side) -- inside every stated tolerance,
+	                            but not bit-identical to 1;
 	                         2: additionally to 1, with one RB-GS pre-sweep on a uniformly refined 3D level,
 	                            the sweep from the zero iterate, the residual and its restriction are one pass over f;
 	                            the coarse right-hand side differs from 1 by a few ulp along patch faces (the ghost
@@ -215,6 +229,20 @@ int te_gmg_set_allreduce(te_gmg *g, te_allreduce_fn fn, void *user);
  * Independently, a watchdog thread ends the process (exit status 86, message on stderr) when an exchange has not
  * completed TE_EXCHANGE_TIMEOUT seconds (default 300; 0 = off) after it was issued. */
 int te_gmg_verify_schedule(te_gmg *g, const te_cycle_opts *o);
+/* Chooses, on the live communicator, how the sweeps of the sharded levels meet their face exchanges: everything in line on
+ * the solver stream; the exchange on a second stream under the interior patches, boundary patches behind it (north star:
+ * "ghost-cell exchange ... overlapped with interior smoothing"); or the interior patches on the second stream beside
+ * exchange + boundary patches. Each candidate runs `reps` te_vcycle(o) behind two warm-up cycles on a scratch right-hand
+ * side; the maximum over the ranks decides (one scalar reduction per candidate, so all ranks choose alike), the in-line
+ * form winning ties within 2 %. All candidates give bit-identical results -- the choice changes no number. Collective;
+ * call it once after te_gmg_use_rccl / te_gmg_set_exchange. *best_ms (may be NULL) = the chosen form's milliseconds per
+ * cycle; report (may be NULL) receives one line with every candidate's time and the choice. Without a call the size rule
+ * TE_OVERLAP_MIN decides. Replaces nothing in the reference (PETSc's VecScatterBegin/End pair, SchurHelper.h:123-150, is
+ * the same idea: start the scatter, compute, finish it). */
+int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms, char *report, int report_len);
+/* ncclCommCount / ncclCommUserRank of the communicator te_gmg_use_rccl created (0 / -1 without one): evidence for a
+ * benchmark line that RCCL itself saw N ranks. */
+int te_gmg_comm_info(te_gmg *g, int *rccl_nranks, int *rccl_rank);
 /* moves n doubles through the active exchange back-end with this rank as its own peer (diagnostic) */
 int te_gmg_exchange_selftest(te_gmg *g, int n);
 /* diagnostic for the watchdog: `seconds` of exchanges enqueued without a host synchronisation (the host runs ahead of the
@@ -225,7 +253,11 @@ int te_gmg_watchdog_selftest(te_gmg *g, double seconds);
 
 /* Domain<D>::integrate (Domain.h:258-278) and Domain<D>::volume (:237-251), this rank's part (the host adds the
  * ranks as it does for norms): sum over local patches of (sum of the patch's cells) * (cell volume), resp. of the
- * patch volumes. What the drivers need for pure-Neumann problems (apps/3d/steady.cpp:330-334, 539-549). */
+ * patch volumes. What the drivers need for pure-Neumann problems (apps/3d/steady.cpp:330-334, 539-549).
+ * A level that lives on EVERY rank (te_hier_level_replicated) is counted once: rank 0 returns the whole level, every other
+ * rank 0.0, so that the sum over the ranks is the level's integral / volume as on any other level. The same holds for
+ * te_vec_two_norm_sq and te_vec_dot on such a level (te_vec_inf_norm returns the level's value on every rank: a maximum
+ * over the ranks is unchanged). */
 int te_integrate(te_gmg *g, int level, const te_vec *v, double *out);
 int te_volume(te_gmg *g, int level, double *out);
 

@@ -62,6 +62,8 @@ SYMBOLS = {
     "te_mesh_get_nodes": (_I, [_P, _P, _P, _P, _P, _P]),
     "te_mesh_destroy": (None, [_P]),
     "te_hier_build": (_I, [_P, _I, _I, _I, _D, _I, _I, C.POINTER(_P)]),
+    "te_hier_build_placed": (_I, [_P, _I, _I, _I, _D, _I, _I, _D, _I, _I, C.POINTER(_P)]),
+    "te_hier_placement": (_I, [_P, _PD, C.POINTER(_I), C.POINTER(_I)]),
     "te_hier_num_levels": (_I, [_P]),
     "te_hier_dim": (_I, [_P]),
     "te_hier_n": (_I, [_P]),
@@ -113,6 +115,8 @@ SYMBOLS = {
     "te_gmg_use_rccl": (_I, [_P, C.c_char_p, C.c_char_p, _I, _I]),
     "te_gmg_set_allreduce": (_I, [_P, ALLREDUCE_FN, _P]),
     "te_gmg_verify_schedule": (_I, [_P, C.POINTER(CycleOpts)]),
+    "te_gmg_autotune": (_I, [_P, C.POINTER(CycleOpts), _I, _PD, C.c_char_p, _I]),
+    "te_gmg_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
     "te_gmg_exchange_selftest": (_I, [_P, _I]),
     "te_gmg_watchdog_selftest": (_I, [_P, _D]),
     "te_gmg_profile": (_I, [_P, _I]),
@@ -219,10 +223,17 @@ class Mesh:
 class Hierarchy:
     """DomainGenerator + the CycleFactory level loop (ThundereggDomGen.h, CycleFactory3d.cpp:98-127)."""
 
-    def __init__(self, mesh, n, neumann=False, max_levels=0, patches_per_proc=0.0, rank=0, nranks=1):
+    def __init__(self, mesh, n, neumann=False, max_levels=0, patches_per_proc=0.0, rank=0, nranks=1, placement=None):
+        """placement = (agglomerate, agglomerate_max, replicate) spelled out (a negative entry = the default), or None: the
+        environment's TE_AGGLOMERATE / TE_AGGLOMERATE_MAX / TE_REPLICATE, read once by te_hier_build"""
         self.h = C.c_void_p()
-        check(lib().te_hier_build(mesh.h, n, int(neumann), max_levels, float(patches_per_proc), rank, nranks,
-                                  C.byref(self.h)))
+        if placement is None:
+            check(lib().te_hier_build(mesh.h, n, int(neumann), max_levels, float(patches_per_proc), rank, nranks,
+                                      C.byref(self.h)))
+        else:
+            agg, cap, rep = placement
+            check(lib().te_hier_build_placed(mesh.h, n, int(neumann), max_levels, float(patches_per_proc), rank, nranks,
+                                             float(agg), int(cap), int(rep), C.byref(self.h)))
         self.n = n
         self.neumann = bool(neumann)
         self.dim = lib().te_hier_dim(self.h)
@@ -233,6 +244,12 @@ class Hierarchy:
         a, b = C.c_int(), C.c_int()
         check(lib().te_hier_level_sizes(self.h, level, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def placement(self):
+        """(agglomerate, agglomerate_max, replicate) this hierarchy was built with"""
+        a, b, c = C.c_double(), C.c_int(), C.c_int()
+        check(lib().te_hier_placement(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def replicated(self, level):
         """the level lives on every rank (a gathered coarse level, TE_REPLICATE): each rank holds and computes all of it"""
@@ -395,6 +412,18 @@ class GMG:
 
     def patch_apply(self, u, f, level=0): check(lib().te_patch_apply(self.h, level, u.h, f.h))
     def verify_schedule(self, opts): check(lib().te_gmg_verify_schedule(self.h, C.byref(opts)))
+
+    def autotune(self, opts, reps=10):
+        """te_gmg_autotune (collective): -> (ms per cycle of the chosen form, report line)"""
+        ms, buf = C.c_double(), C.create_string_buffer(1024)
+        check(lib().te_gmg_autotune(self.h, C.byref(opts), reps, C.byref(ms), buf, 1024))
+        return ms.value, buf.value.decode()
+
+    def comm_info(self):
+        """(ranks, rank) of the native RCCL communicator, (0, -1) without one"""
+        a, b = C.c_int(), C.c_int()
+        check(lib().te_gmg_comm_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_option(self, name, value="1"):
         """one TE_* switch of this solver (they are read from the environment once, at creation); None clears it"""

@@ -81,17 +81,38 @@ int te_mesh_get_nodes(const te_mesh *m, int32_t *ilp, double *lengths, double *s
 }
 void te_mesh_destroy(te_mesh *m) { delete m; }
 
-int te_hier_build(const te_mesh *m, int n, int neumann, int max_levels, double patches_per_proc,
-                  int rank, int nranks, te_hier **out)
+int te_hier_build_placed(const te_mesh *m, int n, int neumann, int max_levels, double patches_per_proc,
+                         int rank, int nranks, double agglomerate, int agglomerate_max, int replicate, te_hier **out)
 {
 	if (!m || !out) return te::fail(TE_EINVAL, "te_hier_build: null argument");
+	if (nranks < 1 || rank < 0 || rank >= nranks) return te::fail(TE_EINVAL, "te_hier_build: rank outside [0, nranks)");
 	try {
+		te::Placement pl;
+		pl.agglomerate     = agglomerate;
+		pl.agglomerate_max = agglomerate_max;
+		pl.replicate       = replicate;
 		*out = new te_hier{te::Hierarchy::build(m->tree, n, neumann != 0, max_levels,
-		                                        patches_per_proc, rank, nranks)};
+		                                        patches_per_proc, rank, nranks, pl)};
 		return TE_OK;
 	} catch (const std::exception &e) {
 		return te::fail(TE_EINVAL, e.what());
 	}
+}
+// the placement of the small levels from the environment (each variable read here, once per call; unset = the default)
+int te_hier_build(const te_mesh *m, int n, int neumann, int max_levels, double patches_per_proc,
+                  int rank, int nranks, te_hier **out)
+{
+	const char *e = getenv("TE_AGGLOMERATE"), *em = getenv("TE_AGGLOMERATE_MAX"), *er = getenv("TE_REPLICATE");
+	return te_hier_build_placed(m, n, neumann, max_levels, patches_per_proc, rank, nranks, e ? atof(e) : -1.0, em ? atoi(em) : -1,
+	                            er ? (atoi(er) != 0) : -1, out);
+}
+int te_hier_placement(const te_hier *h, double *agglomerate, int *agglomerate_max, int *replicate)
+{
+	if (!h) return te::fail(TE_EINVAL, "te_hier_placement: null");
+	if (agglomerate) *agglomerate = h->h.agglomerate;
+	if (agglomerate_max) *agglomerate_max = h->h.agglomerate_max;
+	if (replicate) *replicate = h->h.replicate;
+	return TE_OK;
 }
 int te_hier_num_levels(const te_hier *h) { return h ? (int) h->h.levels.size() : TE_EINVAL; }
 int te_hier_dim(const te_hier *h) { return h ? h->h.dim : TE_EINVAL; }

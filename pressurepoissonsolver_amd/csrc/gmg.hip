@@ -70,12 +70,12 @@ const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_j
 enum Opt : int {
 	O_2D_SIMPLE, O_2D_NO_MFMA, O_2D_NO_PF, O_2D_NO_MR_FUSE, O_2D_TPB, O_NO_FUSE2, O_NO_FUSE3, O_NO_FUSE3_CF, O_NO_CFP, O_NO_XF,
 	O_NO_FCORR, O_NO_FCORR_CF, O_NO_GTAB, O_NO_OVERLAP, O_OVERLAP_MIN, O_NO_PS_FACES, O_PS_MODE, O_PS_SLOW, O_RBGS_NOSLAB,
-	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_COUNT
+	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_COUNT
 };
 const char *optName[O_COUNT] = {"TE_2D_SIMPLE", "TE_2D_NO_MFMA", "TE_2D_NO_PF", "TE_2D_NO_MR_FUSE", "TE_2D_TPB", "TE_NO_FUSE2", "TE_NO_FUSE3",
                                 "TE_NO_FUSE3_CF", "TE_NO_CFP", "TE_NO_XF", "TE_NO_FCORR", "TE_NO_FCORR_CF", "TE_NO_GTAB", "TE_NO_OVERLAP",
                                 "TE_OVERLAP_MIN", "TE_NO_PS_FACES", "TE_PS_MODE", "TE_PS_SLOW", "TE_RBGS_NOSLAB", "TE_ZS_FORCE", "TE_NO_ZS8",
-                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS"};
+                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS", "TE_PACK_FACES", "TE_OVERLAP_MODE"};
 // options that shape the level tables te_gmg_create builds: fixed for the solver's lifetime
 inline bool optStructural(int o) { return o == O_2D_SIMPLE || o == O_NO_CFP || o == O_2D_NO_MR_FUSE || o == O_NO_OVERLAP || o == O_EXCHANGE_TIMEOUT; }
 struct Cfg {
@@ -128,6 +128,8 @@ struct ExPlan {
 
 struct LevelHost {
 	int    dim = 3, n = 0, P = 0, P_global = 0;
+	bool   gathered = false; // the level lives on rank 0 alone or on every rank (the hierarchy's placement): no face exchange
+	bool   replicated = false; // ... on every rank: sums over the level count it once (rank 0's; te_integrate, te_vec_dot, ...)
 	bool   prolong_fusable = false; // every patch is an octant child of a LOCAL parent and there is no coarse/fine face
 	// refined levels: every patch has a LOCAL parent (octant children and patches that copy through), coarse/fine
 	// faces allowed: the RB-GS sweep on u + P e has a variant for that (k_rbgs3d<..., CFP>)
@@ -255,6 +257,11 @@ struct LevelHost {
 	// interior patches (no ghost-slot face) first, then boundary patches
 	DevBuf<int32_t> order;
 	int             n_int = 0, n_bnd = 0;
+	// how a stencil / sweep launch of this level meets its face exchange (withGhosts): 0 the exchange, then one launch over all
+	// patches; 1 the exchange on the communication stream, the interior patches under it on the solver stream, then the boundary
+	// patches; 2 the interior patches on the second stream, exchange and boundary patches on the solver stream (no hand-over
+	// in front of the exchange); -1: by size (TE_OVERLAP_MIN). Set by te_gmg_autotune from measurements on the live communicator.
+	int             overlap_mode = -1;
 	LevelDev        devPart(bool boundary) const
 	{
 		LevelDev L = dev();
@@ -317,6 +324,11 @@ struct te_gmg {
 	std::vector<ExRec>         record;
 	int                        cur_level = 0;
 	std::set<uint64_t>         verified_opts;
+	// how the hierarchy placed its small levels (te_hier_build: agglomerate, agglomerate_max, replicate) and its depth: every rank
+	// must have built the same (checked across the ranks before the first cycle, whatever TE_NO_VERIFY says)
+	double      placement[4]      = {0, 0, 0, 0};
+	bool        placement_checked = false;
+	std::string autotune_report; // what te_gmg_autotune measured and chose
 	// watchdog: an exchange that has not completed TE_EXCHANGE_TIMEOUT seconds after it was issued ends the process.
 	// Outstanding exchanges sit in a ring in issue order, each with its own event and issue time: the deadline always
 	// belongs to the OLDEST one that has not completed (a host that runs ahead of the GPU keeps the newest event
@@ -346,6 +358,8 @@ struct te_gmg {
 		int (*Recv)(void *, size_t, int, int, void *, hipStream_t)                   = nullptr;
 		int (*CommDestroy)(void *)                                                   = nullptr;
 		int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+		int (*CommCount)(void *, int *)                                              = nullptr;
+		int (*CommUserRank)(void *, int *)                                           = nullptr;
 		const char *(*GetErrorString)(int)                                           = nullptr;
 	} rccl;
 	// profiling
@@ -511,6 +525,8 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	L->n   = n;
 	L->P   = lv.P;
 	L->P_global = lv.P_global;
+	L->replicated = lv.replicated;
+	L->gathered = lv.replicated || (H.nranks > 1 && std::all_of(lv.g_rank.begin(), lv.g_rank.end(), [&](int32_t r) { return r == lv.g_rank[0]; }));
 	L->nc  = (D == 3) ? (size_t) n * n * n : (size_t) n * n;
 	L->nf  = (D == 3) ? (size_t) n * n : (size_t) n;
 	const int P = lv.P, NS = 2 * D, NCH = 1 << D, NQ = 1 << (D - 1), me = H.rank;
@@ -1275,10 +1291,29 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 	// (3 x 256). Measured per rank with the exchanges in loop-back (tools/mr8_budget.py): at 512 local patches (512^3 on eight
 	// ranks) the cycle is 525 us with the split and 475 us without it.
 	L.ghost_has_v = false;
-	if (L.patch_local || g->recording || L.nremote == 0 || !g->overlap || L.n_int == 0 || L.P < g->cfg.num(O_OVERLAP_MIN, 768)) {
+	const int mode = L.overlap_mode >= 0 ? L.overlap_mode : (L.P < g->cfg.num(O_OVERLAP_MIN, 768) ? 0 : (g->cfg.num(O_OVERLAP_MODE, 1) == 2 ? 2 : 1));
+	if (L.patch_local || g->recording || L.nremote == 0 || !g->overlap || L.n_int == 0 || mode == 0) {
 		int rc = prepareGhosts<N>(g, L, u, ps);
 		if (rc) return rc;
 		launch(L.dev());
+		return TE_OK;
+	}
+	if (mode == 2) {
+		// the interior patches go to the second stream (they wait for nothing but what the solver stream has done so far); pack,
+		// exchange, coarse/fine ghosts and the boundary patches stay on the solver stream, which then waits for the interior
+		HIPCHK(hipEventRecord(g->ev_pack, g->stream));
+		HIPCHK(hipStreamWaitEvent(g->comm_stream, g->ev_pack, 0));
+		std::swap(g->stream, g->comm_stream); // (every launch helper launches on g->stream)
+		launch(L.devPart(false));
+		hipError_t e = hipEventRecord(g->ev_recv, g->stream);
+		std::swap(g->stream, g->comm_stream);
+		HIPCHK(e);
+		packFaces<N>(g, L, u, ps);
+		int rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p);
+		if (rc) return rc;
+		if (L.ncf > 0) cfGhosts<N>(g, L, u, ps);
+		launch(L.devPart(true));
+		HIPCHK(hipStreamWaitEvent(g->stream, g->ev_recv, 0));
 		return TE_OK;
 	}
 	packFaces<N>(g, L, u, ps);
@@ -1771,7 +1806,7 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	int rc;
 	if (L.P > 0) {
 		Timed      t(g, store_u ? KC_ZERO_RESID : (fcorr_in ? KC_ZERO_RESID_FACES_FCORR : KC_ZERO_RESID_FACES), (size_t) L.P * L.nc, true);
-		if (!store_u) L.f6_tab = L.f6off.p != nullptr; // the face layers go where the level's table puts them
+		if (!store_u) L.f6_tab = L.f6off.p != nullptr && !g->cfg.has(O_PACK_FACES); // the face layers go where the level's table puts them
 		LevelDev   D = L.dev();
 		const dim3 grid(8 * ((L.P + 7) / 8)), blk(Tile3<N>::TPB);
 		if (store_u) {
@@ -2290,6 +2325,10 @@ template <int OP> int reduce(const te_vec *a, const te_vec *b, double *out, bool
 		*out = 0.0;
 		return TE_OK;
 	}
+	if (OP != RED_MAXABS && !global && g->rank != 0 && g->levels[a->level]->replicated) { // a level on every rank counts once (rank 0's)
+		*out = 0.0;
+		return TE_OK;
+	}
 	if (a->n == 0) { // a rank without patches still takes part in the reduction over ranks
 		HIPCHK(hipMemsetAsync(g->result.p, 0, sizeof(double), g->stream));
 		int rc0 = finishReduce(g, 1, OP == RED_MAXABS ? 1 : 0, true);
@@ -2593,6 +2632,8 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 		g->n      = h->h.n;
 		g->rank   = h->h.rank;
 		g->nranks = h->h.nranks;
+		g->placement[0] = h->h.agglomerate, g->placement[1] = h->h.agglomerate_max, g->placement[2] = h->h.replicate;
+		g->placement[3] = (double) h->h.levels.size();
 		memset(g->calls, 0, sizeof(g->calls));
 		memset(g->cells, 0, sizeof(g->cells));
 		memset(g->total_ms, 0, sizeof(g->total_ms));
@@ -2722,6 +2763,8 @@ int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank,
 		r.CommDestroy    = (int (*)(void *)) rcclSym(lib, "ncclCommDestroy");
 		r.AllReduce      = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t)) rcclSym(lib, "ncclAllReduce");
 		r.GetErrorString = (const char *(*) (int) ) rcclSym(lib, "ncclGetErrorString");
+		r.CommCount      = (int (*)(void *, int *)) rcclSym(lib, "ncclCommCount");
+		r.CommUserRank   = (int (*)(void *, int *)) rcclSym(lib, "ncclCommUserRank");
 		if (!init || !r.GroupStart || !r.GroupEnd || !r.Send || !r.Recv || !r.CommDestroy || !r.GetErrorString || !r.AllReduce)
 			return te::fail(TE_EIO, "te_gmg_use_rccl: RCCL symbols missing in " + std::string(libpath));
 		if (nranks > 1 && (rank != g->rank || nranks != g->nranks)) // (before the communicator exists: nothing to leak)
@@ -3010,6 +3053,32 @@ static int verifySchedule(te_gmg *g, const te_cycle_opts *o)
 				}
 	return TE_OK;
 }
+// Every rank must have built the same hierarchy placement (te_hier_build's agglomerate / agglomerate_max / replicate -- ranks
+// started with different environments would not): the maximum and the minimum of each number over the ranks agree, or
+// TE_ESTATE on all ranks, by name. Collective; runs once, before the first cycle of a sharded solver, also under TE_NO_VERIFY.
+static int checkPlacement(te_gmg *g)
+{
+	if (g->placement_checked || g->nranks < 2 || (!g->rccl.comm && !g->allreduce)) return TE_OK;
+	double hi[4], lo[4];
+	int    rc;
+	for (int pass = 0; pass < 2; pass++) {
+		double v[4];
+		for (int k = 0; k < 4; k++) v[k] = pass ? -g->placement[k] : g->placement[k];
+		HIPCHK(hipMemcpyAsync(g->result.p, v, sizeof v, hipMemcpyHostToDevice, g->stream));
+		if ((rc = finishReduce(g, 4, 1, true))) return rc;
+		for (int k = 0; k < 4; k++) (pass ? lo : hi)[k] = pass ? -g->result_host[k] : g->result_host[k];
+	}
+	static const char *what[4] = {"agglomerate (TE_AGGLOMERATE)", "agglomerate_max (TE_AGGLOMERATE_MAX)", "replicate (TE_REPLICATE)", "number of levels"};
+	for (int k = 0; k < 4; k++)
+		if (hi[k] != lo[k]) {
+			char buf[256];
+			snprintf(buf, sizeof buf, "the ranks built different hierarchies: %s is %g on this rank (%d), between %g and %g over the ranks", what[k],
+			         g->placement[k], g->rank, lo[k], hi[k]);
+			return te::fail(TE_ESTATE, buf);
+		}
+	g->placement_checked = true;
+	return TE_OK;
+}
 static uint64_t optsKey(const te_cycle_opts *o)
 {
 	uint64_t h = 0;
@@ -3044,6 +3113,7 @@ static int vcycleWith(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec
 	if ((rc = checkLevelVec(g, 0, f, "te_vcycle")) || (rc = checkLevelVec(g, 0, u, "te_vcycle"))) return rc;
 	// several ranks: the first cycle with a new set of options checks that all ranks will issue matching exchange
 	// sequences (a mismatch would otherwise be a silent hang inside RCCL); TE_NO_VERIFY skips it
+	if (!g->recording && (rc = checkPlacement(g))) return rc;
 	if (g->nranks > 1 && !g->recording && (g->rccl.comm || g->allreduce) && !g->verified_opts.count(optsKey(o))
 	    && !g->cfg.has(O_NO_VERIFY)) {
 		if ((rc = verifySchedule(g, o))) return rc;
@@ -3059,6 +3129,137 @@ static int vcycleWith(te_gmg *g, const te_cycle_opts *o, const te_vec *f, te_vec
 	for (auto &L : g->levels) L->xf_valid_for = nullptr, L->ps_faces = L->ps_faces_req = false;
 	return rc;
 	}
+}
+
+// How the sweeps of the sharded levels meet their face exchanges (LevelHost::overlap_mode) is a matter of microseconds that
+// only the machine the job runs on can settle: kernel launches of a rank's share are short, the wire and the peers' skew are
+// not in any single-GPU measurement. Candidates -- every one gives bit-identical results, only the order of independent work on
+// the two streams differs -- are timed here on the live communicator: `reps` cycles each behind two warm-up cycles, the
+// maximum over the ranks (one reduction per candidate: all ranks see the same numbers and choose the same), the fastest kept;
+// the serial form wins ties within 2 %. Collective. One rank: nothing to choose. *best_ms (may be NULL): the chosen form's time
+// per cycle; report (may be NULL): one line naming the candidates' times and the choice.
+int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms, char *report, int report_len)
+{
+	return guarded([&]() -> int {
+		if (!g || !o || reps < 1) return te::fail(TE_EINVAL, "te_gmg_autotune: bad argument");
+		auto say = [&](const std::string &s2) {
+			g->autotune_report = s2;
+			if (report && report_len > 0) {
+				strncpy(report, s2.c_str(), (size_t) report_len - 1);
+				report[report_len - 1] = 0;
+			}
+		};
+		int     rc;
+		te_vec *f = nullptr, *u = nullptr;
+		if ((rc = newVec(g, 0, &f))) return rc;
+		if ((rc = newVec(g, 0, &u))) {
+			te_vec_destroy(f);
+			return rc;
+		}
+		struct Free {
+			te_vec *a, *b;
+			~Free()
+			{
+				te_vec_destroy(a);
+				te_vec_destroy(b);
+			}
+		} fr{f, u};
+		if (f->n > 0 && (rc = te_init_problem(g, 0, TE_PROBLEM_RANDOM, 0, f, nullptr))) return rc;
+		hipEvent_t ea, eb;
+		HIPCHK(hipEventCreate(&ea));
+		HIPCHK(hipEventCreate(&eb));
+		struct Ev {
+			hipEvent_t a, b;
+			~Ev()
+			{
+				(void) hipEventDestroy(a);
+				(void) hipEventDestroy(b);
+			}
+		} evs{ea, eb};
+		const bool prof = g->profiling;
+		g->profiling    = false;
+		auto timeIt = [&](double *ms_out) -> int { // max over the ranks of this rank's time per cycle
+			int r2;
+			for (int i = 0; i < 2; i++)
+				if ((r2 = vcycleWith(g, o, f, u, nullptr))) return r2;
+			HIPCHK(hipEventRecord(ea, g->stream));
+			for (int i = 0; i < reps; i++)
+				if ((r2 = vcycleWith(g, o, f, u, nullptr))) return r2;
+			HIPCHK(hipEventRecord(eb, g->stream));
+			HIPCHK(hipEventSynchronize(eb));
+			float ms = 0;
+			HIPCHK(hipEventElapsedTime(&ms, ea, eb));
+			double v = (double) ms / reps;
+			if (g->nranks > 1) {
+				HIPCHK(hipMemcpyAsync(g->result.p, &v, sizeof v, hipMemcpyHostToDevice, g->stream));
+				if ((r2 = finishReduce(g, 1, 1, true))) return r2;
+				v = g->result_host[0];
+			}
+			*ms_out = v;
+			return TE_OK;
+		};
+		WatchdogBatch batch(g);
+		const int nl = (int) g->levels.size();
+		// sharded levels = the leading levels that are not gathered (a global fact: the hierarchy's placement)
+		int nsh = 0;
+		while (nsh < nl && g->levels[nsh]->P_global >= g->nranks && !g->levels[nsh]->gathered) nsh++;
+		struct Cand {
+			int         mode, depth;
+			const char *name;
+		};
+		std::vector<Cand> cands = {{0, 0, "serial"}};
+		if (g->nranks > 1 && g->overlap) {
+			cands.push_back({1, 1, "exchange-under-interior/level0"});
+			cands.push_back({2, 1, "interior-on-2nd-stream/level0"});
+			if (nsh >= 2) {
+				cands.push_back({1, 2, "exchange-under-interior/levels0-1"});
+				cands.push_back({2, 2, "interior-on-2nd-stream/levels0-1"});
+			}
+		}
+		std::vector<double> t(cands.size(), 0.0);
+		auto apply = [&](const Cand &c) {
+			for (int l = 0; l < nl; l++) g->levels[l]->overlap_mode = (l < c.depth) ? c.mode : 0;
+		};
+		for (size_t i = 0; i < cands.size(); i++) {
+			apply(cands[i]);
+			if ((rc = timeIt(&t[i]))) {
+				g->profiling = prof;
+				return rc;
+			}
+		}
+		size_t best = 0;
+		for (size_t i = 1; i < cands.size(); i++)
+			if (t[i] < t[best] && t[i] < 0.98 * t[0]) best = i;
+		apply(cands[best]);
+		g->profiling = prof;
+		std::string s2 = "overlap:";
+		char        buf[96];
+		for (size_t i = 0; i < cands.size(); i++) {
+			snprintf(buf, sizeof buf, " %s=%.1fus", cands[i].name, t[i] * 1e3);
+			s2 += buf;
+		}
+		s2 += std::string(" -> ") + cands[best].name;
+		say(s2);
+		if (best_ms) *best_ms = t[best];
+		return TE_OK;
+	});
+}
+// The communicator the native back-end really runs on: ncclCommCount / ncclCommUserRank of te_gmg_use_rccl's communicator
+// (0 / -1 without one) -- so that a bench line can show that RCCL saw N ranks rather than say so.
+int te_gmg_comm_info(te_gmg *g, int *rccl_nranks, int *rccl_rank)
+{
+	return guarded([&]() -> int {
+		if (!g) return te::fail(TE_EINVAL, "te_gmg_comm_info: null");
+		int n = 0, r = -1;
+		if (g->rccl.comm && g->rccl.CommCount && g->rccl.CommUserRank) {
+			int rc = g->rccl.CommCount(g->rccl.comm, &n);
+			if (rc == 0) rc = g->rccl.CommUserRank(g->rccl.comm, &r);
+			if (rc) return te::fail(TE_ESTATE, std::string("ncclCommCount failed: ") + g->rccl.GetErrorString(rc));
+		}
+		if (rccl_nranks) *rccl_nranks = n;
+		if (rccl_rank) *rccl_rank = r;
+		return TE_OK;
+	});
 }
 
 // BiCGStab.h:45-106, statement for statement, on device vectors. Several ranks: every scalar is summed over the
@@ -3309,7 +3510,7 @@ int te_integrate(te_gmg *g, int level, const te_vec *v, double *out)
 		if ((rc = checkLevelVec(g, level, v, "te_integrate"))) return rc;
 		LevelHost &L = *g->levels[level];
 		*out         = 0.0;
-		if (L.P == 0) return TE_OK;
+		if (L.P == 0 || (L.replicated && g->rank != 0)) return TE_OK; // (a level on every rank counts once: rank 0's)
 		DevBuf<double> part;
 		if ((rc = part.alloc(L.P))) return rc;
 		hipLaunchKernelGGL(k_patch_integrals, dim3(L.P), dim3(256), 0, g->stream, (int) L.nc, v->d, L.cellvol.p, part.p);
@@ -3328,7 +3529,8 @@ int te_volume(te_gmg *g, int level, double *out)
 	return guarded([&]() -> int {
 		if (!g || !out || level < 0 || level >= (int) g->levels.size()) return te::fail(TE_EINVAL, "te_volume: bad argument");
 		double sum = 0.0;
-		for (double x : g->levels[level]->patch_vol) sum += x;
+		if (!(g->levels[level]->replicated && g->rank != 0)) // (a level on every rank counts once: rank 0's)
+			for (double x : g->levels[level]->patch_vol) sum += x;
 		*out = sum;
 		return TE_OK;
 	});

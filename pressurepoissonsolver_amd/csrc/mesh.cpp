@@ -192,7 +192,7 @@ LevelNodes collectLevel(const Tree &t, int L)
 } // namespace
 
 Hierarchy Hierarchy::build(const Tree &t, int n, bool neumann, int max_levels,
-                           double patches_per_proc, int rank, int nranks)
+                           double patches_per_proc, int rank, int nranks, const Placement &pl)
 {
 	if (n < 2 || (n & 1)) throw std::runtime_error("te::Hierarchy: n must be even and >= 2");
 	if (nranks < 1 || rank < 0 || rank >= nranks) throw std::runtime_error("te::Hierarchy: bad rank");
@@ -327,11 +327,13 @@ Hierarchy Hierarchy::build(const Tree &t, int n, bool neumann, int max_levels,
 		// same bytes per link) and runs the small levels itself, redundantly and bit for bit the same; the way back up then needs
 		// no transfer at all, every parent being local. One exchange per cycle less on the critical path, and the level above
 		// keeps its fused post-sweep (its parents are local). 0: rank 0 alone, as before.
+		h.agglomerate     = pl.agglomerate >= 0 ? pl.agglomerate : 16.0;
+		h.agglomerate_max = pl.agglomerate_max >= 0 ? pl.agglomerate_max : 64;
+		h.replicate       = (h.dim == 3 && (pl.replicate < 0 || pl.replicate != 0)) ? 1 : 0;
 		if (nranks > 1) {
-			const char  *e   = getenv("TE_AGGLOMERATE"), *em = getenv("TE_AGGLOMERATE_MAX"), *er = getenv("TE_REPLICATE");
-			const double agg = e ? atof(e) : 16.0;
-			const int    cap = em ? atoi(em) : 64;
-			const bool   rep = h.dim == 3 && (er ? atoi(er) != 0 : true);
+			const double agg = h.agglomerate;
+			const int    cap = h.agglomerate_max;
+			const bool   rep = h.replicate != 0;
 			bool         gathered = false;
 			for (size_t li = 1; li < h.levels.size(); li++) {
 				Level &lv = h.levels[li];

@@ -87,18 +87,32 @@ struct Level {
 	std::vector<int32_t> l2g;     ///< [P] local -> global index
 };
 
+/// Where the levels with few patches live when nranks > 1 (the patches_per_proc idea of CycleFactory3d.cpp:104 without
+/// cutting the hierarchy): a level with fewer than `agglomerate` patches per rank -- and at most `agglomerate_max` patches
+/// in total -- and every level below it is gathered: on every rank (`replicate`, 3D) or on rank 0. Negative = the default
+/// (16 / 64 / 1), which the environment may override (TE_AGGLOMERATE, TE_AGGLOMERATE_MAX, TE_REPLICATE: read by
+/// te_hier_build only, once per call, and recorded in the hierarchy).
+struct Placement {
+	double agglomerate     = -1.0;
+	int    agglomerate_max = -1, replicate = -1;
+};
+
 struct Hierarchy {
 	int                dim = 3;
 	int                n   = 0;
 	int                rank = 0, nranks = 1;
 	bool               neumann = false;
 	std::vector<Level> levels; ///< [0] = finest
+	/// placement of the small levels over the ranks (see Placement), as this hierarchy was built: part of what every rank
+	/// must agree on (te_gmg checks it across the ranks before the first cycle)
+	double agglomerate = 16.0;
+	int    agglomerate_max = 64, replicate = 1;
 
 	/// Build every level the reference's CycleFactory would build
 	/// (CycleFactory3d.cpp:69-134): finest first, then coarser tree levels while
 	/// (max_levels <= 0 || built < max_levels) and patches/nranks >= patches_per_proc.
 	static Hierarchy build(const Tree &t, int n, bool neumann, int max_levels,
-	                       double patches_per_proc, int rank, int nranks);
+	                       double patches_per_proc, int rank, int nranks, const Placement &pl = Placement());
 };
 
 uint64_t mortonKey(const double *starts, const double *root_starts, const double *root_lengths,

@@ -50,9 +50,12 @@ def shard_run(mesh, n, nranks, fn, dim=3):
                                                 ("2refine.bin", 2, 4, 3)])
 def test_sharded_ops_equal_single_rank(nranks, name, divides, n, dim, monkeypatch):
     # levels with fewer than 768 local patches skip the interior/boundary overlap by default: these small meshes must
-    # exercise it (the 8-rank run keeps the default, i.e. covers the non-overlapped path too)
+    # exercise it (the 8-rank run keeps the default, i.e. covers the non-overlapped path too); the 2-rank runs take its
+    # second form (interior patches on the second stream, exchange + boundary patches on the solver stream)
     if nranks != 8:
         monkeypatch.setenv("TE_OVERLAP_MIN", "0")
+    if nranks == 2:
+        monkeypatch.setenv("TE_OVERLAP_MODE", "2")
     # coarse levels with few patches per rank are gathered by default (TE_AGGLOMERATE = 16 per rank) -- on every rank in 3D
     # (TE_REPLICATE, the default: 2 and 8 ranks here), on rank 0 alone otherwise (3 ranks here); the 4-rank runs keep every
     # level spread out: all three placements are compared with the single-rank result
@@ -236,6 +239,93 @@ def test_sharded_bicgstab(nranks):
     assert np.linalg.norm(got["x"] - got["xh"]) <= 1e-9 * np.linalg.norm(want)
 
 
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_autotune_chooses_alike_on_every_rank_and_changes_no_result(nranks, monkeypatch):
+    """te_gmg_autotune on virtual ranks: every rank is handed the same candidate times (maximum over the ranks) and makes the
+    same choice; whatever it chose, the cycle afterwards equals the single-rank cycle bit for bit -- also with each of the
+    three forms forced on every sharded level (what a different machine might choose)."""
+    monkeypatch.delenv("TE_OVERLAP_MIN", raising=False)
+    n = 8
+    mesh = util.mesh("uniform", 3)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    f = util.rand_vec(H1.cells(0), 5)
+    d1 = g1.new_vector(0)
+    g1.cycle(g1.default_opts(smoother=capi.SMOOTH_RBGS), g1.new_vector(0, f), d1)
+    want = d1.download()
+    nc = n ** 3
+
+    def per_rank(r, H, g, fab):
+        o = g.default_opts(smoother=capi.SMOOTH_RBGS)
+        ms, rep = g.autotune(o, reps=3)
+        df, du = g.new_vector(0, f.reshape(-1, nc)[H.l2g(0)].ravel()), g.new_vector(0)
+        g.cycle(o, df, du)
+        return {"u": du.download(), "ms": ms, "rep": rep}
+
+    got = shard_run(mesh, n, nranks, per_rank)
+    assert len(set(got["rep"])) == 1 and len(set(got["ms"])) == 1, got["rep"]
+    assert "serial=" in got["rep"][0] and "->" in got["rep"][0]
+    assert np.array_equal(got["u"], want)
+
+
+def test_placement_mismatch_is_reported_by_name():
+    """Ranks that built their hierarchies with different placements of the small levels (different environments) are told so,
+    by name, before the first cycle -- also with TE_NO_VERIFY (the schedule check would have caught it; without it the run
+    used to hang until the watchdog fired)."""
+    n = 8
+    mesh = util.mesh("uniform", 2)
+    fab = tedist.LocalFabric(2)
+    hs = [capi.Hierarchy(mesh, n, rank=r, nranks=2, placement=(16, 64, 1 if r == 0 else 0)) for r in range(2)]
+    assert hs[0].placement() == (16.0, 64, 1) and hs[1].placement() == (16.0, 64, 0)
+    gs = [capi.GMG(h) for h in hs]
+    for r, g in enumerate(gs):
+        fab.attach(g, r)
+        g.set_option("TE_NO_VERIFY", "1")
+
+    def per_rank(r):
+        g = gs[r]
+        try:
+            g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), g.new_vector(0), g.new_vector(0))
+        except capi.TeError as e:
+            return str(e)
+        return "no error"
+
+    msgs = fab.run(per_rank)
+    assert all("replicate (TE_REPLICATE)" in m and "different hierarchies" in m for m in msgs), msgs
+
+
+def test_sums_over_a_replicated_level_count_it_once():
+    """A level that lives on every rank (TE_REPLICATE): te_integrate, te_volume, te_vec_two_norm_sq and te_vec_dot return the
+    level's value on rank 0 and zero elsewhere, so that a host that adds the ranks (as it does on every other level) gets
+    the level's integral -- not nranks times it."""
+    n = 8
+    nranks = 4
+    mesh = util.mesh("uniform", 2)  # 64 + 8 + 1 patches: the two coarse levels are gathered on every rank
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    lvl = 1
+    v = util.rand_vec(H1.cells(lvl), 9)
+    d1 = g1.new_vector(lvl, v)
+    want = (g1.integrate(d1, level=lvl), g1.volume(level=lvl), d1.twoNormSqLocal(), d1.dot(d1))
+
+    def per_rank(r, H, g, fab):
+        assert H.replicated(lvl) and H.sizes(lvl)[0] == H.sizes(lvl)[1]
+        d = g.new_vector(lvl, v)
+        return {"vals": (g.integrate(d, level=lvl), g.volume(level=lvl), d.twoNormSqLocal(), d.dot(d)), "inf": d.infNorm()}
+
+    fab = tedist.LocalFabric(nranks)
+    hs = [capi.Hierarchy(mesh, n, rank=r, nranks=nranks, placement=(16, 64, 1)) for r in range(nranks)]
+    gs = [capi.GMG(h) for h in hs]
+    for r, g in enumerate(gs):
+        fab.attach(g, r)
+    outs = fab.run(lambda r: per_rank(r, hs[r], gs[r], fab))
+    sums = [sum(o["vals"][k] for o in outs) for k in range(4)]
+    assert sums[0] == pytest.approx(want[0], rel=1e-13) and sums[1] == pytest.approx(want[1], rel=1e-13)
+    assert sums[2] == want[2] and sums[3] == want[3]
+    assert all(o["vals"] == (0.0, 0.0, 0.0, 0.0) for o in outs[1:])
+    assert all(o["inf"] == outs[0]["inf"] for o in outs)
+
+
 def test_schedule_check_catches_diverging_ranks():
     """A rank that would issue a different exchange sequence (here: rank 1 is handed two pre-sweeps) is an error on
     EVERY rank before anything is exchanged (te_gmg_verify_schedule: a collective the host calls at setup, and
@@ -305,7 +395,7 @@ def test_watchdog_stays_quiet_while_the_host_runs_ahead():
     assert r.returncode == 0 and "WD_OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
 
 
-@pytest.mark.parametrize("overlap_min", ["0", None], ids=["overlapped", "default"])
+@pytest.mark.parametrize("overlap_min", ["0", "0:2", None], ids=["overlapped", "interior-on-2nd-stream", "default"])
 def test_two_processes_gloo(overlap_min):
     """Real processes + torch.distributed (gloo staging through host) on the single GPU: one attached callback
     serves the level-0 face exchange on the communication stream (overlapped apply, TE_OVERLAP_MIN=0) and on the
@@ -317,8 +407,11 @@ def test_two_processes_gloo(overlap_min):
         port = str(s.getsockname()[1])
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     env.pop("TE_OVERLAP_MIN", None)
+    env.pop("TE_OVERLAP_MODE", None)
     if overlap_min is not None:
-        env["TE_OVERLAP_MIN"] = overlap_min
+        env["TE_OVERLAP_MIN"] = overlap_min.split(":")[0]
+        if ":" in overlap_min:
+            env["TE_OVERLAP_MODE"] = overlap_min.split(":")[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", port, os.path.join(root, "tests", "mr_worker.py"), "--backend", "gloo"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)

@@ -42,19 +42,27 @@ def cycle_single(mesh, n, sm, f):
 
 
 # (name, TE_OVERLAP_MIN, TE_REPLICATE); None = the default
+# replicate = "packed": levels on every rank, but with round 3's transport (every exchange behind a pack kernel, the restricted
+# blocks through send / receive buffers, a second face exchange for level 1's post-sweep): TE_PACK_FACES, TE_REPL_BLOCKS, TE_POST_EXCHANGE
 CASES = [(name, None, None) for name in CONFIGS] + [("C3-512^3-8ranks", "128", None), ("C3-512^3-8ranks", None, "0"),
-                                                      ("C4-2refine-div2-4ranks", None, "0")]
+                                                      ("C4-2refine-div2-4ranks", None, "0"), ("C3-512^3-8ranks", None, "packed")]
 
 
 def case_id(c):
-    return c[0] + ("" if c[1] is None else "-overlap-forced") + ("" if c[2] is None else "-gathered-on-rank0")
+    return c[0] + ("" if c[1] is None else "-overlap-forced") + ("" if c[2] is None else ("-gathered-on-rank0" if c[2] == "0" else "-packed"))
 
 
 @pytest.mark.parametrize("smoother", [capi.SMOOTH_RBGS, capi.SMOOTH_PATCH_SOLVE], ids=["rbgs", "patch_solve"])
 @pytest.mark.parametrize("name,overlap_min,replicate", CASES, ids=[case_id(c) for c in CASES])
 def test_production_shape_sharded_cycle_equals_single_rank(name, overlap_min, replicate, smoother, monkeypatch):
-    for k in ("TE_OVERLAP_MIN", "TE_AGGLOMERATE", "TE_AGGLOMERATE_MAX", "TE_NO_OVERLAP", "TE_REPLICATE"):
+    packed = replicate == "packed"
+    for k in ("TE_OVERLAP_MIN", "TE_AGGLOMERATE", "TE_AGGLOMERATE_MAX", "TE_NO_OVERLAP", "TE_REPLICATE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS", "TE_PACK_FACES"):
         monkeypatch.delenv(k, raising=False)  # the defaults are what is under test
+    if replicate == "packed":
+        monkeypatch.setenv("TE_POST_EXCHANGE", "1")
+        monkeypatch.setenv("TE_REPL_BLOCKS", "1")
+        monkeypatch.setenv("TE_PACK_FACES", "1")
+        replicate = None
     if overlap_min is not None:  # the interior/boundary split at a shape where the default (768 local patches) leaves it off
         monkeypatch.setenv("TE_OVERLAP_MIN", overlap_min)
     if replicate is not None:  # the gathered levels on rank 0 alone (round 2's form) instead of on every rank
@@ -103,7 +111,15 @@ def test_production_shape_sharded_cycle_equals_single_rank(name, overlap_min, re
         for r in rows:
             assert r["rbgs_resweep_prolong"]["calls"] == (2 if overlap_min is not None else 1), r["rbgs_resweep_prolong"]
             assert r["rbgs_zero_resid_restrict_faces"]["calls"] == 1
-            assert r["pack"]["calls"] >= 2 and r["exchange"]["calls"] >= 1
+            if replicate is None and not packed:
+                # the face layers of the two pre-sweeps leave from where they lie (LevelHost::f6off), level 1's restricted blocks are
+                # whole coarse patches exchanged in place, and level 1's post-sweep needs nothing from other ranks (its parents live
+                # on every rank): ONE pack launch per cycle (level 0's face layers of v + P e) and four exchanges
+                assert r["pack"]["calls"] == 1 and r["exchange"]["calls"] == 4, (r["pack"], r["exchange"])
+            elif packed:
+                assert r["pack"]["calls"] == 6 and r["exchange"]["calls"] == 5, (r["pack"], r["exchange"])
+            else:
+                assert r["pack"]["calls"] >= 2 and r["exchange"]["calls"] >= 1
     if name.startswith("C3"):
         # levels with 64, 8 and 1 patches are gathered: on every rank (each computes them itself; nothing travels back up), or on
         # rank 0 alone (the other ranks launch nothing there)
