@@ -115,7 +115,8 @@ def test_production_shape_sharded_cycle_equals_single_rank(name, overlap_min, re
                 # the face layers of the two pre-sweeps leave from where they lie (LevelHost::f6off), level 1's restricted blocks are
                 # whole coarse patches exchanged in place, and level 1's post-sweep needs nothing from other ranks (its parents live
                 # on every rank): ONE pack launch per cycle (level 0's face layers of v + P e) and four exchanges
-                assert r["pack"]["calls"] == 1 and r["exchange"]["calls"] == 4, (r["pack"], r["exchange"])
+                # (an exchange on the communication stream -- the overlapped level-0 post-sweep -- is not in the solver stream's table)
+                assert r["pack"]["calls"] == 1 and r["exchange"]["calls"] == (4 if overlap_min is None else 3), (r["pack"], r["exchange"])
             elif packed:
                 assert r["pack"]["calls"] == 6 and r["exchange"]["calls"] == 5, (r["pack"], r["exchange"])
             else:
