@@ -67,6 +67,10 @@ ALG_BYTES = {
     "patch_solve_3pass": 16.0,   # three-pass patch solve: read 8 + write 8 per launch
     # the small classes (face layers, blocks between ranks): per cell they touch -- read 8, write 8
     "cf_ghost": 16.0, "pack": 16.0, "reduce": 8.0,
+    # te_bicgstab's own passes (BiCGStab.h:71-104 between the operator applications and the cycles)
+    "bicg_update": 72.0,         # read x, resid, M p, M s, A p, A s, rhat; write x, resid; two dot products on the way
+    "bicg_s": 24.0, "bicg_p": 32.0,   # the stand-alone s and p statements (paths where no cycle kernel forms them)
+    "stencil_apply_dot": 24.0,   # f = A u with one or two dot products summed while f is in registers: read u, the operand; write f
     "exchange": 0.0,             # RCCL / callback time on the solver stream: no HBM pass of this library's own
 }
 # fp64 matrix-core work of the exact patch solve per lattice site (DESIGN.md "The reference smoother"): k_ps_sym runs 3072
@@ -224,11 +228,23 @@ def self_launch(ngpus, json_out):
     return p.returncode
 
 
-def roofline_of(name, st, tkey=None, world=1):
-    """the contract's `roofline` object for one kernel class from its HIP-event rows of the timed region"""
+# classes whose launches on a REFINED level move more than on a uniform one: a patch that does not coarsen (AvgRstr.h:103-107,
+# DrctIntp.h:107-111 copy it through) reads its correction, resp. writes its residual, at full size -- 8 B per site where an
+# octant child moves 1 (its eighth of a coarse patch): + 7 B per site of such patches
+COPY_THROUGH_CLASSES = ("rbgs_resweep_prolong", "rbgs_zero_resid_restrict_faces", "stencil_rbgs_prolong", "rbgs_zero_resid_restrict",
+                        "resid_restrict", "restrict", "prolong_add")
+
+
+def roofline_of(name, st, tkey=None, world=1, copy_sites_per_cycle=0, cycles=1):
+    """the contract's `roofline` object for one kernel class from its HIP-event rows of the timed region.
+    copy_sites_per_cycle: lattice sites of this rank's patches that copy through to the next level on the levels this class
+    runs on (refined meshes; 0 on a uniform grid), `cycles`: cycles the rows cover"""
     avg_ms = st["ms"] / st["calls"]
     sites = st["cells"] / st["calls"]
-    achieved = ALG_BYTES.get(name, 24.0) * sites / (avg_ms * 1e-3) / 1e9
+    alg = ALG_BYTES.get(name, 24.0)
+    if name in COPY_THROUGH_CLASSES and copy_sites_per_cycle > 0 and st["cells"] > 0:
+        alg = alg + 7.0 * copy_sites_per_cycle * cycles / st["cells"]  # the average over the class's launches
+    achieved = alg * sites / (avg_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if tkey is not None and os.path.exists(tf):
@@ -241,7 +257,8 @@ def roofline_of(name, st, tkey=None, world=1):
             traffic = None
     return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_measured_at_commit": traffic_src,
-            "avg_launch_ms": avg_ms, "launches": st["calls"], "alg_bytes_per_site": ALG_BYTES.get(name, 24.0)}
+            "avg_launch_ms": avg_ms, "launches": st["calls"], "alg_bytes_per_site": alg,
+            "alg_bytes_per_site_uniform_level": ALG_BYTES.get(name, 24.0)}
 
 
 def roofline_mfma_of(name, st):
@@ -347,8 +364,9 @@ def main():
     if world > 1 and os.environ.get("TE_BENCH_NO_AUTOTUNE") is None:
         pinned = any(os.environ.get(k) is not None for k in ("TE_AGGLOMERATE", "TE_AGGLOMERATE_MAX", "TE_REPLICATE"))
         cands = [("environment", None)] if pinned else (
-            [("gathered-on-every-rank", (16, 64, 1)), ("gathered-on-rank-0", (16, 64, 0)), ("never-gathered", (0, 64, 0))] if a.dim == 3
-            else [("gathered-on-rank-0", (16, 64, 0)), ("never-gathered", (0, 64, 0))])
+            [("gathered<=64-on-every-rank", (64, 64, 1)), ("gathered<16/rank-on-every-rank", (16, 64, 1)), ("gathered<=64-on-rank-0", (64, 64, 0)),
+             ("never-gathered", (0, 64, 0))] if a.dim == 3
+            else [("gathered<=64-on-rank-0", (64, 64, 0)), ("gathered<16/rank-on-rank-0", (16, 64, 0)), ("never-gathered", (0, 64, 0))])
         tried, best = [], None
         for cname, pl in cands:
             Hc, gc, bname = make(pl)
@@ -369,6 +387,12 @@ def main():
     g.init_problem(f, None, problem=capi.PROBLEM_RANDOM)  # U(-1,1) splitmix64(0x5EED + patch id), generated on the device
     u = g.new_vector(0)
     cells_global = [H.sizes(l)[1] * n ** a.dim for l in range(H.num_levels)]
+    # this rank's sites in patches that copy through to the next level, summed over the levels (refined meshes only)
+    copy_sites = 0
+    if a.mesh:
+        for l in range(H.num_levels - 1):
+            t_l = H.tables(l)
+            copy_sites += int(np.count_nonzero((t_l["orth_on_parent"] < 0) & (t_l["rank"] == rank))) * n ** a.dim
     # patches per rank and level; a gathered level that every rank holds and computes itself (TE_REPLICATE) is "replicated"
     placement = [("replicated" if H.replicated(l) else [int(c) for c in np.bincount(H.tables(l)["rank"], minlength=world)])
                  for l in range(H.num_levels)] if world > 1 else None
@@ -511,11 +535,53 @@ def main():
                 "roofline": roofline_of(name2, st2, ps_key, world), "roofline_mfma": roofline_mfma_of(name2, st2),
                 "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4)} for k, v in m2["rows_all"].items()}}}
 
+    # (f)2 in the driver's run: time to solution of the call a user makes (apps/3d/steady.cpp:519-524): BiCGStab (BiCGStab.h:45-106,
+    # tolerance 1e-12) preconditioned with one V-cycle, the drivers' trig problem on the same grid, both smoothers. A first solve
+    # warms up (work vectors, code), the second is timed between two synchronisations, a third runs with every kernel class
+    # timed and gives the algorithmic bytes per site and iteration.
+    if a.dim == 3 and not a.no_secondary and not a.mesh and os.environ.get("TE_BENCH_NOPROFILE") is None:
+        solve = {}
+        sites_local = H.sizes(0)[0] * n ** a.dim
+        bb, xx = g.new_vector(0), g.new_vector(0)
+        g.init_problem(bb, None, problem=capi.PROBLEM_TRIG)
+        for sname in ("rbgs", "patch_solve"):
+            o3 = g.default_opts(smoother=smoothers[sname])
+            xx.set(0.0)
+            its, rr = g.bicgstab(xx, bb, o3)
+            xx.set(0.0)
+            barrier()
+            t0s = time.perf_counter()
+            its, rr = g.bicgstab(xx, bb, o3)
+            barrier()
+            dts = time.perf_counter() - t0s
+            xx.set(0.0)
+            g.profile(True)
+            g.profile_select(None)
+            g.profile_reset()
+            g.bicgstab(xx, bb, o3)
+            prow = g.profile_rows()
+            g.profile(False)
+            if dist is not None:
+                tt = torch.tensor([dts], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dts = float(tt.item())
+            cyc = {k for k in prow if k.startswith(("rbgs_", "stencil_rbgs", "stencil_slabs", "patch_solve", "restrict", "fcorr", "resid_restrict", "prolong", "patch_rhs", "dst_axis", "cf_ghost"))}
+            krylov = sum(ALG_BYTES.get(k, 8.0) * v["cells"] for k, v in prow.items() if k not in cyc and k not in ("exchange", "pack")) / max(its, 1) / max(sites_local, 1)
+            allb = sum(ALG_BYTES.get(k, 8.0) * v["cells"] for k, v in prow.items()) / max(its, 1) / max(sites_local, 1)
+            solve[sname] = {"iterations": its, "ms": dts * 1e3, "rel_resid": rr, "ms_per_iteration": dts * 1e3 / max(its, 1),
+                            "alg_bytes_per_site_per_iteration": {"outside_the_two_cycles": krylov, "all_kernels": allb}}
+        del bb, xx
+        g.release_workspace()
+        if rank == 0:
+            secondary = secondary or {}
+            secondary["solve"] = {"what": f"te_bicgstab + one V(1,1) cycle as preconditioner to 1e-12, trig problem (apps/3d/steady.cpp:253-265) on the benchmarked grid, "
+                                          "second of two solves, wall time between two synchronisations (max over ranks)", **solve}
+
     if rank == 0 and not rows:  # TE_BENCH_NOPROFILE=1 (tooling): wall time only
         print(json.dumps({"ms_per_step": ms_per_step, "value": value}), file=json_out, flush=True)
     elif rank == 0:
         name, st = max(((k, v) for k, v in rows.items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
-        roof = roofline_of(name, st, workload_key(a), world)
+        roof = roofline_of(name, st, workload_key(a), world, copy_sites, a.steps)
         roof["measured_triad_GBs"] = triad_gbs
         roof["frac_of_measured_triad"] = roof["achieved"] / triad_gbs
         b_alg = vcycle_alg_bytes_per_finest_cell(cells_global)
@@ -524,6 +590,7 @@ def main():
         counted = sorted(k for k in rows_all if k in ALG_BYTES)
         uncounted = sorted(k for k in rows_all if k not in ALG_BYTES)
         fused_bytes = sum(ALG_BYTES[k] * rows_all[k]["cells"] for k in counted) / max(1, m["profiled_warm"])
+        fused_bytes += 14.0 * copy_sites  # (refined meshes: the residual down and the correction up of a patch that copies through, at full size)
         local_sites = H.sizes(0)[0] * n ** a.dim
         default_wl = (a.size == 512 and a.dim == 3 and not a.mesh and n == 32)
         out = {

@@ -60,7 +60,7 @@ int te_hier_build(const te_mesh *m, int n, int neumann, int max_levels, double p
 /* The same with the placement of the small levels over the ranks spelled out instead of taken from the environment
  * (te_hier_build reads TE_AGGLOMERATE, TE_AGGLOMERATE_MAX, TE_REPLICATE once per call and comes here): a level with fewer
  * than `agglomerate` patches per rank and at most `agglomerate_max` patches in total, and every level below it, is gathered --
- * on every rank (`replicate` != 0, 3D only) or on rank 0. A negative value = the default (16, 64, 1); agglomerate = 0 never
+ * on every rank (`replicate` != 0, 3D only) or on rank 0. A negative value = the default (64, 64, 1); agglomerate = 0 never
  * gathers. What the reference does instead is cut the hierarchy (patches_per_proc, CycleFactory3d.cpp:104). Every rank must
  * pass the same values: te_vcycle / te_bicgstab compare them across the ranks before the first cycle (TE_ESTATE, by name). */
 int te_hier_build_placed(const te_mesh *m, int n, int neumann, int max_levels, double patches_per_proc,

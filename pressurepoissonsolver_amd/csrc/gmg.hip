@@ -55,14 +55,18 @@ enum KClass : int {
 	// the instantiations that read their right-hand side together with exported ghost terms (FCORR): other symbols again
 	KC_RESWEEP_FCORR, KC_ZERO_RESID_FACES_FCORR, KC_FCORR_GATHER,
 	// the reference smoother's zero-guess pre-sweep that stores face layers only (k_ps_sym<false, FACES>): other bytes per site
-	KC_PS_MFMA_FACES, KC_COUNT
+	KC_PS_MFMA_FACES,
+	// te_bicgstab's own passes: x / resid update with its two dot products (72 B/site), the stand-alone s and p statements
+	// (24 / 32), the operator application that also sums one or two dot products (16 + 8)
+	KC_BICG_UPDATE, KC_BICG_S, KC_BICG_P, KC_APPLY_DOT, KC_COUNT
 };
 const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_jacobi", "stencil_rbgs",
                                     "cf_ghost", "restrict", "prolong_add", "patch_rhs", "dst_axis",
                                     "vecop", "reduce", "pack", "exchange", "stencil_rbgs_zero", "resid_restrict", "patch_solve_mfma", "stencil_rbgs_prolong",
                                     "stencil_rbgs_slabs", "stencil_slabs", "patch_solve_3pass", "rbgs_zero_resid_restrict",
                                     "restrict_fixup", "rbgs_resweep_prolong", "rbgs_zero_resid_restrict_faces",
-                                    "rbgs_resweep_prolong_fcorr", "rbgs_zero_resid_restrict_faces_fcorr", "fcorr_gather", "patch_solve_mfma_faces"};
+                                    "rbgs_resweep_prolong_fcorr", "rbgs_zero_resid_restrict_faces_fcorr", "fcorr_gather", "patch_solve_mfma_faces",
+                                    "bicg_update", "bicg_s", "bicg_p", "stencil_apply_dot"};
 
 // Every TE_* switch of this library. They are read from the environment ONCE, in te_gmg_create;
 // te_gmg_set_option changes one afterwards (the tests pin one implementation against another that way). Nothing on a
@@ -1371,7 +1375,8 @@ template <int N, int MODE> int launchStencilN(te_gmg *g, LevelHost &L, const dou
 	auto launch = [&](LevelDev D) {
 		if (D.count == 0) return;
 		Timed t(g, zs > 1 ? KC_STENCIL_SLABS
-		                  : (MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : (MODE == MODE_JACOBI ? KC_JACOBI : KC_RESID_RESTRICT))),
+		                  : (MODE == MODE_APPLY ? (redmode != RED_NONE ? KC_APPLY_DOT : KC_APPLY)
+		                                        : (MODE == MODE_RESID ? KC_RESID : (MODE == MODE_JACOBI ? KC_JACOBI : KC_RESID_RESTRICT))),
 		        (size_t) D.count * L.nc);
 		auto         grid = [&](int z) { return dim3(8 * ((D.count * z + 7) / 8)); };
 		const RedSrc rs{red_a, g->partial.p, D.first * zs}; // (interior patches are launched before the boundary patches)
@@ -2424,7 +2429,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		const PendingRhs &r = *pend;
 		pend                = nullptr;
 		if (r.n2 == 0 || g->recording) return TE_OK;
-		Timed      t(g, KC_VECOP, r.n2 * 2);
+		Timed      t(g, r.kind == 1 ? KC_BICG_S : KC_BICG_P, r.n2 * 2);
 		const dim3 grid(gridFor(r.n2, 256, 1 << 30));
 		if (r.kind == 1)
 			hipLaunchKernelGGL(k_bicg_s, grid, dim3(256), 0, g->stream, r.n2, (double2 *) r.args.out, (const double2 *) r.args.a,
@@ -3355,7 +3360,7 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 				TE_TRY(vcycleWith(g, o, s, ms, &ps));
 			} else {
 				if (n2 > 0) {
-					Timed t(g, KC_VECOP, x->n);
+					Timed t(g, KC_BICG_S, x->n);
 					hipLaunchKernelGGL(k_bicg_s, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) s->d, (const double2 *) resid->d,
 					                   (const double2 *) ap->d, -alpha);
 				}
@@ -3377,7 +3382,7 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 			const te_vec *dp = o ? mp : p, *ds = o ? ms : s;
 			double         rho_new = 0.0;
 			if (n2 > 0) {
-				Timed t(g, KC_VECOP, x->n);
+				Timed t(g, KC_BICG_UPDATE, x->n);
 				hipLaunchKernelGGL(k_bicg_update, dim3(rb), dim3(256), 0, g->stream, n2, (double2 *) x->d, (double2 *) resid->d,
 				                   (const double2 *) dp->d, (const double2 *) ds->d, (const double2 *) ap->d,
 				                   (const double2 *) as->d, (const double2 *) rhat->d, alpha, omega, g->partial.p);
@@ -3388,7 +3393,7 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 				pend_p      = PendingRhs{2, FSrc{p->d, ap->d, resid->d, p->d, -omega, beta}, n2};
 				have_pend_p = true;
 			} else if (n2 > 0) {
-				Timed t(g, KC_VECOP, x->n);
+				Timed t(g, KC_BICG_P, x->n);
 				hipLaunchKernelGGL(k_bicg_p, dim3(fat), dim3(256), 0, g->stream, n2, (double2 *) p->d, (const double2 *) ap->d,
 				                   (const double2 *) resid->d, -omega, beta);
 			}

@@ -327,7 +327,10 @@ Hierarchy Hierarchy::build(const Tree &t, int n, bool neumann, int max_levels,
 		// same bytes per link) and runs the small levels itself, redundantly and bit for bit the same; the way back up then needs
 		// no transfer at all, every parent being local. One exchange per cycle less on the critical path, and the level above
 		// keeps its fused post-sweep (its parents are local). 0: rank 0 alone, as before.
-		h.agglomerate     = pl.agglomerate >= 0 ? pl.agglomerate : 16.0;
+		// (64 per rank since round 4: above a level that lives on every rank the post-sweep needs no exchange at all, so gathering
+		// the 64-patch level at 2 and 4 ranks as well takes three exchanges out of a 512^3 cycle: 659 -> 622, 528 -> 475 us per
+		// rank in loop-back, profiles/r04_mr8_budget.txt)
+		h.agglomerate     = pl.agglomerate >= 0 ? pl.agglomerate : 64.0;
 		h.agglomerate_max = pl.agglomerate_max >= 0 ? pl.agglomerate_max : 64;
 		h.replicate       = (h.dim == 3 && (pl.replicate < 0 || pl.replicate != 0)) ? 1 : 0;
 		if (nranks > 1) {

@@ -90,7 +90,7 @@ struct Level {
 /// Where the levels with few patches live when nranks > 1 (the patches_per_proc idea of CycleFactory3d.cpp:104 without
 /// cutting the hierarchy): a level with fewer than `agglomerate` patches per rank -- and at most `agglomerate_max` patches
 /// in total -- and every level below it is gathered: on every rank (`replicate`, 3D) or on rank 0. Negative = the default
-/// (16 / 64 / 1), which the environment may override (TE_AGGLOMERATE, TE_AGGLOMERATE_MAX, TE_REPLICATE: read by
+/// (64 / 64 / 1), which the environment may override (TE_AGGLOMERATE, TE_AGGLOMERATE_MAX, TE_REPLICATE: read by
 /// te_hier_build only, once per call, and recorded in the hierarchy).
 struct Placement {
 	double agglomerate     = -1.0;
@@ -105,7 +105,7 @@ struct Hierarchy {
 	std::vector<Level> levels; ///< [0] = finest
 	/// placement of the small levels over the ranks (see Placement), as this hierarchy was built: part of what every rank
 	/// must agree on (te_gmg checks it across the ranks before the first cycle)
-	double agglomerate = 16.0;
+	double agglomerate = 64.0;
 	int    agglomerate_max = 64, replicate = 1;
 
 	/// Build every level the reference's CycleFactory would build

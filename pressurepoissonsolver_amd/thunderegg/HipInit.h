@@ -1,8 +1,10 @@
-// Init::initDirichlet / Init::initNeumann (apps/shared/Init.cpp:152-245, :57-151) for vectors of ANY Vector<3>
-// subclass, filled through getLocalData(i) one patch at a time -- for HipVector<3> that is one n^3 patch up and down
-// per patch (te_vec_download_patches / te_vec_upload_patches), never the whole vector.
+// Init::initDirichlet / Init::initNeumann (apps/shared/Init.cpp:152-245, :57-151) and their 2D twins Init::initDirichlet2d /
+// Init::initNeumann2d (:304-361, :246-303) for vectors of ANY Vector<D> subclass, filled through getLocalData(i) one patch at
+// a time -- for HipVector<D> that is one n^D patch up and down per patch (te_vec_download_patches / te_vec_upload_patches),
+// never the whole vector.
 //
-// The reference's Init takes a Domain<3>& and raw PETSc Vec handles (f->vec, apps/3d/steady.cpp:319-321): geometry
+// The reference's Init takes a Domain<D>& and raw PETSc Vec handles (f->vec, apps/3d/steady.cpp:319-321, apps/2d/steady.cpp:
+// 383-386): geometry
 // from PatchInfo, data through VecGetArray. Here geometry comes from the te_hier level tables (the same starts /
 // lengths / neighbour facts, in this library's patch order) and data goes through the reference's own Vector<3>
 // interface. Same arguments otherwise: user callbacks for f, the exact solution and (Neumann) its derivatives;
@@ -14,6 +16,7 @@
 #ifndef THUNDEREGG_HIP_INIT_H
 #define THUNDEREGG_HIP_INIT_H
 #include <Thunderegg/Vector.h>
+#include <array>
 #include <functional>
 #include <memory>
 #include <te_hip.h>
@@ -21,24 +24,26 @@
 
 namespace tehip
 {
-struct LevelGeometry { // this rank's patches of one level, in vector order
-	int                  n = 0, P = 0;
-	std::vector<double>  starts, lengths; // [P][3]
-	std::vector<int32_t> nbr_kind;        // [P][6], 0 = physical boundary
+struct LevelGeometry { // this rank's patches of one level, in vector order (2D or 3D: te_hier_dim)
+	int                  n = 0, P = 0, dim = 3;
+	std::vector<double>  starts, lengths; // [P][dim]
+	std::vector<int32_t> nbr_kind;        // [P][2 dim], 0 = physical boundary
 	LevelGeometry(const te_hier *h, int level)
 	{
 		int Pl = 0, Pg = 0;
 		if (te_hier_level_sizes(h, level, &Pl, &Pg) != TE_OK) throw 3;
-		n = te_hier_n(h);
-		P = Pl;
-		std::vector<double>  gs((size_t) Pg * 3), gl((size_t) Pg * 3);
-		std::vector<int32_t> gk((size_t) Pg * 6), l2g((size_t) (Pl > 0 ? Pl : 1));
+		n   = te_hier_n(h);
+		dim = te_hier_dim(h);
+		P   = Pl;
+		const int D = dim, NS = 2 * dim;
+		std::vector<double>  gs((size_t) Pg * D), gl((size_t) Pg * D);
+		std::vector<int32_t> gk((size_t) Pg * NS), l2g((size_t) (Pl > 0 ? Pl : 1));
 		if (te_hier_level_tables(h, level, nullptr, nullptr, nullptr, gs.data(), gl.data(), gk.data(), nullptr, nullptr, nullptr, nullptr) != TE_OK) throw 3;
 		if (te_hier_level_l2g(h, level, l2g.data()) != TE_OK) throw 3;
-		starts.resize((size_t) Pl * 3), lengths.resize((size_t) Pl * 3), nbr_kind.resize((size_t) Pl * 6);
+		starts.resize((size_t) Pl * D), lengths.resize((size_t) Pl * D), nbr_kind.resize((size_t) Pl * NS);
 		for (int p = 0; p < Pl; p++) {
-			for (int a = 0; a < 3; a++) starts[p * 3 + a] = gs[(size_t) l2g[p] * 3 + a], lengths[p * 3 + a] = gl[(size_t) l2g[p] * 3 + a];
-			for (int s = 0; s < 6; s++) nbr_kind[p * 6 + s] = gk[(size_t) l2g[p] * 6 + s];
+			for (int a = 0; a < D; a++) starts[p * D + a] = gs[(size_t) l2g[p] * D + a], lengths[p * D + a] = gl[(size_t) l2g[p] * D + a];
+			for (int s = 0; s < NS; s++) nbr_kind[p * NS + s] = gk[(size_t) l2g[p] * NS + s];
 		}
 	}
 };
@@ -46,36 +51,56 @@ struct LevelGeometry { // this rank's patches of one level, in vector order
 namespace detail
 {
 using Fun3 = std::function<double(double, double, double)>;
+using Fun2 = std::function<double(double, double)>;
 // Init.cpp:25-50: index -1 / n = the patch face, else the cell centre
 inline double coord(double start, double h, int n, int i) { return i == -1 ? start : (i == n ? start + h * n : start + h / 2.0 + h * i); }
-template <class Face> void init(const LevelGeometry &G, std::shared_ptr<Vector<3>> f, std::shared_ptr<Vector<3>> exact, Fun3 ffun, Fun3 efun, Face face)
+// the common loop: F(x[D]) / E(x[D]) at the cell centres, then on every physical face (west, east, south, north[, bottom,
+// top]: Init.cpp:186-240 / :329-358 order) f += face(side, x[D] on the face, h of the face's axis) for the cells along it
+template <size_t D, class FF, class EF, class Face>
+void init(const LevelGeometry &G, std::shared_ptr<Vector<D>> f, std::shared_ptr<Vector<D>> exact, FF ffun, EF efun, Face face)
 {
+	if (G.dim != (int) D) throw 3;
 	const int n = G.n;
 	for (int p = 0; p < G.P; p++) {
-		LocalData<3> fv = f->getLocalData(p), ev = exact->getLocalData(p);
-		const double *st = &G.starts[p * 3];
-		double        h[3];
-		for (int a = 0; a < 3; a++) h[a] = G.lengths[p * 3 + a] / n;
+		LocalData<D>  fv = f->getLocalData(p), ev = exact->getLocalData(p);
+		const double *st = &G.starts[p * D];
+		double        h[D];
+		for (size_t a = 0; a < D; a++) h[a] = G.lengths[p * D + a] / n;
 		auto X = [&](int a, int i) { return coord(st[a], h[a], n, i); };
-		for (int zi = 0; zi < n; zi++)
-			for (int yi = 0; yi < n; yi++)
-				for (int xi = 0; xi < n; xi++) {
-					const double x = X(0, xi), y = X(1, yi), z = X(2, zi);
-					fv[{{xi, yi, zi}}] = ffun(x, y, z);
-					ev[{{xi, yi, zi}}] = efun(x, y, z);
-				}
-		for (int s = 0; s < 6; s++) { // west, east, south, north, bottom, top (Init.cpp:186-240 order)
-			if (G.nbr_kind[p * 6 + s] != 0) continue;
+		std::array<int, D> c;
+		int                total = 1;
+		for (size_t a = 0; a < D; a++) total *= n;
+		for (int i = 0; i < total; i++) { // x fastest, as the reference's nested loops
+			int    r = i;
+			double x[D];
+			for (size_t a = 0; a < D; a++) {
+				c[a] = r % n;
+				r /= n;
+				x[a] = X((int) a, c[a]);
+			}
+			fv[c] = ffun(x);
+			ev[c] = efun(x);
+		}
+		for (int s = 0; s < 2 * (int) D; s++) {
+			if (G.nbr_kind[p * 2 * D + s] != 0) continue;
 			const int ax = s / 2, fixed = (s & 1) ? n - 1 : 0, out = (s & 1) ? n : -1;
-			for (int b = 0; b < n; b++)
-				for (int a = 0; a < n; a++) {
-					int c[3], o[3];
-					c[ax] = fixed, o[ax] = out;
-					const int a0 = (ax == 0) ? 1 : 0, a1 = (ax == 2) ? 1 : 2; // the two other axes in order
-					c[a0] = o[a0] = a;
-					c[a1] = o[a1] = b;
-					fv[{{c[0], c[1], c[2]}}] += face(s, X(0, o[0]), X(1, o[1]), X(2, o[2]), h[ax]);
+			int       ftotal = 1;
+			for (size_t a = 0; a + 1 < D; a++) ftotal *= n;
+			for (int i = 0; i < ftotal; i++) {
+				int    r = i;
+				double x[D];
+				for (size_t a = 0; a < D; a++) { // the other axes in order, the first fastest
+					if ((int) a == ax) {
+						c[a] = fixed;
+						x[a] = X((int) a, out);
+					} else {
+						c[a] = r % n;
+						r /= n;
+						x[a] = X((int) a, c[a]);
+					}
 				}
+				fv[c] += face(s, x, h[ax]);
+			}
 		}
 	}
 }
@@ -84,16 +109,34 @@ template <class Face> void init(const LevelGeometry &G, std::shared_ptr<Vector<3
 /// Init::initDirichlet(domain, f, exact, ffun, efun), Init.cpp:152-245
 inline void initDirichlet(const LevelGeometry &G, std::shared_ptr<Vector<3>> f, std::shared_ptr<Vector<3>> exact, detail::Fun3 ffun, detail::Fun3 efun)
 {
-	detail::init(G, f, exact, ffun, efun, [&](int, double x, double y, double z, double h) { return -(2 * efun(x, y, z) / (h * h)); });
+	detail::init<3>(G, f, exact, [&](const double *x) { return ffun(x[0], x[1], x[2]); }, [&](const double *x) { return efun(x[0], x[1], x[2]); },
+	                [&](int, const double *x, double h) { return -(2 * efun(x[0], x[1], x[2]) / (h * h)); });
 }
 /// Init::initNeumann(domain, f, exact, ffun, efun, nfunx, nfuny, nfunz), Init.cpp:57-151: += n_x / h on the low side, -= on the high side
 inline void initNeumann(const LevelGeometry &G, std::shared_ptr<Vector<3>> f, std::shared_ptr<Vector<3>> exact, detail::Fun3 ffun, detail::Fun3 efun,
                         detail::Fun3 nfunx, detail::Fun3 nfuny, detail::Fun3 nfunz)
 {
-	detail::init(G, f, exact, ffun, efun, [&](int s, double x, double y, double z, double h) {
-		const double g = (s / 2 == 0) ? nfunx(x, y, z) : (s / 2 == 1 ? nfuny(x, y, z) : nfunz(x, y, z));
-		return (s & 1) ? -(g / h) : g / h;
-	});
+	detail::init<3>(G, f, exact, [&](const double *x) { return ffun(x[0], x[1], x[2]); }, [&](const double *x) { return efun(x[0], x[1], x[2]); },
+	                [&](int s, const double *x, double h) {
+		                const double g = (s / 2 == 0) ? nfunx(x[0], x[1], x[2]) : (s / 2 == 1 ? nfuny(x[0], x[1], x[2]) : nfunz(x[0], x[1], x[2]));
+		                return (s & 1) ? -(g / h) : g / h;
+	                });
+}
+/// Init::initDirichlet2d(domain, f, exact, ffun, efun), Init.cpp:304-361 (-= efun(face) * 2 / h^2 on every physical face)
+inline void initDirichlet2d(const LevelGeometry &G, std::shared_ptr<Vector<2>> f, std::shared_ptr<Vector<2>> exact, detail::Fun2 ffun, detail::Fun2 efun)
+{
+	detail::init<2>(G, f, exact, [&](const double *x) { return ffun(x[0], x[1]); }, [&](const double *x) { return efun(x[0], x[1]); },
+	                [&](int, const double *x, double h) { return -(efun(x[0], x[1]) * 2 / (h * h)); });
+}
+/// Init::initNeumann2d(domain, f, exact, ffun, efun, nfunx, nfuny), Init.cpp:246-303
+inline void initNeumann2d(const LevelGeometry &G, std::shared_ptr<Vector<2>> f, std::shared_ptr<Vector<2>> exact, detail::Fun2 ffun, detail::Fun2 efun,
+                          detail::Fun2 nfunx, detail::Fun2 nfuny)
+{
+	detail::init<2>(G, f, exact, [&](const double *x) { return ffun(x[0], x[1]); }, [&](const double *x) { return efun(x[0], x[1]); },
+	                [&](int s, const double *x, double h) {
+		                const double g = (s / 2 == 0) ? nfunx(x[0], x[1]) : nfuny(x[0], x[1]);
+		                return (s & 1) ? -(g / h) : g / h;
+	                });
 }
 } // namespace tehip
 #endif

@@ -106,10 +106,10 @@ def test_parent_links(name, dim, div):
 
 
 @pytest.mark.parametrize("replicate", [1, 0], ids=["replicated", "rank0"])
-@pytest.mark.parametrize("agg,cap", [(0, 64), (16, 64), (16, 8)])
+@pytest.mark.parametrize("agg,cap", [(0, 64), (16, 64), (16, 8), (64, 64)])
 @pytest.mark.parametrize("nranks", [2, 4, 8])
 def test_morton_partition(nranks, agg, cap, replicate, monkeypatch):
-    """agg = patches per rank below which a level (and every coarser one) is gathered (TE_AGGLOMERATE, default 16; SURVEY
+    """agg = patches per rank below which a level (and every coarser one) is gathered (TE_AGGLOMERATE, default 64; SURVEY
     8(e), CycleFactory3d.cpp:104 semantics); 0 = never. cap = the largest level (patches in total) that may be the first
     gathered one (TE_AGGLOMERATE_MAX, default 64): the per-rank threshold alone grows with the number of ranks. Gathered =
     on EVERY rank (TE_REPLICATE, the default in 3D: each rank holds and computes the whole level) or on rank 0 alone."""
