@@ -83,10 +83,10 @@ int main(int argc, char **argv)
 	auto sstamps = [&] {
 		long long st[8][12];
 		CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(pss_stamp), sizeof st));
-		const char *nm[12] = {"start", "A", "B1", "X1", "Zfwd", "Zinv", "B4", "B5", "C0", "B6", "B7", "C1"};
+		const char *nm[12] = {"start", "A", "b1", "Z0", "b2", "C1", "b34", "Z1", "b5", "C2", "-", "-"};
 		for (int w = 0; w < 8; w += 7) {
 			printf("  wave %d:", w);
-			for (int k = 1; k < 12; k++) printf(" %s=%lld", nm[k], st[w][k] - st[0][0]);
+			for (int k = 1; k < 10; k++) printf(" %s=%lld", nm[k], st[w][k] - st[0][0]);
 			printf("\n");
 		}
 	};
