@@ -1094,8 +1094,11 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_zero_resid3d(LevelDev
 	                        STORE_U ? nullptr : L.f6_out + f6Face<N>(L.f6off, pid, 5) + 2 * X + N * (2 * Yp)};
 	double *const xrs = EXPORT ? rs + (xs > 0 ? H * H : 0) + Yp : nullptr;
 	double *const yrs = EXPORT ? rs + (2 + (ys > 0 ? 1 : 0)) * (H * H) + X : nullptr;
-	// (the residual's stencil needs no closure at the patch faces: physical faces are part of the diagonal the red values were
-	// formed with -- see redResid --, and the ghost across a face with a neighbour is zero here: that term is k_restrict_fixup3d's)
+	// ghost of the residual's stencil on each side, as a multiple of the cell just inside: -1 Dirichlet, +1 Neumann
+	// (StarPatchOp.h:39-65); 0 on faces with a neighbour (that term is k_restrict_fixup3d's)
+	const double gW = (X == 0) ? kinds.phys(0) : 0.0, gE = (X == H - 1) ? kinds.phys(1) : 0.0;
+	const double gS = (Yp == 0) ? kinds.phys(2) : 0.0, gN = (Yp == H - 1) ? kinds.phys(3) : 0.0;
+	const double gB = kinds.phys(4), gT = kinds.phys(5);
 
 	// fused restriction target (see k_stencil3d<MODE_RESID_RESTRICT>): the parent's octant, or the block this rank
 	// ships to the parent's rank; no copy-through patches on these levels
@@ -1269,24 +1272,29 @@ __global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_zero_resid3d(LevelDev
 			const int zr = z - 2;
 			// the black values of plane z-2 other waves wrote in the previous step are visible (barrier above)
 			double a = ZPAR ? racc : 0.0; // zr and z have the same parity
-			// ... and of a red cell only the off-diagonal part is left: its value is v = (0 - f) / diag (diag with the physical
-			// faces folded in, as the relaxation folds them), so f + diag v vanishes up to the rounding of that one update and
-			// r = f - (sum of the neighbours' terms - diag v) = -(sum over the cell's black neighbours INSIDE the patch of
-			// nb / h^2): no diagonal term, no right-hand side, no boundary closure (that is what diag holds; a ghost across a
-			// face with a neighbour is zero here and comes later) -- half the arithmetic of the red residual again
-			// (round 4: the kernel is bound by vector-instruction issue, 110 fp64 operations per thread and two plane steps).
 			auto redResid = [&](auto kk, auto cr) {
-#pragma clang fp contract(off)
 				constexpr int K = decltype(kk)::value, CR = decltype(cr)::value; // row of the pair; which of its cells is red in plane zr
 				const double *t0 = t2 + lds[K];
 				const double2 c  = u2[K];
-				const double  outer = t2[ldo[K] + CR];                                    // row y-1 (K = 0) / y+2 (K = 1): LDS (halo ring: zero)
+				const double  cc = CR ? c.y : c.x;
+				const double  outer = t2[ldo[K] + CR];                                    // row y-1 (K = 0) / y+2 (K = 1): LDS
 				const double  inner = CR ? u2[1 - K].y : u2[1 - K].x;                     // the other row of the pair: a register
-				const double  below = (zr == 0) ? 0.0 : (CR ? u3[K].y : u3[K].x);
-				const double  above = (zr == N - 1) ? 0.0 : (CR ? u1[K].y : u1[K].x);
-				const double  xs2   = CR ? c.x + t0[2] : t0[-1] + c.y; // west + east neighbour
-				const double  s9    = __builtin_fma(below + above, rhz, __builtin_fma(outer + inner, rhy, xs2 * rhx));
-				const double  r     = -s9;
+				double        ym = (K == 0) ? outer : inner, yp = (K == 0) ? inner : outer;
+				if (K == 0) ym += gS * cc;
+				if (K == 1) yp += gN * cc;
+				const double below = (zr == 0) ? gB * cc : (CR ? u3[K].y : u3[K].x);
+				const double above = (zr == N - 1) ? gT * cc : (CR ? u1[K].y : u1[K].x);
+				double       lap;
+				if (CR == 0) {
+					const double xl = t0[-1] + gW * c.x;
+					lap             = (xl - 2 * c.x + c.y) * rhx;
+				} else {
+					const double xr = t0[2] + gE * c.y;
+					lap             = (c.x - 2 * c.y + xr) * rhx;
+				}
+				lap += (ym - 2 * cc + yp) * rhy;
+				lap += (below - 2 * cc + above) * rhz;
+				const double r = (CR ? f2[K].y : f2[K].x) - lap;
 				if (rcpy && act) rcpy[zr * NP + q[K]] = CR ? double2{0.0, r} : double2{r, 0.0}; // (wave-uniform) AvgRstr.h:103-107
 				a += r / 8; // AvgRstr.h:95-102 order: x, then y, then z; each /2^D first (the black cells add exactly 0)
 			};

@@ -62,9 +62,7 @@ def waits_in(body, s, e):
 CASES = [
     # mangled-name fragment, smallest vmcnt allowed inside the march, why
     ("k_rbgs_zero_resid3dILi32ELb0ELb1ELb0ELi4ELi0E", 6, "pre-sweep, level 0: four planes of f in flight, three steps between request and use"),
-    # (three loads per step here -- two of f, one of the exported terms --, so vmcnt(5) still leaves the requests of the last step
-    # and two thirds of the one before in flight; since round 4's shorter red residual the scheduler places one wait there)
-    ("k_rbgs_zero_resid3dILi32ELb0ELb0ELb1ELi4ELi0E", 5, "pre-sweep with exported ghost terms (level 1)"),
+    ("k_rbgs_zero_resid3dILi32ELb0ELb0ELb1ELi4ELi0E", 6, "pre-sweep with exported ghost terms (level 1)"),
     ("k_rbgs_resweep_prolong3dILi32ELi27ELb0ELb0E", 2, "post-sweep, three workgroups per CU: the newest pair of f loads stays in flight"),
     ("k_rbgs_resweep_prolong3dILi32ELi59ELb0ELb0E", 2, "post-sweep at 512^3: two workgroups per CU, four slots"),
     ("k_rbgs_resweep_prolong3dILi32ELi3ELb1ELb0E", 2, "post-sweep with exported ghost terms (level 1)"),
