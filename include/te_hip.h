@@ -240,6 +240,20 @@ int te_gmg_verify_schedule(te_gmg *g, const te_cycle_opts *o);
  * TE_OVERLAP_MIN decides. Replaces nothing in the reference (PETSc's VecScatterBegin/End pair, SchurHelper.h:123-150, is
  * the same idea: start the scatter, compute, finish it). */
 int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms, char *report, int report_len);
+/* A second transport for the exchanges that have a direct form (the face exchanges of 3D levels, the in-place exchange of
+ * restricted blocks into a level that lives on every rank): each rank STORES what a peer needs straight into that peer's
+ * receive buffer -- device memory of another process / GPU of the node, mapped through hipIpcGetMemHandle /
+ * hipIpcOpenMemHandle -- and raises a flag there; a one-workgroup kernel on the receiver's stream waits for the flags. Two
+ * small launches per exchange instead of an RCCL group. enable != 0: prepares it (collective; once; needs te_gmg_use_rccl or
+ * te_gmg_set_allreduce, through which the handles and receive offsets are published) and switches it on; 0: switches back.
+ * Results are bit-identical either way. A wait is bounded (TE_PUSH_TIMEOUT seconds, default 20): te_gmg_push_failed then
+ * returns 1 and the watchdog ends the process as for any exchange that never completes. te_gmg_autotune, when this
+ * transport has been prepared, first checks it against the other one ON THE MACHINE AT HAND (bit-identical result after a
+ * cycle on different data, no wait given up, all ranks agreeing) and keeps it only if it passes and is faster.
+ * The RCCL point-to-point path stays the default. Same replacement as te_gmg_use_rccl: SchurHelper.h:123-150,
+ * GMG/InterLevelComm.h:169-189. */
+int te_gmg_use_push(te_gmg *g, int enable);
+int te_gmg_push_failed(te_gmg *g);
 /* ncclCommCount / ncclCommUserRank of the communicator te_gmg_use_rccl created (0 / -1 without one): evidence for a
  * benchmark line that RCCL itself saw N ranks. */
 int te_gmg_comm_info(te_gmg *g, int *rccl_nranks, int *rccl_rank);

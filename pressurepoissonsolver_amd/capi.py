@@ -117,6 +117,8 @@ SYMBOLS = {
     "te_gmg_verify_schedule": (_I, [_P, C.POINTER(CycleOpts)]),
     "te_gmg_autotune": (_I, [_P, C.POINTER(CycleOpts), _I, _PD, C.c_char_p, _I]),
     "te_gmg_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
+    "te_gmg_use_push": (_I, [_P, _I]),
+    "te_gmg_push_failed": (_I, [_P]),
     "te_gmg_exchange_selftest": (_I, [_P, _I]),
     "te_gmg_watchdog_selftest": (_I, [_P, _D]),
     "te_gmg_profile": (_I, [_P, _I]),
@@ -418,6 +420,13 @@ class GMG:
         ms, buf = C.c_double(), C.create_string_buffer(1024)
         check(lib().te_gmg_autotune(self.h, C.byref(opts), reps, C.byref(ms), buf, 1024))
         return ms.value, buf.value.decode()
+
+    def use_push(self, enable=True):
+        """the direct-store transport (te_gmg_use_push): collective"""
+        check(lib().te_gmg_use_push(self.h, int(bool(enable))))
+
+    def push_failed(self):
+        return bool(lib().te_gmg_push_failed(self.h))
 
     def comm_info(self):
         """(ranks, rank) of the native RCCL communicator, (0, -1) without one"""

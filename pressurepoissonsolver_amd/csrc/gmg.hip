@@ -11,6 +11,7 @@
 #include "patchsolve32_sym.hpp"
 #include "patchsolve16.hpp"
 #include "initkernels.hpp"
+#include "pushkernels.hpp"
 #include <algorithm>
 #include <array>
 #include <atomic>
@@ -197,7 +198,7 @@ struct LevelHost {
 		L.face_src  = face_src.p;
 		L.face_kadj = face_kadj.p;
 		L.rh2       = rh2.p;
-		L.ghost     = ghost.p;
+		L.ghost     = ghostCur();
 		return L;
 	}
 	LevelDev dev() const
@@ -208,7 +209,7 @@ struct LevelHost {
 		L.face_src  = face_src.p;
 		L.face_kadj = face_kadj.p;
 		L.rh2       = rh2.p;
-		L.ghost     = ghost.p;
+		L.ghost     = ghostCur();
 		L.order     = nullptr;
 		L.first     = 0;
 		L.count     = P;
@@ -240,6 +241,26 @@ struct LevelHost {
 	// (ghost_has_v) -- the second face exchange of the level and its pack kernel do not exist.
 	bool            post_exchange_free = false, ghost_has_v = false;
 	DevBuf<int32_t> slot_parent, slot_orth; // [nremote]
+	// Direct-store transport (te_gmg_use_push, pushkernels.hpp). Faces: the slots of neighbours on other ranks exist twice
+	// (ghost_buf[0] = ghost, [1] = ghost_alt); exchange number e of the level lands in buffer e & 1 on every rank, and ghostCur()
+	// is the buffer the kernels read. A rank can be at most ONE exchange ahead of a peer it trades faces with (it needs that
+	// peer's data of exchange e to get past e), so when it writes buffer (e + 1) & 1 there, the peer has long issued -- in
+	// stream order behind every reader of that buffer -- its own push e: no credit message needed. push_peer_ghost[b][i]: peer
+	// fx.peers[i]'s buffer b, mapped here, already offset to where my range lands.
+	DevBuf<double>        ghost_alt;
+	int                   ghost_par = 0;
+	double               *ghostCur() const { return ghost_par ? ghost_alt.p : ghost.p; }
+	bool                  push_faces = false, push_blocks = false;
+	std::vector<double *> push_peer_ghost[2];
+	uint64_t              face_epoch = 0, blk_epoch = 0;
+	// Blocks (repl_direct): the coarse level's right-hand side exists twice as well (cf_buf[0] = the coarse level's f vector's own
+	// storage, [1] = cf_alt): gather number e fills buffer e & 1 everywhere -- a rank that trades no faces with me may still be one
+	// whole cycle behind, reading the other buffer. push_peer_cf[b][i]: peer tx_direct.peers[i]'s buffer b (offset 0: the runs
+	// sit at the same place on every rank).
+	DevBuf<double>        cf_alt;
+	double               *cf_buf[2] = {nullptr, nullptr};
+	std::vector<double *> push_peer_cf[2];
+	DevBuf<unsigned>      push_done; // [2] arrival counters of the two push kernels' workgroups
 	// repl_up and every rank's patches restrict into whole coarse patches that are a contiguous run of the coarse level:
 	// the restricted blocks are exchanged in place (run to run inside the coarse vector), no pack / unpack kernel
 	bool   repl_direct = false;
@@ -366,6 +387,19 @@ struct te_gmg {
 		int (*CommUserRank)(void *, int *)                                           = nullptr;
 		const char *(*GetErrorString)(int)                                           = nullptr;
 	} rccl;
+	// direct-store transport (te_gmg_use_push): flags [nranks][2 * levels] in fine-grained device memory (mine: the peers
+	// raise them), every peer's table mapped; err: the solver's error word (a wait that gave up), device + pinned host copy
+	struct Push {
+		bool                              on = false; // the exchanges that have a direct form use it
+		bool                              ready = false;
+		unsigned long long               *flags = nullptr;
+		std::vector<unsigned long long *> peer_flags; // [nranks] (mine at [rank])
+		int                              *err = nullptr, *err_host = nullptr;
+		std::vector<void *>               opened; // hipIpcOpenMemHandle results, closed in te_gmg_destroy
+		double                            timeout_s = 20.0;
+		int                               nslot = 0;
+		std::atomic<bool>                 fatal{true}; // a wait that gave up ends the process (watchdog); false inside te_gmg_autotune's trial
+	} push;
 	// profiling
 	bool                   profiling = false;
 	int                    prof_only = -1; // >= 0: only this kernel class is timed
@@ -1037,6 +1071,14 @@ void watchdogLoop(te_gmg *g)
 	auto &w = g->wd;
 	while (!w.stop.load()) {
 		std::this_thread::sleep_for(std::chrono::milliseconds(50));
+		if (g->push.err_host && *g->push.err_host && g->push.fatal.load()) {
+			fprintf(stderr,
+			        "te_hip watchdog: rank %d: a direct-store exchange gave up waiting for a peer's data -- a peer is missing or issued a "
+			        "different exchange sequence; ending the process\n",
+			        g->rank);
+			fflush(stderr);
+			_exit(86);
+		}
 		std::lock_guard<std::mutex> lk(w.mu);
 		watchdogRetire(w);
 		if (w.head == w.tail) continue;
@@ -1230,6 +1272,55 @@ int finishReduce(te_gmg *g, int n, int op, bool global)
 	}
 	return TE_OK;
 }
+// One exchange through the direct-store transport (pushkernels.hpp): kind 1 = the level's face exchange (send: the layers in
+// send order; lands in the peers' ghost slots of this exchange's parity), kind 2 = the in-place exchange of restricted blocks
+// (send = the coarse level's right-hand side of this gather's parity; every rank's run lands at the same offsets there).
+// Two launches on `stream`: push, wait. The epochs only ever grow, so a flag that is already ahead (a fast peer) passes.
+int pushExchange(te_gmg *g, LevelHost &L, int kind, const double *send, hipStream_t stream = nullptr)
+{
+	if (!stream) stream = g->stream;
+	const ExPlan &pl = kind == 1 ? L.fx : L.tx_direct;
+	if (pl.empty()) return TE_OK;
+	if ((int) pl.peers.size() > PUSH_MAX_PEERS) return te::fail(TE_EUNSUPPORTED, "direct-store exchange: too many peers");
+	std::unique_ptr<Timed> t(stream == g->stream ? new Timed(g, KC_EXCHANGE, 0) : nullptr);
+	WatchdogArm            arm(g, stream, kind);
+	uint64_t &ep  = kind == 1 ? L.face_epoch : L.blk_epoch;
+	const int par = (int) (ep & 1); // this exchange's buffer
+	ep++;
+	const int          slot = 2 * g->cur_level + (kind - 1);
+	PushPlan           pp;
+	PushWait           pw;
+	int64_t            most = 0;
+	pp.n = 0, pw.n = 0;
+	for (size_t i = 0; i < pl.peers.size(); i++) {
+		const int r = pl.peers[i];
+		if (pl.send_cnt[i] > 0) {
+			PushPeer &q = pp.p[pp.n++];
+			q.dst       = (kind == 1 ? L.push_peer_ghost[par][i] : L.push_peer_cf[par][i] + pl.send_off[i]);
+			q.src_off   = pl.send_off[i];
+			q.cnt       = pl.send_cnt[i];
+			q.flag      = g->push.peer_flags[r] + (size_t) g->rank * g->push.nslot + slot;
+			most        = std::max(most, q.cnt);
+		}
+		if (pl.recv_cnt[i] > 0) pw.flag[pw.n++] = g->push.flags + (size_t) r * g->push.nslot + slot;
+	}
+	const long long budget = (long long) (g->push.timeout_s * 1e8); // wall_clock64: 100 MHz
+	if (pp.n > 0) {
+		const int bx = (int) std::min<int64_t>(64, std::max<int64_t>(1, most / 2 / 256 / 4));
+		hipLaunchKernelGGL(k_push_ranges, dim3(bx, pp.n), dim3(256), 0, stream, send, pp, (unsigned long long) ep, L.push_done.p + (kind - 1),
+		                   (const int *) g->push.err);
+	}
+	if (pw.n > 0) hipLaunchKernelGGL(k_push_wait, dim3(1), dim3(64), 0, stream, pw, (unsigned long long) ep, budget, g->push.err, g->push.err_host);
+	if (kind == 1) L.ghost_par = par; // what the kernels behind this exchange read
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+// the level's face exchange: remote slots of the current ghost buffer <- the peers' layers (`send` in send order)
+int faceExchange(te_gmg *g, LevelHost &L, const double *send, hipStream_t stream = nullptr)
+{
+	if (g->push.on && L.push_faces && !g->recording && L.dim == 3) return pushExchange(g, L, 1, send, stream);
+	return doExchange(g, 1, L.fx, send, L.ghostCur(), stream);
+}
 // make every ghost plane of `u` current: remote same-level faces (pack -> exchange -> ghost slots
 // [0, nremote)), then the coarse/fine planes. Replaces SchurHelper.h:145-150 updateInterfaceDist.
 // `ps`: the iterate is u + P(ps->coarse) (never stored): the faces are packed with the correction added.
@@ -1252,13 +1343,13 @@ template <int N> void cfGhosts(te_gmg *g, LevelHost &L, const double *u, const P
 	const dim3 grid(L.ncf), blk(N * N < 256 ? N * N : 256);
 	if (L.pack_f6) {
 		if (ps)
-			hipLaunchKernelGGL((k_cf_ghost6_3d<N, true>), grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, L.pack_f6, *ps, L.ghost.p, L.f6Off());
+			hipLaunchKernelGGL((k_cf_ghost6_3d<N, true>), grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, L.pack_f6, *ps, L.ghostCur(), L.f6Off());
 		else
-			hipLaunchKernelGGL((k_cf_ghost6_3d<N, false>), grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, L.pack_f6, ProlongSrc(), L.ghost.p, L.f6Off());
+			hipLaunchKernelGGL((k_cf_ghost6_3d<N, false>), grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, L.pack_f6, ProlongSrc(), L.ghostCur(), L.f6Off());
 	} else if (ps)
-		hipLaunchKernelGGL(k_cf_ghost_prolong3d<N>, grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, u, *ps, L.ghost.p);
+		hipLaunchKernelGGL(k_cf_ghost_prolong3d<N>, grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, u, *ps, L.ghostCur());
 	else
-		hipLaunchKernelGGL(k_cf_ghost3d<N>, grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, u, L.ghost.p);
+		hipLaunchKernelGGL(k_cf_ghost3d<N>, grid, blk, 0, g->stream, L.cf_desc.p, L.cf_slots.p, u, L.ghostCur());
 }
 template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u, const ProlongSrc *ps = nullptr)
 {
@@ -1268,7 +1359,7 @@ template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u, con
 		// the face layers of an iterate that exists only as such already sit in send order (LevelHost::f6off): sent from there
 		const bool direct = L.pack_f6 && !ps && L.f6Off();
 		if (!direct) packFaces<N>(g, L, u, ps);
-		int rc = doExchange(g, 1, L.fx, direct ? L.pack_f6 : L.sendbuf.p, L.ghost.p);
+		int rc = faceExchange(g, L, direct ? L.pack_f6 : L.sendbuf.p);
 		if (rc) return rc;
 	}
 	if (L.ncf == 0) return TE_OK;
@@ -1313,7 +1404,7 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 		std::swap(g->stream, g->comm_stream);
 		HIPCHK(e);
 		packFaces<N>(g, L, u, ps);
-		int rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p);
+		int rc = faceExchange(g, L, L.sendbuf.p);
 		if (rc) return rc;
 		if (L.ncf > 0) cfGhosts<N>(g, L, u, ps);
 		launch(L.devPart(true));
@@ -1323,7 +1414,7 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 	packFaces<N>(g, L, u, ps);
 	HIPCHK(hipEventRecord(g->ev_pack, g->stream));
 	HIPCHK(hipStreamWaitEvent(g->comm_stream, g->ev_pack, 0));
-	int rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p, g->comm_stream);
+	int rc = faceExchange(g, L, L.sendbuf.p, g->comm_stream);
 	if (rc) return rc;
 	HIPCHK(hipEventRecord(g->ev_recv, g->comm_stream));
 	launch(L.devPart(false)); // interior, concurrent with the exchange
@@ -1407,12 +1498,12 @@ int prepareGhosts2d(te_gmg *g, LevelHost &L, const double *u)
 			Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
 			hipLaunchKernelGGL(k_pack_faces2d, dim3(L.nremote), dim3(64), 0, g->stream, L.n, L.send_faces.p, u, L.sendbuf.p);
 		}
-		int rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p);
+		int rc = faceExchange(g, L, L.sendbuf.p);
 		if (rc) return rc;
 	}
 	if (L.ncf == 0) return TE_OK;
 	Timed t(g, KC_CFGHOST, (size_t) L.ncf * L.nf);
-	hipLaunchKernelGGL(k_cf_ghost2d, dim3(L.ncf), dim3(64), 0, g->stream, L.n, L.cf_desc.p, L.cf_slots.p, u, L.ghost.p);
+	hipLaunchKernelGGL(k_cf_ghost2d, dim3(L.ncf), dim3(64), 0, g->stream, L.n, L.cf_desc.p, L.cf_slots.p, u, L.ghostCur());
 	return TE_OK;
 }
 template <int MODE> int launchStencil2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega)
@@ -1437,7 +1528,7 @@ int packProlongFaces2d(te_gmg *g, LevelHost &L, const double *u, const double *e
 		Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
 		hipLaunchKernelGGL(k_pack_faces_prolong2d, dim3(L.nremote), dim3(64), 0, g->stream, L.n, L.send_faces.p, u, e4, ps, L.sendbuf.p);
 	}
-	return doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p);
+	return faceExchange(g, L, L.sendbuf.p);
 }
 // zero_guess: levels with L.lds2d; prolong_from: levels with L.fuse2d && L.prolong_fusable (the caller checks)
 int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false,
@@ -1646,7 +1737,7 @@ int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, doub
 			else
 				hipLaunchKernelGGL(k_pack_edges2d, dim3(L.nremote), dim3(64), 0, g->stream, L.n, L.send_faces.p, L.e4buf.p, L.sendbuf.p);
 		}
-		if ((rc = doExchange(g, 1, L.fx, L.sendbuf.p, L.ghost.p))) return rc;
+		if ((rc = faceExchange(g, L, L.sendbuf.p))) return rc;
 	}
 	if (L.P > 0) {
 		Timed t(g, KC_FIXUP, (size_t) L.P * 4 * L.nf);
@@ -1777,7 +1868,10 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 template <int N> int shipRestricted(te_gmg *g, LevelHost &L, double *coarse)
 {
 	// every rank's blocks are whole coarse patches in one run of the coarse vector: run to run, in place
-	if (L.repl_up && L.repl_direct && !g->cfg.has(O_REPL_BLOCKS)) return doExchange(g, 2, L.tx_direct, coarse, coarse);
+	if (L.repl_up && L.repl_direct && !g->cfg.has(O_REPL_BLOCKS)) {
+		if (g->push.on && L.push_blocks && !g->recording) return pushExchange(g, L, 2, coarse);
+		return doExchange(g, 2, L.tx_direct, coarse, coarse);
+	}
 	if (L.repl_up && L.n_up > 0) {
 		Timed t(g, KC_PACK, (size_t) L.n_up * L.nc / 8);
 		hipLaunchKernelGGL(k_prolong_pack3d<N>, dim3(L.n_up), dim3(256), 0, g->stream, L.bc_desc.p, L.up_off.p, coarse, L.upbuf.p);
@@ -2500,6 +2594,8 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	}
 	LevelHost &C       = *g->levels[l + 1];
 	bool       have_coarse_f = false;
+	// direct-store transport: this visit's restricted blocks gather in the coarse right-hand side's buffer of the gather's parity
+	if (g->push.on && L.push_blocks && !g->recording) C.f->d = L.cf_buf[L.blk_epoch & 1];
 	auto       descend = [&]() -> int {
         int r = materialise();
         if (r) return r;
@@ -2682,6 +2778,12 @@ void te_gmg_destroy(te_gmg *g)
 	watchdogStop(g);
 	(void) hipStreamSynchronize(g->stream);
 	if (g->comm_stream) (void) hipStreamSynchronize(g->comm_stream);
+	for (void *m : g->push.opened) (void) hipIpcCloseMemHandle(m);
+	for (size_t l = 0; l + 1 < g->levels.size(); l++) // (the coarse vectors own their first buffer, the level its second)
+		if (g->levels[l]->cf_buf[0]) g->levels[l + 1]->f->d = g->levels[l]->cf_buf[0];
+	if (g->push.flags) (void) hipFree(g->push.flags);
+	if (g->push.err) (void) hipFree(g->push.err);
+	if (g->push.err_host) (void) hipHostFree(g->push.err_host);
 	for (auto &L : g->levels) {
 		for (te_vec *v : {L->u.get(), L->f.get(), L->r.get(), L->t.get()})
 			if (v && v->d) (void) hipFree(v->d);
@@ -2782,6 +2884,196 @@ int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank,
 		return TE_OK;
 	});
 }
+// The direct-store transport (pushkernels.hpp). Collective over the ranks of the hierarchy; needs a working reduction over the
+// ranks (te_gmg_use_rccl or te_gmg_set_allreduce) to publish, once, every rank's IPC handles and receive offsets: a directory of
+// 32-bit words, one slice per rank, summed over the ranks eight words at a time (each word has one contributor).
+// Ranks that live in this very process (the tests' virtual ranks) are reached through their raw pointers.
+static int pushSetup(te_gmg *g)
+{
+	auto &P = g->push;
+	if (P.ready) return TE_OK;
+	const int R = g->nranks, NL = (int) g->levels.size();
+	if (g->dim != 3) return te::fail(TE_EUNSUPPORTED, "te_gmg_use_push: 3D hierarchies only");
+	if (R < 2) return te::fail(TE_ESTATE, "te_gmg_use_push: one rank has nobody to push to");
+	if (!g->rccl.comm && !g->allreduce) return te::fail(TE_ESTATE, "te_gmg_use_push: needs te_gmg_use_rccl or te_gmg_set_allreduce first (the handles travel through it)");
+	if (R > PUSH_MAX_PEERS) return te::fail(TE_EUNSUPPORTED, "te_gmg_use_push: too many ranks");
+	const bool self = g->cfg.has(O_RCCL_LOOPBACK); // diagnostic: every peer is this rank itself (tools/mr8_budget.py)
+	P.nslot = 2 * NL;
+	const size_t fbytes = sizeof(unsigned long long) * (size_t) R * P.nslot;
+	HIPCHK(hipExtMallocWithFlags((void **) &P.flags, fbytes, hipDeviceMallocFinegrained));
+	HIPCHK(hipMemset(P.flags, 0, fbytes));
+	HIPCHK(hipMalloc((void **) &P.err, 64));
+	HIPCHK(hipMemset(P.err, 0, 64));
+	HIPCHK(hipHostMalloc((void **) &P.err_host, 64, hipHostMallocMapped));
+	*P.err_host = 0;
+	if (const char *t = getenv("TE_PUSH_TIMEOUT")) P.timeout_s = std::max(0.1, atof(t));
+	int rc;
+	for (int l = 0; l < NL; l++) {
+		LevelHost &L = *g->levels[l];
+		if ((rc = L.push_done.alloc(2))) return rc;
+		HIPCHK(hipMemset(L.push_done.p, 0, 2 * sizeof(unsigned)));
+		if (L.nremote > 0) {
+			if ((rc = L.ghost_alt.alloc(L.ghost.n))) return rc;
+			HIPCHK(hipMemset(L.ghost_alt.p, 0, sizeof(double) * L.ghost.n));
+		}
+		if (L.repl_up && L.repl_direct && l + 1 < NL) {
+			te_vec *cf = g->levels[l + 1]->f.get();
+			if ((rc = L.cf_alt.alloc(std::max<size_t>(cf->n, 2)))) return rc;
+			HIPCHK(hipMemset(L.cf_alt.p, 0, sizeof(double) * std::max<size_t>(cf->n, 2)));
+			L.cf_buf[0] = cf->d, L.cf_buf[1] = L.cf_alt.p;
+		}
+	}
+	HIPCHK(hipDeviceSynchronize());
+	// ---- the directory: per rank [pid, flags (handle 16 + pointer 2), per level: 4 x (handle 16 + pointer 2), R x recv offset 2]
+	const int      HW = 18, LW = 4 * HW + 2 * R, W = 1 + HW + NL * LW;
+	std::vector<double> dir((size_t) R * W, 0.0);
+	auto put = [&](double *dst, const void *devptr) { // handle + raw pointer of one allocation (null: zeros)
+		if (!devptr) return TE_OK;
+		hipIpcMemHandle_t h;
+		HIPCHK(hipIpcGetMemHandle(&h, const_cast<void *>(devptr)));
+		uint32_t w[16];
+		static_assert(sizeof h == 64, "hipIpcMemHandle_t is 64 bytes");
+		memcpy(w, &h, 64);
+		for (int k = 0; k < 16; k++) dst[k] = (double) w[k];
+		const uint64_t a = (uint64_t) (uintptr_t) devptr;
+		dst[16] = (double) (uint32_t) (a & 0xFFFFFFFFu), dst[17] = (double) (uint32_t) (a >> 32);
+		return TE_OK;
+	};
+	double *mine = &dir[(size_t) g->rank * W];
+	mine[0]      = (double) (uint32_t) getpid();
+	if ((rc = put(mine + 1, P.flags))) return rc;
+	for (int l = 0; l < NL; l++) {
+		LevelHost &L = *g->levels[l];
+		double    *q = mine + 1 + HW + (size_t) l * LW;
+		if (L.nremote > 0 && ((rc = put(q, L.ghost.p)) || (rc = put(q + HW, L.ghost_alt.p)))) return rc;
+		if (L.cf_buf[0] && ((rc = put(q + 2 * HW, L.cf_buf[0])) || (rc = put(q + 3 * HW, L.cf_buf[1])))) return rc;
+		for (int r = 0; r < R; r++) q[4 * HW + 2 * r] = q[4 * HW + 2 * r + 1] = 0.0;
+		for (size_t i = 0; i < L.fx.peers.size(); i++) { // where rank fx.peers[i]'s layers land in my ghost buffers (+1: 0 = nothing)
+			const uint64_t o = (uint64_t) L.fx.recv_off[i] + 1;
+			q[4 * HW + 2 * L.fx.peers[i]] = (double) (uint32_t) (o & 0xFFFFFFFFu), q[4 * HW + 2 * L.fx.peers[i] + 1] = (double) (uint32_t) (o >> 32);
+		}
+	}
+	for (size_t i = 0; i < dir.size(); i += 8) {
+		const int n = (int) std::min<size_t>(8, dir.size() - i);
+		HIPCHK(hipMemcpyAsync(g->result.p, &dir[i], n * sizeof(double), hipMemcpyHostToDevice, g->stream));
+		if ((rc = finishReduce(g, n, 0, true))) return rc;
+		for (int k = 0; k < n; k++) dir[i + k] = g->result_host[k];
+	}
+	// ---- map the peers
+	const uint32_t mypid = (uint32_t) getpid();
+	auto open = [&](const double *src, void **out) -> int { // handle + pointer words of a peer's allocation -> a pointer usable here
+		const uint64_t raw = (uint64_t) (uint32_t) src[16] | ((uint64_t) (uint32_t) src[17] << 32);
+		*out               = nullptr;
+		if (raw == 0) return TE_OK;
+		hipIpcMemHandle_t h;
+		uint32_t          w[16];
+		for (int k = 0; k < 16; k++) w[k] = (uint32_t) src[k];
+		memcpy(&h, w, 64);
+		void *m = nullptr;
+		HIPCHK(hipIpcOpenMemHandle(&m, h, hipIpcMemLazyEnablePeerAccess));
+		P.opened.push_back(m);
+		*out = m;
+		return TE_OK;
+	};
+	auto peerPtr = [&](int r, const double *src, void *own, void **out) -> int {
+		const double *slice = &dir[(size_t) r * W];
+		if (self || r == g->rank) { // (loop-back: this rank's own buffer stands in for the peer's)
+			*out = own;
+			return TE_OK;
+		}
+		if ((uint32_t) slice[0] == mypid) { // a virtual rank in this process: its pointer as it is
+			*out = (void *) (uintptr_t) ((uint64_t) (uint32_t) src[16] | ((uint64_t) (uint32_t) src[17] << 32));
+			return TE_OK;
+		}
+		return open(src, out);
+	};
+	// (a rank whose mapping fails still takes part in the closing reduction: all ranks succeed, or all fail)
+	auto mapPeers = [&]() -> int {
+	P.peer_flags.assign(R, nullptr);
+	for (int r = 0; r < R; r++) {
+		void *m = nullptr;
+		if ((rc = peerPtr(r, &dir[(size_t) r * W + 1], P.flags, &m))) return rc;
+		// loop-back: my own table stands in, shifted so that "my row of the peer's table" is the peer's row of mine
+		P.peer_flags[r] = self ? P.flags + ((ptrdiff_t) r - g->rank) * P.nslot : (unsigned long long *) m;
+		if (!P.peer_flags[r]) return te::fail(TE_ESTATE, "te_gmg_use_push: rank " + std::to_string(r) + " published no flag table");
+	}
+	for (int l = 0; l < NL; l++) {
+		LevelHost &L = *g->levels[l];
+		if (L.nremote > 0 && !L.fx.empty()) {
+			for (int b = 0; b < 2; b++) L.push_peer_ghost[b].assign(L.fx.peers.size(), nullptr);
+			bool ok = true;
+			for (size_t i = 0; i < L.fx.peers.size() && ok; i++) {
+				const int     r = L.fx.peers[i];
+				const double *q = &dir[(size_t) r * W + 1 + HW + (size_t) l * LW];
+				const uint64_t o1 = (uint64_t) (uint32_t) q[4 * HW + 2 * g->rank] | ((uint64_t) (uint32_t) q[4 * HW + 2 * g->rank + 1] << 32);
+				const int64_t off = self ? L.fx.recv_off[i] : (int64_t) o1 - 1;
+				if (off < 0) { // the peer expects nothing from me here although I send: the plans disagree
+					ok = false;
+					break;
+				}
+				for (int b = 0; b < 2; b++) {
+					void *m = nullptr;
+					// (loop-back: the OTHER buffer of this rank, so that what is being read is not overwritten)
+					if ((rc = peerPtr(r, q + b * HW, b ? L.ghost.p : L.ghost_alt.p, &m))) return rc;
+					if (!m) ok = false;
+					L.push_peer_ghost[b][i] = m ? (double *) m + off : nullptr;
+				}
+			}
+			if (!ok) return te::fail(TE_ESTATE, "te_gmg_use_push: a neighbour rank published no receive buffer for level " + std::to_string(l));
+			L.push_faces = true;
+		}
+		if (L.cf_buf[0] && !L.tx_direct.empty()) {
+			for (int b = 0; b < 2; b++) L.push_peer_cf[b].assign(L.tx_direct.peers.size(), nullptr);
+			for (size_t i = 0; i < L.tx_direct.peers.size(); i++) {
+				const int     r = L.tx_direct.peers[i];
+				const double *q = &dir[(size_t) r * W + 1 + HW + (size_t) l * LW];
+				for (int b = 0; b < 2; b++) {
+					void *m = nullptr;
+					if ((rc = peerPtr(r, q + (2 + b) * HW, L.cf_buf[b ^ 1], &m))) return rc;
+					if (!m) return te::fail(TE_ESTATE, "te_gmg_use_push: a rank published no coarse buffer for level " + std::to_string(l));
+					L.push_peer_cf[b][i] = (double *) m;
+				}
+			}
+			L.push_blocks = true;
+		}
+	}
+	return TE_OK;
+	};
+	const int         map_rc  = mapPeers();
+	const std::string map_msg = map_rc ? std::string(te_last_error()) : std::string();
+	// nobody pushes before everybody has finished mapping (and zeroing): one more reduction, which also carries "somebody failed"
+	double failed = map_rc ? 1.0 : 0.0;
+	HIPCHK(hipMemcpyAsync(g->result.p, &failed, sizeof failed, hipMemcpyHostToDevice, g->stream));
+	if ((rc = finishReduce(g, 1, 1, true))) return rc;
+	if (map_rc) return te::fail(map_rc, map_msg);
+	if (g->result_host[0] != 0.0) return te::fail(TE_ESTATE, "te_gmg_use_push: another rank could not map its peers' buffers");
+	P.ready = true;
+	return TE_OK;
+}
+int te_gmg_use_push(te_gmg *g, int enable)
+{
+	return guarded([&]() -> int {
+		if (!g) return te::fail(TE_EINVAL, "te_gmg_use_push: null");
+		if (!enable) {
+			if (g->push.on) { // back to the other transport: the coarse vectors return to their own storage
+				HIPCHK(hipStreamSynchronize(g->stream));
+				for (size_t l = 0; l + 1 < g->levels.size(); l++)
+					if (g->levels[l]->cf_buf[0]) g->levels[l + 1]->f->d = g->levels[l]->cf_buf[0];
+				for (auto &L : g->levels) L->ghost_par = 0;
+			}
+			g->push.on = false;
+			return TE_OK;
+		}
+		int rc = pushSetup(g);
+		if (rc) return rc;
+		g->push.on = true;
+		return TE_OK;
+	});
+}
+// 0: no direct-store exchange has given up waiting; 1: one has (its data never arrived within TE_PUSH_TIMEOUT seconds: the results
+// since then are garbage, and every later exchange of this solver returns at once). Reads the pinned host copy: no device call.
+int te_gmg_push_failed(te_gmg *g) { return (g && g->push.err_host && *g->push.err_host) ? 1 : 0; }
+
 // moves n doubles from a scratch send buffer to a scratch receive buffer of level 0 through the same
 // code path as a real exchange, with this rank as its own peer; returns TE_OK iff the data arrived intact
 int te_gmg_exchange_selftest(te_gmg *g, int n)
@@ -3212,6 +3504,54 @@ int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms
 			int         mode, depth;
 			const char *name;
 		};
+		// ---- transport first (when te_gmg_use_push has prepared the direct-store exchanges): RCCL groups / the host callback
+		// against direct stores, both with everything in line. The direct form must also PROVE itself on this machine: after a
+		// cycle on another right-hand side (so that stale ghost data would show), its result on f must equal the other transport's
+		// bit for bit on every rank, and no wait may have given up. Otherwise it is switched off, on all ranks alike.
+		std::string tnote;
+		if (g->push.ready && g->nranks > 1) {
+			for (int l = 0; l < nl; l++) g->levels[l]->overlap_mode = 0;
+			te_vec *ref = nullptr, *f2 = nullptr;
+			if ((rc = newVec(g, 0, &ref))) return rc;
+			if ((rc = newVec(g, 0, &f2))) {
+				te_vec_destroy(ref);
+				return rc;
+			}
+			Free   fr2{ref, f2};
+			double t_other = 0, t_push = 0, bad = 0;
+			auto   fail    = [&](int r2) {
+                g->push.fatal.store(true);
+                g->profiling = prof;
+                return r2;
+			};
+			g->push.fatal.store(false);
+			if ((rc = te_gmg_use_push(g, 0)) || (rc = timeIt(&t_other)) || (rc = vcycleWith(g, o, f, ref, nullptr))) return fail(rc);
+			if ((rc = te_vec_copy(f2, f)) || (rc = te_vec_scale(f2, -0.625))) return fail(rc);
+			if ((rc = te_gmg_use_push(g, 1)) || (rc = vcycleWith(g, o, f2, u, nullptr)) || (rc = vcycleWith(g, o, f, u, nullptr))) return fail(rc);
+			if ((rc = te_vec_add_scaled(u, -1.0, ref))) return fail(rc);
+			double dmax = 0;
+			if (u->n > 0 && (rc = reduce<RED_MAXABS>(u, nullptr, &dmax))) return fail(rc);
+			HIPCHK(hipStreamSynchronize(g->stream));
+			bad = (dmax != 0.0 || te_gmg_push_failed(g)) ? 1.0 : 0.0;
+			HIPCHK(hipMemcpyAsync(g->result.p, &bad, sizeof bad, hipMemcpyHostToDevice, g->stream));
+			if ((rc = finishReduce(g, 1, 1, true))) return fail(rc);
+			bad = g->result_host[0];
+			if (bad == 0.0 && (rc = timeIt(&t_push))) return fail(rc);
+			char buf[160];
+			if (bad != 0.0) {
+				(void) te_gmg_use_push(g, 0);
+				g->push.ready = false; // not usable on this machine: never again for this solver
+				snprintf(buf, sizeof buf, "transport: direct-store REJECTED (result differs from the other transport's or a wait gave up) -> %s; ",
+				         g->rccl.comm ? "rccl" : "callback");
+			} else {
+				const bool take = t_push < 0.98 * t_other;
+				if (!take) (void) te_gmg_use_push(g, 0);
+				snprintf(buf, sizeof buf, "transport: %s=%.1fus direct-store=%.1fus (results identical) -> %s; ", g->rccl.comm ? "rccl" : "callback",
+				         t_other * 1e3, t_push * 1e3, take ? "direct-store" : (g->rccl.comm ? "rccl" : "callback"));
+			}
+			tnote = buf;
+			g->push.fatal.store(true);
+		}
 		std::vector<Cand> cands = {{0, 0, "serial"}};
 		if (g->nranks > 1 && g->overlap) {
 			cands.push_back({1, 1, "exchange-under-interior/level0"});
@@ -3237,7 +3577,7 @@ int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms
 			if (t[i] < t[best] && t[i] < 0.98 * t[0]) best = i;
 		apply(cands[best]);
 		g->profiling = prof;
-		std::string s2 = "overlap:";
+		std::string s2 = tnote + "overlap:";
 		char        buf[96];
 		for (size_t i = 0; i < cands.size(); i++) {
 			snprintf(buf, sizeof buf, " %s=%.1fus", cands[i].name, t[i] * 1e3);

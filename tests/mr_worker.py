@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--backend", default="gloo")
     ap.add_argument("--divides", type=int, default=2)
     ap.add_argument("--hang-rank", type=int, default=-1, help="this rank never enters the cycle (watchdog test)")
+    ap.add_argument("--push", action="store_true", help="the direct-store transport (te_gmg_use_push) for the exchanges that have one: "
+                    "real hipIpc mappings between the processes, the attached back-end for everything else")
+    ap.add_argument("--n", type=int, default=8)
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -28,12 +31,19 @@ def main():
     torch.cuda.set_device(dev)
     dist.init_process_group(backend=a.backend)
     from pressurepoissonsolver_amd import capi, dist as tedist, problems, solver
-    n = 8
+    n = a.n
     nc = n ** 3
     mesh = capi.Mesh.uniform(3, a.divides)
     H = capi.Hierarchy(mesh, n, rank=rank, nranks=world)
     g = capi.GMG(H, device=dev)
     tedist.attach(g, dist)
+    report = None
+    if a.push:
+        g.use_push(True)
+        # the transports are compared on this very machine: identical results, then the faster one; force the direct one afterwards
+        _, report = g.autotune(g.default_opts(smoother=capi.SMOOTH_RBGS), reps=3)
+        assert "transport:" in report and "REJECTED" not in report and "results identical" in report, report
+        g.use_push(True)
     t = H.tables(0)
     f_all = problems.random_rhs(t["id"], nc)
     b_all, _ = problems.init_dirichlet(t, n)
@@ -85,7 +95,8 @@ def main():
         assert np.linalg.norm(got["bicg"] - want) <= 1e-9 * np.linalg.norm(want), "sharded BiCGStab differs"
         g1.apply(u1, au1)
         assert np.array_equal(got["apply_last"], au1.download()), "sharded apply (after the cycle) differs"
-        print("MR_WORKER_OK", flush=True)
+        print("MR_WORKER_OK", report or "", flush=True)
+    assert not g.push_failed()
     dist.barrier()
     dist.destroy_process_group()
 

@@ -419,6 +419,74 @@ def test_two_processes_gloo(overlap_min):
     assert "MR_WORKER_OK" in r.stdout
 
 
+@pytest.mark.parametrize("n,divides", [(8, 2), (32, 3)], ids=["64x8^3", "512x32^3-fused-path"])
+def test_two_processes_direct_store_transport(n, divides):
+    """te_gmg_use_push between two real PROCESSES (both on the one GPU of the box: hipIpcGetMemHandle / hipIpcOpenMemHandle
+    mappings, fine-grained flags, the bounded wait kernel): the face exchanges and the in-place exchange of restricted blocks go
+    by direct stores, everything else through the attached gloo back-end. te_gmg_autotune's own check (result identical to the
+    other transport's after a cycle on different data) must pass, and apply / cycle / BiCGStab / apply equal the single-rank
+    run as in test_two_processes_gloo. 32^3 patches: the fused default path (face layers sent from where they lie, no
+    post-sweep exchange above the replicated level)."""
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, TE_PUSH_TIMEOUT="30")
+    for k in ("TE_OVERLAP_MIN", "TE_OVERLAP_MODE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.join(root, "tests", "mr_worker.py"), "--backend", "gloo", "--push",
+           "--n", str(n), "--divides", str(divides)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "MR_WORKER_OK" in r.stdout and "transport:" in r.stdout
+
+
+def test_direct_store_transport_virtual_ranks(monkeypatch):
+    """the same transport between two virtual ranks of ONE process (raw pointers instead of hipIpc mappings; two ranks only: a
+    process has few hardware queues, and a waiting kernel must never sit in front of the kernel it waits for): switched on and
+    off between cycles, W-cycle included (two gathers per cycle and level: the parities of the double buffers), all equal to the
+    single-rank run bit for bit."""
+    monkeypatch.delenv("TE_OVERLAP_MIN", raising=False)
+    monkeypatch.setenv("TE_PUSH_TIMEOUT", "30")
+    n = 8
+    mesh = util.mesh("uniform", 3)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    f = util.rand_vec(H1.cells(0), 11)
+    nc = n ** 3
+    want = {}
+    for ct in (0, 1):
+        d1 = g1.new_vector(0)
+        g1.cycle(g1.default_opts(smoother=capi.SMOOTH_RBGS, cycle_type=ct), g1.new_vector(0, f), d1)
+        want[ct] = d1.download()
+
+    def per_rank(r, H, g, fab):
+        df, du = g.new_vector(0, f.reshape(-1, nc)[H.l2g(0)].ravel()), g.new_vector(0)
+        out = {}
+        g.use_push(True)
+        for rep in range(3):  # (parities 0, 1, 0)
+            g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+            out[f"v{rep}"] = du.download()
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS, cycle_type=1), df, du)
+        out["w"] = du.download()
+        g.use_push(False)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+        out["off"] = du.download()
+        g.use_push(True)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+        out["on"] = du.download()
+        out["failed"] = g.push_failed()
+        return out
+
+    got = shard_run(mesh, n, 2, per_rank)
+    assert not any(got["failed"])
+    for k in ("v0", "v1", "v2", "off", "on"):
+        assert np.array_equal(got[k], want[0]), k
+    assert np.array_equal(got["w"], want[1])
+
+
 def test_native_rccl_backend_selftest():
     """The library's own RCCL back-end (dlopen of the process's librccl.so, ncclCommInitRank, one
     ncclGroup of ncclRecv + ncclSend on the solver stream) moving data with this rank as its own peer:
