@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--hang-rank", type=int, default=-1, help="this rank never enters the cycle (watchdog test)")
     ap.add_argument("--push", action="store_true", help="the direct-store transport (te_gmg_use_push) for the exchanges that have one: "
                     "real hipIpc mappings between the processes, the attached back-end for everything else")
-    ap.add_argument("--n", type=int, default=8)
+    ap.add_argument("--cells", type=int, default=8, help="cells per patch axis")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -31,7 +31,7 @@ def main():
     torch.cuda.set_device(dev)
     dist.init_process_group(backend=a.backend)
     from pressurepoissonsolver_amd import capi, dist as tedist, problems, solver
-    n = a.n
+    n = a.cells
     nc = n ** 3
     mesh = capi.Mesh.uniform(3, a.divides)
     H = capi.Hierarchy(mesh, n, rank=rank, nranks=world)

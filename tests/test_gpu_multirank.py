@@ -437,7 +437,7 @@ def test_two_processes_direct_store_transport(n, divides):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
            "127.0.0.1", "--master-port", port, os.path.join(root, "tests", "mr_worker.py"), "--backend", "gloo", "--push",
-           "--n", str(n), "--divides", str(divides)]
+           "--cells", str(n), "--divides", str(divides)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "MR_WORKER_OK" in r.stdout and "transport:" in r.stdout
