@@ -370,6 +370,13 @@ def main():
         tried, best = [], None
         for cname, pl in cands:
             Hc, gc, bname = make(pl)
+            if a.dim == 3 and os.environ.get("TE_BENCH_PUSH", "1") != "0":
+                # prepare the direct-store transport (hipIpc-mapped receive buffers); te_gmg_autotune then checks it against the
+                # other one on this machine (identical results on every rank, no wait given up) and keeps the faster
+                try:
+                    gc.use_push(True)
+                except capi.TeError as e:  # (all ranks fail together by construction)
+                    print(f"[rank {rank}] direct-store transport not available: {e}", file=sys.stderr)
             ms, rep = gc.autotune(gc.default_opts(smoother=smoothers[a.smoother]), reps=10)
             tried.append({"placement": cname, "agglomerate/max/replicate": list(Hc.placement()), "ms_per_cycle_max_over_ranks": ms, "overlap": rep})
             if best is None or ms < best[0]:

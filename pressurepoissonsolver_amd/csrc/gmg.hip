@@ -2594,11 +2594,16 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	}
 	LevelHost &C       = *g->levels[l + 1];
 	bool       have_coarse_f = false;
-	// direct-store transport: this visit's restricted blocks gather in the coarse right-hand side's buffer of the gather's parity
-	if (g->push.on && L.push_blocks && !g->recording) C.f->d = L.cf_buf[L.blk_epoch & 1];
+	// direct-store transport: a gather of restricted blocks fills the coarse right-hand side's buffer of ITS parity (two gathers
+	// per visit in a W-cycle): called in front of everything that produces the coarse right-hand side
+	auto coarseBuf = [&]() {
+		if (g->push.on && L.push_blocks && !g->recording) C.f->d = L.cf_buf[L.blk_epoch & 1];
+	};
+	coarseBuf();
 	auto       descend = [&]() -> int {
         int r = materialise();
         if (r) return r;
+        if (!have_coarse_f) coarseBuf();
         if (have_coarse_f) { // the fused pre-sweep already left AvgRstr(f - A u) in C.f
             have_coarse_f = false;
         } else if (o->fuse && (L.dim == 3 || L.fuse2d)) {

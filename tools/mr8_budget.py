@@ -30,6 +30,8 @@ ap.add_argument("--ranks", default="1,2,4,8")
 ap.add_argument("--agg", default="16,4,0")
 ap.add_argument("--dim", type=int, default=3)
 ap.add_argument("--patch", type=int, default=None, help="cells per patch axis (default 32 in 3D, 64 in 2D)")
+ap.add_argument("--push", action="store_true", help="the direct-store transport (te_gmg_use_push) in loop-back form: every peer's buffers and "
+                "flags are this rank's own -- the two launches per exchange are real, the wire and the waiting for peers are not")
 a = ap.parse_args()
 
 os.environ["TE_RCCL_LOOPBACK"] = "1"
@@ -54,6 +56,8 @@ def run(nranks, rank, agg):
     g = capi.GMG(H)
     if nranks > 1:
         tedist.attach_rccl(g, None, 0, 1)  # a communicator of one: this rank is every peer (loop-back)
+        if a.push:
+            g.use_push(True)
     f, u = g.new_vector(0), g.new_vector(0)
     g.init_problem(f, None, problem=capi.PROBLEM_RANDOM)
     o = g.default_opts(smoother=sm)
@@ -82,7 +86,8 @@ def run(nranks, rank, agg):
     return dict(host=float(np.median(tq)), wall=wall, rows=rows, sizes=sizes)
 
 
-emit(f"# tools/mr8_budget.py --size {a.size} --smoother {a.smoother}: one rank of N alone on one MI355X, native RCCL back-end in loop-back mode")
+emit(f"# tools/mr8_budget.py --size {a.size} --smoother {a.smoother}{' --push' if a.push else ''}: one rank of N alone on one MI355X, "
+     + ("direct-store transport in loop-back form (exchanges without a direct form: RCCL in loop-back mode)" if a.push else "native RCCL back-end in loop-back mode"))
 emit("# host = host time to enqueue one cycle incl. the RCCL group calls; wall = GPU time per cycle of back-to-back cycles; us")
 for nranks in [int(x) for x in a.ranks.split(",")]:
     for agg in ([16] if nranks == 1 else [int(x) for x in a.agg.split(",")]):
