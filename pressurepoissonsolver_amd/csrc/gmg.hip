@@ -2093,7 +2093,13 @@ template <int N> int interfaceResidRestrictN(te_gmg *g, LevelHost &L, const doub
 	if (rc) return rc;
 	{
 		Timed t(g, KC_VECOP, coarse_n);
-		HIPCHK(hipMemsetAsync(coarse, 0, sizeof(double) * coarse_n, g->stream));
+		// (blocks exchanged in place: only this rank's run -- the others' runs are received, and with the direct-store transport a
+		// peer that is ahead may have stored its run already)
+		if (L.repl_up && L.repl_direct && !g->cfg.has(O_REPL_BLOCKS) && !L.tx_direct.empty()) {
+			if (L.tx_direct.send_cnt[0] > 0)
+				HIPCHK(hipMemsetAsync(coarse + L.tx_direct.send_off[0], 0, sizeof(double) * (size_t) L.tx_direct.send_cnt[0], g->stream));
+		} else
+			HIPCHK(hipMemsetAsync(coarse, 0, sizeof(double) * coarse_n, g->stream));
 		if (L.n_up > 0) HIPCHK(hipMemsetAsync(L.upbuf.p, 0, sizeof(double) * L.upbuf.n, g->stream));
 	}
 	if (L.P > 0) {
@@ -3059,18 +3065,30 @@ int te_gmg_use_push(te_gmg *g, int enable)
 {
 	return guarded([&]() -> int {
 		if (!g) return te::fail(TE_EINVAL, "te_gmg_use_push: null");
+		// Every switch between the transports is a point where ALL ranks have finished what they had queued: the argument that
+		// lets a rank run one exchange ahead of a peer (LevelHost::ghost_alt) needs every exchange to be a direct one -- a rank that
+		// starts pushing while a peer still reads its buffers in a cycle of the other transport would overwrite them. Collective.
+		auto meet = [&]() -> int {
+			HIPCHK(hipStreamSynchronize(g->stream));
+			HIPCHK(hipStreamSynchronize(g->comm_stream));
+			if (g->nranks < 2 || (!g->rccl.comm && !g->allreduce)) return TE_OK;
+			double one = 1.0;
+			HIPCHK(hipMemcpyAsync(g->result.p, &one, sizeof one, hipMemcpyHostToDevice, g->stream));
+			return finishReduce(g, 1, 0, true);
+		};
+		int rc;
 		if (!enable) {
-			if (g->push.on) { // back to the other transport: the coarse vectors return to their own storage
-				HIPCHK(hipStreamSynchronize(g->stream));
-				for (size_t l = 0; l + 1 < g->levels.size(); l++)
-					if (g->levels[l]->cf_buf[0]) g->levels[l + 1]->f->d = g->levels[l]->cf_buf[0];
-				for (auto &L : g->levels) L->ghost_par = 0;
-			}
+			if (!g->push.on) return TE_OK;
+			if ((rc = meet())) return rc;
+			// back to the other transport: the coarse vectors return to their own storage
+			for (size_t l = 0; l + 1 < g->levels.size(); l++)
+				if (g->levels[l]->cf_buf[0]) g->levels[l + 1]->f->d = g->levels[l]->cf_buf[0];
+			for (auto &L : g->levels) L->ghost_par = 0;
 			g->push.on = false;
 			return TE_OK;
 		}
-		int rc = pushSetup(g);
-		if (rc) return rc;
+		if (g->push.on) return TE_OK;
+		if ((rc = pushSetup(g)) || (rc = meet())) return rc;
 		g->push.on = true;
 		return TE_OK;
 	});

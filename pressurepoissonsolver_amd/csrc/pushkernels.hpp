@@ -40,9 +40,11 @@ __global__ __launch_bounds__(256) void k_push_ranges(const double *__restrict__ 
 	double2        *d2 = reinterpret_cast<double2 *>(pp.dst);
 	const size_t    n2 = (size_t) pp.cnt / 2;
 	for (size_t i = blockIdx.x * (size_t) blockDim.x + threadIdx.x; i < n2; i += (size_t) gridDim.x * blockDim.x) d2[i] = s2[i];
-	__threadfence_system();
+	// one release fence per workgroup, behind the barrier that orders every thread's stores before it (a fence per thread costs
+	// 2-4 x as much: MI355X_MICROARCH.md "inter-workgroup visibility")
 	__syncthreads();
 	if (threadIdx.x == 0) {
+		__threadfence_system();
 		const unsigned total = gridDim.x * gridDim.y;
 		if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) { // every workgroup's data is out
 			__hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
