@@ -132,7 +132,7 @@ struct ExPlan {
 };
 
 struct LevelHost {
-	int    dim = 3, n = 0, P = 0, P_global = 0;
+	int    dim = 3, n = 0, P = 0, P_global = 0, index = 0; // index: the level's number in the solver (0 = finest)
 	bool   gathered = false; // the level lives on rank 0 alone or on every rank (the hierarchy's placement): no face exchange
 	bool   replicated = false; // ... on every rank: sums over the level count it once (rank 0's; te_integrate, te_vec_dot, ...)
 	bool   prolong_fusable = false; // every patch is an octant child of a LOCAL parent and there is no coarse/fine face
@@ -261,6 +261,14 @@ struct LevelHost {
 	double               *cf_buf[2] = {nullptr, nullptr};
 	std::vector<double *> push_peer_cf[2];
 	DevBuf<unsigned>      push_done; // [2] arrival counters of the two push kernels' workgroups
+	// pack + push in one launch (PackPush): where face i of the send order goes in its receiver's ghost buffer, per parity, and
+	// the flags to raise
+	DevBuf<double *>             push_face_dst[2];
+	DevBuf<unsigned long long *> push_face_flags;
+	// an exchange in progress (between pushBegin and pushFinish): its parity, epoch, and what to wait for
+	int                push_par = 0;
+	unsigned long long push_ep  = 0;
+	PushWait           push_wait;
 	// repl_up and every rank's patches restrict into whole coarse patches that are a contiguous run of the coarse level:
 	// the restricted blocks are exchanged in place (run to run inside the coarse vector), no pack / unpack kernel
 	bool   repl_direct = false;
@@ -563,6 +571,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 	L->n   = n;
 	L->P   = lv.P;
 	L->P_global = lv.P_global;
+	L->index    = li;
 	L->replicated = lv.replicated;
 	L->gathered = lv.replicated || (H.nranks > 1 && std::all_of(lv.g_rank.begin(), lv.g_rank.end(), [&](int32_t r) { return r == lv.g_rank[0]; }));
 	L->nc  = (D == 3) ? (size_t) n * n * n : (size_t) n * n;
@@ -1276,6 +1285,29 @@ int finishReduce(te_gmg *g, int n, int op, bool global)
 // send order; lands in the peers' ghost slots of this exchange's parity), kind 2 = the in-place exchange of restricted blocks
 // (send = the coarse level's right-hand side of this gather's parity; every rank's run lands at the same offsets there).
 // Two launches on `stream`: push, wait. The epochs only ever grow, so a flag that is already ahead (a fast peer) passes.
+// pushBegin: the exchange's parity and epoch (L.push_par / push_ep) and what it will wait for (L.push_wait); pushFinish: the wait
+// kernel, and the switch of the ghost buffer the kernels read. Between the two: k_push_ranges, or a pack kernel that stores
+// into the peers' buffers itself (PackPush).
+void pushBegin(te_gmg *g, LevelHost &L, int kind)
+{
+	const ExPlan &pl = kind == 1 ? L.fx : L.tx_direct;
+	uint64_t     &ep = kind == 1 ? L.face_epoch : L.blk_epoch;
+	L.push_par       = (int) (ep & 1); // this exchange's buffer
+	L.push_ep        = ++ep;
+	const int slot   = 2 * L.index + (kind - 1);
+	L.push_wait.n    = 0;
+	for (size_t i = 0; i < pl.peers.size(); i++)
+		if (pl.recv_cnt[i] > 0) L.push_wait.flag[L.push_wait.n++] = g->push.flags + (size_t) pl.peers[i] * g->push.nslot + slot;
+}
+int pushFinish(te_gmg *g, LevelHost &L, int kind, hipStream_t stream)
+{
+	const long long budget = (long long) (g->push.timeout_s * 1e8); // wall_clock64: 100 MHz
+	if (L.push_wait.n > 0)
+		hipLaunchKernelGGL(k_push_wait, dim3(1), dim3(64), 0, stream, L.push_wait, L.push_ep, budget, g->push.err, g->push.err_host);
+	if (kind == 1) L.ghost_par = L.push_par; // what the kernels behind this exchange read
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
 int pushExchange(te_gmg *g, LevelHost &L, int kind, const double *send, hipStream_t stream = nullptr)
 {
 	if (!stream) stream = g->stream;
@@ -1284,14 +1316,12 @@ int pushExchange(te_gmg *g, LevelHost &L, int kind, const double *send, hipStrea
 	if ((int) pl.peers.size() > PUSH_MAX_PEERS) return te::fail(TE_EUNSUPPORTED, "direct-store exchange: too many peers");
 	std::unique_ptr<Timed> t(stream == g->stream ? new Timed(g, KC_EXCHANGE, 0) : nullptr);
 	WatchdogArm            arm(g, stream, kind);
-	uint64_t &ep  = kind == 1 ? L.face_epoch : L.blk_epoch;
-	const int par = (int) (ep & 1); // this exchange's buffer
-	ep++;
-	const int          slot = 2 * g->cur_level + (kind - 1);
-	PushPlan           pp;
-	PushWait           pw;
-	int64_t            most = 0;
-	pp.n = 0, pw.n = 0;
+	pushBegin(g, L, kind);
+	const int par  = L.push_par;
+	const int slot = 2 * L.index + (kind - 1);
+	PushPlan  pp;
+	int64_t   most = 0;
+	pp.n           = 0;
 	for (size_t i = 0; i < pl.peers.size(); i++) {
 		const int r = pl.peers[i];
 		if (pl.send_cnt[i] > 0) {
@@ -1302,18 +1332,12 @@ int pushExchange(te_gmg *g, LevelHost &L, int kind, const double *send, hipStrea
 			q.flag      = g->push.peer_flags[r] + (size_t) g->rank * g->push.nslot + slot;
 			most        = std::max(most, q.cnt);
 		}
-		if (pl.recv_cnt[i] > 0) pw.flag[pw.n++] = g->push.flags + (size_t) r * g->push.nslot + slot;
 	}
-	const long long budget = (long long) (g->push.timeout_s * 1e8); // wall_clock64: 100 MHz
 	if (pp.n > 0) {
 		const int bx = (int) std::min<int64_t>(64, std::max<int64_t>(1, most / 2 / 256 / 4));
-		hipLaunchKernelGGL(k_push_ranges, dim3(bx, pp.n), dim3(256), 0, stream, send, pp, (unsigned long long) ep, L.push_done.p + (kind - 1),
-		                   (const int *) g->push.err);
+		hipLaunchKernelGGL(k_push_ranges, dim3(bx, pp.n), dim3(256), 0, stream, send, pp, L.push_ep, L.push_done.p + (kind - 1), (const int *) g->push.err);
 	}
-	if (pw.n > 0) hipLaunchKernelGGL(k_push_wait, dim3(1), dim3(64), 0, stream, pw, (unsigned long long) ep, budget, g->push.err, g->push.err_host);
-	if (kind == 1) L.ghost_par = par; // what the kernels behind this exchange read
-	HIPCHK(hipGetLastError());
-	return TE_OK;
+	return pushFinish(g, L, kind, stream);
 }
 // the level's face exchange: remote slots of the current ghost buffer <- the peers' layers (`send` in send order)
 int faceExchange(te_gmg *g, LevelHost &L, const double *send, hipStream_t stream = nullptr)
@@ -1324,17 +1348,32 @@ int faceExchange(te_gmg *g, LevelHost &L, const double *send, hipStream_t stream
 // make every ghost plane of `u` current: remote same-level faces (pack -> exchange -> ghost slots
 // [0, nremote)), then the coarse/fine planes. Replaces SchurHelper.h:145-150 updateInterfaceDist.
 // `ps`: the iterate is u + P(ps->coarse) (never stored): the faces are packed with the correction added.
-template <int N> void packFaces(te_gmg *g, LevelHost &L, const double *u, const ProlongSrc *ps)
+// may_push: the exchange that follows is on the solver stream -- with the direct-store transport the pack kernel then stores the
+// layers into the receivers' ghost slots itself and raises their flags (PackPush); returns true when it did (the caller finishes
+// with pushFinish instead of an exchange of the send buffer)
+template <int N> bool packFaces(te_gmg *g, LevelHost &L, const double *u, const ProlongSrc *ps, bool may_push = false)
 {
-	Timed      t(g, KC_PACK, (size_t) L.nremote * L.nf);
+	const bool push = may_push && g->push.on && L.push_faces && !g->recording && L.push_face_dst[0].p;
+	Timed      t(g, push ? KC_EXCHANGE : KC_PACK, (size_t) L.nremote * L.nf);
 	const dim3 grid(L.nremote), blk(N * N < 256 ? N * N : 256);
+	PackPush   pp;
+	if (push) {
+		pushBegin(g, L, 1);
+		pp.dst    = L.push_face_dst[L.push_par].p;
+		pp.flags  = L.push_face_flags.p;
+		pp.nflags = (int) L.push_face_flags.n;
+		pp.epoch  = L.push_ep;
+		pp.done   = L.push_done.p;
+		pp.err    = g->push.err;
+	}
 	if (L.pack_f6) { // the iterate exists only as its face layers
 		ProlongSrc none{nullptr, nullptr, nullptr};
-		hipLaunchKernelGGL(k_pack_faces6_3d<N>, grid, blk, 0, g->stream, L.send_faces.p, L.pack_f6, ps ? *ps : none, L.sendbuf.p, L.f6Off());
+		hipLaunchKernelGGL(k_pack_faces6_3d<N>, grid, blk, 0, g->stream, L.send_faces.p, L.pack_f6, ps ? *ps : none, L.sendbuf.p, L.f6Off(), pp);
 	} else if (ps)
-		hipLaunchKernelGGL(k_pack_faces_prolong3d<N>, grid, blk, 0, g->stream, L.send_faces.p, u, *ps, L.sendbuf.p);
+		hipLaunchKernelGGL(k_pack_faces_prolong3d<N>, grid, blk, 0, g->stream, L.send_faces.p, u, *ps, L.sendbuf.p, pp);
 	else
-		hipLaunchKernelGGL(k_pack_faces3d<N>, grid, blk, 0, g->stream, L.send_faces.p, u, L.sendbuf.p);
+		hipLaunchKernelGGL(k_pack_faces3d<N>, grid, blk, 0, g->stream, L.send_faces.p, u, L.sendbuf.p, pp);
+	return push;
 }
 // ghost planes of the coarse/fine faces from the current iterate (u, or its face layers L.pack_f6 when it was never stored)
 template <int N> void cfGhosts(te_gmg *g, LevelHost &L, const double *u, const ProlongSrc *ps)
@@ -1358,8 +1397,8 @@ template <int N> int prepareGhosts(te_gmg *g, LevelHost &L, const double *u, con
 	if (L.nremote > 0) {
 		// the face layers of an iterate that exists only as such already sit in send order (LevelHost::f6off): sent from there
 		const bool direct = L.pack_f6 && !ps && L.f6Off();
-		if (!direct) packFaces<N>(g, L, u, ps);
-		int rc = faceExchange(g, L, direct ? L.pack_f6 : L.sendbuf.p);
+		const bool pushed = !direct && packFaces<N>(g, L, u, ps, true);
+		int        rc     = pushed ? pushFinish(g, L, 1, g->stream) : faceExchange(g, L, direct ? L.pack_f6 : L.sendbuf.p);
 		if (rc) return rc;
 	}
 	if (L.ncf == 0) return TE_OK;
@@ -1403,8 +1442,8 @@ template <int N, class F> int withGhosts(te_gmg *g, LevelHost &L, const double *
 		hipError_t e = hipEventRecord(g->ev_recv, g->stream);
 		std::swap(g->stream, g->comm_stream);
 		HIPCHK(e);
-		packFaces<N>(g, L, u, ps);
-		int rc = faceExchange(g, L, L.sendbuf.p);
+		const bool pushed = packFaces<N>(g, L, u, ps, true);
+		int        rc     = pushed ? pushFinish(g, L, 1, g->stream) : faceExchange(g, L, L.sendbuf.p);
 		if (rc) return rc;
 		if (L.ncf > 0) cfGhosts<N>(g, L, u, ps);
 		launch(L.devPart(true));
@@ -3031,6 +3070,20 @@ static int pushSetup(te_gmg *g)
 				}
 			}
 			if (!ok) return te::fail(TE_ESTATE, "te_gmg_use_push: a neighbour rank published no receive buffer for level " + std::to_string(l));
+			// where every face of the send order goes (pack + push in one launch), and the flags that launch raises
+			std::vector<unsigned long long *> fl;
+			for (int b = 0; b < 2; b++) {
+				std::vector<double *> dst((size_t) L.nremote, nullptr);
+				for (size_t i = 0; i < L.fx.peers.size(); i++)
+					for (int64_t k = 0; k < L.fx.send_cnt[i] / (int64_t) L.nf; k++)
+						dst[(size_t) (L.fx.send_off[i] / (int64_t) L.nf + k)] = L.push_peer_ghost[b][i] + k * (int64_t) L.nf;
+				int rc2 = L.push_face_dst[b].upload(dst);
+				if (rc2) return rc2;
+			}
+			for (size_t i = 0; i < L.fx.peers.size(); i++)
+				if (L.fx.send_cnt[i] > 0) fl.push_back(P.peer_flags[L.fx.peers[i]] + (size_t) g->rank * P.nslot + 2 * l);
+			int rc3 = L.push_face_flags.upload(fl);
+			if (rc3) return rc3;
 			L.push_faces = true;
 		}
 		if (L.cf_buf[0] && !L.tx_direct.empty()) {

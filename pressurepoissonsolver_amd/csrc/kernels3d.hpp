@@ -277,18 +277,44 @@ __global__ void k_cf_ghost3d(const int32_t *__restrict__ desc, const int32_t *__
 }
 
 // Multi-rank: copy the face layers other ranks need into one contiguous send buffer.
+// Direct-store transport (pushkernels.hpp): a pack kernel can store each face layer straight into the receiving rank's ghost
+// slot (dst[i]: where face i of the send order goes) and raise the peers' flags when its last workgroup is done -- pack and
+// push in one launch. dst == null: the ordinary pack into the send buffer.
+struct PackPush {
+	double *const             *dst   = nullptr; // [faces]
+	unsigned long long *const *flags = nullptr; // [nflags] the peers' flags to raise
+	int                        nflags = 0;
+	unsigned long long         epoch  = 0;
+	unsigned                  *done   = nullptr; // arrival counter of the workgroups (zero between launches)
+	const int                 *err    = nullptr; // the solver's error word: nothing is stored once a wait has given up
+};
+__device__ __forceinline__ void packPushTail(const PackPush &pp)
+{
+	if (!pp.dst) return;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		__threadfence_system();
+		if (__hip_atomic_fetch_add(pp.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+			__hip_atomic_store(pp.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__threadfence_system();
+			for (int k = 0; k < pp.nflags; k++) __hip_atomic_store(pp.flags[k], pp.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+	}
+}
 // faces[i] = (patch, side); one workgroup per face; layout (a, b) = remaining axes in order.
 template <int N>
 __global__ void k_pack_faces3d(const int32_t *__restrict__ faces, const double *__restrict__ u,
-                               double *__restrict__ sendbuf)
+                               double *__restrict__ sendbuf, PackPush pp = PackPush())
 {
 	constexpr int NN = N * N, NNN = N * N * N;
 	const int     p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
 	const int     ax = s >> 1;
 	const int     sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
 	const double *up = u + (size_t) p * NNN + ((s & 1) ? (N - 1) * sn : 0);
-	double       *o  = sendbuf + (size_t) blockIdx.x * NN;
-	for (int i = threadIdx.x; i < NN; i += blockDim.x) o[i] = up[(i % N) * sa + (i / N) * sb];
+	double       *o  = pp.dst ? pp.dst[blockIdx.x] : sendbuf + (size_t) blockIdx.x * NN;
+	if (!(pp.dst && *pp.err))
+		for (int i = threadIdx.x; i < NN; i += blockDim.x) o[i] = up[(i % N) * sa + (i / N) * sb];
+	packPushTail(pp);
 }
 
 // restricted value of coarse cell (hx,hy,hz) of the octant a fine patch covers: the eight fine

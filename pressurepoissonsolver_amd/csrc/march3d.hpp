@@ -486,7 +486,7 @@ __global__ void k_cf_ghost6_3d(const int32_t *__restrict__ desc, const int32_t *
 // ranks need, with this rank's coarse correction added on the way out.
 template <int N>
 __global__ void k_pack_faces_prolong3d(const int32_t *__restrict__ faces, const double *__restrict__ u, ProlongSrc ps,
-                                       double *__restrict__ sendbuf)
+                                       double *__restrict__ sendbuf, PackPush pp = PackPush())
 {
 	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
 	const int     p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
@@ -494,19 +494,22 @@ __global__ void k_pack_faces_prolong3d(const int32_t *__restrict__ faces, const 
 	const int     sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
 	const int     face = (s & 1) ? (N - 1) * sn : 0;
 	const double *up   = u + (size_t) p * NNN + face;
-	double       *o    = sendbuf + (size_t) blockIdx.x * NN;
-	if (ps.orth[p] < 0) { // copy-through patch: the correction is the same-size coarse patch
+	double       *o    = pp.dst ? pp.dst[blockIdx.x] : sendbuf + (size_t) blockIdx.x * NN;
+	if (pp.dst && *pp.err) {
+		// (a wait has given up: nothing is stored any more)
+	} else if (ps.orth[p] < 0) { // copy-through patch: the correction is the same-size coarse patch
 		for (int i = threadIdx.x; i < NN; i += blockDim.x) {
 			const int cell = (i % N) * sa + (i / N) * sb;
 			o[i]           = up[cell] + coarseAtCell<N>(ps, p, face + cell);
 		}
-		return;
+	} else {
+		const double *cp = coarseOctant<N>(ps, p) + ((s & 1) ? (H - 1) * sn : 0);
+		for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+			const int a = i % N, b = i / N;
+			o[i] = up[a * sa + b * sb] + cp[(a / 2) * sa + (b / 2) * sb];
+		}
 	}
-	const double *cp = coarseOctant<N>(ps, p) + ((s & 1) ? (H - 1) * sn : 0);
-	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
-		const int a = i % N, b = i / N;
-		o[i] = up[a * sa + b * sb] + cp[(a / 2) * sa + (b / 2) * sb];
-	}
+	packPushTail(pp);
 }
 
 // Relax cell CB (0: even x, 1: odd x) of row k of the plane held in `cen` (LDS copy in tl):
@@ -1447,25 +1450,28 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 // red update of plane z and black update of plane z-1 exactly as in k_rbgs3d.
 template <int N>
 __global__ void k_pack_faces6_3d(const int32_t *__restrict__ faces, const double *__restrict__ f6, ProlongSrc ps,
-                                 double *__restrict__ sendbuf, const int32_t *__restrict__ f6off)
+                                 double *__restrict__ sendbuf, const int32_t *__restrict__ f6off, PackPush pp = PackPush())
 {
 	constexpr int NN = N * N, H = N / 2;
 	const int     p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
 	const int     ax = s >> 1;
 	const int     sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
 	const double *fp = f6 + f6Face<N>(f6off, p, s);
-	double       *o  = sendbuf + (size_t) blockIdx.x * NN;
-	if (ps.coarse && ps.orth[p] < 0) { // a patch that copies through (refined level): its correction is the same-size coarse
+	double       *o  = pp.dst ? pp.dst[blockIdx.x] : sendbuf + (size_t) blockIdx.x * NN;
+	if (pp.dst && *pp.err) {
+		// (a wait has given up: nothing is stored any more)
+	} else if (ps.coarse && ps.orth[p] < 0) { // a patch that copies through (refined level): its correction is the same-size coarse
 		// patch, cell by cell -- as k_pack_faces_prolong3d and k_cf_ghost6_3d<N, true> form it for local readers
 		const int face = (s & 1) ? (N - 1) * sn : 0;
 		for (int i = threadIdx.x; i < NN; i += blockDim.x) o[i] = fp[i] + coarseAtCell<N>(ps, p, face + (i % N) * sa + (i / N) * sb);
-		return;
+	} else {
+		const double *cp = ps.coarse ? coarseOctant<N>(ps, p) + ((s & 1) ? (H - 1) * sn : 0) : nullptr;
+		for (int i = threadIdx.x; i < NN; i += blockDim.x) {
+			const int a = i % N, b = i / N;
+			o[i] = cp ? fp[i] + cp[(a / 2) * sa + (b / 2) * sb] : fp[i];
+		}
 	}
-	const double *cp = ps.coarse ? coarseOctant<N>(ps, p) + ((s & 1) ? (H - 1) * sn : 0) : nullptr;
-	for (int i = threadIdx.x; i < NN; i += blockDim.x) {
-		const int a = i % N, b = i / N;
-		o[i] = cp ? fp[i] + cp[(a / 2) * sa + (b / 2) * sb] : fp[i];
-	}
+	packPushTail(pp);
 }
 
 // V (tuning variants, all bit-identical): bit 0: the black values of the recomputed plane and of the sweep's plane z-1 are
