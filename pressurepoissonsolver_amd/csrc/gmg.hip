@@ -75,12 +75,12 @@ const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_j
 enum Opt : int {
 	O_2D_SIMPLE, O_2D_NO_MFMA, O_2D_NO_PF, O_2D_NO_MR_FUSE, O_2D_TPB, O_NO_FUSE2, O_NO_FUSE3, O_NO_FUSE3_CF, O_NO_CFP, O_NO_XF,
 	O_NO_FCORR, O_NO_FCORR_CF, O_NO_GTAB, O_NO_OVERLAP, O_OVERLAP_MIN, O_NO_PS_FACES, O_PS_MODE, O_PS_SLOW, O_RBGS_NOSLAB,
-	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_COUNT
+	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_PUSH_TIMEOUT, O_COUNT
 };
 const char *optName[O_COUNT] = {"TE_2D_SIMPLE", "TE_2D_NO_MFMA", "TE_2D_NO_PF", "TE_2D_NO_MR_FUSE", "TE_2D_TPB", "TE_NO_FUSE2", "TE_NO_FUSE3",
                                 "TE_NO_FUSE3_CF", "TE_NO_CFP", "TE_NO_XF", "TE_NO_FCORR", "TE_NO_FCORR_CF", "TE_NO_GTAB", "TE_NO_OVERLAP",
                                 "TE_OVERLAP_MIN", "TE_NO_PS_FACES", "TE_PS_MODE", "TE_PS_SLOW", "TE_RBGS_NOSLAB", "TE_ZS_FORCE", "TE_NO_ZS8",
-                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS", "TE_PACK_FACES", "TE_OVERLAP_MODE"};
+                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS", "TE_PACK_FACES", "TE_OVERLAP_MODE", "TE_PUSH_TIMEOUT"};
 // options that shape the level tables te_gmg_create builds: fixed for the solver's lifetime
 inline bool optStructural(int o) { return o == O_2D_SIMPLE || o == O_NO_CFP || o == O_2D_NO_MR_FUSE || o == O_NO_OVERLAP || o == O_EXCHANGE_TIMEOUT; }
 struct Cfg {
@@ -1075,6 +1075,24 @@ void watchdogRetire(te_gmg::Watchdog &w) // (mutex held) drop completed exchange
 		w.head++;
 	}
 }
+// (mutex held through `lk`) The ring is full -- the host is RING exchanges ahead of the GPU: wait for the oldest outstanding one
+// (without the mutex: the polling thread needs it) until a slot is free. Nothing that is being watched is ever given up.
+void watchdogMakeRoom(te_gmg::Watchdog &w, std::unique_lock<std::mutex> &lk)
+{
+	watchdogRetire(w);
+	while (w.tail - w.head == te_gmg::Watchdog::RING) {
+		auto      &sl = w.slot[w.head % te_gmg::Watchdog::RING];
+		hipEvent_t ev = sl.ev;
+		const bool rec = sl.recorded;
+		lk.unlock();
+		if (rec)
+			(void) hipEventSynchronize(ev);
+		else
+			std::this_thread::sleep_for(std::chrono::milliseconds(1)); // (still inside its host call on another thread)
+		lk.lock();
+		watchdogRetire(w);
+	}
+}
 void watchdogLoop(te_gmg *g)
 {
 	auto &w = g->wd;
@@ -1133,7 +1151,7 @@ struct WatchdogArm { // around the issue of one exchange: takes a ring slot (iss
 	{
 		auto &w = g->wd;
 		if (!w.th.joinable()) return;
-		std::lock_guard<std::mutex> lk(w.mu);
+		std::unique_lock<std::mutex> lk(w.mu);
 		if (w.batch >= 0) { // inside a V-cycle or a Krylov solve: the call's one slot stands for this exchange too
 			auto &sl = w.slot[w.batch % te_gmg::Watchdog::RING];
 			sl.since = std::chrono::steady_clock::now(); // (the host got this far: the deadline runs from the newest issue)
@@ -1141,19 +1159,13 @@ struct WatchdogArm { // around the issue of one exchange: takes a ring slot (iss
 			sl.level = g->cur_level;
 			return;
 		}
-		watchdogRetire(w);
-		if (w.tail - w.head == te_gmg::Watchdog::RING) {
-			// ring full (the host is more than RING exchanges ahead of the GPU): the newest slot is reused -- it keeps its
-			// issue time, which is the older one; a deadline can only fire later than strictly necessary, never earlier
-			idx = (int64_t) (w.tail - 1);
-		} else {
-			idx          = (int64_t) w.tail++;
-			auto &sl     = w.slot[idx % te_gmg::Watchdog::RING];
-			sl.since     = std::chrono::steady_clock::now();
-			sl.tag       = tag;
-			sl.level     = g->cur_level;
-		}
-		w.slot[idx % te_gmg::Watchdog::RING].recorded = false; // a blocking host callback is covered too: no event yet, only the deadline
+		watchdogMakeRoom(w, lk); // (ring full: the host waits for the oldest exchange instead of dropping a watched one)
+		idx      = (int64_t) w.tail++;
+		auto &sl = w.slot[idx % te_gmg::Watchdog::RING];
+		sl.since = std::chrono::steady_clock::now();
+		sl.tag   = tag;
+		sl.level = g->cur_level;
+		sl.recorded = false; // a blocking host callback is covered too: no event yet, only the deadline
 	}
 	~WatchdogArm()
 	{
@@ -1178,10 +1190,9 @@ struct WatchdogBatch {
 	{
 		auto &w = g->wd;
 		if (!w.th.joinable()) return;
-		std::lock_guard<std::mutex> lk(w.mu);
+		std::unique_lock<std::mutex> lk(w.mu);
 		if (w.batch >= 0) return; // (nested: the outer call's slot)
-		watchdogRetire(w);
-		if (w.tail - w.head == te_gmg::Watchdog::RING) return; // ring full: this call's exchanges take slots of their own
+		watchdogMakeRoom(w, lk);
 		idx      = (int64_t) w.tail++;
 		auto &sl = w.slot[idx % te_gmg::Watchdog::RING];
 		sl.since = std::chrono::steady_clock::now();
@@ -1214,21 +1225,29 @@ int doExchange(te_gmg *g, int tag, const ExPlan &pl, const double *send, double 
 	if (g->rccl.comm) {
 		// one RCCL group per exchange, enqueued on the solver stream behind the pack kernel: every
 		// send/recv of the exchange progresses together over the direct xGMI links, no host round trip
+		int64_t total = 0; // (loop-back only)
+		if (g->cfg.has(O_RCCL_LOOPBACK)) {
+			for (size_t i = 0; i < pl.peers.size(); i++) total += std::max(pl.send_cnt[i], pl.recv_cnt[i]);
+			if ((size_t) (2 * total) > g->loopbuf.n) { // (grows to the largest plan of the solver within the first cycle; outside the timed scope)
+				HIPCHK(hipStreamSynchronize(g->stream));
+				HIPCHK(hipStreamSynchronize(g->comm_stream)); // (overlapped exchanges use it too)
+				if (g->loopbuf.p) HIPCHK(hipFree(g->loopbuf.p));
+				g->loopbuf.p = nullptr;
+				g->loopbuf.n = 0;
+				int rc0      = g->loopbuf.alloc((size_t) (2 * total));
+				if (rc0) {
+					g->loopbuf.p = nullptr;
+					g->loopbuf.n = 0;
+					return rc0;
+				}
+			}
+		}
 		std::unique_ptr<Timed> t(timed ? new Timed(g, KC_EXCHANGE, 0) : nullptr);
 		if (g->cfg.has(O_RCCL_LOOPBACK)) {
 			// DIAGNOSTIC (tools/mr8_budget.py): one rank of an N-rank hierarchy alone on a GPU, every peer replaced by the rank
 			// itself -- the same group of ncclRecv/ncclSend calls with the same message sizes, between scratch buffers. What
 			// is measured is real (host enqueue cost, RCCL's launch, this rank's kernels with the GPU to themselves); the
 			// exchanged DATA are not: results are meaningless in this mode.
-			int64_t total = 0;
-			for (size_t i = 0; i < pl.peers.size(); i++) total += std::max(pl.send_cnt[i], pl.recv_cnt[i]);
-			if ((size_t) (2 * total) > g->loopbuf.n) {
-				(void) hipStreamSynchronize(g->stream);
-				if (g->loopbuf.p) (void) hipFree(g->loopbuf.p);
-				g->loopbuf.p = nullptr;
-				int rc0     = g->loopbuf.alloc((size_t) (2 * total));
-				if (rc0) return rc0;
-			}
 			int     rc  = g->rccl.GroupStart();
 			int64_t off = 0;
 			for (size_t i = 0; i < pl.peers.size() && rc == 0; i++) {
@@ -2956,7 +2975,7 @@ static int pushSetup(te_gmg *g)
 	HIPCHK(hipMemset(P.err, 0, 64));
 	HIPCHK(hipHostMalloc((void **) &P.err_host, 64, hipHostMallocMapped));
 	*P.err_host = 0;
-	if (const char *t = getenv("TE_PUSH_TIMEOUT")) P.timeout_s = std::max(0.1, atof(t));
+	P.timeout_s = std::max(0.1, g->cfg.real(O_PUSH_TIMEOUT, P.timeout_s));
 	int rc;
 	for (int l = 0; l < NL; l++) {
 		LevelHost &L = *g->levels[l];
@@ -3148,7 +3167,10 @@ int te_gmg_use_push(te_gmg *g, int enable)
 }
 // 0: no direct-store exchange has given up waiting; 1: one has (its data never arrived within TE_PUSH_TIMEOUT seconds: the results
 // since then are garbage, and every later exchange of this solver returns at once). Reads the pinned host copy: no device call.
-int te_gmg_push_failed(te_gmg *g) { return (g && g->push.err_host && *g->push.err_host) ? 1 : 0; }
+int te_gmg_push_failed(te_gmg *g)
+{
+	return guarded([&]() -> int { return (g && g->push.err_host && *g->push.err_host) ? 1 : 0; });
+}
 
 // moves n doubles from a scratch send buffer to a scratch receive buffer of level 0 through the same
 // code path as a real exchange, with this rank as its own peer; returns TE_OK iff the data arrived intact

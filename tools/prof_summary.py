@@ -73,15 +73,17 @@ def main():
                     w.writerow([short(r[0]), r[1], f"{r[2]:.0f}", f"{r[3]:.1f}", f"{r[4]:.2f}", f"{r[5]:.0f}", f"{r[6]:.0f}"])
     # 2. SQ counters
     sq = counters(os.path.join(run, "sq1"))
-    for k, v in counters(os.path.join(run, "sq2")).items():
-        sq[k].update(v)
+    for extra in ("sq2", "sq3"):
+        for k, v in counters(os.path.join(run, extra)).items():
+            sq[k].update(v)
     if sq:
         names = sorted({c for v in sq.values() for c in v})
         with open(out + "_pmc_sq.csv", "w") as f:
             f.write(head)
             f.write("# per-launch means; WAIT_ANY + WAIT_INST_ANY + ACTIVE_INST_ANY ~ WAVE_CYCLES (MI355X_MICROARCH.md, PMC slots)\n")
             w = csv.writer(f)
-            w.writerow(["kernel", "launches"] + names + ["wait_any_frac", "wait_inst_frac", "active_frac", "lds_conflict_frac"])
+            f.write("# mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES): share of the time a matrix pipe of a busy CU works\n")
+            w.writerow(["kernel", "launches"] + names + ["wait_any_frac", "wait_inst_frac", "active_frac", "lds_conflict_frac", "mfma_busy_frac"])
             for k, v in sorted(sq.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", [0, 1])[0]):
                 if not k.startswith("k_"):
                     continue
@@ -90,7 +92,8 @@ def main():
                 lds = m.get("SQ_LDS_IDX_ACTIVE", 0) or 1
                 w.writerow([k, max(x[1] for x in v.values())] + [f"{m.get(c, 0):.0f}" for c in names]
                            + [f"{m.get('SQ_WAIT_ANY', 0) / wc:.3f}", f"{m.get('SQ_WAIT_INST_ANY', 0) / wc:.3f}",
-                              f"{m.get('SQ_ACTIVE_INST_ANY', 0) / wc:.3f}", f"{m.get('SQ_LDS_BANK_CONFLICT', 0) / lds:.3f}"])
+                              f"{m.get('SQ_ACTIVE_INST_ANY', 0) / wc:.3f}", f"{m.get('SQ_LDS_BANK_CONFLICT', 0) / lds:.3f}",
+                              f"{m.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (4.0 * m['SQ_BUSY_CU_CYCLES']):.3f}" if m.get("SQ_BUSY_CU_CYCLES") else ""])
     # 3. traffic
     fe, wr = counters(os.path.join(run, "fetch")), counters(os.path.join(run, "write"))
     if fe or wr:

@@ -18,6 +18,9 @@ pass() { # name, counters
 }
 pass sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "$@" &&
 pass sq2 "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES" "$@"
+# the matrix pipe and the LDS next to each other (which unit is saturated, if any: k_ps_sym); a pass of its own that may fail
+# (an unknown counter name fails the whole pass) without taking the others with it
+pass sq3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_INSTS_MFMA" "$@" || true
 pass fetch "FETCH_SIZE" "$@" && pass write "WRITE_SIZE" "$@"
 python3 tools/prof_summary.py $OUT $OUT/summary $COMMIT "bench.py --steps 20 --warmup 5 $*" || true
 ls -la $OUT/summary_*
