@@ -8,15 +8,22 @@ H = capi.Hierarchy(mesh, 32)
 g = capi.GMG(H)
 f = g.new_vector(0); ex = g.new_vector(0); x = g.new_vector(0)
 g.init_problem(f, ex, problem=capi.PROBLEM_TRIG)
+import hashlib
 for sm, name in ((capi.SMOOTH_PATCH_SOLVE, "patch_solve"), (capi.SMOOTH_RBGS, "rbgs")):
     o = g.default_opts(smoother=sm)
-    for rep in range(3):
-        x.set(0.0)
-        g.sync(); t0 = time.perf_counter()
-        its, rr = g.bicgstab(x, f, o, 200, 1e-12)
-        g.sync(); dt = time.perf_counter() - t0
-    err = np.abs(x.download() - ex.download()).max()
-    print(f"{name}: {its} iterations, rel resid {rr:.2e}, {dt*1e3:.1f} ms, max error vs exact {err:.3e}")
+    for opt in (None, "TE_NO_BICG_XF", None, "TE_NO_BICG_XF"):  # same process, alternating: with / without the cycle's x-face columns for A
+        if opt:
+            g.set_option(opt, "1")
+        for rep in range(3):
+            x.set(0.0)
+            g.sync(); t0 = time.perf_counter()
+            its, rr = g.bicgstab(x, f, o, 200, 1e-12)
+            g.sync(); dt = time.perf_counter() - t0
+        if opt:
+            g.set_option(opt, None)
+        xh = x.download()
+        err = np.abs(xh - ex.download()).max()
+        print(f"{name} [{opt or 'default'}]: {its} iterations, rel resid {rr:.2e}, {dt*1e3:.1f} ms, max error vs exact {err:.3e}, sha {hashlib.sha1(xh.tobytes()).hexdigest()[:10]}")
 # what the solve spends outside its iterations (work vectors, first residual)
 x.set(0.0)
 g.sync(); t0 = time.perf_counter()
