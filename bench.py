@@ -364,20 +364,25 @@ def main():
     if world > 1 and os.environ.get("TE_BENCH_NO_AUTOTUNE") is None:
         pinned = any(os.environ.get(k) is not None for k in ("TE_AGGLOMERATE", "TE_AGGLOMERATE_MAX", "TE_REPLICATE"))
         cands = [("environment", None)] if pinned else (
-            [("gathered<=64-on-every-rank", (64, 64, 1)), ("gathered<16/rank-on-every-rank", (16, 64, 1)), ("gathered<=64-on-rank-0", (64, 64, 0)),
-             ("never-gathered", (0, 64, 0))] if a.dim == 3
+            [("gathered<=64-on-every-rank", (64, 64, 1)), ("gathered<16/rank-on-every-rank", (16, 64, 1)), ("gathered<4/rank-on-every-rank", (4, 64, 1)),
+             ("gathered<=64-on-rank-0", (64, 64, 0)), ("never-gathered", (0, 64, 0))] if a.dim == 3
             else [("gathered<=64-on-rank-0", (64, 64, 0)), ("gathered<16/rank-on-rank-0", (16, 64, 0)), ("never-gathered", (0, 64, 0))])
         tried, best = [], None
+        push_ok = a.dim == 3 and os.environ.get("TE_BENCH_PUSH", "1") != "0"
+        os.environ.setdefault("TE_PUSH_TIMEOUT", "5")  # (a transport that does not work here is found out within seconds)
         for cname, pl in cands:
             Hc, gc, bname = make(pl)
-            if a.dim == 3 and os.environ.get("TE_BENCH_PUSH", "1") != "0":
+            if push_ok:
                 # prepare the direct-store transport (hipIpc-mapped receive buffers); te_gmg_autotune then checks it against the
                 # other one on this machine (identical results on every rank, no wait given up) and keeps the faster
                 try:
                     gc.use_push(True)
                 except capi.TeError as e:  # (all ranks fail together by construction)
                     print(f"[rank {rank}] direct-store transport not available: {e}", file=sys.stderr)
+                    push_ok = False
             ms, rep = gc.autotune(gc.default_opts(smoother=smoothers[a.smoother]), reps=10)
+            if "REJECTED" in rep:  # (the same verdict on every rank: it comes out of a reduction) -- not tried again on this machine
+                push_ok = False
             tried.append({"placement": cname, "agglomerate/max/replicate": list(Hc.placement()), "ms_per_cycle_max_over_ranks": ms, "overlap": rep})
             if best is None or ms < best[0]:
                 best = (ms, Hc, gc, bname, cname)

@@ -419,9 +419,10 @@ def test_two_processes_gloo(overlap_min):
     assert "MR_WORKER_OK" in r.stdout
 
 
-@pytest.mark.parametrize("n,divides", [(8, 2), (32, 3)], ids=["64x8^3", "512x32^3-fused-path"])
-def test_two_processes_direct_store_transport(n, divides):
-    """te_gmg_use_push between two real PROCESSES (both on the one GPU of the box: hipIpcGetMemHandle / hipIpcOpenMemHandle
+@pytest.mark.parametrize("n,divides,nproc", [(8, 2, 2), (32, 3, 2), (32, 3, 4)], ids=["64x8^3", "512x32^3-fused-path", "512x32^3-4-processes"])
+def test_two_processes_direct_store_transport(n, divides, nproc):
+    """te_gmg_use_push between real PROCESSES (two, and four: more peers per exchange, the blocks of a gather from three ranks;
+    all on the one GPU of the box: hipIpcGetMemHandle / hipIpcOpenMemHandle
     mappings, fine-grained flags, the bounded wait kernel): the face exchanges and the in-place exchange of restricted blocks go
     by direct stores, everything else through the attached gloo back-end. te_gmg_autotune's own check (result identical to the
     other transport's after a cycle on different data) must pass, and apply / cycle / BiCGStab / apply equal the single-rank
@@ -435,7 +436,7 @@ def test_two_processes_direct_store_transport(n, divides):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, TE_PUSH_TIMEOUT="30")
     for k in ("TE_OVERLAP_MIN", "TE_OVERLAP_MODE"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
            "127.0.0.1", "--master-port", port, os.path.join(root, "tests", "mr_worker.py"), "--backend", "gloo", "--push",
            "--cells", str(n), "--divides", str(divides)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
