@@ -167,7 +167,7 @@ int te_patch_apply(te_gmg *g, int level, const te_vec *u, te_vec *f);
 int te_residual(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *r);
 /* the same with ||r||^2 (this rank's part; Vector.h:294 twoNorm before its MPI_Allreduce and sqrt) summed by the residual
  * kernel itself while r is in registers: per thread in plane order, then wave shuffles -> LDS -> one partial per workgroup
- * -> a fixed-order final pass. No second pass over r (3D; 2D runs the two kernels). */
+ * -> a fixed-order final pass. No second pass over r (3D and 2D). */
 int te_residual_norm_sq(te_gmg *g, int level, const te_vec *u, const te_vec *f, te_vec *r, double *norm_sq);
 /* GMG::Smoother<D>::smooth(f, u) (GMG/Smoother.h:39), `sweeps` times */
 int te_smooth(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, double omega,

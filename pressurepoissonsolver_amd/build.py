@@ -31,26 +31,46 @@ def hipcc():
     raise RuntimeError("hipcc not found: the product library cannot be built")
 
 
+# translation units of libte_hip.so (gmg_internal.hpp says what lives where); compiled in parallel, one object file each
+UNITS = ("gmg_core.hip", "gmg_transport.hip", "gmg_launch3d.hip", "gmg_fused3d.hip", "gmg_patchsolve.hip", "gmg_launch2d.hip", "gmg_cycle.hip", "gmg_krylov.hip", "capi_mesh.cpp", "mesh.cpp")
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-function"]
+
+
+def _compile_link(out, defines=()):
+    """every unit to an object file under csrc/../build/<library name>/ (as many at once as there are CPUs), then one link"""
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(ROOT, "pressurepoissonsolver_amd", "build", os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(objdir, exist_ok=True)
+    cc = hipcc()
+
+    def one(unit):
+        obj = os.path.join(objdir, os.path.splitext(unit)[0] + ".o")
+        cmd = [cc] + CFLAGS + list(defines) + ["-c", "-x", "hip", os.path.join(CSRC, unit), "-o", obj]
+        print("+", " ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{unit}: hipcc failed\n{r.stderr[-4000:]}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(one, UNITS))
+    _run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-soname," + os.path.basename(out)] + objs + ["-o", out])
+    return out
+
+
 def build_hip(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("gmg.hip", "capi_mesh.cpp", "mesh.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in UNITS]
     deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     deps.append(os.path.join(ROOT, "include", "te_hip.h"))
     if not force and not _newer(LIB_HIP, deps):
         return LIB_HIP
-    _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-          "-Wno-unused-result", "-Wl,-soname,libte_hip.so", "-x", "hip", srcs[0], "-x", "hip", srcs[1], "-x", "hip", srcs[2],
-          "-o", LIB_HIP])
-    return LIB_HIP
+    return _compile_link(LIB_HIP)
 
 
 def build_variant(name, defines):
     """tooling: a second library with other compile-time switches (e.g. build_variant("noskew", ["-DTE_LDS_SKEW=0"])) for
     same-box A/B runs: TE_HIP_LIB_PATH=<returned path> python tools/variant_bench.py ..."""
-    out = os.path.join(ROOT, "pressurepoissonsolver_amd", f"libte_hip_{name}.so")
-    srcs = [os.path.join(CSRC, f) for f in ("gmg.hip", "capi_mesh.cpp", "mesh.cpp")]
-    _run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result"] + list(defines)
-         + ["-Wl,-soname," + os.path.basename(out), "-x", "hip", srcs[0], "-x", "hip", srcs[1], "-x", "hip", srcs[2], "-o", out])
-    return out
+    return _compile_link(os.path.join(ROOT, "pressurepoissonsolver_amd", f"libte_hip_{name}.so"), defines)
 
 
 def build_all(force=False):

@@ -1,4 +1,4 @@
-// Shared between capi_mesh.cpp (host only) and gmg.hip (device): handle structs + error slot.
+// Shared between capi_mesh.cpp (host only) and gmg_*.hip (device): handle structs + error slot.
 #pragma once
 #include "../../include/te_hip.h"
 #include "mesh.hpp"

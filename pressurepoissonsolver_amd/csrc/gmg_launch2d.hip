@@ -1,0 +1,315 @@
+// The 2D twins of the kernel launches (see gmg_internal.hpp).
+#include "gmg_internal.hpp"
+
+namespace tei
+{
+// ------------------------------------------------------------------------------ 2D launches
+int prepareGhosts2d(te_gmg *g, LevelHost &L, const double *u)
+{
+	if (L.patch_local) return TE_OK;
+	if (L.nremote > 0) {
+		{
+			Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
+			hipLaunchKernelGGL(k_pack_faces2d, dim3(L.nremote), dim3(64), 0, g->stream, L.n, L.send_faces.p, u, L.sendbuf.p);
+		}
+		int rc = faceExchange(g, L, L.sendbuf.p);
+		if (rc) return rc;
+	}
+	if (L.ncf == 0) return TE_OK;
+	Timed t(g, KC_CFGHOST, (size_t) L.ncf * L.nf);
+	hipLaunchKernelGGL(k_cf_ghost2d, dim3(L.ncf), dim3(64), 0, g->stream, L.n, L.cf_desc.p, L.cf_slots.p, u, L.ghostCur());
+	return TE_OK;
+}
+
+template <int MODE> int launchStencil2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega)
+{
+	int rc = prepareGhosts2d(g, L, u);
+	if (rc) return rc;
+	Timed t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : KC_JACOBI), (size_t) L.P * L.nc);
+	hipLaunchKernelGGL(k_stencil2d<MODE>, dim3(gridFor((size_t) L.P * L.nc / 2, 256, 65536)), dim3(256), 0, g->stream, L.dev2(),
+	                   u, f, out, omega);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
+// r = f - A u together with the partial sums of its squares, one per workgroup, in g->partial (*blocks of them): the residual norm
+// without a second pass over r (the 2D twin of k_stencil3d's RED_OUT_OUT)
+int residualSumsq2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, int *blocks)
+{
+	int rc = prepareGhosts2d(g, L, u);
+	if (rc) return rc;
+	*blocks = gridFor((size_t) L.P * L.nc / 2, 256, (int) std::min<size_t>((size_t) g->red_blocks, g->partial.n));
+	Timed t(g, KC_RESID, (size_t) L.P * L.nc);
+	hipLaunchKernelGGL((k_stencil2d<MODE_RESID, true>), dim3(*blocks), dim3(256), 0, g->stream, L.dev2(), u, f, out, 0.0, g->partial.p);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
+// 64^2 patches: 512 threads per workgroup (four x-pairs per thread instead of eight: half the registers, twice the waves per
+// CU at the same four resident patches)
+static int tpb2d(const te_gmg *g) { return g->cfg.num(O_2D_TPB, 512) == 256 ? 256 : 512; }
+
+// faces of u + P(coarse) for the neighbours on other ranks (u: the stored iterate, or e4: only its edge layers exist), and
+// their values into this rank's ghost slots
+int packProlongFaces2d(te_gmg *g, LevelHost &L, const double *u, const double *e4, const Prolong2D &ps)
+{
+	if (L.nremote == 0 || L.patch_local) return TE_OK;
+	{
+		Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
+		hipLaunchKernelGGL(k_pack_faces_prolong2d, dim3(L.nremote), dim3(64), 0, g->stream, L.n, L.send_faces.p, u, e4, ps, L.sendbuf.p);
+	}
+	return faceExchange(g, L, L.sendbuf.p);
+}
+
+// zero_guess: levels with L.lds2d; prolong_from: levels with L.fuse2d && L.prolong_fusable (the caller checks)
+int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess, const double *prolong_from)
+{
+	int rc;
+	if (!zero_guess && !prolong_from && (rc = prepareGhosts2d(g, L, u))) return rc;
+	if (prolong_from && (rc = packProlongFaces2d(g, L, u, nullptr, Prolong2D{L.parent.p, L.orth.p, prolong_from}))) return rc;
+	if (L.P == 0) return TE_OK;
+	if (L.n <= 64 && !g->cfg.has(O_2D_SIMPLE)) { // the patch and its halo ring fit in LDS: one pass
+		const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
+		Prolong2D    ps{L.parent.p, L.orth.p, prolong_from};
+		Timed        t(g, zero_guess ? KC_RBGS_ZERO : (prolong_from ? KC_RBGS_PROLONG : KC_RBGS), (size_t) L.P * L.nc, true);
+#define TE_RB2(Z, PR)                                                                                                          \
+	if (L.n == 64 && tpb2d(g) == 512)                                                                                           \
+		launchT(t, (k_rbgs2d_lds<Z, PR, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), u, f, out, ps);     \
+	else if (L.n == 64)                                                                                                        \
+		launchT(t, (k_rbgs2d_lds<Z, PR, 64>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps);          \
+	else                                                                                                                       \
+		launchT(t, (k_rbgs2d_lds<Z, PR, 0>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f, out, ps)
+		if (zero_guess)
+			TE_RB2(true, false);
+		else if (prolong_from)
+			TE_RB2(false, true);
+		else
+			TE_RB2(false, false);
+#undef TE_RB2
+		HIPCHK(hipGetLastError());
+		return TE_OK;
+	}
+	if (zero_guess || prolong_from) return te::fail(TE_ESTATE, "launchRbgs2d: fused variants need patches that fit in LDS");
+	Timed      t(g, KC_RBGS, (size_t) L.P * L.nc);
+	const dim3 grid(gridFor((size_t) L.P * L.nc, 256, 65536));
+	hipLaunchKernelGGL(k_rbgs2d<0>, grid, dim3(256), 0, g->stream, L.dev2(), u, f, out);
+	hipLaunchKernelGGL(k_rbgs2d<1>, grid, dim3(256), 0, g->stream, L.dev2(), u, f, out);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
+// coarse f = AvgRstr(f - A u) in one pass (levels with L.fuse2d)
+int residRestrict2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse)
+{
+	if (L.P == 0) return TE_OK; // a rank without patches on this level (fuse2d: it has no transfers either)
+	int rc = prepareGhosts2d(g, L, u);
+	if (rc) return rc;
+	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
+	Timed        t(g, KC_RESID_RESTRICT, (size_t) L.P * L.nc);
+	hipLaunchKernelGGL(k_resid_restrict2d_lds, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f,
+	                   Prolong2D{L.parent.p, L.orth.p, nullptr}, coarse);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
+// *swapped: the result went to s1 (= L.t) instead of u: the caller exchanges the two vectors' buffers
+int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1, bool zero_guess, bool *swapped)
+{
+	*swapped = false;
+	int          rc;
+	const size_t total = (size_t) L.P * L.nc;
+	if (L.n == 64 && L.matsT.p && !g->cfg.has(O_2D_SIMPLE) && !g->cfg.has(O_2D_NO_MFMA)) { // 64^2 patches: the four products on the matrix cores
+		if (!zero_guess && (rc = prepareGhosts2d(g, L, u))) return rc;
+		const size_t lds = sizeof(double) * 64 * PS2D_LD;
+		bool        &attr = g->ps2d_attr;
+		const bool   pf = L.P <= 256 && !g->cfg.has(O_2D_NO_PF); // few patches: a workgroup has its CU to itself anyway
+		Timed        t(g, KC_PS_MFMA, total, true);
+		auto         launch = [&](auto kern) -> int {
+            launchT(t, kern, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.matsT.p, L.lam.p, L.zero_mode.p, f, u, s1);
+            return TE_OK;
+		};
+		if (!attr) { // all four once, so that the attribute is set whichever runs first
+			const void *ks[4] = {reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, false>),
+			                     reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, false>)};
+			for (const void *k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+			attr = true;
+		}
+		if (zero_guess)
+			rc = pf ? launch(k_patch_solve2d_mfma<true, true>) : launch(k_patch_solve2d_mfma<true, false>);
+		else
+			rc = pf ? launch(k_patch_solve2d_mfma<false, true>) : launch(k_patch_solve2d_mfma<false, false>);
+		if (rc) return rc;
+		HIPCHK(hipGetLastError());
+		*swapped = true;
+		return TE_OK;
+	}
+	if (L.n <= 64 && L.matsT.p && !g->cfg.has(O_2D_SIMPLE)) { // one launch, the patch in LDS
+		if (!zero_guess && (rc = prepareGhosts2d(g, L, u))) return rc;
+		const size_t lds = sizeof(double) * 2 * L.nc;
+		Timed        t(g, KC_PS_MFMA, total);
+#define TE_PS2(Z, NC, T)                                                                                                     \
+	hipLaunchKernelGGL((k_patch_solve2d_lds<Z, NC, T>), dim3(L.P), dim3(T), lds, g->stream, L.dev2(), L.plan.p, L.mats.p, \
+	                   L.matsT.p, L.lam.p, L.zero_mode.p, f, u, s1)
+		const bool wide = L.n == 64 && L.P <= 128; // few patches: sixteen waves per patch
+		if (zero_guess) {
+			if (wide)
+				TE_PS2(true, 64, 1024);
+			else if (L.n == 64)
+				TE_PS2(true, 64, 256);
+			else
+				TE_PS2(true, 0, 256);
+		} else {
+			if (wide)
+				TE_PS2(false, 64, 1024);
+			else if (L.n == 64)
+				TE_PS2(false, 64, 256);
+			else
+				TE_PS2(false, 0, 256);
+		}
+#undef TE_PS2
+		HIPCHK(hipGetLastError());
+		*swapped = true;
+		return TE_OK;
+	}
+	if (zero_guess) {
+		Timed t(g, KC_VECOP, total);
+		HIPCHK(hipMemsetAsync(u, 0, sizeof(double) * total, g->stream));
+	}
+	if ((rc = prepareGhosts2d(g, L, u))) return rc;
+	const dim3   grid(gridFor(total, 256, 65536)), blk(256);
+	{
+		Timed t(g, KC_PATCH_RHS, total);
+		hipLaunchKernelGGL(k_patch_rhs2d, grid, blk, 0, g->stream, L.dev2(), u, f, s0);
+	}
+	const bool mfma2d = L.n % 16 == 0 && !g->cfg.has(O_2D_SIMPLE); // large patches: the passes on the matrix cores
+	const dim3 gridm(((size_t) L.P * (L.n / 16) * (L.n / 16) + 3) / 4);
+#define TE_DST2(STAGE, IN, OUT)                                                                                          \
+	{                                                                                                                    \
+		Timed t(g, KC_DST, total);                                                                                       \
+		if (mfma2d)                                                                                                      \
+			hipLaunchKernelGGL(k_dst_axis2d_mfma<STAGE>, gridm, blk, 0, g->stream, L.n, L.P, L.plan.p, L.mats.p, L.lam.p, \
+			                   L.zero_mode.p, L.rh2.p, IN, OUT);                                                         \
+		else                                                                                                             \
+			hipLaunchKernelGGL(k_dst_axis2d<STAGE>, grid, blk, 0, g->stream, L.n, L.P, L.plan.p, L.mats.p, L.lam.p,      \
+			                   L.zero_mode.p, L.rh2.p, IN, OUT);                                                         \
+	}
+	TE_DST2(0, s0, s1)
+	TE_DST2(1, s1, s0)
+	TE_DST2(2, s0, s1)
+	TE_DST2(3, s1, u)
+#undef TE_DST2
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
+int restrict2d(te_gmg *g, LevelHost &L, const double *fine, double *coarse)
+{
+	if (L.n_up > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_up * L.nc / 4);
+		hipLaunchKernelGGL(k_restrict_pack2d, dim3(L.n_up), dim3(256), 0, g->stream, L.n, L.up_desc.p, L.up_off.p, fine, L.upbuf.p);
+	}
+	int rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p);
+	if (rc) return rc;
+	if (L.Pc == 0) return TE_OK;
+	Timed t(g, KC_RESTRICT, (size_t) L.P * L.nc);
+	hipLaunchKernelGGL(k_restrict2d, dim3(gridFor((size_t) L.Pc * L.nc, 256, 65536)), dim3(256), 0, g->stream, L.n, L.Pc,
+	                   L.child.p, L.copy.p, fine, L.downbuf.p, L.down_off.p, coarse);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
+int prolong2d(te_gmg *g, LevelHost &L, const double *coarse, double *fine)
+{
+	if (L.n_down > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 4);
+		hipLaunchKernelGGL(k_prolong_pack2d, dim3(L.n_down), dim3(256), 0, g->stream, L.n, L.down_desc.p, L.down_off.p, coarse,
+		                   L.downbuf.p);
+	}
+	int rc = doExchange(g, 3, L.tx_down, L.downbuf.p, L.upbuf.p);
+	if (rc) return rc;
+	if (L.P == 0) return TE_OK;
+	Timed t(g, KC_PROLONG, (size_t) L.P * L.nc);
+	hipLaunchKernelGGL(k_prolong2d, dim3(gridFor((size_t) L.P * L.nc, 256, 65536)), dim3(256), 0, g->stream, L.n, L.P, L.parent.p,
+	                   L.orth.p, coarse, L.upbuf.p, L.up_off.p, fine);
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
+// opts.fuse = 2 / 3 in 2D (levels with L.fuse2_ok: patches in LDS, every parent and neighbour local): see kernels2d.hpp
+int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, bool store_u)
+{
+	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
+	Prolong2D    dst{L.parent.p, L.orth.p, nullptr};
+	int          rc;
+	if (L.P > 0) {
+		Timed t(g, store_u ? KC_ZERO_RESID : KC_ZERO_RESID_FACES, (size_t) L.P * L.nc, true);
+#define TE_ZR2(S, NC)                                                                                                             \
+	launchT(t, (k_rbgs_zero_resid2d_lds<S, NC>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, \
+	                   coarse, L.upbuf.p, L.up_off.p)
+		if (L.n == 64 && tpb2d(g) == 512) {
+			if (store_u)
+				launchT(t, (k_rbgs_zero_resid2d_lds<true, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst,
+				                   coarse, L.upbuf.p, L.up_off.p);
+			else
+				launchT(t, (k_rbgs_zero_resid2d_lds<false, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst,
+				                   coarse, L.upbuf.p, L.up_off.p);
+		} else if (store_u && L.n == 64)
+			TE_ZR2(true, 64);
+		else if (store_u)
+			TE_ZR2(true, 0);
+		else if (L.n == 64)
+			TE_ZR2(false, 64);
+		else
+			TE_ZR2(false, 0);
+#undef TE_ZR2
+	}
+	if (L.nremote > 0) { // the new edge layers of neighbours on other ranks
+		{
+			Timed t(g, KC_PACK, (size_t) L.nremote * L.nf);
+			if (store_u)
+				hipLaunchKernelGGL(k_pack_faces2d, dim3(L.nremote), dim3(64), 0, g->stream, L.n, L.send_faces.p, out, L.sendbuf.p);
+			else
+				hipLaunchKernelGGL(k_pack_edges2d, dim3(L.nremote), dim3(64), 0, g->stream, L.n, L.send_faces.p, L.e4buf.p, L.sendbuf.p);
+		}
+		if ((rc = faceExchange(g, L, L.sendbuf.p))) return rc;
+	}
+	if (L.P > 0) {
+		Timed t(g, KC_FIXUP, (size_t) L.P * 4 * L.nf);
+		hipLaunchKernelGGL(k_restrict_fixup2d, dim3(L.P), dim3(128), 0, g->stream, L.dev2(), out,
+		                   store_u ? (const double *) nullptr : (const double *) L.e4buf.p, dst, coarse, L.upbuf.p, L.up_off.p);
+	}
+	// children whose parent lives on another rank: ship the finished blocks
+	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
+	if (L.n_down > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 4);
+		hipLaunchKernelGGL(k_restrict_unpack2d, dim3(L.n_down), dim3(256), 0, g->stream, L.n, L.down_desc.p, L.down_off.p, L.downbuf.p, coarse);
+	}
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
+int resweepProlong2d(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from)
+{
+	int rc = packProlongFaces2d(g, L, nullptr, L.e4buf.p, Prolong2D{L.parent.p, L.orth.p, prolong_from});
+	if (rc) return rc;
+	if (L.P == 0) return TE_OK;
+	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
+	Timed        t(g, KC_RESWEEP, (size_t) L.P * L.nc, true);
+	if (L.n == 64 && tpb2d(g) == 512)
+		launchT(t, (k_rbgs_resweep_prolong2d_lds<64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
+		                   Prolong2D{L.parent.p, L.orth.p, prolong_from});
+	else if (L.n == 64)
+		launchT(t, k_rbgs_resweep_prolong2d_lds<64>, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
+		                   Prolong2D{L.parent.p, L.orth.p, prolong_from});
+	else
+		launchT(t, k_rbgs_resweep_prolong2d_lds<0>, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, L.e4buf.p, out,
+		                   Prolong2D{L.parent.p, L.orth.p, prolong_from});
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
+template int launchStencil2d<MODE_APPLY>(te_gmg *, LevelHost &, const double *, const double *, double *, double);
+template int launchStencil2d<MODE_RESID>(te_gmg *, LevelHost &, const double *, const double *, double *, double);
+template int launchStencil2d<MODE_JACOBI>(te_gmg *, LevelHost &, const double *, const double *, double *, double);
+} // namespace tei
+

@@ -141,7 +141,7 @@ template <int PROB, bool NEUMANN> __global__ __launch_bounds__(256) void k_init2
 }
 // f ~ U(-1, 1): element k of patch p = splitmix64 output number k+1 of the stream seeded with seed + node id (the same
 // integers and the same exact conversion as problems.random_rhs: bit-identical, mesh-order independent)
-__global__ __launch_bounds__(256) void k_init_random(InitGeom G, size_t nc, uint64_t seed, double *__restrict__ f, double *__restrict__ exact)
+static __global__ __launch_bounds__(256) void k_init_random(InitGeom G, size_t nc, uint64_t seed, double *__restrict__ f, double *__restrict__ exact)
 {
 	const size_t total = nc * G.P;
 	for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t) gridDim.x * 256) {

@@ -60,12 +60,16 @@ __device__ __forceinline__ double offdiag2d(double xl, double xr, double yl, dou
 }
 
 // MODE_APPLY / MODE_RESID / MODE_JACOBI as in k_stencil3d
-template <int MODE>
+// SUMSQ (te_residual_norm_sq, Vector.h:294 twoNorm before its MPI_Allreduce and sqrt): the sum of the squares of the result is formed
+// while it is in registers -- per thread in the order of its grid-stride loop, then wave shuffles -> LDS -> one partial per
+// workgroup in partial[blockIdx.x]; the caller's k_reduce_final adds those in a fixed order (a fixed grid: deterministic).
+template <int MODE, bool SUMSQ = false>
 __global__ __launch_bounds__(256) void k_stencil2d(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
-                                                   double *__restrict__ out, double omega)
+                                                   double *__restrict__ out, double omega, double *__restrict__ partial = nullptr)
 {
 	const int    n = L.n, h = n / 2;
 	const size_t total = (size_t) L.P * n * h;
+	double       ssq   = 0.0;
 	for (size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t) gridDim.x * blockDim.x) {
 		const int     p = (int) (idx / ((size_t) n * h)), q = (int) (idx % ((size_t) n * h));
 		const int     y = q / h, x = 2 * (q % h);
@@ -103,6 +107,14 @@ __global__ __launch_bounds__(256) void k_stencil2d(Level2D L, const double *__re
 			}
 		}
 		*reinterpret_cast<double2 *>(out + (size_t) p * n * n + x + n * y) = r;
+		if (SUMSQ) {
+			ssq += r.x * r.x;
+			ssq += r.y * r.y;
+		}
+	}
+	if (SUMSQ) {
+		ssq = blockReduce<RED_SUMSQ>(ssq);
+		if (threadIdx.x == 0) partial[blockIdx.x] = ssq;
 	}
 }
 
@@ -152,7 +164,7 @@ __device__ __forceinline__ double coarseAt2d(const Prolong2D &ps, int n, int p, 
 // fine patch loads u and its ghost ring, each thread forms the four residuals of a coarse cell and adds
 // them in AvgRstr's order (restrictCell2d): bit-identical to k_stencil2d<MODE_RESID> + k_restrict2d,
 // 18 B per site (read u, f; write 1/4) instead of 34. Parents are local (checked by the host).
-__global__ __launch_bounds__(256) void k_resid_restrict2d_lds(Level2D L, const double *__restrict__ u,
+static __global__ __launch_bounds__(256) void k_resid_restrict2d_lds(Level2D L, const double *__restrict__ u,
                                                               const double *__restrict__ f, Prolong2D dst /* coarse = coarse f (written) */,
                                                               double *__restrict__ coarse)
 {
@@ -531,7 +543,7 @@ __global__ __launch_bounds__(TPB) void k_rbgs_zero_resid2d_lds(Level2D L, const 
 // values behind a pair of face cells) is added to the coarse cell behind the pair; faces in the order W,E,S,N.
 // edges = e4 of the new iterate, or null: read them from u.
 // A neighbour on another rank: its edge arrived in a ghost slot. A parent on another rank: the block in `remote`.
-__global__ __launch_bounds__(128) void k_restrict_fixup2d(Level2D L, const double *__restrict__ u, const double *__restrict__ e4,
+static __global__ __launch_bounds__(128) void k_restrict_fixup2d(Level2D L, const double *__restrict__ u, const double *__restrict__ e4,
                                                           Prolong2D dst, double *__restrict__ coarse, double *__restrict__ remote,
                                                           const int64_t *__restrict__ remote_off)
 {
@@ -578,13 +590,13 @@ __global__ __launch_bounds__(128) void k_restrict_fixup2d(Level2D L, const doubl
 	}
 }
 // the edge layers other ranks need, from e4 (the iterate itself was never stored)
-__global__ void k_pack_edges2d(int n, const int32_t *__restrict__ faces, const double *__restrict__ e4, double *__restrict__ sendbuf)
+static __global__ void k_pack_edges2d(int n, const int32_t *__restrict__ faces, const double *__restrict__ e4, double *__restrict__ sendbuf)
 {
 	const int p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
 	for (int i = threadIdx.x; i < n; i += blockDim.x) sendbuf[(size_t) blockIdx.x * n + i] = e4[((size_t) p * 4 + s) * n + i];
 }
 // restricted blocks that arrived from children on other ranks: into their quadrant of the coarse patch (as k_restrict_unpack3d)
-__global__ __launch_bounds__(256) void k_restrict_unpack2d(int n, const int32_t *__restrict__ desc, const int64_t *__restrict__ off,
+static __global__ __launch_bounds__(256) void k_restrict_unpack2d(int n, const int32_t *__restrict__ desc, const int64_t *__restrict__ off,
                                                            const double *__restrict__ buf, double *__restrict__ coarse)
 {
 	const int     nn = n * n, h = n / 2;
@@ -648,7 +660,7 @@ __global__ __launch_bounds__(TPB) void k_rbgs_resweep_prolong2d_lds(Level2D L, c
 
 // ghost slots of coarse/fine faces: 2*gamma - m, weights of BilinearInterpolator.cpp:76-115.
 // desc[8] = {patch, side, kind (2 = my neighbour is coarser, 3 = finer), half of the coarse face, nbr0, nbr1, -, -}
-__global__ void k_cf_ghost2d(int n, const int32_t *__restrict__ desc, const int32_t *__restrict__ slots,
+static __global__ void k_cf_ghost2d(int n, const int32_t *__restrict__ desc, const int32_t *__restrict__ slots,
                              const double *__restrict__ u, double *__restrict__ ghost)
 {
 	const int32_t *d = desc + (size_t) blockIdx.x * 8;
@@ -677,7 +689,7 @@ __global__ void k_cf_ghost2d(int n, const int32_t *__restrict__ desc, const int3
 	}
 }
 
-__global__ void k_pack_faces2d(int n, const int32_t *__restrict__ faces, const double *__restrict__ u,
+static __global__ void k_pack_faces2d(int n, const int32_t *__restrict__ faces, const double *__restrict__ u,
                                double *__restrict__ sendbuf)
 {
 	const int     p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
@@ -689,7 +701,7 @@ __global__ void k_pack_faces2d(int n, const int32_t *__restrict__ faces, const d
 
 // the facing values of u + P(coarse) -- u stored, or (e4 != null) only its edge layers -- for neighbours on other ranks: the
 // sums a local neighbour would form itself (k_rbgs2d_lds<false, true>, k_rbgs_resweep_prolong2d_lds), same operands, same order
-__global__ void k_pack_faces_prolong2d(int n, const int32_t *__restrict__ faces, const double *__restrict__ u, const double *__restrict__ e4,
+static __global__ void k_pack_faces_prolong2d(int n, const int32_t *__restrict__ faces, const double *__restrict__ u, const double *__restrict__ e4,
                                        Prolong2D ps, double *__restrict__ sendbuf)
 {
 	const int p = faces[2 * blockIdx.x], s = faces[2 * blockIdx.x + 1];
@@ -710,7 +722,7 @@ __device__ __forceinline__ double restrictCell2d(const double *fp, int n, int hx
 	acc += fp[2 * hx + 1 + n * (2 * hy + 1)] / 4;
 	return acc;
 }
-__global__ __launch_bounds__(256) void k_restrict2d(int n, int Pc, const int32_t *__restrict__ child,
+static __global__ __launch_bounds__(256) void k_restrict2d(int n, int Pc, const int32_t *__restrict__ child,
                                                     const int32_t *__restrict__ copy, const double *__restrict__ fine,
                                                     const double *__restrict__ remote, const int64_t *__restrict__ remote_off,
                                                     double *__restrict__ coarse)
@@ -729,7 +741,7 @@ __global__ __launch_bounds__(256) void k_restrict2d(int n, int Pc, const int32_t
 		coarse[idx]   = (src >= 0) ? restrictCell2d(fine + (size_t) src * nn, n, hx, hy) : remote[remote_off[-(src + 2)] + hx + h * hy];
 	}
 }
-__global__ __launch_bounds__(256) void k_restrict_pack2d(int n, const int32_t *__restrict__ desc, const int64_t *__restrict__ off,
+static __global__ __launch_bounds__(256) void k_restrict_pack2d(int n, const int32_t *__restrict__ desc, const int64_t *__restrict__ off,
                                                          const double *__restrict__ fine, double *__restrict__ buf)
 {
 	const int     nn = n * n, h = n / 2;
@@ -741,7 +753,7 @@ __global__ __launch_bounds__(256) void k_restrict_pack2d(int n, const int32_t *_
 	else
 		for (int i = threadIdx.x; i < h * h; i += blockDim.x) b[i] = restrictCell2d(fp, n, i % h, i / h);
 }
-__global__ __launch_bounds__(256) void k_prolong2d(int n, int Pf, const int32_t *__restrict__ parent,
+static __global__ __launch_bounds__(256) void k_prolong2d(int n, int Pf, const int32_t *__restrict__ parent,
                                                    const int32_t *__restrict__ orth, const double *__restrict__ coarse,
                                                    const double *__restrict__ remote, const int64_t *__restrict__ remote_off,
                                                    double *__restrict__ fine)
@@ -763,7 +775,7 @@ __global__ __launch_bounds__(256) void k_prolong2d(int n, int Pf, const int32_t 
 		fine[idx] += cv;
 	}
 }
-__global__ __launch_bounds__(256) void k_prolong_pack2d(int n, const int32_t *__restrict__ desc, const int64_t *__restrict__ off,
+static __global__ __launch_bounds__(256) void k_prolong_pack2d(int n, const int32_t *__restrict__ desc, const int64_t *__restrict__ off,
                                                         const double *__restrict__ coarse, double *__restrict__ buf)
 {
 	const int     nn = n * n, h = n / 2;
@@ -779,7 +791,7 @@ __global__ __launch_bounds__(256) void k_prolong_pack2d(int n, const int32_t *__
 }
 
 // ---- reference block-Jacobi patch solve in 2D (FftwPatchSolver<2>): rhs, then 4 dense transform passes
-__global__ __launch_bounds__(256) void k_patch_rhs2d(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
+static __global__ __launch_bounds__(256) void k_patch_rhs2d(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
                                                      double *__restrict__ rhs)
 {
 	const int    n = L.n, nn = n * n;

@@ -53,7 +53,7 @@ struct LevelDev {
 	double       *f6_out;
 	// where face layer (p, s) sits inside f6 / f6_out, in units of N*N doubles (null: at p * 6 + s). A level cut by rank
 	// boundaries keeps the layers that travel to other ranks first, in send order: the exchange sends them from where
-	// they are and no pack kernel runs (gmg.hip buildLevel)
+	// they are and no pack kernel runs (gmg_core.hip buildLevel)
 	const int32_t *f6off;
 	// ghost terms that still belong to this level's right-hand side (march3d.hpp FCorrSrc), or null
 	const double *fcorr;
@@ -680,7 +680,7 @@ __device__ __forceinline__ void blockReduce2(double &a, double &b)
 		}
 	}
 }
-__global__ __launch_bounds__(256) void k_reduce_final2(int nparts, const double *__restrict__ partial, double *__restrict__ result)
+static __global__ __launch_bounds__(256) void k_reduce_final2(int nparts, const double *__restrict__ partial, double *__restrict__ result)
 {
 	double a = 0.0, b = 0.0;
 	for (int i = threadIdx.x; i < nparts; i += blockDim.x) {
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void k_reduce_final2(int nparts, const double 
 // Domain::integrate (Domain.h:258-278): per patch, the sum of its cells times the cell volume; one workgroup per
 // patch (cells summed in a fixed order), the per-patch values are added on the host in patch order.
 // vol[p] = product of the patch's spacings.
-__global__ __launch_bounds__(256) void k_patch_integrals(int nc, const double *__restrict__ v, const double *__restrict__ vol,
+static __global__ __launch_bounds__(256) void k_patch_integrals(int nc, const double *__restrict__ v, const double *__restrict__ vol,
                                                          double *__restrict__ out)
 {
 	const double *p = v + (size_t) blockIdx.x * nc;
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(256) void k_patch_integrals(int nc, const double *_
 }
 
 // s = resid; s += ap * (-alpha)          (BiCGStab.h:79-80)
-__global__ __launch_bounds__(256) void k_bicg_s(size_t n2, double2 *__restrict__ s, const double2 *__restrict__ resid,
+static __global__ __launch_bounds__(256) void k_bicg_s(size_t n2, double2 *__restrict__ s, const double2 *__restrict__ resid,
                                                 const double2 *__restrict__ ap, double malpha)
 {
 	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void k_bicg_s(size_t n2, double2 *__restrict__
 	s[i]            = double2{__builtin_fma(a.x, malpha, r.x), __builtin_fma(a.y, malpha, r.y)}; // (as march3d.hpp fsrcCombine<1>)
 }
 // (as . s, as . as)                      (BiCGStab.h:87)
-__global__ __launch_bounds__(256) void k_bicg_omega(size_t n2, const double2 *__restrict__ as, const double2 *__restrict__ s,
+static __global__ __launch_bounds__(256) void k_bicg_omega(size_t n2, const double2 *__restrict__ as, const double2 *__restrict__ s,
                                                     double *__restrict__ partial)
 {
 	double d0 = 0.0, d1 = 0.0;
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(256) void k_bicg_omega(size_t n2, const double2 *__
 	}
 }
 // x += mp*alpha + ms*omega; resid += ap*(-alpha) + as*(-omega); (resid . rhat, resid . resid)   (BiCGStab.h:90-97,71)
-__global__ __launch_bounds__(256) void k_bicg_update(size_t n2, double2 *__restrict__ x, double2 *__restrict__ resid,
+static __global__ __launch_bounds__(256) void k_bicg_update(size_t n2, double2 *__restrict__ x, double2 *__restrict__ resid,
                                                      const double2 *__restrict__ mp, const double2 *__restrict__ ms,
                                                      const double2 *__restrict__ ap, const double2 *__restrict__ as,
                                                      const double2 *__restrict__ rhat, double alpha, double omega,
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void k_bicg_update(size_t n2, double2 *__restr
 	}
 }
 // p += ap*(-omega); p = beta*p + resid      (BiCGStab.h:99-100)
-__global__ __launch_bounds__(256) void k_bicg_p(size_t n2, double2 *__restrict__ p, const double2 *__restrict__ ap,
+static __global__ __launch_bounds__(256) void k_bicg_p(size_t n2, double2 *__restrict__ p, const double2 *__restrict__ ap,
                                                 const double2 *__restrict__ resid, double momega, double beta)
 {
 	const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;

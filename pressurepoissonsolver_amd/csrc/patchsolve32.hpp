@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict_
 
 // lam: [nplans][3][32] = 4 sin^2(.), eigenvalue = -(lam_x rh2x + lam_y rh2y + lam_z rh2z)
 // (FftwPatchSolver.h:143-168). One wave = one x-row (fixed y) of a patch, all z.
-__global__ __launch_bounds__(256) void k_ps_z(int P, const int32_t *__restrict__ plan, const double *__restrict__ mats,
+static __global__ __launch_bounds__(256) void k_ps_z(int P, const int32_t *__restrict__ plan, const double *__restrict__ mats,
                                               const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
                                               const double *__restrict__ rh2, const double *__restrict__ in,
                                               double *__restrict__ out)

@@ -11,7 +11,7 @@
 // coherent across agents without a kernel boundary). The waiting kernel polls its own flag with system-scope acquire loads,
 // fences, and ends; the kernels that read the received data start after it on the same stream (kernel boundary = acquire).
 // Receive buffers are double buffered by the parity of the exchange count, which is what lets a rank run at most one exchange
-// ahead of a peer without a credit message (gmg.hip pushExchange). A wait is bounded: after `budget` ticks of the 100 MHz wall
+// ahead of a peer without a credit message (gmg_transport.hip pushExchange). A wait is bounded: after `budget` ticks of the 100 MHz wall
 // clock it sets *err and returns, and every later push / wait of the solver returns at once -- the host turns that into an error
 // (or, inside te_gmg_autotune, into "this transport is not usable here").
 #pragma once
@@ -31,7 +31,7 @@ struct PushPlan {
 	int      n;
 };
 // grid (blocks per peer, peers); even counts and 16-byte aligned ranges (face layers and blocks are multiples of 16 doubles)
-__global__ __launch_bounds__(256) void k_push_ranges(const double *__restrict__ src, PushPlan plan, unsigned long long epoch, unsigned *done,
+static __global__ __launch_bounds__(256) void k_push_ranges(const double *__restrict__ src, PushPlan plan, unsigned long long epoch, unsigned *done,
                                                      const int *__restrict__ err)
 {
 	if (*err) return;
@@ -60,7 +60,7 @@ struct PushWait {
 };
 // err: this solver's error word in device memory (what the kernels test); err_host: the same in pinned host memory, written
 // only when a wait gives up (what the host's watchdog reads without touching the device)
-__global__ __launch_bounds__(64) void k_push_wait(PushWait w, unsigned long long epoch, long long budget, int *err, int *err_host)
+static __global__ __launch_bounds__(64) void k_push_wait(PushWait w, unsigned long long epoch, long long budget, int *err, int *err_host)
 {
 	const int k = threadIdx.x;
 	if (k < w.n && !*err) {

@@ -56,7 +56,7 @@ def test_product_never_imports_oracle():
 
 def test_no_getenv_on_launch_paths():
     """the TE_* switches are read once (te_gmg_create -> Cfg::fromEnv; te_hier_build for the partition), never per launch"""
-    src = open(os.path.join(ROOT, "pressurepoissonsolver_amd", "csrc", "gmg.hip")).read()
+    src = _device_sources()
     calls = [ln for ln in src.splitlines() if "getenv(" in ln]
     assert len(calls) == 1 and "optName[o]" in calls[0], calls
     for hdr in os.listdir(os.path.join(ROOT, "pressurepoissonsolver_amd", "csrc")):
@@ -64,10 +64,15 @@ def test_no_getenv_on_launch_paths():
             assert "getenv(" not in open(os.path.join(ROOT, "pressurepoissonsolver_amd", "csrc", hdr)).read(), hdr
 
 
+def _device_sources():
+    """the translation units of the device half of the library (pressurepoissonsolver_amd/build.py UNITS), concatenated"""
+    d = os.path.join(ROOT, "pressurepoissonsolver_amd", "csrc")
+    return "\n".join(open(os.path.join(d, f)).read() for f in sorted(os.listdir(d)) if f.startswith("gmg_") and f.endswith(".hip"))
+
+
 def test_every_extern_c_entry_has_an_exception_barrier():
-    """no C++ exception may unwind into a C caller: every int-returning entry point of gmg.hip runs inside guarded()"""
-    src = open(os.path.join(ROOT, "pressurepoissonsolver_amd", "csrc", "gmg.hip")).read()
-    body = src[src.index('extern "C" {'):]
+    """no C++ exception may unwind into a C caller: every int-returning entry point of the device units runs inside guarded()"""
+    body = _device_sources()
     entries = re.findall(r"^int\s+(te_\w+)\(", body, flags=re.M)
     assert len(entries) >= 40
     for name in entries:

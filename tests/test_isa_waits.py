@@ -11,7 +11,7 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "pressurepoissonsolver_amd", "csrc", "gmg.hip")
+SRC = os.path.join(ROOT, "pressurepoissonsolver_amd", "csrc", "gmg_fused3d.hip")  # the unit that instantiates the fused level-0 kernels
 
 
 @pytest.fixture(scope="module")
