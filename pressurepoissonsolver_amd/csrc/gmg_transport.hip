@@ -244,7 +244,7 @@ int pushExchange(te_gmg *g, LevelHost &L, int kind, const double *send, hipStrea
 // the level's face exchange: remote slots of the current ghost buffer <- the peers' layers (`send` in send order)
 int faceExchange(te_gmg *g, LevelHost &L, const double *send, hipStream_t stream)
 {
-	if (g->push.on && L.push_faces && !g->recording && L.dim == 3) return pushExchange(g, L, 1, send, stream);
+	if (g->push.on && L.push_faces && !g->recording) return pushExchange(g, L, 1, send, stream);
 	return doExchange(g, 1, L.fx, send, L.ghostCur(), stream);
 }
 
@@ -336,7 +336,6 @@ static int pushSetup(te_gmg *g)
 	auto &P = g->push;
 	if (P.ready) return TE_OK;
 	const int R = g->nranks, NL = (int) g->levels.size();
-	if (g->dim != 3) return te::fail(TE_EUNSUPPORTED, "te_gmg_use_push: 3D hierarchies only");
 	if (R < 2) return te::fail(TE_ESTATE, "te_gmg_use_push: one rank has nobody to push to");
 	if (!g->rccl.comm && !g->allreduce) return te::fail(TE_ESTATE, "te_gmg_use_push: needs te_gmg_use_rccl or te_gmg_set_allreduce first (the handles travel through it)");
 	if (R > PUSH_MAX_PEERS) return te::fail(TE_EUNSUPPORTED, "te_gmg_use_push: too many ranks");

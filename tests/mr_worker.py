@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--push", action="store_true", help="the direct-store transport (te_gmg_use_push) for the exchanges that have one: "
                     "real hipIpc mappings between the processes, the attached back-end for everything else")
     ap.add_argument("--cells", type=int, default=8, help="cells per patch axis")
+    ap.add_argument("--dim", type=int, default=3)
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -32,8 +33,8 @@ def main():
     dist.init_process_group(backend=a.backend)
     from pressurepoissonsolver_amd import capi, dist as tedist, problems, solver
     n = a.cells
-    nc = n ** 3
-    mesh = capi.Mesh.uniform(3, a.divides)
+    nc = n ** a.dim
+    mesh = capi.Mesh.uniform(a.dim, a.divides)
     H = capi.Hierarchy(mesh, n, rank=rank, nranks=world)
     g = capi.GMG(H, device=dev)
     tedist.attach(g, dist)
@@ -46,7 +47,7 @@ def main():
         g.use_push(True)
     t = H.tables(0)
     f_all = problems.random_rhs(t["id"], nc)
-    b_all, _ = problems.init_dirichlet(t, n)
+    b_all, _ = (problems.init_dirichlet if a.dim == 3 else problems.init_dirichlet_2d)(t, n)
     idx = H.l2g(0)
     local = lambda v: v.reshape(-1, nc)[idx].ravel()  # noqa: E731
     opts = g.default_opts(smoother=capi.SMOOTH_RBGS)

@@ -419,8 +419,9 @@ def test_two_processes_gloo(overlap_min):
     assert "MR_WORKER_OK" in r.stdout
 
 
-@pytest.mark.parametrize("n,divides,nproc", [(8, 2, 2), (32, 3, 2), (32, 3, 4)], ids=["64x8^3", "512x32^3-fused-path", "512x32^3-4-processes"])
-def test_two_processes_direct_store_transport(n, divides, nproc):
+@pytest.mark.parametrize("n,divides,nproc,dim", [(8, 2, 2, 3), (32, 3, 2, 3), (32, 3, 4, 3), (64, 4, 2, 2)],
+                         ids=["64x8^3", "512x32^3-fused-path", "512x32^3-4-processes", "2D-256x64^2"])
+def test_two_processes_direct_store_transport(n, divides, nproc, dim):
     """te_gmg_use_push between real PROCESSES (two, and four: more peers per exchange, the blocks of a gather from three ranks;
     all on the one GPU of the box: hipIpcGetMemHandle / hipIpcOpenMemHandle
     mappings, fine-grained flags, the bounded wait kernel): the face exchanges and the in-place exchange of restricted blocks go
@@ -438,7 +439,7 @@ def test_two_processes_direct_store_transport(n, divides, nproc):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr",
            "127.0.0.1", "--master-port", port, os.path.join(root, "tests", "mr_worker.py"), "--backend", "gloo", "--push",
-           "--cells", str(n), "--divides", str(divides)]
+           "--cells", str(n), "--divides", str(divides), "--dim", str(dim)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "MR_WORKER_OK" in r.stdout and "transport:" in r.stdout
