@@ -368,7 +368,7 @@ def main():
              ("gathered<=64-on-rank-0", (64, 64, 0)), ("never-gathered", (0, 64, 0))] if a.dim == 3
             else [("gathered<=64-on-rank-0", (64, 64, 0)), ("gathered<16/rank-on-rank-0", (16, 64, 0)), ("never-gathered", (0, 64, 0))])
         tried, best = [], None
-        push_ok = a.dim == 3 and os.environ.get("TE_BENCH_PUSH", "1") != "0"
+        push_ok = os.environ.get("TE_BENCH_PUSH", "1") != "0"
         os.environ.setdefault("TE_PUSH_TIMEOUT", "5")  # (a transport that does not work here is found out within seconds)
         for cname, pl in cands:
             Hc, gc, bname = make(pl)
