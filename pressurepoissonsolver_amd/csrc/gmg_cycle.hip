@@ -608,6 +608,11 @@ int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms
 			if (bad != 0.0) {
 				(void) te_gmg_use_push(g, 0);
 				g->push.ready = false; // not usable on this machine: never again for this solver
+				g->push.rejected = true;
+				// (its error word is cleared: the watchdog must not end a process that has gone back to the other transport)
+				HIPCHK(hipStreamSynchronize(g->stream));
+				HIPCHK(hipMemset(g->push.err, 0, sizeof(int)));
+				*g->push.err_host = 0;
 				snprintf(buf, sizeof buf, "transport: direct-store REJECTED (result differs from the other transport's or a wait gave up) -> %s; ",
 				         g->rccl.comm ? "rccl" : "callback");
 			} else {

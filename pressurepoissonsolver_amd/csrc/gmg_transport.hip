@@ -236,7 +236,10 @@ int pushExchange(te_gmg *g, LevelHost &L, int kind, const double *send, hipStrea
 	}
 	if (pp.n > 0) {
 		const int bx = (int) std::min<int64_t>(64, std::max<int64_t>(1, most / 2 / 256 / 4));
-		hipLaunchKernelGGL(k_push_ranges, dim3(bx, pp.n), dim3(256), 0, stream, send, pp, L.push_ep, L.push_done.p + (kind - 1), (const int *) g->push.err);
+		// (TE_PUSH_FAULT, diagnostic: the flags are raised to the PREVIOUS epoch -- a transport whose data never "arrives", so that
+		// the give-up / rejection path can be tested)
+		hipLaunchKernelGGL(k_push_ranges, dim3(bx, pp.n), dim3(256), 0, stream, send, pp, g->cfg.has(O_PUSH_FAULT) ? L.push_ep - 1 : L.push_ep,
+		                   L.push_done.p + (kind - 1), (const int *) g->push.err);
 	}
 	return pushFinish(g, L, kind, stream);
 }
@@ -534,6 +537,9 @@ int te_gmg_use_push(te_gmg *g, int enable)
 			return TE_OK;
 		}
 		if (g->push.on) return TE_OK;
+		if (g->push.rejected)
+			return te::fail(TE_ESTATE, "te_gmg_use_push: te_gmg_autotune rejected the direct-store transport on this machine (its result differed from "
+			                           "the other transport's, or a wait gave up)");
 		if ((rc = pushSetup(g)) || (rc = meet())) return rc;
 		g->push.on = true;
 		return TE_OK;

@@ -23,6 +23,8 @@ def main():
                     "real hipIpc mappings between the processes, the attached back-end for everything else")
     ap.add_argument("--cells", type=int, default=8, help="cells per patch axis")
     ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--push-fault", action="store_true", help="TE_PUSH_FAULT: the direct-store transport never delivers; te_gmg_autotune must "
+                    "reject it on all ranks and everything must then run correctly through the attached back-end")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -42,9 +44,19 @@ def main():
     if a.push:
         g.use_push(True)
         # the transports are compared on this very machine: identical results, then the faster one; force the direct one afterwards
+        if a.push_fault:
+            g.set_option("TE_PUSH_FAULT", "1")
         _, report = g.autotune(g.default_opts(smoother=capi.SMOOTH_RBGS), reps=3)
-        assert "transport:" in report and "REJECTED" not in report and "results identical" in report, report
-        g.use_push(True)
+        if a.push_fault:
+            assert "REJECTED" in report, report
+            try:
+                g.use_push(True)  # (not usable any more for this solver: set up again would be a second collective; it must refuse or stay off)
+            except capi.TeError:
+                pass
+            g.use_push(False)
+        else:
+            assert "transport:" in report and "REJECTED" not in report and "results identical" in report, report
+            g.use_push(True)
     t = H.tables(0)
     f_all = problems.random_rhs(t["id"], nc)
     b_all, _ = (problems.init_dirichlet if a.dim == 3 else problems.init_dirichlet_2d)(t, n)
@@ -97,7 +109,7 @@ def main():
         g1.apply(u1, au1)
         assert np.array_equal(got["apply_last"], au1.download()), "sharded apply (after the cycle) differs"
         print("MR_WORKER_OK", report or "", flush=True)
-    assert not g.push_failed()
+    assert not g.push_failed(), "a direct-store wait gave up (or a rejected transport left its error word set)"
     dist.barrier()
     dist.destroy_process_group()
 
