@@ -30,6 +30,8 @@ ap.add_argument("--ranks", default="1,2,4,8")
 ap.add_argument("--agg", default="16,4,0")
 ap.add_argument("--dim", type=int, default=3)
 ap.add_argument("--patch", type=int, default=None, help="cells per patch axis (default 32 in 3D, 64 in 2D)")
+ap.add_argument("--mesh", default=None, help="octree file instead of the uniform grid (config C4: tests/golden/2refine.bin --divide 2)")
+ap.add_argument("--divide", type=int, default=0)
 ap.add_argument("--push", action="store_true", help="the direct-store transport (te_gmg_use_push) in loop-back form: every peer's buffers and "
                 "flags are this rank's own -- the two launches per exchange are real, the wire and the waiting for peers are not")
 a = ap.parse_args()
@@ -51,7 +53,12 @@ def emit(s=""):
 
 def run(nranks, rank, agg):
     os.environ["TE_AGGLOMERATE"] = str(agg)
-    mesh = capi.Mesh.uniform(a.dim, div)
+    if a.mesh:
+        mesh = capi.Mesh.read(a.mesh, a.dim)
+        for _ in range(a.divide):
+            mesh.refine_leaves()
+    else:
+        mesh = capi.Mesh.uniform(a.dim, div)
     H = capi.Hierarchy(mesh, n, rank=rank, nranks=nranks)
     g = capi.GMG(H)
     if nranks > 1:
@@ -86,7 +93,7 @@ def run(nranks, rank, agg):
     return dict(host=float(np.median(tq)), wall=wall, rows=rows, sizes=sizes)
 
 
-emit(f"# tools/mr8_budget.py --size {a.size} --smoother {a.smoother}{' --push' if a.push else ''}: one rank of N alone on one MI355X, "
+emit(f"# tools/mr8_budget.py {('--mesh ' + os.path.basename(a.mesh) + ' --divide ' + str(a.divide)) if a.mesh else '--size ' + str(a.size)} --smoother {a.smoother}{' --push' if a.push else ''}: one rank of N alone on one MI355X, "
      + ("direct-store transport in loop-back form (exchanges without a direct form: RCCL in loop-back mode)" if a.push else "native RCCL back-end in loop-back mode"))
 emit("# host = host time to enqueue one cycle incl. the RCCL group calls; wall = GPU time per cycle of back-to-back cycles; us")
 for nranks in [int(x) for x in a.ranks.split(",")]:
