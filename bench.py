@@ -70,6 +70,8 @@ ALG_BYTES = {
     # te_bicgstab's own passes (BiCGStab.h:71-104 between the operator applications and the cycles)
     "bicg_update": 72.0,         # read x, resid, M p, M s, A p, A s, rhat; write x, resid; two dot products on the way
     "bicg_s": 24.0, "bicg_p": 32.0,   # the stand-alone s and p statements (paths where no cycle kernel forms them)
+    # TE_SMOOTH_PATCH_BCGS (2D): compute-resident Krylov solve per patch; HBM sees the right-hand side and u in, u out, once per sweep
+    "patch_bcgs": 24.0,
     "stencil_apply_dot": 24.0,   # f = A u with one or two dot products summed while f is in registers: read u, the operand; write f
     "exchange": 0.0,             # RCCL / callback time on the solver stream: no HBM pass of this library's own
 }

@@ -114,6 +114,10 @@ typedef struct {
 #define TE_SMOOTH_PATCH_SOLVE 0 /* reference: FFTBlockJacobiSmoother.h:55-58 (block Jacobi, exact patch solves) */
 #define TE_SMOOTH_JACOBI 1      /* weighted point Jacobi */
 #define TE_SMOOTH_RBGS 2        /* patch-local red-black Gauss-Seidel, neighbour ghosts frozen */
+#define TE_SMOOTH_PATCH_BCGS 3  /* 2D only: block Jacobi whose patch solves are the reference's OTHER patch solver, PatchSolvers/
+                                   BiCGStabSolver.h:114-132 (apps/2d/steady.cpp:326-327, --patch_solver bcgs): per patch, unpreconditioned
+                                   BiCGStab<2>::solve (BiCGStab.h:45-106) on StarPatchOp<2>::apply from the patch's current values, to
+                                   te_gmg_set_patch_bcgs's tolerance; one workgroup per patch, the Krylov vectors in registers */
 
 void te_cycle_opts_default(te_cycle_opts *o);
 
@@ -254,6 +258,13 @@ int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms
  * GMG/InterLevelComm.h:169-189. */
 int te_gmg_use_push(te_gmg *g, int enable);
 int te_gmg_push_failed(te_gmg *g);
+
+/* BiCGStabSolver(op, tol = 1e-12, max_it = 1000), PatchSolvers/BiCGStabSolver.h:103-108: the stopping rule of
+ * TE_SMOOTH_PATCH_BCGS's patch solves (||resid|| / ||resid_0|| <= tol or max_it iterations, BiCGStab.h:69). */
+int te_gmg_set_patch_bcgs(te_gmg *g, double tol, int max_it);
+/* iterations each of this rank's patches of `level` took in the last TE_SMOOTH_PATCH_BCGS sweep there (its[P local], host memory;
+ * synchronises the solver's stream). TE_ESTATE when no such sweep has run on the level. */
+int te_gmg_patch_bcgs_iterations(te_gmg *g, int level, int32_t *its);
 /* ncclCommCount / ncclCommUserRank of the communicator te_gmg_use_rccl created (0 / -1 without one): evidence for a
  * benchmark line that RCCL itself saw N ranks. */
 int te_gmg_comm_info(te_gmg *g, int *rccl_nranks, int *rccl_rank);

@@ -62,6 +62,21 @@ def level_case(mesh_file, dim, n, neumann, seed):
     return out
 
 
+def bcgs_case(mesh_file, dim, n, neumann, seed, tol=1e-12, max_it=1000):
+    """one block-Jacobi sweep with the reference's Krylov patch solver (refslice.smooth_bcgs: BiCGStab<D>::solve per patch on
+    StarPatchOp<D>::apply, the calls of PatchSolvers/BiCGStabSolver.h:114-132) from a seeded iterate"""
+    m = capi.Mesh.read(os.path.join(GOLDEN, mesh_file), dim)
+    H = capi.Hierarchy(m, n, neumann=neumann)
+    L = orc.Level.from_tables(H.tables(0), dim, n, neumann)
+    rng = np.random.default_rng(seed)
+    u, f = rng.uniform(-1, 1, L.size), rng.uniform(-1, 1, L.size)
+    out = dict(dim=dim, n=n, neumann=int(neumann), mesh=mesh_file, u=u, f=f, tol=tol, max_it=max_it)
+    for k, v in L.a.items():
+        out["t_" + k] = v
+    out["u_out"], out["its"] = refslice.smooth_bcgs(L, f, u, tol, max_it)
+    return out
+
+
 def vecop_case(seed):
     REF = refslice.lib()
     p = refslice.p
@@ -92,6 +107,13 @@ def main():
         name = f"ref_{mf.split('.')[0]}_n{n}{'_neumann' if neu else ''}.npz"
         np.savez_compressed(os.path.join(GOLDEN, name), **d)
         print(name, "P", len(d["t_id"]), "ifaces", d["num_ifaces"], "bicg its", d.get("bicg_its"))
+    if not only or only == "bcgs":
+        for j, (mf, dim, n, neu) in enumerate([("2d2uni.bin", 2, 8, False), ("2d2ref.bin", 2, 8, False), ("2d2ref.bin", 2, 4, True),
+                                               ("2refine.bin", 3, 4, False)]):
+            d = bcgs_case(mf, dim, n, neu, 2000 + j)
+            name = f"bcgs_ref_{mf.split('.')[0]}_n{n}{'_neumann' if neu else ''}.npz"
+            np.savez_compressed(os.path.join(GOLDEN, name), **d)
+            print(name, "P", len(d["t_id"]), "its", d["its"].min(), "..", d["its"].max())
     if not only:
         np.savez_compressed(os.path.join(GOLDEN, "ref_vecops.npz"), **vecop_case(7))
     for mf, dim, div in [("2uni.bin", 3, 1), ("2refine.bin", 3, 1), ("2refine.bin", 3, 2), ("2d2ref.bin", 2, 2),

@@ -40,6 +40,8 @@ def lib():
             "orc_add_iface_rhs": (None, [pl, pd, pd]),
             "orc_patch_solve": (None, [pl, pd, pd, pd]),
             "orc_smooth": (None, [pl, pd, pd]),
+            "orc_smooth_bcgs": (None, [pl, pd, pd, C.c_double, C.c_int, pi]),
+            "orc_set_patch_bcgs": (None, [C.c_double, C.c_int]),
             "orc_restrict": (None, [pl, pl, pd, pd]),
             "orc_prolong_add": (None, [pl, pl, pd, pd]),
             "orc_jacobi": (None, [pl, pd, pd, C.c_double]),
@@ -145,6 +147,18 @@ def smooth(L, f, u):
     u = _vec(u).copy()
     lib().orc_smooth(C.byref(L.c), _p(_vec(f)), _p(u))
     return u
+
+
+def smooth_bcgs(L, f, u, tol=1e-12, max_it=1000):
+    """-> (u after one block-Jacobi sweep with BiCGStabSolver patch solves, iterations per patch)"""
+    u = _vec(u).copy()
+    its = np.zeros(max(L.c.P, 1), dtype=np.int32)
+    lib().orc_smooth_bcgs(C.byref(L.c), _p(_vec(f)), _p(u), tol, max_it, _p(its))
+    return u, its[:L.c.P]
+
+
+def set_patch_bcgs(tol=1e-12, max_it=1000):
+    lib().orc_set_patch_bcgs(tol, max_it)
 
 
 def jacobi(L, f, u, omega):

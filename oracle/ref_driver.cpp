@@ -200,6 +200,48 @@ template <size_t D> int bicgstab(const ref_level *L, const double *b, double *x,
 	unwrap<D>(*xv, L->n, L->P, x);
 	return it;
 }
+// One block-Jacobi sweep with the reference's Krylov patch solver. PatchSolvers/BiCGStabSolver.h itself cannot be compiled here
+// (it includes Domain.h -> PETSc and fftw3.h), so the calls its solve() makes (BiCGStabSolver.h:114-132: copy f, addInterfaceToRHS,
+// BiCGStab<D>::solve over a one-patch operator from the patch's current values) are issued here on the reference's own classes:
+// StarPatchOp<D>::addInterfaceToRHS / apply, BiCGStab<D>::solve, ValVector<D>. The interface values come from the interpolator on
+// the old iterate, as SchurHelper<D>::solveWithInterface's caller provides them (SchurHelper.h:318-331).
+template <size_t D> class OnePatchOp : public Operator<D>
+{
+	public:
+	SchurInfo<D>                      sinfo;
+	std::shared_ptr<PatchOperator<D>> op;
+	void apply(std::shared_ptr<const Vector<D>> x, std::shared_ptr<Vector<D>> b) const override
+	{
+		op->apply(const_cast<SchurInfo<D> &>(sinfo), x->getLocalData(0), b->getLocalData(0));
+	}
+};
+template <size_t D> void smoothBcgs(const ref_level *L, const double *f, double *u, double tol, int max_it, int32_t *its)
+{
+	auto B  = build<D>(L);
+	auto uv = wrap<D>(L->n, L->P, u);
+	auto gv = wrap<D - 1>(L->n, B.num_ifaces, nullptr);
+	gv->set(0);
+	auto it = makeInterp<D>();
+	for (auto &sd : B.sinfos) it->interpolate(sd, uv, gv);
+	size_t nc = 1;
+	for (size_t i = 0; i < D; i++) nc *= L->n;
+	std::shared_ptr<PatchOperator<D>> op(new StarPatchOp<D>());
+	std::shared_ptr<RefVG<D>>         vg(new RefVG<D>());
+	vg->n = L->n;
+	vg->P = 1;
+	for (auto &sd : B.sinfos) {
+		const int p   = sd.pinfo->local_index;
+		auto      f1  = wrap<D>(L->n, 1, f + (size_t) p * nc); // f_copy->copy(f_single)
+		auto      u1  = wrap<D>(L->n, 1, u + (size_t) p * nc);
+		op->addInterfaceToRHS(sd, gv, f1->getLocalData(0));
+		std::shared_ptr<OnePatchOp<D>> A(new OnePatchOp<D>());
+		A->sinfo = sd;
+		A->op    = op;
+		int n_it = BiCGStab<D>::solve(vg, A, u1, f1, nullptr, max_it, tol);
+		if (its) its[p] = n_it;
+		unwrap<D>(*u1, L->n, 1, u + (size_t) p * nc);
+	}
+}
 } // namespace
 
 extern "C" {
@@ -235,6 +277,11 @@ int ref_bicgstab(const ref_level *L, const double *b, double *x, int max_it, dou
 {
 	ref_init();
 	return L->dim == 3 ? bicgstab<3>(L, b, x, max_it, tol) : bicgstab<2>(L, b, x, max_it, tol);
+}
+void ref_smooth_bcgs(const ref_level *L, const double *f, double *u, double tol, int max_it, int32_t *its)
+{
+	ref_init();
+	L->dim == 3 ? smoothBcgs<3>(L, f, u, tol, max_it, its) : smoothBcgs<2>(L, f, u, tol, max_it, its);
 }
 // Vector<D> BLAS-1 virtuals (Vector.h:190-321) on ValVector<3>; op codes follow te_hip.h order
 void ref_vecop(int op, int n, int P, double *v, const double *a, const double *b, double alpha, double beta, double gamma)

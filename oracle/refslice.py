@@ -34,6 +34,7 @@ def lib():
                 ("ref_interp", None, [PL, V, V]), ("ref_apply_with_gamma", None, [PL, V, V, V]),
                 ("ref_apply_with_gamma_7pt", None, [PL, V, V, V]), ("ref_patch_apply", None, [PL, V, V]),
                 ("ref_add_iface_rhs", None, [PL, V, V]), ("ref_bicgstab", C.c_int, [PL, V, V, C.c_int, C.c_double]),
+                ("ref_smooth_bcgs", None, [PL, V, V, C.c_double, C.c_int, V]),
                 ("ref_vecop", None, [C.c_int, C.c_int, C.c_int, V, V, V, C.c_double, C.c_double, C.c_double]),
                 ("ref_tree_nodes", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, V, V, V, V, V, V]),
                 ("ref_init", C.c_int, [])]:
@@ -85,6 +86,15 @@ def bicgstab(L, b, max_it=1000, tol=1e-12):
     x = np.zeros(L.size)
     its = lib().ref_bicgstab(C.byref(L.c), p(_v(b)), p(x), max_it, tol)
     return x, its
+
+
+def smooth_bcgs(L, f, u, tol=1e-12, max_it=1000):
+    """one sweep of the reference's own BiCGStab<D>::solve per patch on StarPatchOp<D>::apply (the body of
+    PatchSolvers/BiCGStabSolver.h:114-132) -> (u, iterations per patch)"""
+    u = _v(u).copy()
+    its = np.zeros(max(L.c.P, 1), np.int32)
+    lib().ref_smooth_bcgs(C.byref(L.c), p(_v(f)), p(u), tol, max_it, p(its))
+    return u, its[:L.c.P]
 
 
 def tree_nodes(path, dim, divides):

@@ -490,6 +490,62 @@ void orc_smooth(const orc_level *L, const double *f, double *u)
 	for (int p = 0; p < L->P; p++) solvePatch(L, G, I, PC, p, gamma.data(), f, u);
 }
 
+// PatchSolvers/BiCGStabSolver.h:114-132 under SchurHelper::solveWithInterface's loop (SchurHelper.h:318-331), the smoother the
+// 2D driver builds with --patch_solver bcgs (apps/2d/steady.cpp:326-327): gamma from the old iterate, then per patch
+// f_copy = f - interface terms (addInterfaceToRHS) and BiCGStab<D>::solve (BiCGStab.h:45-106, no preconditioner) with
+// StarPatchOp::apply as the operator, the patch's current values as the initial guess. its[p] = iterations of patch p (may be null).
+static double g_bcgs_tol    = 1e-12; // BiCGStabSolver(op, tol = 1e-12, max_it = 1000), BiCGStabSolver.h:103-108: what a cycle
+static int    g_bcgs_max_it = 1000;  // with smoother == 3 uses
+void orc_set_patch_bcgs(double tol, int max_it)
+{
+	g_bcgs_tol    = tol;
+	g_bcgs_max_it = max_it;
+}
+void orc_smooth_bcgs(const orc_level *L, const double *f, double *u, double tol, int max_it, int *its)
+{
+	Geo                 G(L);
+	Ifaces              I = buildIfaces(L);
+	const size_t        N = (size_t) L->P * G.nc;
+	std::vector<double> gamma((size_t) I.count * G.nf, 0.0);
+	for (int p = 0; p < L->P; p++) interpPatch(L, G, I, p, u, gamma.data());
+	std::vector<double> b(f, f + N);
+	orc_add_iface_rhs(L, gamma.data(), b.data());
+	// level-sized scratch: patch p only ever touches its own n^D slot of each
+	std::vector<double> resid(N), rhat(N), pv(N), ap(N), s(N), as(N);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1)
+	for (int p = 0; p < L->P; p++) {
+		const size_t o0 = (size_t) p * G.nc, o1 = o0 + G.nc;
+		auto dot = [&](const std::vector<double> &a, const std::vector<double> &c) {
+			double t = 0;
+			for (size_t i = o0; i < o1; i++) t += a[i] * c[i];
+			return t;
+		};
+		auto A = [&](const double *x, double *y) { applyPatch(L, G, nullptr, p, x, nullptr, y, false); };
+		A(u, resid.data());
+		for (size_t i = o0; i < o1; i++) resid[i] = -1 * resid[i] + b[i];
+		const double r0_norm = sqrt(dot(resid, resid));
+		for (size_t i = o0; i < o1; i++) rhat[i] = pv[i] = resid[i];
+		double rho     = dot(rhat, resid);
+		int    num_its = 0;
+		while (sqrt(dot(resid, resid)) / r0_norm > tol && num_its < max_it) {
+			A(pv.data(), ap.data());
+			const double alpha = rho / dot(rhat, ap);
+			for (size_t i = o0; i < o1; i++) s[i] = resid[i] + ap[i] * -alpha;
+			A(s.data(), as.data());
+			const double omega = dot(as, s) / dot(as, as);
+			for (size_t i = o0; i < o1; i++) u[i] += pv[i] * alpha + s[i] * omega;
+			for (size_t i = o0; i < o1; i++) resid[i] += ap[i] * -alpha + as[i] * -omega;
+			const double rho_new = dot(resid, rhat);
+			const double beta    = rho_new * alpha / (rho * omega);
+			for (size_t i = o0; i < o1; i++) pv[i] += ap[i] * -omega;
+			for (size_t i = o0; i < o1; i++) pv[i] = beta * pv[i] + resid[i];
+			num_its++;
+			rho = rho_new;
+		}
+		if (its) its[p] = num_its;
+	}
+}
+
 void orc_restrict(const orc_level *fine, const orc_level *coarse, const double *fv, double *cv)
 {
 	Geo       G(fine);
@@ -671,6 +727,8 @@ static void smoothLevel(const orc_level *L, const orc_cycle_opts *o, bool coarse
 		orc_smooth(L, f, u);
 	else if (o->smoother == 1)
 		orc_jacobi(L, f, u, o->omega);
+	else if (o->smoother == 3)
+		orc_smooth_bcgs(L, f, u, g_bcgs_tol, g_bcgs_max_it, nullptr);
 	else
 		orc_patch_rbgs(L, f, u);
 }

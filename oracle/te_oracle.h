@@ -68,6 +68,11 @@ void orc_add_iface_rhs(const orc_level *L, const double *gamma, double *f);
 void orc_patch_solve(const orc_level *L, const double *gamma, const double *f, double *u);
 /* a8: SchurHelper.h:318-331 */
 void orc_smooth(const orc_level *L, const double *f, double *u);
+/* the same loop with the reference's other patch solver: PatchSolvers/BiCGStabSolver.h:114-132 (BiCGStab.h:45-106 per patch on
+ * StarPatchOp::apply, initial guess = the patch's current values); its[P] may be null */
+void orc_smooth_bcgs(const orc_level *L, const double *f, double *u, double tol, int max_it, int *its);
+/* the stopping rule orc_cycle's smoother == 3 (the loop above) uses; defaults as the reference's constructor */
+void orc_set_patch_bcgs(double tol, int max_it);
 /* a11 / a12: GMG/AvgRstr.h:78-113, GMG/DrctIntp.h:80-113. coarse is overwritten by restrict. */
 void orc_restrict(const orc_level *fine, const orc_level *coarse, const double *fine_v,
                   double *coarse_v);

@@ -26,7 +26,7 @@ class TeLibraryMissing(ImportError):
 
 
 TE_OK, TE_EINVAL, TE_EHIP, TE_ESTATE, TE_EIO, TE_EUNSUPPORTED, TE_ENOMEM = 0, -1, -2, -3, -4, -5, -6
-SMOOTH_PATCH_SOLVE, SMOOTH_JACOBI, SMOOTH_RBGS = 0, 1, 2
+SMOOTH_PATCH_SOLVE, SMOOTH_JACOBI, SMOOTH_RBGS, SMOOTH_PATCH_BCGS = 0, 1, 2, 3
 PROBLEM_TRIG, PROBLEM_GAUSS, PROBLEM_RANDOM = 0, 1, 2
 
 
@@ -119,6 +119,8 @@ SYMBOLS = {
     "te_gmg_comm_info": (_I, [_P, C.POINTER(_I), C.POINTER(_I)]),
     "te_gmg_use_push": (_I, [_P, _I]),
     "te_gmg_push_failed": (_I, [_P]),
+    "te_gmg_set_patch_bcgs": (_I, [_P, _D, _I]),
+    "te_gmg_patch_bcgs_iterations": (_I, [_P, _I, _P]),
     "te_gmg_exchange_selftest": (_I, [_P, _I]),
     "te_gmg_watchdog_selftest": (_I, [_P, _D]),
     "te_gmg_profile": (_I, [_P, _I]),
@@ -428,6 +430,16 @@ class GMG:
     def push_failed(self):
         return bool(lib().te_gmg_push_failed(self.h))
 
+    def set_patch_bcgs(self, tol=1e-12, max_it=1000):
+        """BiCGStabSolver(op, tol, max_it), PatchSolvers/BiCGStabSolver.h:103-108"""
+        check(lib().te_gmg_set_patch_bcgs(self.h, float(tol), int(max_it)))
+
+    def patch_bcgs_iterations(self, level, n_local):
+        import numpy as np
+        its = np.zeros(max(int(n_local), 1), dtype=np.int32)
+        check(lib().te_gmg_patch_bcgs_iterations(self.h, level, its.ctypes.data_as(_P)))
+        return its[:n_local]
+
     def comm_info(self):
         """(ranks, rank) of the native RCCL communicator, (0, -1) without one"""
         a, b = C.c_int(), C.c_int()
@@ -491,11 +503,11 @@ class GMG:
     def profile_select(self, name=None): check(lib().te_gmg_profile_select(self.h, (name or "").encode()))
 
     def profile_rows(self):
-        names = (C.c_char * 64 * 32)()
-        calls = (C.c_int64 * 32)()
-        ms = (C.c_double * 32)()
-        cells = (C.c_int64 * 32)()
-        n = lib().te_gmg_profile_rows(self.h, 32, names, calls, ms, cells)
+        names = (C.c_char * 64 * 64)()
+        calls = (C.c_int64 * 64)()
+        ms = (C.c_double * 64)()
+        cells = (C.c_int64 * 64)()
+        n = lib().te_gmg_profile_rows(self.h, 64, names, calls, ms, cells)
         if n < 0:
             check(n)
         return {bytes(names[i]).split(b"\0")[0].decode(): dict(calls=calls[i], ms=ms[i], cells=cells[i])

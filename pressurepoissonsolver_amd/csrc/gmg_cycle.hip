@@ -28,6 +28,9 @@ int smoothOnce(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, d
 			if (xfok) xfProduced(L, L.t->d);
 			swapData(u, L.t.get());
 			return TE_OK;
+		case TE_SMOOTH_PATCH_BCGS: // (zero_guess never set: the smoothing lambda materialises the zeros first -- they ARE the initial guess)
+			L.xf_valid_for = nullptr;
+			return patchBcgs2d(g, L, f->d, u->d, L.t->d);
 		default: return te::fail(TE_EINVAL, "te_smooth: unknown smoother");
 	}
 }
@@ -447,6 +450,29 @@ int te_smooth(te_gmg *g, int level, const te_vec *f, te_vec *u, int smoother, do
 		if ((rc = checkLevelVec(g, level, u, "te_smooth")) || (rc = checkLevelVec(g, level, f, "te_smooth"))) return rc;
 		for (int i = 0; i < sweeps; i++)
 			if ((rc = smoothOnce(g, level, f, u, smoother, omega))) return rc;
+		return TE_OK;
+	});
+}
+
+int te_gmg_set_patch_bcgs(te_gmg *g, double tol, int max_it)
+{
+	return guarded([&]() -> int {
+		if (!g || !(tol >= 0.0) || max_it < 0) return te::fail(TE_EINVAL, "te_gmg_set_patch_bcgs: tol >= 0 and max_it >= 0");
+		g->bcgs_tol    = tol;
+		g->bcgs_max_it = max_it;
+		return TE_OK;
+	});
+}
+
+int te_gmg_patch_bcgs_iterations(te_gmg *g, int level, int32_t *its)
+{
+	return guarded([&]() -> int {
+		if (!g || !its || level < 0 || level >= (int) g->levels.size()) return te::fail(TE_EINVAL, "te_gmg_patch_bcgs_iterations: bad argument");
+		LevelHost &L = *g->levels[level];
+		if (L.P == 0) return TE_OK;
+		if (!L.bcgs_its.p) return te::fail(TE_ESTATE, "te_gmg_patch_bcgs_iterations: no TE_SMOOTH_PATCH_BCGS sweep has run on this level");
+		HIPCHK(hipStreamSynchronize(g->stream));
+		HIPCHK(hipMemcpy(its, L.bcgs_its.p, sizeof(int32_t) * (size_t) L.P, hipMemcpyDeviceToHost));
 		return TE_OK;
 	});
 }

@@ -67,7 +67,10 @@ enum KClass : int {
 	KC_PS_MFMA_FACES,
 	// te_bicgstab's own passes: x / resid update with its two dot products (72 B/site), the stand-alone s and p statements
 	// (24 / 32), the operator application that also sums one or two dot products (16 + 8)
-	KC_BICG_UPDATE, KC_BICG_S, KC_BICG_P, KC_APPLY_DOT, KC_COUNT
+	KC_BICG_UPDATE, KC_BICG_S, KC_BICG_P, KC_APPLY_DOT,
+	// the patch-local Krylov solve of PatchSolvers/BiCGStabSolver.h (2D): compute-resident, its HBM bytes are one read of the
+	// right-hand side and a read + write of the patch (24 B/site) whatever the iteration count
+	KC_PATCH_BCGS, KC_COUNT
 };
 extern const char *kclassName[KC_COUNT]; // (gmg_core.hip)
 
@@ -176,6 +179,7 @@ struct LevelHost {
 	DevBuf<double>  upbuf, downbuf;
 	// patch solve
 	DevBuf<int32_t> plan, zero_mode;
+	DevBuf<int32_t> bcgs_its; // [P]: iterations of the last TE_SMOOTH_PATCH_BCGS sweep on this level (allocated on first use)
 	DevBuf<double>  mats, lam, corr; // corr: [P][6][n^2] interface terms of the patch right-hand sides
 	DevBuf<double>  matsT;           // 2D: the transform matrices transposed (k_patch_solve2d_lds)
 	DevBuf<double>  matsym;          // half matrices in MFMA fragment order (patchsolve32_sym.hpp), 32^3 patches
@@ -349,7 +353,9 @@ struct te_gmg {
 	te_vec *bicg_work[8] = {nullptr}; // te_bicgstab's work vectors (level 0), allocated at its first call
 	const PendingRhs *pending_rhs = nullptr; // set by te_bicgstab around a cycle: level 0's right-hand side is still to be formed
 	bool recording = false;
-	bool ps2d_attr = false, ps_lds_ok = false; // dynamic-LDS attributes of the patch-solve kernels set on this solver's device
+	double bcgs_tol = 1e-12; // BiCGStabSolver(op, tol = 1e-12, max_it = 1000), BiCGStabSolver.h:103-108
+	int    bcgs_max_it = 1000;
+	bool ps2d_attr = false, ps_lds_ok = false, bcgs_attr = false; // dynamic-LDS attributes of the patch-solve kernels set on this solver's device
 	int  ncu = 0;
 	struct ExRec {
 		int     tag, level, peer;
@@ -586,6 +592,7 @@ int residualSumsq2d(te_gmg *g, LevelHost &L, const double *u, const double *f, d
 int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false, const double *prolong_from = nullptr);
 int residRestrict2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse);
 int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1, bool zero_guess, bool *swapped);
+int patchBcgs2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0);
 int restrict2d(te_gmg *g, LevelHost &L, const double *fine, double *coarse);
 int prolong2d(te_gmg *g, LevelHost &L, const double *coarse, double *fine);
 int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, bool store_u);

@@ -202,6 +202,50 @@ int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0
 	return TE_OK;
 }
 
+// PatchSolvers/BiCGStabSolver.h:114-132 for every patch of the level: s0 = f - interface terms of the old iterate, then each
+// patch's own BiCGStab from its current values, in place (see k_patch_bcgs2d)
+int patchBcgs2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0)
+{
+	if (L.dim != 2) return te::fail(TE_EUNSUPPORTED, "TE_SMOOTH_PATCH_BCGS: the reference builds BiCGStabSolver in its 2D driver only (apps/2d/steady.cpp:326-327)");
+	if (L.n > 64) return te::fail(TE_EUNSUPPORTED, "TE_SMOOTH_PATCH_BCGS: patches up to 64^2 (one workgroup keeps the Krylov vectors in registers)");
+	int rc;
+	if ((rc = prepareGhosts2d(g, L, u))) return rc;
+	if (L.P == 0) return TE_OK;
+	if (!L.bcgs_its.p && (rc = L.bcgs_its.alloc((size_t) L.P))) return rc;
+	const size_t total = (size_t) L.P * L.nc;
+	{
+		Timed t(g, KC_PATCH_RHS, total);
+		hipLaunchKernelGGL(k_patch_rhs2d, dim3(gridFor(total, 256, 65536)), dim3(256), 0, g->stream, L.dev2(), u, f, s0);
+	}
+	const int    cpt = L.n <= 16 ? 1 : (L.n <= 32 ? 4 : 16), spr = (L.n + cpt - 1) / cpt;
+	const size_t lds = sizeof(double) * ((size_t) L.n * spr * (cpt > 1 ? cpt + 2 : 1) + (cpt >= 16 ? 256 * cpt : 0)); // tile (+ rhat)
+	const bool   full = L.n % cpt == 0;
+	Timed        t(g, KC_PATCH_BCGS, total);
+#define TE_BCGS(C, F) \
+	hipLaunchKernelGGL((k_patch_bcgs2d<C, F>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), s0, u, g->bcgs_tol, g->bcgs_max_it, L.bcgs_its.p)
+	if (cpt == 16 && !g->bcgs_attr) { // up to 68 KiB of dynamic LDS
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_patch_bcgs2d<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+		HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_patch_bcgs2d<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+		g->bcgs_attr = true;
+	}
+	if (cpt == 1)
+		TE_BCGS(1, true);
+	else if (cpt == 4) {
+		if (full)
+			TE_BCGS(4, true);
+		else
+			TE_BCGS(4, false);
+	} else {
+		if (full)
+			TE_BCGS(16, true);
+		else
+			TE_BCGS(16, false);
+	}
+#undef TE_BCGS
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
 int restrict2d(te_gmg *g, LevelHost &L, const double *fine, double *coarse)
 {
 	if (L.n_up > 0) {

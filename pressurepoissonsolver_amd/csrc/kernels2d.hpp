@@ -814,6 +814,187 @@ static __global__ __launch_bounds__(256) void k_patch_rhs2d(Level2D L, const dou
 		rhs[idx] = v;
 	}
 }
+// ---- the reference's OTHER patch solver in 2D: PatchSolvers/BiCGStabSolver.h:114-132 (apps/2d/steady.cpp:326-327, --patch_solver bcgs)
+// Per patch: the right-hand side with its interface terms (addInterfaceToRHS: `rhs`, formed by k_patch_rhs2d from the old iterate),
+// then BiCGStab<2>::solve (BiCGStab.h:45-106, no preconditioner, statement for statement) on the ONE patch with
+// StarPatchOp<2>::apply (StarPatchOp.h:204-319: faces with a neighbour closed as homogeneous Dirichlet) from the patch's current
+// values as the initial guess, to `tol` on ||resid|| / ||resid_0|| or `max_it` iterations. One workgroup of 256 threads owns a patch
+// for the whole solve. A thread owns CPT consecutive cells of one row (ceil(n / CPT) segments per row, n rows: <= 256 threads
+// for n <= 64 with CPT = 16, n <= 32 with 4, n <= 16 with 1): the seven Krylov vectors live in its registers, an operator
+// application takes the x-neighbours from registers and only the rows above / below plus two segment-end cells from an LDS tile
+// (segments CPT + 2 doubles apart: 128-bit accesses, and the 16 lanes of one LDS pass fall into 16 different bank groups), the
+// closure of the patch operator on its four sides (ghost = -cell, or +cell on a Neumann side) is formed in registers, dot
+// products are block reductions in a fixed order (a thread's cells, wave shuffles, four partial sums through LDS). An iteration
+// costs five barriers. u is updated in place (its neighbours' old values are in `rhs` already). its[p] = iterations taken.
+// FULL: n is a multiple of CPT (every size the drivers use): no partly filled segments.
+template <int CPT, bool FULL>
+__global__ __launch_bounds__(256, 2) void k_patch_bcgs2d(Level2D L, const double *__restrict__ rhs, double *__restrict__ u, double tol, int max_it,
+                                                      int32_t *__restrict__ its)
+{
+	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // n rows of spr segments of SS doubles
+	constexpr int SS = CPT > 1 ? CPT + 2 : 1;
+	const int     n = L.n, p = blockIdx.x, tid = threadIdx.x;
+	const int     spr = (n + CPT - 1) / CPT, lw = spr * SS, row = tid / spr, seg = tid - row * spr, x0 = seg * CPT;
+	const bool    act = row < n;
+	const int     nv  = !act ? 0 : (FULL ? CPT : min(CPT, n - x0)); // valid cells of the segment (cells beyond hold zeros throughout)
+	const bool    last_seg = seg == spr - 1;
+	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
+	double        sg[4];
+#pragma unroll
+	for (int s2 = 0; s2 < 4; s2++) sg[s2] = (L.face_kind[p * 4 + s2] == FACE_NEUMANN) ? 1.0 : -1.0;
+	double       *mine = tile2d + row * lw + seg * SS;
+	double        x[CPT], r[CPT], pv[CPT], ap[CPT], sv[CPT], as[CPT];
+	// rhat never changes after the start: with 16 cells per thread it lives in the thread's own slot of LDS behind the tile and is
+	// streamed into the two dot products that read it (32 registers less: two workgroups fit a CU, each hiding the other's latencies)
+	constexpr bool RH_LDS = CPT >= 16;
+	double         rh_reg[RH_LDS ? 1 : CPT];
+	double        *rh_lds = tile2d + n * lw + tid * CPT;
+	auto           loadRh = [&](double(&o)[CPT]) {
+        if (RH_LDS) {
+#pragma unroll
+            for (int k = 0; k < CPT; k += 2) {
+                const double2 t = *reinterpret_cast<const double2 *>(rh_lds + k);
+                o[k] = t.x, o[k + (CPT > 1)] = t.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CPT; k++) o[k] = rh_reg[RH_LDS ? 0 : k];
+        }
+	};
+	double       *up = u + (size_t) p * n * n + (size_t) row * n + x0;
+	const double *bp = rhs + (size_t) p * n * n + (size_t) row * n + x0;
+	// out = A_patch v. (The tile's previous readers are done: a dot product's barrier lies between any two applications.)
+	auto apply = [&](const double(&v)[CPT], double(&out)[CPT]) {
+		if (act) {
+			if (CPT > 1) {
+#pragma unroll
+				for (int k = 0; k < CPT; k += 2) *reinterpret_cast<double2 *>(mine + k) = make_double2(v[k], v[k + (CPT > 1)]);
+			} else
+				mine[0] = v[0];
+		}
+		__syncthreads();
+		if (act) {
+			double ym[CPT], yp[CPT];
+			if (row > 0) {
+				if (CPT > 1) {
+#pragma unroll
+					for (int k = 0; k < CPT; k += 2) {
+						const double2 t = *reinterpret_cast<const double2 *>(mine - lw + k);
+						ym[k] = t.x, ym[k + (CPT > 1)] = t.y;
+					}
+				} else
+					ym[0] = mine[-lw];
+			} else {
+#pragma unroll
+				for (int k = 0; k < CPT; k++) ym[k] = sg[2] * v[k];
+			}
+			if (row < n - 1) {
+				if (CPT > 1) {
+#pragma unroll
+					for (int k = 0; k < CPT; k += 2) {
+						const double2 t = *reinterpret_cast<const double2 *>(mine + lw + k);
+						yp[k] = t.x, yp[k + (CPT > 1)] = t.y;
+					}
+				} else
+					yp[0] = mine[lw];
+			} else {
+#pragma unroll
+				for (int k = 0; k < CPT; k++) yp[k] = sg[3] * v[k];
+			}
+			const double left  = seg > 0 ? mine[-SS + CPT - 1] : sg[0] * v[0];
+			const double right = last_seg ? sg[1] * v[CPT - 1] : mine[SS]; // (FULL, or a full segment: its last cell is cell CPT - 1)
+#pragma unroll
+			for (int k = 0; k < CPT; k++) {
+				const double l = k == 0 ? left : v[k > 0 ? k - 1 : 0];
+				double       rt = k == CPT - 1 ? right : v[k < CPT - 1 ? k + 1 : 0];
+				if (!FULL && k + 1 == nv) rt = sg[1] * v[k]; // the patch's east side inside a partly filled (hence last) segment
+				out[k] = lap2d(l, v[k], rt, ym[k], yp[k], rhx, rhy);
+				if (!FULL && k >= nv) out[k] = 0.0;
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < CPT; k++) out[k] = 0.0;
+		}
+	};
+	// (sum a b, sum c d) over the patch, the same value in every thread; partial sums alternate between two LDS slots, so one
+	// barrier per call separates a slot's writers from the readers of its previous use
+	__shared__ double red[2][2][4];
+	int               par = 0;
+	auto dot2 = [&](const double(&a)[CPT], const double(&b)[CPT], const double(&c2)[CPT], const double(&d)[CPT], double &o0, double &o1) {
+		double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+		for (int k = 0; k < CPT; k++) {
+			s0 += a[k] * b[k];
+			s1 += c2[k] * d[k];
+		}
+#pragma unroll
+		for (int off = 32; off > 0; off >>= 1) {
+			s0 += __shfl_down(s0, off, 64);
+			s1 += __shfl_down(s1, off, 64);
+		}
+		if ((tid & 63) == 0) red[par][0][tid >> 6] = s0, red[par][1][tid >> 6] = s1;
+		__syncthreads();
+		o0 = ((red[par][0][0] + red[par][0][1]) + red[par][0][2]) + red[par][0][3];
+		o1 = ((red[par][1][0] + red[par][1][1]) + red[par][1][2]) + red[par][1][3];
+		par ^= 1;
+	};
+#pragma unroll
+	for (int k = 0; k < CPT; k++) x[k] = k < nv ? up[k] : 0.0;
+	apply(x, r); // A->apply(x, resid)
+#pragma unroll
+	for (int k = 0; k < CPT; k++) {
+		r[k]  = k < nv ? -1.0 * r[k] + bp[k] : 0.0; // resid->scaleThenAdd(-1, b)
+		pv[k] = r[k];                               // rhat->copy(resid); p->copy(resid)
+		if (RH_LDS)
+			rh_lds[k] = r[k];
+		else
+			rh_reg[RH_LDS ? 0 : k] = r[k];
+	}
+	double rr, rho;
+	dot2(r, r, r, r, rr, rho); // (rhat == resid here: rho = rhat . resid)
+	rho = rr;
+	const double r0_norm = sqrt(rr);
+	int          num     = 0;
+	while (sqrt(rr) / r0_norm > tol && num < max_it) {
+		apply(pv, ap);
+		double d0, d1;
+		{
+			double rh[CPT];
+			loadRh(rh);
+			dot2(rh, ap, rh, ap, d0, d1);
+		}
+		const double alpha = rho / d0;
+#pragma unroll
+		for (int k = 0; k < CPT; k++) sv[k] = r[k] + -alpha * ap[k]; // s->copy(resid); s->addScaled(-alpha, ap)
+		apply(sv, as);
+		dot2(as, sv, as, as, d0, d1);
+		const double omega = d0 / d1;
+#pragma unroll
+		for (int k = 0; k < CPT; k++) {
+			x[k] = x[k] + (alpha * pv[k] + omega * sv[k]);   // x->addScaled(alpha, p, omega, s)
+			r[k] = r[k] + (-alpha * ap[k] + -omega * as[k]); // resid->addScaled(-alpha, ap, -omega, as)
+		}
+		double rho_new;
+		{
+			double rh[CPT];
+			loadRh(rh);
+			dot2(r, rh, r, r, rho_new, rr);
+		}
+		const double beta = rho_new * alpha / (rho * omega);
+#pragma unroll
+		for (int k = 0; k < CPT; k++) {
+			pv[k] = pv[k] + -omega * ap[k]; // p->addScaled(-omega, ap)
+			pv[k] = beta * pv[k] + r[k];    // p->scaleThenAdd(beta, resid)
+		}
+		num++;
+		rho = rho_new;
+	}
+#pragma unroll
+	for (int k = 0; k < CPT; k++)
+		if (k < nv) up[k] = x[k];
+	if (tid == 0 && its) its[p] = num;
+}
+
 // STAGE 0,1 forward x,y; 2,3 inverse x,y. mats: [nplans][4][n*n] row-major; lam: [nplans][2][n]
 template <int STAGE>
 __global__ __launch_bounds__(256) void k_dst_axis2d(int n, int P, const int32_t *__restrict__ plan,

@@ -217,7 +217,9 @@ template <size_t D> class HipSmoother : public GMG::Smoother<D>
 	double                   omega;
 
 	public:
-	/// kind: TE_SMOOTH_PATCH_SOLVE (the reference's FFTBlockJacobiSmoother), TE_SMOOTH_JACOBI, TE_SMOOTH_RBGS
+	/// kind: TE_SMOOTH_PATCH_SOLVE (the reference's FFTBlockJacobiSmoother), TE_SMOOTH_JACOBI, TE_SMOOTH_RBGS, or (D = 2)
+	/// TE_SMOOTH_PATCH_BCGS: the block-Jacobi sweep over BiCGStabSolver<2>(p_operator, ps_tol, ps_max_it) that
+	/// apps/2d/steady.cpp:326-327 builds for --patch_solver bcgs; its stopping rule through te_gmg_set_patch_bcgs(ctx->g, ...)
 	HipSmoother(std::shared_ptr<Context> ctx_, int level_, int kind_ = TE_SMOOTH_PATCH_SOLVE, double omega_ = 6.0 / 7.0)
 	: ctx(ctx_), level(level_), kind(kind_), omega(omega_)
 	{

@@ -34,7 +34,9 @@ def test_reference_bicgstab_runs_over_the_adaptors(mesh, div, n, smoother):
     ("2d2ref.bin", 0, 8, 0, None),  # refined quadtree (apps/2d/meshes/2d2ref.bin): coarse/fine edges, BilinearInterpolator weights
     ("2d2ref.bin", 1, 8, 2, None),
     ("uniform", 3, 64, 2, None),    # 64 patches of 64^2 (config C5's patch size), RB-GS: the fused LDS kernels behind HipCycle<2>
-    ("uniform", 3, 64, 0, None)])   # ... and the reference's block-Jacobi smoother on the matrix cores
+    ("uniform", 3, 64, 0, None),    # ... and the reference's block-Jacobi smoother on the matrix cores
+    ("2d2ref.bin", 1, 8, 3, None),  # --patch_solver bcgs (apps/2d/steady.cpp:326-327): HipSmoother<2>(TE_SMOOTH_PATCH_BCGS)
+    ("uniform", 2, 64, 3, None)])
 def test_reference_bicgstab_runs_over_the_2d_adaptors(mesh, div, n, smoother, its_expected):
     """the D = 2 half of the boundary (apps/2d/steady.cpp:322-331, 494, 523, 563-568): HipVector<2> / HipVG<2> / HipOperator<2> /
     HipCycle<2> / HipSmoother<2> / HipRestrictor<2> / HipInterpolator<2> under the reference's own BiCGStab<2>::solve, the

@@ -1,0 +1,149 @@
+"""-m gpu: TE_SMOOTH_PATCH_BCGS, the reference's Krylov patch solver in 2D (PatchSolvers/BiCGStabSolver.h:114-132, built by
+apps/2d/steady.cpp:326-327 for --patch_solver bcgs): k_patch_bcgs2d against
+  (a) a sweep of the reference's own BiCGStab<2>::solve per patch on StarPatchOp<2>::apply (tests/golden/bcgs_ref_*.npz, written
+      by oracle/gen_golden.py from the reference's compiled classes), keyed by patch id;
+  (b) the oracle's restatement (orc_smooth_bcgs) on fresh inputs: sweeps, V-cycles and the preconditioned solve;
+  (c) the exact patch solve (TE_SMOOTH_PATCH_SOLVE): both solve the same patch systems.
+Tolerances: the patch systems are solved to tol = 1e-12 relative RESIDUAL, so two correct solvers' iterates agree to
+tol x the patch operator's condition number (2 n / pi)^2 (x 4 for the two solves and the norm change): btol(n) below, 1e-10 for
+n = 8, 6.6e-9 for n = 64; iteration counts are rounding-order sensitive by a few."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from pressurepoissonsolver_amd import capi
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = sorted(f for f in glob.glob(os.path.join(util.GOLDEN, "bcgs_ref_2d*.npz")))
+
+
+def btol(n, tol=1e-12):
+    return max(1e-10, 4 * tol * (2 * n / np.pi) ** 2)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300)
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(f)[9:-4] for f in FIXTURES])
+def test_hip_sweep_equals_the_references_bicgstab_patch_solves(path):
+    d = dict(np.load(path))
+    dim, n, neu = int(d["dim"]), int(d["n"]), bool(int(d["neumann"]))
+    m, H, levels = util.setup(str(d["mesh"]), n, 0, neumann=neu, dim=dim)
+    g = capi.GMG(H)
+    g.set_patch_bcgs(float(d["tol"]), int(d["max_it"]))
+    ids = H.tables(0)["id"]
+    pos = {int(i): k for k, i in enumerate(d["t_id"])}
+    perm = np.array([pos[int(i)] for i in ids])
+    nc = n ** dim
+
+    def mine(v):
+        return np.ascontiguousarray(v.reshape(-1, nc)[perm]).ravel()
+
+    du, df = g.new_vector(0, mine(d["u"])), g.new_vector(0, mine(d["f"]))
+    g.smooth(df, du, smoother=capi.SMOOTH_PATCH_BCGS)
+    want = mine(d["u_out"])
+    assert np.abs(du.download() - want).max() <= btol(n) * np.abs(want).max()
+    its = g.patch_bcgs_iterations(0, len(ids))
+    assert np.abs(its.astype(int) - d["its"][perm].astype(int)).max() <= 3
+
+
+def test_fixtures_present():
+    assert len(FIXTURES) >= 3
+
+
+CASES = [("2d2ref.bin", 8, 1, False), ("2d2ref.bin", 16, 2, False), ("uniform", 32, 2, False), ("uniform", 64, 2, False),
+         ("2d2ref.bin", 64, 0, False), ("2d2ref.bin", 8, 1, True), ("2d2ref.bin", 6, 1, False), ("uniform", 20, 1, False)]
+
+
+@pytest.mark.parametrize("mesh,n,div,neumann", CASES)
+def test_hip_sweep_against_oracle_and_exact_patch_solve(mesh, n, div, neumann):
+    """every register blocking of the kernel (1, 4, 16 cells per thread), patch sizes that are no multiple of anything, coarse /
+    fine edges and Neumann sides"""
+    m, H, levels = util.setup(mesh, n, div, neumann=neumann, dim=2)
+    L = levels[0]
+    g = capi.GMG(H)
+    f, u0 = util.rand_vec(L.size, 11), util.rand_vec(L.size, 12)
+    du, df = g.new_vector(0, u0), g.new_vector(0, f)
+    g.smooth(df, du, smoother=capi.SMOOTH_PATCH_BCGS)
+    got = du.download()
+    want, its_ref = orc.smooth_bcgs(L, f, u0)
+    assert np.abs(got - want).max() <= btol(n) * np.abs(want).max()
+    its = g.patch_bcgs_iterations(0, L.P)
+    assert its.min() >= 1 and np.abs(its.astype(int) - its_ref.astype(int)).max() <= max(3, int(its_ref.max()) // 10)
+    # the patch systems are solved: StarPatchOp::apply(u') = f - interface terms of the old iterate, to the tolerance
+    rhs = orc.add_iface_rhs(L, orc.interp(L, u0), f)
+    dr = g.new_vector(0)
+    g.patch_apply(du, dr)
+    assert np.abs(dr.download() - rhs).max() <= 1e-9 * np.abs(rhs).max()
+    # and the exact solver solves the same systems
+    dv = g.new_vector(0, u0)
+    g.smooth(df, dv, smoother=capi.SMOOTH_PATCH_SOLVE)
+    assert np.abs(got - dv.download()).max() <= btol(n) * np.abs(got).max()
+
+
+def test_iteration_cap_and_tolerance_are_honoured():
+    """BiCGStab.h:69: while (resid / r0 > tol && its < max_it)"""
+    m, H, levels = util.setup("uniform", 32, 1, dim=2)
+    L = levels[0]
+    g = capi.GMG(H)
+    f = util.rand_vec(L.size, 3)
+    nc = L.size // L.P
+    for tol, max_it in ((1e-12, 5), (1e-3, 1000), (1e-12, 0)):
+        g.set_patch_bcgs(tol, max_it)
+        du, df, dr = g.new_vector(0), g.new_vector(0, f), g.new_vector(0)
+        g.smooth(df, du, smoother=capi.SMOOTH_PATCH_BCGS)
+        its = g.patch_bcgs_iterations(0, L.P)
+        want, its_ref = orc.smooth_bcgs(L, f, np.zeros(L.size), tol, max_it)
+        got = du.download()
+        if max_it == 0:
+            assert (its == 0).all() and not got.any()
+        elif max_it == 5:  # capped long before convergence: the same five iterations as the oracle's
+            assert (its == 5).all() and (its_ref == 5).all()
+            assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+        else:  # stopped by the tolerance: every patch's residual is below it (zero iterate: no interface terms, r0 = f), and
+            #    not a whole iteration early (counts within a few of the oracle's: BiCGStab's residual is not monotone)
+            g.patch_apply(du, dr)
+            r = (f - dr.download()).reshape(L.P, nc)
+            ratio = np.linalg.norm(r, axis=1) / np.linalg.norm(f.reshape(L.P, nc), axis=1)
+            assert (ratio <= tol * 1.01).all() and (ratio >= tol * 1e-3).all()
+            assert np.abs(its.astype(int) - its_ref.astype(int)).max() <= 4 and its.max() < 100
+    with pytest.raises(capi.TeError):
+        g.set_patch_bcgs(-1.0, 10)
+
+
+@pytest.mark.parametrize("mesh,n,div,cycle_type", [("2d2ref.bin", 8, 1, 0), ("uniform", 32, 3, 0), ("2d2ref.bin", 16, 1, 1)])
+def test_cycles_and_the_solve_with_the_krylov_patch_solver(mesh, n, div, cycle_type):
+    """the smoother inside te_vcycle (every fuse setting takes the same unfused path for it) and as BiCGStab's preconditioner"""
+    m, H, levels = util.setup(mesh, n, div, dim=2)
+    g = capi.GMG(H)
+    f = util.rand_vec(levels[0].size, 21)
+    df, du = g.new_vector(0, f), g.new_vector(0)
+    want = orc.cycle(levels, orc.cycle_opts(smoother=3, cycle_type=cycle_type), f)
+    for fuse in (0, 3):
+        o = g.default_opts(smoother=capi.SMOOTH_PATCH_BCGS)
+        o.fuse, o.cycle_type = fuse, cycle_type
+        g.cycle(o, df, du)
+        assert rel(du.download(), want) <= 10 * btol(n)  # (a cycle applies a handful of sweeps)
+    dx = g.new_vector(0)
+    its, rr = g.bicgstab(dx, df, g.default_opts(smoother=capi.SMOOTH_PATCH_BCGS))
+    x_ref, its_ref, rr_ref = orc.bicgstab(levels, orc.cycle_opts(smoother=3), f)
+    assert rr <= 1e-12 and rr_ref <= 1e-12 and abs(its - its_ref) <= 1
+    assert rel(dx.download(), x_ref) <= 1e-8
+    # same convergence as with the exact patch solver (the patch systems are solved to 1e-12 either way)
+    its_exact, _ = g.bicgstab(g.new_vector(0), df, g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE))
+    assert abs(its - its_exact) <= 1
+
+
+def test_three_dimensional_levels_refuse_the_smoother():
+    """the reference instantiates BiCGStabSolver in its 2D driver only; the 3D driver has no such option (apps/3d/steady.cpp)"""
+    m, H, levels = util.setup("2uni.bin", 4)
+    g = capi.GMG(H)
+    du, df = g.new_vector(0), g.new_vector(0)
+    with pytest.raises(capi.TeError):
+        g.smooth(df, du, smoother=capi.SMOOTH_PATCH_BCGS)

@@ -166,3 +166,44 @@ def test_live_against_reference_slice(name, n, div):
     assert np.abs(orc.interp(L, u) - refslice.interp(L, u)).max() <= 4 * util.EPS
     assert np.abs(orc.apply(L, u) - refslice.apply(L, u)).max() <= util.op_tol(L, u)
     assert np.abs(orc.patch_apply(L, u) - refslice.patch_apply(L, u)).max() <= util.op_tol(L, u)
+
+
+# ---- the reference's Krylov patch solver (PatchSolvers/BiCGStabSolver.h:114-132, apps/2d/steady.cpp:326-327) ----------------------
+BCGS_FIXTURES = sorted(glob.glob(os.path.join(util.GOLDEN, "bcgs_ref_*.npz")))
+
+
+@pytest.mark.parametrize("path", BCGS_FIXTURES, ids=[os.path.basename(f)[9:-4] for f in BCGS_FIXTURES])
+def test_patch_bicgstab_sweep_against_reference(path):
+    """orc_smooth_bcgs against a sweep of the reference's own BiCGStab<D>::solve per patch on StarPatchOp<D>::apply
+    (oracle/gen_golden.py bcgs_case): the patch systems are solved to 1e-12, so the iterates agree far below that times the
+    condition number; iteration counts are rounding-order sensitive by one or two."""
+    d = dict(np.load(path))
+    L = level_of(d)
+    u, its = orc.smooth_bcgs(L, d["f"], d["u"], float(d["tol"]), int(d["max_it"]))
+    assert np.abs(u - d["u_out"]).max() <= 1e-9 * np.abs(d["u_out"]).max()
+    assert np.abs(its.astype(int) - d["its"].astype(int)).max() <= 2
+    # each patch's system is solved: StarPatchOp::apply(u_new) == f - interface terms of the OLD iterate
+    rhs = orc.add_iface_rhs(L, orc.interp(L, d["u"]), d["f"])
+    assert np.abs(orc.patch_apply(L, u) - rhs).max() <= 1e-9 * np.abs(rhs).max()
+
+
+def test_patch_bicgstab_fixtures_present():
+    assert len(BCGS_FIXTURES) >= 4
+
+
+def test_patch_bicgstab_sweep_is_the_exact_block_jacobi_sweep_at_tight_tolerance():
+    """both patch solvers solve the same patch systems: one sweep of either from the same iterate agrees to the tolerance"""
+    m, H, levels = util.setup("2d2ref.bin", 8, 1, dim=2)
+    L = levels[0]
+    f, u0 = util.rand_vec(L.size, 5), util.rand_vec(L.size, 6)
+    a = orc.smooth(L, f, u0)
+    b, its = orc.smooth_bcgs(L, f, u0, 1e-13, 1000)
+    assert np.abs(a - b).max() <= 1e-9 * np.abs(a).max() and its.max() < 100
+
+
+def test_cycle_with_the_krylov_patch_solver_converges_like_the_exact_one():
+    m, H, levels = util.setup("2d2ref.bin", 8, 1, dim=2)
+    f = util.rand_vec(levels[0].size, 9)
+    a = orc.cycle(levels, orc.cycle_opts(smoother=0), f)
+    b = orc.cycle(levels, orc.cycle_opts(smoother=3), f)
+    assert np.abs(a - b).max() <= 1e-8 * np.abs(a).max()
