@@ -48,6 +48,9 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 	g->cur_level        = l;
 	const double *fcorr_in = (L.f_has_corr && L.fcorr.p) ? L.fcorr.p : nullptr; // ghost terms that still belong to f (see below)
 	L.f_has_corr           = false;
+	const Fold2DHost fold_in = L.fold_pending; // (2D) ghost terms this level's pre-sweep kernel still has to add to f itself
+	L.fold_pending           = Fold2DHost();
+	if (fold_in.fine && coarsest) return te::fail(TE_ESTATE, "te_vcycle: folded ghost terms without a reader");
 	// te_bicgstab may hand over a right-hand side that is still a pending vector statement (PendingRhs): the fused pre-sweep
 	// of level 0 forms it while reading its operands; every other path runs the stand-alone kernel first
 	const PendingRhs *pend = (l == 0) ? g->pending_rhs : nullptr;
@@ -186,14 +189,22 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		                        : nullptr; // (the next level uniformly refined; this one may be refined: the gather forms the terms;
 		                                   //  not into a replicated level: its x terms would have to travel with the blocks)
 		if (fcorr_in && !u_unstored) return te::fail(TE_ESTATE, "te_vcycle: exported ghost terms without a reader");
+		// 2D: if the next level runs this very branch (it is visited with a zero iterate and is not the coarsest), ITS pre-sweep
+		// kernel adds the ghost terms of the restricted residual to its right-hand side before reading it, and the fix-up launch
+		// of this level does not happen (bit-identical: the same additions in the same order; rank-local: every child of a local
+		// coarse patch is local, no block travels)
+		const bool fold_out = L.dim == 2 && l + 2 < nl && C.fuse2_ok && L.n >= 4 && L.n <= 64 && L.tx_up.empty() && L.n_down == 0 && !L.repl_up
+		                      && L.child.p && L.Pc == C.P && !g->cfg.has(O_2D_NO_FOLD);
 		// (the kernel variants that form a pending right-hand side exist for the 3D path that does not store the iterate)
 		const PendingRhs *fs = (pend && u_unstored && L.dim == 3 && !fcorr_in && L.P > 0 && !g->recording) ? pend : nullptr;
 		if (fs)
 			pend = nullptr;
 		else if ((rc = formRhs()))
 			return rc;
-		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p, !u_unstored, fcorr_out, fcorr_in, fs))) return rc;
+		if ((rc = zeroSweepResid(g, L, f->d, L.t->d, C.f->d, L.xfbuf[L.xf_cur ^ 1].p, !u_unstored, fcorr_out, fcorr_in, fs, &fold_in, fold_out)))
+			return rc;
 		C.f_has_corr = fcorr_out != nullptr;
+		if (fold_out) C.fold_pending = Fold2DHost{&L, u_unstored ? nullptr : L.t->d};
 		if (u_unstored) {
 			L.xf_valid_for = nullptr;
 		} else {
@@ -214,7 +225,7 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		if ((rc = smoothOnce(g, l, f, u, TE_SMOOTH_PATCH_SOLVE, o->omega, true))) return rc;
 		if ((rc = interfaceResidRestrict(g, L, u->d, xfFor(L, u->d), C.f->d, C.f->n))) return rc;
 		have_coarse_f = true;
-	} else if (fcorr_in) {
+	} else if (fcorr_in || fold_in.fine) {
 		return te::fail(TE_ESTATE, "te_vcycle: exported ghost terms without a reader");
 	} else if ((rc = formRhs()) || (rc = smooth(o->pre_sweeps, false))) {
 		return rc;

@@ -80,7 +80,7 @@ extern const char *kclassName[KC_COUNT]; // (gmg_core.hip)
 enum Opt : int {
 	O_2D_SIMPLE, O_2D_NO_MFMA, O_2D_NO_PF, O_2D_NO_MR_FUSE, O_2D_TPB, O_NO_FUSE2, O_NO_FUSE3, O_NO_FUSE3_CF, O_NO_CFP, O_NO_XF,
 	O_NO_FCORR, O_NO_FCORR_CF, O_NO_GTAB, O_NO_OVERLAP, O_OVERLAP_MIN, O_NO_PS_FACES, O_PS_MODE, O_PS_SLOW, O_RBGS_NOSLAB,
-	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_PUSH_TIMEOUT, O_NO_BICG_XF, O_PUSH_FAULT, O_COUNT
+	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_PUSH_TIMEOUT, O_NO_BICG_XF, O_PUSH_FAULT, O_2D_NO_FOLD, O_COUNT
 };
 extern const char *optName[O_COUNT]; // (gmg_core.hip)
 // options that shape the level tables te_gmg_create builds: fixed for the solver's lifetime
@@ -130,6 +130,13 @@ struct ExPlan {
 	bool empty() const { return peers.empty(); }
 };
 
+struct LevelHost;
+// 2D, opts.fuse >= 2: the ghost terms of a coarse right-hand side that the FINER level's pre-sweep left out and that no fix-up pass
+// has added: the coarse level's own pre-sweep adds them (k_rbgs_zero_resid2d_lds<.., FOLD>). fine == null: nothing pending.
+struct Fold2DHost {
+	LevelHost    *fine = nullptr;
+	const double *u    = nullptr; // the finer level's new iterate when it was stored; null: its edge layers are in fine->e4buf
+};
 struct LevelHost {
 	int    dim = 3, n = 0, P = 0, P_global = 0, index = 0; // index: the level's number in the solver (0 = finest)
 	bool   gathered = false; // the level lives on rank 0 alone or on every rank (the hierarchy's placement): no face exchange
@@ -277,6 +284,7 @@ struct LevelHost {
 	// adding them in a fix-up pass (march3d.hpp FCorrSrc); f_has_corr: they belong to the current L.f (inside te_vcycle)
 	DevBuf<double> fcorr;
 	bool           f_has_corr = false;
+	Fold2DHost     fold_pending; // (2D) belongs to the current L.f, inside te_vcycle: see Fold2DHost
 	DevBuf<double> rs6; // [P][6][(n/2)^2]: the 2x2 sums of the face layers, as the producer of the next level's fcorr
 	DevBuf<int32_t> gtab; // 3D: [Pc][48] block starts in rs6 for k_fcorr_gather3d (built at its first launch)
 	DevBuf<double> e4buf; // 2D: [P][4][n] edge layers of an iterate that is never stored (the 2D twin of f6buf)
@@ -575,7 +583,8 @@ extern template int launchStencil<MODE_JACOBI>(te_gmg *, LevelHost &, const doub
 int resweepProlong(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from, double *xf_out, const double *fcorr_in);
 int interfaceResidRestrict(te_gmg *g, LevelHost &L, const double *u, const double *xf, double *coarse, size_t coarse_n);
 int zeroSweepResid(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, double *xf_out, bool store_u,
-                   double *fcorr_out = nullptr, const double *fcorr_in = nullptr, const PendingRhs *fs = nullptr);
+                   double *fcorr_out = nullptr, const double *fcorr_in = nullptr, const PendingRhs *fs = nullptr,
+                   const Fold2DHost *fold_in = nullptr, bool skip_fixup = false);
 int launchRbgs(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false,
                const double *prolong_from = nullptr, const double *xf_in = nullptr, double *xf_out = nullptr);
 int residRestrict(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse, const double *xf_in = nullptr);
@@ -595,7 +604,8 @@ int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0
 int patchBcgs2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0);
 int restrict2d(te_gmg *g, LevelHost &L, const double *fine, double *coarse);
 int prolong2d(te_gmg *g, LevelHost &L, const double *coarse, double *fine);
-int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, bool store_u);
+int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, bool store_u, const Fold2DHost *fold_in = nullptr,
+                     bool skip_fixup = false);
 int resweepProlong2d(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from);
 // ---- gmg_cycle.hip
 int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, bool u_zero);

@@ -280,31 +280,49 @@ int prolong2d(te_gmg *g, LevelHost &L, const double *coarse, double *fine)
 }
 
 // opts.fuse = 2 / 3 in 2D (levels with L.fuse2_ok: patches in LDS, every parent and neighbour local): see kernels2d.hpp
-int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, bool store_u)
+int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, double *coarse, bool store_u, const Fold2DHost *fold_in,
+                     bool skip_fixup)
 {
 	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
 	Prolong2D    dst{L.parent.p, L.orth.p, nullptr};
 	int          rc;
 	if (L.P > 0) {
 		Timed t(g, store_u ? KC_ZERO_RESID : KC_ZERO_RESID_FACES, (size_t) L.P * L.nc, true);
-#define TE_ZR2(S, NC)                                                                                                             \
-	launchT(t, (k_rbgs_zero_resid2d_lds<S, NC>), dim3(L.P), dim3(256), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, \
-	                   coarse, L.upbuf.p, L.up_off.p)
+		// fold_in: this level's right-hand side still lacks the ghost terms of the finer level's restricted residual; the kernel
+		// adds them to f (this solver's own coarse vector) before it reads it
+		Fold2D fold = Fold2D();
+		if (fold_in && fold_in->fine) {
+			LevelHost &Lf = *fold_in->fine;
+			if (Lf.Pc != L.P || Lf.n != L.n || !Lf.child.p) return te::fail(TE_ESTATE, "zeroSweepResid2d: folded fix-up from a level that is not this level's finer one");
+			fold.fine  = Lf.dev2();
+			fold.u     = fold_in->u;
+			fold.e4    = fold_in->u ? nullptr : Lf.e4buf.p;
+			fold.child = Lf.child.p;
+		}
+		const bool fo = fold.child != nullptr;
+		double    *fw = const_cast<double *>(f);
+#define TE_ZR2(S, NC, T)                                                                                                           \
+	do {                                                                                                                           \
+		if (fo)                                                                                                                    \
+			launchT(t, (k_rbgs_zero_resid2d_lds<S, NC, T, true>), dim3(L.P), dim3(T), lds, g->stream, L.dev2(), fw, out, L.e4buf.p, dst, \
+			        coarse, L.upbuf.p, L.up_off.p, fold);                                                                          \
+		else                                                                                                                       \
+			launchT(t, (k_rbgs_zero_resid2d_lds<S, NC, T, false>), dim3(L.P), dim3(T), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst, \
+			        coarse, L.upbuf.p, L.up_off.p, Fold2D());                                                                      \
+	} while (0)
 		if (L.n == 64 && tpb2d(g) == 512) {
 			if (store_u)
-				launchT(t, (k_rbgs_zero_resid2d_lds<true, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst,
-				                   coarse, L.upbuf.p, L.up_off.p);
+				TE_ZR2(true, 64, 512);
 			else
-				launchT(t, (k_rbgs_zero_resid2d_lds<false, 64, 512>), dim3(L.P), dim3(512), lds, g->stream, L.dev2(), f, out, L.e4buf.p, dst,
-				                   coarse, L.upbuf.p, L.up_off.p);
+				TE_ZR2(false, 64, 512);
 		} else if (store_u && L.n == 64)
-			TE_ZR2(true, 64);
+			TE_ZR2(true, 64, 256);
 		else if (store_u)
-			TE_ZR2(true, 0);
+			TE_ZR2(true, 0, 256);
 		else if (L.n == 64)
-			TE_ZR2(false, 64);
+			TE_ZR2(false, 64, 256);
 		else
-			TE_ZR2(false, 0);
+			TE_ZR2(false, 0, 256);
 #undef TE_ZR2
 	}
 	if (L.nremote > 0) { // the new edge layers of neighbours on other ranks
@@ -317,7 +335,7 @@ int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, doub
 		}
 		if ((rc = faceExchange(g, L, L.sendbuf.p))) return rc;
 	}
-	if (L.P > 0) {
+	if (L.P > 0 && !skip_fixup) { // (skip_fixup: the coarser level's pre-sweep adds the terms itself, Fold2DHost)
 		Timed t(g, KC_FIXUP, (size_t) L.P * 4 * L.nf);
 		hipLaunchKernelGGL(k_restrict_fixup2d, dim3(L.P), dim3(128), 0, g->stream, L.dev2(), out,
 		                   store_u ? (const double *) nullptr : (const double *) L.e4buf.p, dst, coarse, L.upbuf.p, L.up_off.p);

@@ -457,14 +457,83 @@ __global__ __launch_bounds__(TPB) void k_rbgs2d_lds(Level2D L, const double *__r
 // NC: the patch size as a compile-time constant (0: run-time L.n) -- every cell's (x, y) comes from an integer division by n,
 // dozens of instructions each at run time, shifts for NC = 64 (config C5)
 // A parent on another rank (dst.parent < -1): the restricted block goes to `remote` (h x h, shipped afterwards), as in 3D.
-template <bool STORE_U, int NC, int TPB = 256>
-__global__ __launch_bounds__(TPB) void k_rbgs_zero_resid2d_lds(Level2D L, const double *__restrict__ f, double *__restrict__ out,
-                                                               double *__restrict__ e4, Prolong2D dst, double *__restrict__ coarse,
-                                                               double *__restrict__ remote, const int64_t *__restrict__ remote_off)
+// The ghost terms the kernel below leaves out of the restricted residual, for ONE fine patch p whose restricted block starts at
+// cb (row stride cs): for every face with a neighbour, -(1/h^2)/4 * (the two neighbour values behind a pair of face cells) belongs
+// to the coarse cell behind the pair. edges = e4 of the new iterate, or null: read them from u. A neighbour on another rank: its
+// edge arrived in a ghost slot. Shared by k_restrict_fixup2d (a pass of its own) and the FOLD prologue of the coarse level's
+// pre-sweep (the reader of the coarse right-hand side completes it itself): the same expressions, bit-identical.
+struct Fixup2D {
+	const Level2D &L;
+	const double  *u, *e4;
+	int            p;
+	double        *cb;
+	int            cs;
+	// the sum of face s for the coarse cell number i along it
+	__device__ __forceinline__ double term(int s, int kind, int i) const
+	{
+		const int    n = L.n, nn = n * n;
+		const int    src = L.face_src[p * 4 + s], ax = s >> 1;
+		const double w   = -L.rh2[p * 3 + ax];
+		double       acc = 0.0;
+#pragma unroll
+		for (int d = 0; d < 2; d++) {
+			const int t = 2 * i + d;
+			double    g;
+			if (kind == FACE_GHOST)
+				g = L.ghost[(size_t) src * n + t];
+			else if (e4)
+				g = e4[((size_t) src * 4 + (s ^ 1)) * n + t];
+			else
+				g = u[(size_t) src * nn + (s == 0 ? n - 1 + n * t : (s == 1 ? n * t : (s == 2 ? t + n * (n - 1) : t)))];
+			acc += (w * g) / 4;
+		}
+		return acc;
+	}
+	__device__ __forceinline__ int cell(int s, int i) const
+	{
+		const int h = L.n / 2;
+		return (s >> 1) == 0 ? ((s & 1) ? h - 1 : 0) + cs * i : i + cs * ((s & 1) ? h - 1 : 0);
+	}
+};
+// FOLD: where the finer level's pre-sweep left its neighbours' edge layers (and which fine patch sits in which quadrant of a patch
+// of this level): see k_rbgs_zero_resid2d_lds
+struct Fold2D {
+	Level2D        fine;
+	const double  *u, *e4;  // the finer level's new iterate (stored), or its four edge layers
+	const int32_t *child;   // [P][4]: the fine patch in quadrant ox + 2 oy
+};
+
+// FOLD: this level's right-hand side was produced by the same kernel one level up WITHOUT its ghost terms, and no
+// k_restrict_fixup2d pass has run: the workgroup adds them to its own patch of f first (the fix-up's expressions in the fix-up's
+// order -- W/E terms, barrier, S/N terms -- on global memory, which the waves of one workgroup see coherently after a barrier:
+// they share the CU's L1), then proceeds as usual. A launch of 3-12 us per level becomes a prologue of three dependent loads; the
+// corrected f is what the post-sweep reads later. 4 <= n <= 64, every child local (the host decides).
+template <bool STORE_U, int NC, int TPB = 256, bool FOLD = false>
+__global__ __launch_bounds__(TPB) void k_rbgs_zero_resid2d_lds(Level2D L, std::conditional_t<FOLD, double *, const double *__restrict__> f,
+                                                               double *__restrict__ out, double *__restrict__ e4, Prolong2D dst,
+                                                               double *__restrict__ coarse, double *__restrict__ remote,
+                                                               const int64_t *__restrict__ remote_off, Fold2D fold = Fold2D())
 {
 	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // the colour-split tile (Tile2D), then 9 diagonals
 	const int     n = NC ? NC : L.n, nn = n * n, h = n / 2;
 	const int     p = blockIdx.x, tid = threadIdx.x;
+	if constexpr (FOLD) {
+		static_assert(TPB % 128 == 0, "a quadrant's four faces take 128 threads");
+#pragma unroll 1
+		for (int base = 0; base < 4; base += TPB / 128) {
+			const int     qd = base + (tid >> 7), t = tid & 127, s = t >> 5, i = t & 31;
+			const int     c  = fold.child[(size_t) p * 4 + qd];
+			double       *cb = f + (size_t) p * nn + ((qd & 1) ? h : 0) + n * ((qd & 2) ? h : 0);
+			const Fixup2D fx{fold.fine, fold.u, fold.e4, c, cb, n};
+			const int     kind = fold.fine.face_kind[c * 4 + s];
+			const bool    actf = i < h && kind >= FACE_LOCAL;
+			const double  acc  = actf ? fx.term(s, kind, i) : 0.0;
+			if (actf && s < 2) cb[fx.cell(s, i)] += acc;
+			__syncthreads();
+			if (actf && s >= 2) cb[fx.cell(s, i)] += acc;
+			__syncthreads();
+		}
+	}
 	const double *fp = f + (size_t) p * nn;
 	const Tile2D  T(tile2d, n);
 	double       *idg = tile2d + 2 * T.cs;
@@ -539,10 +608,8 @@ __global__ __launch_bounds__(TPB) void k_rbgs_zero_resid2d_lds(Level2D L, const 
 		}
 	}
 }
-// the ghost terms the kernel above left out: for every face with a (local) neighbour, -(1/h^2)/4 * (the two neighbour
-// values behind a pair of face cells) is added to the coarse cell behind the pair; faces in the order W,E,S,N.
-// edges = e4 of the new iterate, or null: read them from u.
-// A neighbour on another rank: its edge arrived in a ghost slot. A parent on another rank: the block in `remote`.
+// the ghost terms the kernel above left out (Fixup2D), as a pass of its own: faces in the order W,E,S,N. A parent on another rank:
+// the block in `remote`.
 static __global__ __launch_bounds__(128) void k_restrict_fixup2d(Level2D L, const double *__restrict__ u, const double *__restrict__ e4,
                                                           Prolong2D dst, double *__restrict__ coarse, double *__restrict__ remote,
                                                           const int64_t *__restrict__ remote_off)
@@ -550,27 +617,10 @@ static __global__ __launch_bounds__(128) void k_restrict_fixup2d(Level2D L, cons
 	const int n = L.n, nn = n * n, h = n / 2, p = blockIdx.x;
 	const int pa = dst.parent[p], o = dst.orth[p];
 	double   *cb = pa >= 0 ? coarse + (size_t) pa * nn + ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0) : remote + remote_off[-(pa + 2)];
-	const int cs = pa >= 0 ? n : h;
-	// the sum of face s for the coarse cell number i along it
-	auto term = [&](int s, int kind, int i) {
-		const int    src = L.face_src[p * 4 + s], ax = s >> 1;
-		const double w   = -L.rh2[p * 3 + ax];
-		double       acc = 0.0;
-#pragma unroll
-		for (int d = 0; d < 2; d++) {
-			const int t = 2 * i + d;
-			double    g;
-			if (kind == FACE_GHOST)
-				g = L.ghost[(size_t) src * n + t];
-			else if (e4)
-				g = e4[((size_t) src * 4 + (s ^ 1)) * n + t];
-			else
-				g = u[(size_t) src * nn + (s == 0 ? n - 1 + n * t : (s == 1 ? n * t : (s == 2 ? t + n * (n - 1) : t)))];
-			acc += (w * g) / 4;
-		}
-		return acc;
-	};
-	auto cell = [&](int s, int i) { return (s >> 1) == 0 ? ((s & 1) ? h - 1 : 0) + cs * i : i + cs * ((s & 1) ? h - 1 : 0); };
+	const int     cs = pa >= 0 ? n : h;
+	const Fixup2D fx{L, u, e4, p, cb, cs};
+	auto          term = [&](int s, int kind, int i) { return fx.term(s, kind, i); };
+	auto          cell = [&](int s, int i) { return fx.cell(s, i); };
 	if (h >= 2 && h <= 32) {
 		// one 32-lane group per face, all four sums in flight at once; W and E touch different cells, S and N too: two rounds of
 		// additions (a corner cell takes its W/E term, then its S/N term -- the order of the face-by-face loop below)
