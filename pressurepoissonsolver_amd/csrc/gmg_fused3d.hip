@@ -250,7 +250,7 @@ int zeroSweepResid(te_gmg *g, LevelHost &L, const double *f, double *out, double
                    double *fcorr_out, const double *fcorr_in, const PendingRhs *fs, const Fold2DHost *fold_in, bool skip_fixup)
 {
 	if (L.dim == 2) return zeroSweepResid2d(g, L, f, out, coarse, store_u, fold_in, skip_fixup);
-	if (fold_in || skip_fixup) return te::fail(TE_ESTATE, "zeroSweepResid: the folded fix-up exists in 2D only");
+	if ((fold_in && fold_in->fine) || skip_fixup) return te::fail(TE_ESTATE, "zeroSweepResid: the folded fix-up exists in 2D only");
 	switch (L.n) {
 		case 4: return zeroSweepResidN<4>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in, fs);
 		case 8: return zeroSweepResidN<8>(g, L, f, out, coarse, xf_out, store_u, fcorr_out, fcorr_in, fs);

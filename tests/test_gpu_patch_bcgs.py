@@ -147,3 +147,33 @@ def test_three_dimensional_levels_refuse_the_smoother():
     du, df = g.new_vector(0), g.new_vector(0)
     with pytest.raises(capi.TeError):
         g.smooth(df, du, smoother=capi.SMOOTH_PATCH_BCGS)
+
+
+@pytest.mark.parametrize("nranks,mesh,div,n", [(2, "uniform", 3, 16), (4, "2d2ref.bin", 2, 8)])
+def test_sharded_sweeps_and_cycles_equal_single_rank(nranks, mesh, div, n, monkeypatch):
+    """the patch solves are independent of each other and see their neighbours through the same ghost exchange as every other 2D
+    smoother: N virtual ranks == one rank bit for bit (sweep, V-cycle), iteration counts included"""
+    from tests.test_gpu_multirank import shard_run
+    monkeypatch.setenv("TE_AGGLOMERATE", "0")  # rank boundaries on every level
+    m = util.mesh(mesh, div, 2)
+    H1 = capi.Hierarchy(m, n)
+    g1 = capi.GMG(H1)
+    nc = n * n
+    f, u0 = util.rand_vec(H1.cells(0), 31), util.rand_vec(H1.cells(0), 32)
+    du, df, dc = g1.new_vector(0, u0), g1.new_vector(0, f), g1.new_vector(0)
+    g1.smooth(df, du, smoother=capi.SMOOTH_PATCH_BCGS)
+    its1 = g1.patch_bcgs_iterations(0, H1.sizes(0)[0])
+    g1.cycle(g1.default_opts(smoother=capi.SMOOTH_PATCH_BCGS), df, dc)
+    want = {"u": du.download(), "c": dc.download()}
+
+    def per_rank(r, H, g, fab):
+        idx = H.l2g(0)
+        du, df, dc = g.new_vector(0, u0.reshape(-1, nc)[idx].ravel()), g.new_vector(0, f.reshape(-1, nc)[idx].ravel()), g.new_vector(0)
+        g.smooth(df, du, smoother=capi.SMOOTH_PATCH_BCGS)
+        its = g.patch_bcgs_iterations(0, len(idx))
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_BCGS), df, dc)
+        return {"u": du.download(), "c": dc.download(), "its": np.repeat(its.astype(float), nc)}
+
+    got = shard_run(m, n, nranks, per_rank, dim=2)
+    assert np.array_equal(got["u"], want["u"]) and np.array_equal(got["c"], want["c"])
+    assert np.array_equal(got["its"].reshape(-1, nc)[:, 0], its1.astype(float))
