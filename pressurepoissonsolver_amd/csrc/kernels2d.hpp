@@ -874,9 +874,32 @@ static __global__ __launch_bounds__(256) void k_patch_rhs2d(Level2D L, const dou
 // application takes the x-neighbours from registers and only the rows above / below plus two segment-end cells from an LDS tile
 // (segments CPT + 2 doubles apart: 128-bit accesses, and the 16 lanes of one LDS pass fall into 16 different bank groups), the
 // closure of the patch operator on its four sides (ghost = -cell, or +cell on a Neumann side) is formed in registers, dot
-// products are block reductions in a fixed order (a thread's cells, wave shuffles, four partial sums through LDS). An iteration
+// products are block reductions in a fixed order (a thread's cells, waveSum64, four partial sums through LDS). An iteration
 // costs five barriers. u is updated in place (its neighbours' old values are in `rhs` already). its[p] = iterations taken.
 // FULL: n is a multiple of CPT (every size the drivers use): no partly filled segments.
+// the sum of v over the 64 lanes of a wave, the same value in every lane: butterflies inside each row of 16 lanes, then the rows
+// combined (row 1 += row 0, row 3 += row 2; rows 2, 3 += lane 31) and lane 63 read back -- data-parallel-primitive moves on the
+// vector ALU in a fixed order. (__shfl_down compiles to ds_bpermute_b32: 24 LDS-pipe instructions per pair of sums; the solve
+// below waited for the LDS pipe 30 % of its time with them, SQ_WAIT_INST_LDS.)
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dppMove0(double v)
+{
+	int lo = __double2loint(v), hi = __double2hiint(v);
+	lo     = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, true); // (rows outside ROW_MASK, lanes without a source: 0)
+	hi     = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, true);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double waveSum64(double v)
+{
+	v += dppMove0<0xB1, 0xF>(v);  // quad_perm [1, 0, 3, 2]
+	v += dppMove0<0x4E, 0xF>(v);  // quad_perm [2, 3, 0, 1]
+	v += dppMove0<0x141, 0xF>(v); // row_half_mirror
+	v += dppMove0<0x140, 0xF>(v); // row_mirror: every lane holds its row's sum
+	v += dppMove0<0x142, 0xA>(v); // row_bcast:15 into rows 1 and 3
+	v += dppMove0<0x143, 0xC>(v); // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+	return __hiloint2double(hi, lo);
+}
+
 template <int CPT, bool FULL>
 __global__ __launch_bounds__(256, 2) void k_patch_bcgs2d(Level2D L, const double *__restrict__ rhs, double *__restrict__ u, double tol, int max_it,
                                                       int32_t *__restrict__ its)
@@ -894,16 +917,19 @@ __global__ __launch_bounds__(256, 2) void k_patch_bcgs2d(Level2D L, const double
 	for (int s2 = 0; s2 < 4; s2++) sg[s2] = (L.face_kind[p * 4 + s2] == FACE_NEUMANN) ? 1.0 : -1.0;
 	double       *mine = tile2d + row * lw + seg * SS;
 	double        x[CPT], r[CPT], pv[CPT], ap[CPT], sv[CPT], as[CPT];
-	// rhat never changes after the start: with 16 cells per thread it lives in the thread's own slot of LDS behind the tile and is
-	// streamed into the two dot products that read it (32 registers less: two workgroups fit a CU, each hiding the other's latencies)
+	// rhat never changes after the start: with 16 cells per thread it lives in LDS behind the tile and is streamed into the two dot
+	// products that read it (32 registers less: two workgroups fit a CU, each hiding the other's latencies). Pair k / 2 of thread t
+	// sits at 16-byte slot (k / 2) * 256 + t: the lanes of an access read consecutive slots. (A thread's sixteen values side by
+	// side -- 128 bytes from lane to lane -- put eight lanes of every 16-lane group on one slot: SQ_LDS_BANK_CONFLICT was 54 % of
+	// the kernel's LDS cycles.)
 	constexpr bool RH_LDS = CPT >= 16;
 	double         rh_reg[RH_LDS ? 1 : CPT];
-	double        *rh_lds = tile2d + n * lw + tid * CPT;
+	double2       *rh_lds = reinterpret_cast<double2 *>(tile2d + n * lw) + tid;
 	auto           loadRh = [&](double(&o)[CPT]) {
         if (RH_LDS) {
 #pragma unroll
             for (int k = 0; k < CPT; k += 2) {
-                const double2 t = *reinterpret_cast<const double2 *>(rh_lds + k);
+                const double2 t = rh_lds[(k / 2) * 256];
                 o[k] = t.x, o[k + (CPT > 1)] = t.y;
             }
         } else {
@@ -977,11 +1003,7 @@ __global__ __launch_bounds__(256, 2) void k_patch_bcgs2d(Level2D L, const double
 			s0 += a[k] * b[k];
 			s1 += c2[k] * d[k];
 		}
-#pragma unroll
-		for (int off = 32; off > 0; off >>= 1) {
-			s0 += __shfl_down(s0, off, 64);
-			s1 += __shfl_down(s1, off, 64);
-		}
+		s0 = waveSum64(s0), s1 = waveSum64(s1);
 		if ((tid & 63) == 0) red[par][0][tid >> 6] = s0, red[par][1][tid >> 6] = s1;
 		__syncthreads();
 		o0 = ((red[par][0][0] + red[par][0][1]) + red[par][0][2]) + red[par][0][3];
@@ -995,10 +1017,11 @@ __global__ __launch_bounds__(256, 2) void k_patch_bcgs2d(Level2D L, const double
 	for (int k = 0; k < CPT; k++) {
 		r[k]  = k < nv ? -1.0 * r[k] + bp[k] : 0.0; // resid->scaleThenAdd(-1, b)
 		pv[k] = r[k];                               // rhat->copy(resid); p->copy(resid)
-		if (RH_LDS)
-			rh_lds[k] = r[k];
-		else
-			rh_reg[RH_LDS ? 0 : k] = r[k];
+		if (!RH_LDS) rh_reg[RH_LDS ? 0 : k] = r[k];
+	}
+	if (RH_LDS) {
+#pragma unroll
+		for (int k = 0; k < CPT; k += 2) rh_lds[(k / 2) * 256] = make_double2(r[k], r[k + (CPT > 1)]);
 	}
 	double rr, rho;
 	dot2(r, r, r, r, rr, rho); // (rhat == resid here: rho = rhat . resid)
