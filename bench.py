@@ -263,16 +263,17 @@ def roofline_of(name, st, tkey=None, world=1, copy_sites_per_cycle=0, cycles=1):
             "alg_bytes_per_site_uniform_level": ALG_BYTES.get(name, 24.0)}
 
 
-def roofline_mfma_of(name, st):
+def roofline_mfma_of(name, st, dim=3, n=32):
     """second roof of the exact patch solve ('report it against both roofs'): its transform flops on the fp64
-    matrix cores"""
+    matrix cores. 2D (k_patch_solve2d_mfma, n = 64): four full n x n x n products per patch = 4 * 2 n flops per site"""
     if name not in MFMA_FLOPS_PER_SITE:
         return None
+    per_site = MFMA_FLOPS_PER_SITE[name] if dim == 3 else 8.0 * n
     avg_ms = st["ms"] / st["calls"]
-    tf = MFMA_FLOPS_PER_SITE[name] * st["cells"] / st["calls"] / (avg_ms * 1e-3) / 1e12
+    tf = per_site * st["cells"] / st["calls"] / (avg_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": name, "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / MFMA_F64_PEAK_TFLOPS, "avg_launch_ms": avg_ms, "launches": st["calls"],
-            "flops_per_site": MFMA_FLOPS_PER_SITE[name]}
+            "flops_per_site": per_site}
 
 
 def main():
@@ -546,7 +547,7 @@ def main():
                         "default options (fuse = 3)",
                 "steps": k2, "warmup": 3, "ms_per_step": m2["dt"] / k2 * 1e3, "value": cells_global[0] / (m2["dt"] / k2),
                 "unit": "lattice-site updates/s", "residual_reduction_per_cycle": red2,
-                "roofline": roofline_of(name2, st2, ps_key, world), "roofline_mfma": roofline_mfma_of(name2, st2),
+                "roofline": roofline_of(name2, st2, ps_key, world), "roofline_mfma": roofline_mfma_of(name2, st2, a.dim, n),
                 "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4)} for k, v in m2["rows_all"].items()}}}
 
     # (f)2 in the driver's run: time to solution of the call a user makes (apps/3d/steady.cpp:519-524): BiCGStab (BiCGStab.h:45-106,
@@ -645,7 +646,7 @@ def main():
                                    "GBs": (ALG_BYTES.get(k, 0) * v["cells"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None}
                                for k, v in rows_all.items()},
         }
-        rm = roofline_mfma_of(name, st)
+        rm = roofline_mfma_of(name, st, a.dim, n)
         if rm:
             out["roofline_mfma"] = rm
         if secondary:

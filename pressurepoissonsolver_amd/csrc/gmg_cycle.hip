@@ -92,10 +92,12 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 				pending_prolong = nullptr;
 				const bool last = final_call && i == sweeps - 1 && !(l == 0 && g->keep_final_xf);
 				if (sm == TE_SMOOTH_PATCH_SOLVE) { // reads u + P c on the face layers only, then overwrites u
+					bool swapped    = false;
 					g->no_xf_export = last;
-					r               = patchSolve(g, L, f->d, u->d, false, c);
+					r               = patchSolve(g, L, f->d, u->d, false, c, &swapped);
 					g->no_xf_export = false;
 					if (r) return r;
+					if (swapped) swapData(u, L.t.get()); // (2D: out of place)
 					continue;
 				}
 				double *xo = last ? nullptr : L.xfbuf[L.xf_cur ^ 1].p;
@@ -157,7 +159,8 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
         if (o->fuse && next_sweeps > 0
             && (L.prolong_fusable || L.prolong_fusable_cf)
             && (o->smoother == TE_SMOOTH_RBGS
-                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.dim == 3 && !g->cfg.has(O_PS_SLOW)))) {
+                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && L.dim == 3 && !g->cfg.has(O_PS_SLOW))
+                || (o->smoother == TE_SMOOTH_PATCH_SOLVE && patchSolve2dFusable(g, L)))) {
             pending_prolong = C.u->d;
             return TE_OK;
         }
@@ -224,6 +227,13 @@ int visit(te_gmg *g, const te_cycle_opts *o, int l, const te_vec *f, te_vec *u, 
 		                 && !g->cfg.has(O_NO_PS_FACES);
 		if ((rc = smoothOnce(g, l, f, u, TE_SMOOTH_PATCH_SOLVE, o->omega, true))) return rc;
 		if ((rc = interfaceResidRestrict(g, L, u->d, xfFor(L, u->d), C.f->d, C.f->n))) return rc;
+		have_coarse_f = true;
+	} else if (o->fuse >= 2 && u_zero && o->pre_sweeps == 1 && o->smoother == TE_SMOOTH_PATCH_SOLVE && ps2dResidFusable(g, L) && !fold_in.fine) {
+		// the same in 2D (64^2 patches on the matrix cores): the residual of the exact patch solves lives on the patch edges
+		if ((rc = formRhs())) return rc;
+		u_zero = false;
+		if ((rc = smoothOnce(g, l, f, u, TE_SMOOTH_PATCH_SOLVE, o->omega, true))) return rc;
+		if ((rc = interfaceResidRestrict2d(g, L, u->d, C.f->d, C.f->n))) return rc;
 		have_coarse_f = true;
 	} else if (fcorr_in || fold_in.fine) {
 		return te::fail(TE_ESTATE, "te_vcycle: exported ghost terms without a reader");

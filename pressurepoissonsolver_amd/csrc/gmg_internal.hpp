@@ -600,7 +600,11 @@ extern template int launchStencil2d<MODE_JACOBI>(te_gmg *, LevelHost &, const do
 int residualSumsq2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, int *blocks);
 int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false, const double *prolong_from = nullptr);
 int residRestrict2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse);
-int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1, bool zero_guess, bool *swapped);
+int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1, bool zero_guess, bool *swapped,
+                 const double *prolong_from = nullptr);
+bool ps2dResidFusable(const te_gmg *g, const LevelHost &L);    // (global facts) the 2D block-Jacobi cycle takes its residual on the patch edges
+bool patchSolve2dFusable(const te_gmg *g, const LevelHost &L); // (rank-local) its post-sweep adds the prolongation itself
+int  interfaceResidRestrict2d(te_gmg *g, LevelHost &L, const double *u, double *coarse, size_t coarse_n);
 int patchBcgs2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0);
 int restrict2d(te_gmg *g, LevelHost &L, const double *fine, double *coarse);
 int prolong2d(te_gmg *g, LevelHost &L, const double *coarse, double *fine);

@@ -113,29 +113,85 @@ int residRestrict2d(te_gmg *g, LevelHost &L, const double *u, const double *f, d
 }
 
 // *swapped: the result went to s1 (= L.t) instead of u: the caller exchanges the two vectors' buffers
-int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1, bool zero_guess, bool *swapped)
+// The fused forms of the block-Jacobi cycle in 2D: 64^2 patches on the matrix cores, uniformly refined levels.
+// ps2dResidFusable: the residual after the pre-sweep is taken on the patch edges only. NOT bit-identical to the residual pass, so
+// every rank -- and a single-rank run -- must take the same decision: global facts only (fuse2_ok, the patch size, options).
+// patchSolve2dFusable: the post-sweep adds the prolongation itself. Bit-identical to the prolongation pass, so a rank decides by
+// itself (every parent and child here: it has no part in the level's inter-level exchanges, whatever its peers do).
+bool ps2dResidFusable(const te_gmg *g, const LevelHost &L)
+{
+	return L.dim == 2 && L.n == 64 && L.fuse2_ok && !g->cfg.has(O_2D_SIMPLE) && !g->cfg.has(O_2D_NO_MFMA) && !g->cfg.has(O_NO_FUSE2);
+}
+bool patchSolve2dFusable(const te_gmg *g, const LevelHost &L)
+{
+	return ps2dResidFusable(g, L) && (L.matsT.p || L.P == 0) && L.fuse2d && L.prolong_fusable && L.tx_up.empty() && L.n_down == 0 && !L.repl_up;
+}
+
+// Cycle.h:57-65 after one block-Jacobi sweep from the zero iterate: inside a patch the residual of an exact patch solve vanishes
+// (up to the solve's rounding: defined as 0), on the edge cells of a face with a neighbour it is -(g + m)/h^2 (the patch operator
+// closed that face with ghost = -m where the operator has the neighbour's g): the coarse right-hand side is zero except along
+// the quadrant edges, which k_restrict_fixup2d<own> fills from the edge values alone -- no pass over u and f (17 B per site).
+int interfaceResidRestrict2d(te_gmg *g, LevelHost &L, const double *u, double *coarse, size_t coarse_n)
+{
+	int rc = prepareGhosts2d(g, L, u); // the new edge values of neighbours on other ranks
+	if (rc) return rc;
+	if (coarse_n > 0) {
+		Timed t(g, KC_VECOP, coarse_n);
+		HIPCHK(hipMemsetAsync(coarse, 0, sizeof(double) * coarse_n, g->stream));
+	}
+	if (L.n_up > 0 && L.upbuf.n > 0) { // blocks of children whose parent lives on another rank start from zero as well
+		Timed t(g, KC_VECOP, L.upbuf.n);
+		HIPCHK(hipMemsetAsync(L.upbuf.p, 0, sizeof(double) * L.upbuf.n, g->stream));
+	}
+	if (L.P > 0) {
+		Timed t(g, KC_FIXUP, (size_t) L.P * 4 * L.nf);
+		hipLaunchKernelGGL(k_restrict_fixup2d, dim3(L.P), dim3(128), 0, g->stream, L.dev2(), u, (const double *) nullptr,
+		                   Prolong2D{L.parent.p, L.orth.p, nullptr}, coarse, L.upbuf.p, L.up_off.p, true);
+	}
+	// children whose parent lives on another rank: ship the finished blocks (as zeroSweepResid2d)
+	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
+	if (L.n_down > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 4);
+		hipLaunchKernelGGL(k_restrict_unpack2d, dim3(L.n_down), dim3(256), 0, g->stream, L.n, L.down_desc.p, L.down_off.p, L.downbuf.p, coarse);
+	}
+	HIPCHK(hipGetLastError());
+	return TE_OK;
+}
+
+int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1, bool zero_guess, bool *swapped,
+                 const double *prolong_from)
 {
 	*swapped = false;
 	int          rc;
 	const size_t total = (size_t) L.P * L.nc;
+	if (prolong_from && (zero_guess || !patchSolve2dFusable(g, L))) return te::fail(TE_ESTATE, "patchSolve2d: no fused prolongation on this level");
 	if (L.n == 64 && L.matsT.p && !g->cfg.has(O_2D_SIMPLE) && !g->cfg.has(O_2D_NO_MFMA)) { // 64^2 patches: the four products on the matrix cores
-		if (!zero_guess && (rc = prepareGhosts2d(g, L, u))) return rc;
+		const Prolong2D ps{L.parent.p, L.orth.p, prolong_from};
+		if (prolong_from) { // neighbours on other ranks send their facing values of u + P e
+			if ((rc = packProlongFaces2d(g, L, u, nullptr, ps))) return rc;
+		} else if (!zero_guess && (rc = prepareGhosts2d(g, L, u))) {
+			return rc;
+		}
+		if (L.P == 0) return TE_OK;
 		const size_t lds = sizeof(double) * 64 * PS2D_LD;
 		bool        &attr = g->ps2d_attr;
 		const bool   pf = L.P <= 256 && !g->cfg.has(O_2D_NO_PF); // few patches: a workgroup has its CU to itself anyway
 		Timed        t(g, KC_PS_MFMA, total, true);
 		auto         launch = [&](auto kern) -> int {
-            launchT(t, kern, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.matsT.p, L.lam.p, L.zero_mode.p, f, u, s1);
+            launchT(t, kern, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.matsT.p, L.lam.p, L.zero_mode.p, f, u, s1, ps);
             return TE_OK;
 		};
-		if (!attr) { // all four once, so that the attribute is set whichever runs first
-			const void *ks[4] = {reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, false>),
-			                     reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, false>)};
+		if (!attr) { // all six once, so that the attribute is set whichever runs first
+			const void *ks[6] = {reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, false>),
+			                     reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, false>),
+			                     reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, true, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, false, true>)};
 			for (const void *k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 			attr = true;
 		}
 		if (zero_guess)
 			rc = pf ? launch(k_patch_solve2d_mfma<true, true>) : launch(k_patch_solve2d_mfma<true, false>);
+		else if (prolong_from)
+			rc = pf ? launch(k_patch_solve2d_mfma<false, true, true>) : launch(k_patch_solve2d_mfma<false, false, true>);
 		else
 			rc = pf ? launch(k_patch_solve2d_mfma<false, true>) : launch(k_patch_solve2d_mfma<false, false>);
 		if (rc) return rc;

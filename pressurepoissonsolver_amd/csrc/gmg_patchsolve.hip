@@ -183,10 +183,10 @@ int patchSolve(te_gmg *g, LevelHost &L, const double *f, double *u, bool zero_gu
 	bool dummy;
 	if (!swapped) swapped = &dummy;
 	*swapped = false;
-	if (L.P == 0) return TE_OK;
+	if (L.P == 0) return TE_OK; // (no patches: no faces towards other ranks either)
 	double *s0 = L.r->d, *s1 = L.t->d;
 	if (L.dim == 2) {
-		int rc = patchSolve2d(g, L, f, u, s0, s1, zero_guess, swapped);
+		int rc = patchSolve2d(g, L, f, u, s0, s1, zero_guess, swapped, prolong_from);
 		if (rc == TE_OK && *swapped && swapped == &dummy) return te::fail(TE_ESTATE, "patchSolve: 2D result left in scratch");
 		return rc;
 	}

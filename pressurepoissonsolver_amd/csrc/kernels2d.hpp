@@ -468,6 +468,10 @@ struct Fixup2D {
 	int            p;
 	double        *cb;
 	int            cs;
+	// own: the residual that is being completed was formed with the PATCH operator (exact patch solves: faces with a neighbour
+	// closed as homogeneous Dirichlet, ghost = -m, StarPatchOp.h:204-319) instead of a zero ghost: the missing term is
+	// -(g + m)/h^2 = -2 gamma/h^2 with m = this patch's own value behind the face (u: the stored iterate). As k_restrict_fixup3d<N, OWN>.
+	bool own = false;
 	// the sum of face s for the coarse cell number i along it
 	__device__ __forceinline__ double term(int s, int kind, int i) const
 	{
@@ -485,6 +489,7 @@ struct Fixup2D {
 				g = e4[((size_t) src * 4 + (s ^ 1)) * n + t];
 			else
 				g = u[(size_t) src * nn + (s == 0 ? n - 1 + n * t : (s == 1 ? n * t : (s == 2 ? t + n * (n - 1) : t)))];
+			if (own) g = g + u[(size_t) p * nn + (s == 0 ? n * t : (s == 1 ? n - 1 + n * t : (s == 2 ? t : t + n * (n - 1))))];
 			acc += (w * g) / 4;
 		}
 		return acc;
@@ -612,13 +617,13 @@ __global__ __launch_bounds__(TPB) void k_rbgs_zero_resid2d_lds(Level2D L, std::c
 // the block in `remote`.
 static __global__ __launch_bounds__(128) void k_restrict_fixup2d(Level2D L, const double *__restrict__ u, const double *__restrict__ e4,
                                                           Prolong2D dst, double *__restrict__ coarse, double *__restrict__ remote,
-                                                          const int64_t *__restrict__ remote_off)
+                                                          const int64_t *__restrict__ remote_off, bool own = false)
 {
 	const int n = L.n, nn = n * n, h = n / 2, p = blockIdx.x;
 	const int pa = dst.parent[p], o = dst.orth[p];
 	double   *cb = pa >= 0 ? coarse + (size_t) pa * nn + ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0) : remote + remote_off[-(pa + 2)];
 	const int     cs = pa >= 0 ? n : h;
-	const Fixup2D fx{L, u, e4, p, cb, cs};
+	const Fixup2D fx{L, u, e4, p, cb, cs, own};
 	auto          term = [&](int s, int kind, int i) { return fx.term(s, kind, i); };
 	auto          cell = [&](int s, int i) { return fx.cell(s, i); };
 	if (h >= 2 && h <= 32) {
@@ -1273,12 +1278,17 @@ constexpr int PS2D_LD = 65; // padded row length of the LDS tiles
 // PF: the matrix fragments of the next stage are fetched into registers a stage ahead (246 VGPRs, one workgroup per CU: for
 // levels of few patches, where the latency of the matrix loads is all there is); without it they are read where they are used
 // and two workgroups share a CU.
-template <bool ZERO, bool PF>
+// PROLONG (opts.fuse >= 2, the post-sweep of a V-cycle): the old iterate is u + P(coarse) with the prolongation never carried out --
+// a block-Jacobi sweep reads the old iterate only through its interface terms, i.e. on the patch's own edge cells and its
+// neighbours' facing cells: both take their coarse value here (a neighbour on another rank sent the sum, k_pack_faces_prolong2d)
+// and the result overwrites u. No k_prolong2d pass (17 B per site).
+template <bool ZERO, bool PF, bool PROLONG = false>
 __global__ __launch_bounds__(256) void k_patch_solve2d_mfma(Level2D L, const int32_t *__restrict__ plan, const double *__restrict__ matsT,
                                                             const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
                                                             const double *__restrict__ f, const double *__restrict__ u,
-                                                            double *__restrict__ out)
+                                                            double *__restrict__ out, Prolong2D ps = Prolong2D())
 {
+	static_assert(!(ZERO && PROLONG), "a zero iterate has no correction to take");
 	constexpr int n = 64, nn = n * n, LD = PS2D_LD;
 	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // one tile of 64 x 65: stages 0 and 2 work on a wave's own rows in place
 	double       *A = tile2d, *B = tile2d;
@@ -1309,17 +1319,21 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_mfma(Level2D L, const int
 	for (int c = tid; c < nn; c += 256) { // k_patch_rhs2d into tile A [y][x]
 		const int x = c % n, y = c / n;
 		double    v = fp[c];
-		if (!ZERO) {
-			const int    xy[2] = {x, y};
-			const double m = up[c];
+		if (!ZERO && (x == 0 || x == n - 1 || y == 0 || y == n - 1)) { // (the old iterate matters on the patch's edge cells only)
+			const int xy[2] = {x, y};
+			double    m = up[c];
+			if (PROLONG) m += coarseAt2d(ps, n, p, x, y);
 #pragma unroll
 			for (int ax = 0; ax < 2; ax++)
 #pragma unroll
 				for (int side = 0; side < 2; side++) {
 					if (xy[ax] != (side ? n - 1 : 0)) continue;
-					const int s = 2 * ax + side;
-					if (L.face_kind[p * 4 + s] < FACE_LOCAL) continue;
-					const double gh = ghost2d(L, u, p, s, xy[1 - ax], m, false);
+					const int s = 2 * ax + side, kind = L.face_kind[p * 4 + s];
+					if (kind < FACE_LOCAL) continue;
+					const int t  = xy[1 - ax];
+					double    gh = ghost2d(L, u, p, s, t, m, false);
+					if (PROLONG && kind == FACE_LOCAL)
+						gh += coarseAt2d(ps, n, L.face_src[p * 4 + s], s == 0 ? n - 1 : (s == 1 ? 0 : t), s == 2 ? n - 1 : (s == 3 ? 0 : t));
 					v -= 2.0 * L.rh2[p * 3 + ax] * (0.5 * m + 0.5 * gh);
 				}
 		}

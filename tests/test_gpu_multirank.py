@@ -527,3 +527,34 @@ def test_native_rccl_backend_selftest():
     g = capi.GMG(H)
     tedist.attach_rccl(g, None, 0, 1)
     capi.check(capi.lib().te_gmg_exchange_selftest(g.h, 1000))
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_sharded_2d_fused_block_jacobi_cycle(nranks, monkeypatch):
+    """the reference smoother's fused 2D cycle cut by rank boundaries (64 patches of 64^2): the post-sweep's neighbours on other ranks
+    send their facing values of u + P e, the interface residual reads the neighbours' new edges from ghost slots: sharded == single
+    rank bit for bit for every fuse setting"""
+    monkeypatch.setenv("TE_AGGLOMERATE", "4")
+    n = 64
+    mesh = util.mesh("uniform", 3, 2)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    f = util.rand_vec(H1.cells(0), 13)
+    nc = n * n
+    want = {}
+    for fuse in (1, 3):
+        df, du = g1.new_vector(0, f), g1.new_vector(0)
+        g1.cycle(g1.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE, fuse=fuse), df, du)
+        want[fuse] = du.download()
+
+    def per_rank(r, H, g, fab):
+        idx = H.l2g(0)
+        out = {}
+        for fuse in (1, 3):
+            df, du = g.new_vector(0, f.reshape(-1, nc)[idx].ravel()), g.new_vector(0)
+            g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE, fuse=fuse), df, du)
+            out[f"u{fuse}"] = du.download()
+        return out
+
+    got = shard_run(mesh, n, nranks, per_rank, dim=2)
+    assert np.array_equal(got["u1"], want[1]) and np.array_equal(got["u3"], want[3])

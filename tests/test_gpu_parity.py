@@ -448,3 +448,37 @@ def test_post_sweep_tuning_variants_bit_identical():
         ref = got[(None, None)]
         for k, x in got.items():
             assert np.array_equal(x, ref), k
+
+
+@pytest.mark.parametrize("div,neumann", [(2, False), (3, False), (2, True)])
+def test_fused_block_jacobi_cycle_2d(div, neumann):
+    """The reference smoother's V-cycle on uniform 2D levels of 64^2 patches (config C5's shape): fuse = 1 adds the prolongation
+    inside the post-sweep (a block-Jacobi sweep reads the old iterate on patch edges only: k_patch_solve2d_mfma<.., PROLONG>; the
+    same additions: bit-identical to fuse = 0); fuse >= 2 also takes the residual after the exact patch solves on the patch edges
+    only (interfaceResidRestrict2d: it vanishes inside a patch up to the rounding of the solve) -- no k_prolong2d and no
+    residual pass on those levels; against the unfused cycle <= 1e-11, against the oracle <= 1e-10."""
+    m, H, levels = util.setup("uniform", 64, div, neumann=neumann, dim=2)
+    g, L = capi.GMG(H), levels[0]
+    f = util.rand_vec(L.size, 57) / L.a["h"].min() ** 2
+    got, rows = {}, {}
+    for fuse in (0, 1, 2, 3):
+        df, dc = g.new_vector(0, f), g.new_vector(0)
+        g.profile(True)
+        g.profile_reset()
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE, fuse=fuse), df, dc)
+        rows[fuse] = g.profile_rows()
+        g.profile(False)
+        got[fuse] = dc.download()
+    assert np.array_equal(got[0], got[1])
+    assert "prolong_add" in rows[0] and "prolong_add" not in rows[1]
+    assert "resid_restrict" in rows[1] and "resid_restrict" not in rows[2] and "restrict_fixup" in rows[2]
+    assert np.array_equal(got[2], got[3])
+    assert rel(got[2], got[1]) <= 1e-11 and not np.array_equal(got[2], got[1])
+    assert rel(got[3], orc.cycle(levels, orc.cycle_opts(smoother=0), f)) <= 1e-10
+    # W-cycle: the pre-sweep and its interface residual, then mid- and post-sweeps with the prolongation inside
+    outs = []
+    for fuse in (0, 3):
+        df, dc = g.new_vector(0, f), g.new_vector(0)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE, fuse=fuse, cycle_type=1), df, dc)
+        outs.append(dc.download())
+    assert rel(outs[1], outs[0]) <= 1e-11
