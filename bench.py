@@ -265,10 +265,12 @@ def roofline_of(name, st, tkey=None, world=1, copy_sites_per_cycle=0, cycles=1):
 
 def roofline_mfma_of(name, st, dim=3, n=32):
     """second roof of the exact patch solve ('report it against both roofs'): its transform flops on the fp64
-    matrix cores. 2D (k_patch_solve2d_mfma, n = 64): four full n x n x n products per patch = 4 * 2 n flops per site"""
+    matrix cores: the flops the kernel EXECUTES. 2D, n = 64: four half-size products per transform pair (k_patch_solve2d_sym:
+    128 v_mfma_f64_16x16x4 per patch and stage pair... 4 * n flops per site; patches with a mixed Dirichlet / Neumann axis run the
+    full products, twice that, and are counted at the half-size figure), 8 * n with TE_2D_NO_SYM (k_patch_solve2d_mfma)"""
     if name not in MFMA_FLOPS_PER_SITE:
         return None
-    per_site = MFMA_FLOPS_PER_SITE[name] if dim == 3 else 8.0 * n
+    per_site = MFMA_FLOPS_PER_SITE[name] if dim == 3 else ((8.0 if os.environ.get("TE_2D_NO_SYM") else 4.0) * n)
     avg_ms = st["ms"] / st["calls"]
     tf = per_site * st["cells"] / st["calls"] / (avg_ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": name, "achieved": tf, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",

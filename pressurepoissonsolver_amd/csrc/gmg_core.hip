@@ -13,7 +13,7 @@ const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_j
 const char *optName[O_COUNT] = {"TE_2D_SIMPLE", "TE_2D_NO_MFMA", "TE_2D_NO_PF", "TE_2D_NO_MR_FUSE", "TE_2D_TPB", "TE_NO_FUSE2", "TE_NO_FUSE3",
                                 "TE_NO_FUSE3_CF", "TE_NO_CFP", "TE_NO_XF", "TE_NO_FCORR", "TE_NO_FCORR_CF", "TE_NO_GTAB", "TE_NO_OVERLAP",
                                 "TE_OVERLAP_MIN", "TE_NO_PS_FACES", "TE_PS_MODE", "TE_PS_SLOW", "TE_RBGS_NOSLAB", "TE_ZS_FORCE", "TE_NO_ZS8",
-                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS", "TE_PACK_FACES", "TE_OVERLAP_MODE", "TE_PUSH_TIMEOUT", "TE_NO_BICG_XF", "TE_PUSH_FAULT", "TE_2D_NO_FOLD"};
+                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_NO_GRAPH", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS", "TE_PACK_FACES", "TE_OVERLAP_MODE", "TE_PUSH_TIMEOUT", "TE_NO_BICG_XF", "TE_PUSH_FAULT", "TE_2D_NO_FOLD", "TE_2D_NO_SYM"};
 
 void drainEvents(te_gmg *g)
 {
@@ -390,6 +390,46 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 				for (int i = 0; i < n; i++)
 					for (int j = 0; j < n; j++) mt[m * n * n + (size_t) j * n + i] = mats[m * n * n + (size_t) i * n + j];
 			if ((rc = L->matsT.upload(mt))) return rc;
+		}
+		if (D == 2 && n == 64 && P > 0) { // k_patch_solve2d_sym's tables (see there): stage 0 / 1 forward x / y, 2 / 3 inverse x / y
+			std::vector<double> fs((size_t) np * PS2S_PLAN, 0.0);
+			std::vector<char>   pure(np, 1);
+			for (int k = 0; k < np; k++) {
+				for (int a = 0; a < 2; a++) pure[k] &= (((keys[k] >> (2 * a)) & 1) == ((keys[k] >> (2 * a + 1)) & 1));
+				if (!pure[k]) continue;
+				const double *Fx = &mats[((size_t) k * 4 + 0) * n * n], *Fy = &mats[((size_t) k * 4 + 1) * n * n];
+				const double *Gx = &mats[((size_t) k * 4 + 2) * n * n], *Gy = &mats[((size_t) k * 4 + 3) * n * n];
+				// the symmetry the kernel rests on: F[k][63 - j] = (-1)^k F[k][j], G[63 - j][k] = (-1)^k G[j][k]
+				for (int i = 0; i < n && pure[k]; i++)
+					for (int jj = 0; jj < n / 2; jj++) {
+						const double sg = (i & 1) ? -1.0 : 1.0;
+						const double e  = 1e-12;
+						if (fabs(Fx[i * n + n - 1 - jj] - sg * Fx[i * n + jj]) > e || fabs(Fy[i * n + n - 1 - jj] - sg * Fy[i * n + jj]) > e
+						    || fabs(Gx[(n - 1 - jj) * n + i] - sg * Gx[jj * n + i]) > e || fabs(Gy[(n - 1 - jj) * n + i] - sg * Gy[jj * n + i]) > e)
+							pure[k] = 0;
+					}
+				if (!pure[k]) continue;
+				double *S = &fs[(size_t) k * PS2S_PLAN];
+				for (int ks = 0; ks < 8; ks++)
+					for (int t = 0; t < 4; t++)
+						for (int ln = 0; ln < 64; ln++) {
+							const int    j = ln & 15, gq = ln >> 4, kk = 4 * ks + gq;
+							const size_t e = ((size_t) ks * 4 + t) * 64 + ln;
+							const int    wv = t < 2 ? 2 * (16 * t + j) : 2 * (16 * (t - 2) + j) + 1; // the wave number behind position 16 t + j
+							S[0 * PS2S_STAGE + e] = Fx[wv * n + kk];
+							S[1 * PS2S_STAGE + e] = Fy[wv * n + kk];
+							S[2 * PS2S_STAGE + e] = Gx[(16 * (t & 1) + j) * n + 2 * kk + (t >> 1)];
+							S[3 * PS2S_STAGE + e] = Gy[(16 * (t & 1) + j) * n + 2 * kk + (t >> 1)];
+						}
+			}
+			std::vector<int32_t> lst, mixed;
+			for (int p = 0; p < P; p++) (pure[plan[p]] ? lst : mixed).push_back(p);
+			L->n_pure2 = (int) lst.size();
+			if (L->n_pure2 > 0 && (rc = L->mat2sym.upload(fs))) return rc;
+			if (L->n_pure2 > 0 && L->n_pure2 < P) {
+				lst.insert(lst.end(), mixed.begin(), mixed.end());
+				if ((rc = L->ps2_list.upload(lst))) return rc;
+			}
 		}
 		if ((rc = L->corr.alloc((size_t) std::max(P, 1) * NS * L->nf))) return rc;
 		if ((rc = L->plan.upload(plan)) || (rc = L->mats.upload(mats)) || (rc = L->lam.upload(lam))

@@ -80,7 +80,7 @@ extern const char *kclassName[KC_COUNT]; // (gmg_core.hip)
 enum Opt : int {
 	O_2D_SIMPLE, O_2D_NO_MFMA, O_2D_NO_PF, O_2D_NO_MR_FUSE, O_2D_TPB, O_NO_FUSE2, O_NO_FUSE3, O_NO_FUSE3_CF, O_NO_CFP, O_NO_XF,
 	O_NO_FCORR, O_NO_FCORR_CF, O_NO_GTAB, O_NO_OVERLAP, O_OVERLAP_MIN, O_NO_PS_FACES, O_PS_MODE, O_PS_SLOW, O_RBGS_NOSLAB,
-	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_PUSH_TIMEOUT, O_NO_BICG_XF, O_PUSH_FAULT, O_2D_NO_FOLD, O_COUNT
+	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_NO_GRAPH, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_PUSH_TIMEOUT, O_NO_BICG_XF, O_PUSH_FAULT, O_2D_NO_FOLD, O_2D_NO_SYM, O_COUNT
 };
 extern const char *optName[O_COUNT]; // (gmg_core.hip)
 // options that shape the level tables te_gmg_create builds: fixed for the solver's lifetime
@@ -193,6 +193,10 @@ struct LevelHost {
 	bool            sym_ok = false;  // every plan of the level has pure (DST-II/III or DCT-II/III) axes
 	DevBuf<int32_t> ps_list;         // otherwise: [patches with pure axes (n_pure) | the others]
 	int             n_pure = 0;
+	// 2D, 64^2 patches: half-size transforms for patches whose plan has two pure axes (kernels2d.hpp k_patch_solve2d_sym):
+	DevBuf<double>  mat2sym;         // [plan][4][8][4][64] fragments (zeros for plans with a mixed axis)
+	DevBuf<int32_t> ps2_list;        // [patches with two pure axes (n_pure2) | the others]; empty when all or none are pure
+	int             n_pure2 = 0;
 	// scratch
 	std::unique_ptr<te_vec> u, f, r, t;
 

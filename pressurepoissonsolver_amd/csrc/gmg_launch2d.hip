@@ -177,23 +177,41 @@ int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0
 		bool        &attr = g->ps2d_attr;
 		const bool   pf = L.P <= 256 && !g->cfg.has(O_2D_NO_PF); // few patches: a workgroup has its CU to itself anyway
 		Timed        t(g, KC_PS_MFMA, total, true);
+		// patches whose two axes close the same way on both sides take the half-size transforms (k_patch_solve2d_sym), the others
+		// (Neumann boundary patches) the full ones: two launches on a level that has both
+		const int    nsym = (L.mat2sym.p && !g->cfg.has(O_2D_NO_SYM)) ? L.n_pure2 : 0;
+		const int32_t *lst = (nsym > 0 && nsym < L.P) ? L.ps2_list.p : nullptr;
 		auto         launch = [&](auto kern) -> int {
-            launchT(t, kern, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.matsT.p, L.lam.p, L.zero_mode.p, f, u, s1, ps);
+            if (nsym < L.P)
+                launchT(t, kern, dim3(L.P - nsym), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.matsT.p, L.lam.p, L.zero_mode.p, f, u, s1, ps,
+                        lst ? lst + nsym : nullptr);
             return TE_OK;
 		};
+		auto launchSym = [&](auto kern) -> int {
+			if (nsym > 0)
+				launchT(t, kern, dim3(nsym), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.mat2sym.p, L.lam.p, L.zero_mode.p, f, u, s1, lst, ps);
+			return TE_OK;
+		};
 		if (!attr) { // all six once, so that the attribute is set whichever runs first
-			const void *ks[6] = {reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, false>),
-			                     reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, false>),
-			                     reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, true, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, false, true>)};
+			const void *ks[12] = {reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<true, false>),
+			                      reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, false>),
+			                      reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, true, true>), reinterpret_cast<const void *>(k_patch_solve2d_mfma<false, false, true>),
+			                      reinterpret_cast<const void *>(k_patch_solve2d_sym<true, true>), reinterpret_cast<const void *>(k_patch_solve2d_sym<true, false>),
+			                      reinterpret_cast<const void *>(k_patch_solve2d_sym<false, true>), reinterpret_cast<const void *>(k_patch_solve2d_sym<false, false>),
+			                      reinterpret_cast<const void *>(k_patch_solve2d_sym<false, true, true>), reinterpret_cast<const void *>(k_patch_solve2d_sym<false, false, true>)};
 			for (const void *k : ks) HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 			attr = true;
 		}
-		if (zero_guess)
+		if (zero_guess) {
+			rc = pf ? launchSym(k_patch_solve2d_sym<true, true>) : launchSym(k_patch_solve2d_sym<true, false>);
 			rc = pf ? launch(k_patch_solve2d_mfma<true, true>) : launch(k_patch_solve2d_mfma<true, false>);
-		else if (prolong_from)
+		} else if (prolong_from) {
+			rc = pf ? launchSym(k_patch_solve2d_sym<false, true, true>) : launchSym(k_patch_solve2d_sym<false, false, true>);
 			rc = pf ? launch(k_patch_solve2d_mfma<false, true, true>) : launch(k_patch_solve2d_mfma<false, false, true>);
-		else
+		} else {
+			rc = pf ? launchSym(k_patch_solve2d_sym<false, true>) : launchSym(k_patch_solve2d_sym<false, false>);
 			rc = pf ? launch(k_patch_solve2d_mfma<false, true>) : launch(k_patch_solve2d_mfma<false, false>);
+		}
 		if (rc) return rc;
 		HIPCHK(hipGetLastError());
 		*swapped = true;

@@ -1266,6 +1266,39 @@ __global__ __launch_bounds__(TPB) void k_patch_solve2d_lds(Level2D L, const int3
 	}
 }
 
+// The right-hand side of a 64^2 patch's solve in an LDS tile [y][x] (row stride PS2D_LD): f, minus the interface terms of the old
+// iterate on the edge cells (k_patch_rhs2d's expressions in its order: a corner cell takes its x-face term, then its y-face
+// term). 256 threads: all of them bring f in; then thread (s, t) = (tid >> 6, tid & 63) forms the term of position t on side s,
+// so the chain of dependent loads (face tables -> own and neighbour's value -> their coarse values) is one deep per workgroup.
+// (With a thread owning cells tid + 256 k, the 62 cells of a west or east column belonged to four threads: sixteen chains in a
+// row on each, 100 us of the 257 us post-sweep at 4096 patches.) PROLONG: the old iterate is u + P(coarse), see below.
+// No barrier at the end: the caller's.
+constexpr int PS2D_LD = 65; // padded row length of the LDS tiles
+template <bool ZERO, bool PROLONG>
+__device__ __forceinline__ void patchRhsTile2d(const Level2D &L, int p, const double *__restrict__ fp, const double *__restrict__ up,
+                                               const double *__restrict__ u, const Prolong2D &ps, double *T, int tid)
+{
+	constexpr int n = 64, nn = n * n, LD = PS2D_LD;
+	for (int c = tid; c < nn; c += 256) T[(c / n) * LD + c % n] = fp[c];
+	if (ZERO) return;
+	const int  s = tid >> 6, t = tid & 63, kind = L.face_kind[p * 4 + s];
+	const int  x = s == 0 ? 0 : (s == 1 ? n - 1 : t), y = s == 2 ? 0 : (s == 3 ? n - 1 : t);
+	const bool has = kind >= FACE_LOCAL;
+	double     term = 0.0;
+	if (has) {
+		double m = up[x + n * y];
+		if (PROLONG) m += coarseAt2d(ps, n, p, x, y);
+		double gh = ghost2d(L, u, p, s, t, m, false);
+		if (PROLONG && kind == FACE_LOCAL)
+			gh += coarseAt2d(ps, n, L.face_src[p * 4 + s], s == 0 ? n - 1 : (s == 1 ? 0 : t), s == 2 ? n - 1 : (s == 3 ? 0 : t));
+		term = 2.0 * L.rh2[p * 3 + (s >> 1)] * (0.5 * m + 0.5 * gh);
+	}
+	__syncthreads(); // f is in the tile
+	if (has && s < 2) T[y * LD + x] -= term;
+	__syncthreads();
+	if (has && s >= 2) T[y * LD + x] -= term;
+}
+
 // The exact 2D patch solve for 64^2 patches on the fp64 matrix cores: four 64x64x64 products (x forward, y forward +
 // eigenvalue division, x inverse, y inverse) as v_mfma_f64_16x16x4 tiles, D(16x16) += A(16x4) B(4x16) with lane
 // (j = l & 15, g = l >> 4) holding A[i = j][k = g], B[k = g][col = j], D[row = g + 4r][col = j]. Wave w owns the output rows
@@ -1274,7 +1307,6 @@ __global__ __launch_bounds__(TPB) void k_patch_solve2d_lds(Level2D L, const int3
 // transposed (matsT) so that sixteen lanes read 128 contiguous bytes. One workgroup per patch, out of place (block Jacobi
 // reads the neighbours' OLD values). Sums run in the MFMA's order, not k_dst_axis2d's: equal to rounding.
 typedef double v4f64_2d __attribute__((ext_vector_type(4)));
-constexpr int PS2D_LD = 65; // padded row length of the LDS tiles
 // PF: the matrix fragments of the next stage are fetched into registers a stage ahead (246 VGPRs, one workgroup per CU: for
 // levels of few patches, where the latency of the matrix loads is all there is); without it they are read where they are used
 // and two workgroups share a CU.
@@ -1286,13 +1318,14 @@ template <bool ZERO, bool PF, bool PROLONG = false>
 __global__ __launch_bounds__(256) void k_patch_solve2d_mfma(Level2D L, const int32_t *__restrict__ plan, const double *__restrict__ matsT,
                                                             const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
                                                             const double *__restrict__ f, const double *__restrict__ u,
-                                                            double *__restrict__ out, Prolong2D ps = Prolong2D())
+                                                            double *__restrict__ out, Prolong2D ps = Prolong2D(),
+                                                            const int32_t *__restrict__ list = nullptr)
 {
 	static_assert(!(ZERO && PROLONG), "a zero iterate has no correction to take");
 	constexpr int n = 64, nn = n * n, LD = PS2D_LD;
 	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // one tile of 64 x 65: stages 0 and 2 work on a wave's own rows in place
 	double       *A = tile2d, *B = tile2d;
-	const int     p = blockIdx.x, tid = threadIdx.x, pl = plan[p];
+	const int     p = list ? list[blockIdx.x] : blockIdx.x, tid = threadIdx.x, pl = plan[p]; // (list: the patches the half-size kernel leaves)
 	const int     w = tid >> 6, l = tid & 63, j = l & 15, g = l >> 4;
 	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
 	const double *fp = f + (size_t) p * nn, *up = u + (size_t) p * nn;
@@ -1316,29 +1349,7 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_mfma(Level2D L, const int
 	auto fragB = [&](int stage, int ks, int ct) { return PF ? mc[ks * 4 + ct] : MT[stage * nn + (4 * ks + g) * n + 16 * ct + j]; };
 	auto fragA = [&](int stage, int ks) { return PF ? mr[ks] : MT[stage * nn + (4 * ks + g) * n + 16 * w + j]; };
 	loadB(0); // stage 0's matrix, in flight while the right-hand side is formed
-	for (int c = tid; c < nn; c += 256) { // k_patch_rhs2d into tile A [y][x]
-		const int x = c % n, y = c / n;
-		double    v = fp[c];
-		if (!ZERO && (x == 0 || x == n - 1 || y == 0 || y == n - 1)) { // (the old iterate matters on the patch's edge cells only)
-			const int xy[2] = {x, y};
-			double    m = up[c];
-			if (PROLONG) m += coarseAt2d(ps, n, p, x, y);
-#pragma unroll
-			for (int ax = 0; ax < 2; ax++)
-#pragma unroll
-				for (int side = 0; side < 2; side++) {
-					if (xy[ax] != (side ? n - 1 : 0)) continue;
-					const int s = 2 * ax + side, kind = L.face_kind[p * 4 + s];
-					if (kind < FACE_LOCAL) continue;
-					const int t  = xy[1 - ax];
-					double    gh = ghost2d(L, u, p, s, t, m, false);
-					if (PROLONG && kind == FACE_LOCAL)
-						gh += coarseAt2d(ps, n, L.face_src[p * 4 + s], s == 0 ? n - 1 : (s == 1 ? 0 : t), s == 2 ? n - 1 : (s == 3 ? 0 : t));
-					v -= 2.0 * L.rh2[p * 3 + ax] * (0.5 * m + 0.5 * gh);
-				}
-		}
-		A[y * LD + x] = v;
-	}
+	patchRhsTile2d<ZERO, PROLONG>(L, p, fp, up, u, ps, A, tid);
 	__syncthreads();
 	v4f64_2d d[4];
 	// ---- stage 0: Y1[y][kx] = sum_x X[y][x] Fx[kx][x]: A operand = X rows (LDS), B operand = Fx^T (registers)
@@ -1406,5 +1417,147 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_mfma(Level2D L, const int
 	for (int ct = 0; ct < 4; ct++)
 #pragma unroll
 		for (int r = 0; r < 4; r++) op[(16 * w + g + 4 * r) * n + 16 * ct + j] = d[ct][r] * (4.0 / ((double) n * n));
+}
+// ---- the same solve with HALF-SIZE transforms (the 2D twin of k_ps_sym): on an axis whose two sides close the same way
+// (Dirichlet / neighbour on both, or Neumann on both: DST-II/III resp. DCT-II/III) basis function k is even about the patch
+// centre for even k and odd for odd k, so a transform of length 64 is two of length 32 on the sums and differences of mirrored
+// entries: forward  Y[k even] = sum_{j<32} F[k][j] (x[j] + x[63-j]),  Y[k odd] = sum_{j<32} F[k][j] (x[j] - x[63-j]);
+//          inverse  x[j], x[63-j] = E[j] +- O[j],  E[j] = sum_{k even} G[j][k] y[k],  O[j] = sum_{k odd} G[j][k] y[k].
+// Each of the four stages is 32 instead of 64 v_mfma_f64_16x16x4 per wave (the kernel is bound by them: 54 of 78.6 TFLOP/s on the
+// full-size products); the butterflies ride on the LDS reads and on the accumulators. Transformed data sits in parity-split order
+// (position c < 32: wave number 2c, c >= 32: 2(c - 32) + 1) between the stages, along both axes.
+// sym [plan][stage 4][k-step 8][t 4][lane 64]: the matrix fragments in MFMA operand order (built by the host, gmg_core.hip):
+//   stage 0 (B side): t = column tile;            F_x[kx(t, j)][4 ks + g]
+//   stage 1 (A side): t = wave;                   F_y[ky(w, j)][4 ks + g]
+//   stage 2 (B side): t = parity * 2 + column tile of x' < 32;   G_x[16 ct + j][2 (4 ks + g) + parity]
+//   stage 3 (A side): t = parity * 2 + row tile of y' < 32;      G_y[16 rt + j][2 (4 ks + g) + parity]
+// Only patches whose plan has two pure axes (list, n of them); the others take k_patch_solve2d_mfma. Sums run in another order
+// than there: equal to rounding (<= 1e-13).
+constexpr int PS2S_STAGE = 8 * 4 * 64, PS2S_PLAN = 4 * PS2S_STAGE;
+template <bool ZERO, bool PF, bool PROLONG = false>
+__global__ __launch_bounds__(256) void k_patch_solve2d_sym(Level2D L, const int32_t *__restrict__ plan, const double *__restrict__ sym,
+                                                           const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
+                                                           const double *__restrict__ f, const double *__restrict__ u,
+                                                           double *__restrict__ out, const int32_t *__restrict__ list, Prolong2D ps = Prolong2D())
+{
+	static_assert(!(ZERO && PROLONG), "a zero iterate has no correction to take");
+	constexpr int n = 64, nn = n * n, LD = PS2D_LD;
+	extern __shared__ __attribute__((aligned(16))) double tile2d[]; // one tile of 64 x 65
+	double       *T = tile2d;
+	const int     p = list ? list[blockIdx.x] : blockIdx.x, tid = threadIdx.x, pl = plan[p];
+	const int     w = tid >> 6, l = tid & 63, j = l & 15, g = l >> 4;
+	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
+	const double *fp = f + (size_t) p * nn, *up = u + (size_t) p * nn;
+	const double *S  = sym + (size_t) pl * PS2S_PLAN;
+	const double *lm = lam + (size_t) pl * 2 * n;
+	auto          frag = [&](int stage, int ks, int t) { return S[stage * PS2S_STAGE + (ks * 4 + t) * 64 + l]; };
+	double        mb[PF ? 32 : 1], ma[PF ? 16 : 1]; // fragments of a B-side stage (8 k-steps x 4) and of an A-side stage (8, or 2 x 8)
+	auto          loadB = [&](int stage) {
+        if constexpr (PF) {
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) mb[ks * 4 + t] = frag(stage, ks, t);
+        }
+	};
+	auto fB = [&](int stage, int ks, int t) { return PF ? mb[ks * 4 + t] : frag(stage, ks, t); };
+	loadB(0);
+	patchRhsTile2d<ZERO, PROLONG>(L, p, fp, up, u, ps, T, tid);
+	__syncthreads();
+	v4f64_2d d[4];
+	// ---- stage 0: Y1[y][c'] = sum_{x'<32} (X[y][x'] +- X[y][63-x']) Fx[kx(c')][x']: tiles 0, 1 even kx (sums), 2, 3 odd kx (differences)
+	if constexpr (PF) {
+#pragma unroll
+		for (int ks = 0; ks < 8; ks++) ma[ks] = frag(1, ks, w);
+	}
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++) d[ct] = v4f64_2d{0, 0, 0, 0};
+#pragma clang loop unroll_count(PF ? 8 : 2)
+	for (int ks = 0; ks < 8; ks++) {
+		const double xl = T[(16 * w + j) * LD + 4 * ks + g], xh = T[(16 * w + j) * LD + 63 - 4 * ks - g];
+		const double ae = xl + xh, ao = xl - xh;
+#pragma unroll
+		for (int ct = 0; ct < 4; ct++) d[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(ct < 2 ? ae : ao, fB(0, ks, ct), d[ct], 0, 0, 0);
+	}
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) T[(16 * w + g + 4 * r) * LD + 16 * ct + j] = d[ct][r]; // (the wave's own rows, in place)
+	loadB(2);
+	__syncthreads();
+	// ---- stage 1: Y2[r'][c'] = sum_{y'<32} Fy[ky(r')][y'] (Y1[y'][c'] +- Y1[63-y'][c']): waves 0, 1 even ky, 2, 3 odd ky
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++) d[ct] = v4f64_2d{0, 0, 0, 0};
+#pragma clang loop unroll_count(PF ? 8 : 2)
+	for (int ks = 0; ks < 8; ks++) {
+		const double a = PF ? ma[ks] : frag(1, ks, w);
+#pragma unroll
+		for (int ct = 0; ct < 4; ct++) {
+			const double yl = T[(4 * ks + g) * LD + 16 * ct + j], yh = T[(63 - 4 * ks - g) * LD + 16 * ct + j];
+			d[ct]           = __builtin_amdgcn_mfma_f64_16x16x4f64(a, w < 2 ? yl + yh : yl - yh, d[ct], 0, 0, 0);
+		}
+	}
+	if constexpr (PF) {
+#pragma unroll
+		for (int ks = 0; ks < 8; ks++) ma[ks] = frag(3, ks, w & 1), ma[8 + ks] = frag(3, ks, 2 + (w & 1));
+	}
+	__syncthreads(); // every wave has read all rows of Y1 before any overwrites its own
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int rp = 16 * w + g + 4 * r, cp = 16 * ct + j; // positions; the wave numbers behind them:
+			const int ky = rp < 32 ? 2 * rp : 2 * (rp - 32) + 1, kx = cp < 32 ? 2 * cp : 2 * (cp - 32) + 1;
+			double    v  = d[ct][r] / -(lm[kx] * rhx + lm[n + ky] * rhy);
+			if (zero_mode[pl] && kx == 0 && ky == 0) v = 0.0;
+			T[rp * LD + cp] = v;
+		}
+	__syncthreads();
+	// ---- stage 2: E[r'][x'] = sum_{kx even} Y2 Gx[x'][kx], O[r'][x'] = sum_{kx odd} ...; Y3[r'][x'], Y3[r'][63-x'] = E +- O
+	v4f64_2d e2[2], o2[2];
+#pragma unroll
+	for (int c2 = 0; c2 < 2; c2++) e2[c2] = o2[c2] = v4f64_2d{0, 0, 0, 0};
+#pragma clang loop unroll_count(PF ? 8 : 2)
+	for (int ks = 0; ks < 8; ks++) {
+		const double ae = T[(16 * w + j) * LD + 4 * ks + g], ao = T[(16 * w + j) * LD + 32 + 4 * ks + g];
+#pragma unroll
+		for (int c2 = 0; c2 < 2; c2++) {
+			e2[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, fB(2, ks, c2), e2[c2], 0, 0, 0);
+			o2[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, fB(2, ks, 2 + c2), o2[c2], 0, 0, 0);
+		}
+	}
+#pragma unroll
+	for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int rp = 16 * w + g + 4 * r, xp = 16 * c2 + j;
+			T[rp * LD + xp]      = e2[c2][r] + o2[c2][r];
+			T[rp * LD + 63 - xp] = e2[c2][r] - o2[c2][r];
+		}
+	__syncthreads();
+	// ---- stage 3: E[y'][x] = sum_{ky even} Gy[y'][ky] Y3[ky][x], O likewise; U[y'][x], U[63-y'][x] = (E +- O) * scale.
+	// Wave w: row tile w & 1 of y' < 32, column tiles 2 (w >> 1) and 2 (w >> 1) + 1
+	const int rt = w & 1, cb = 2 * (w >> 1);
+#pragma unroll
+	for (int c2 = 0; c2 < 2; c2++) e2[c2] = o2[c2] = v4f64_2d{0, 0, 0, 0};
+#pragma clang loop unroll_count(PF ? 8 : 2)
+	for (int ks = 0; ks < 8; ks++) {
+		const double ae = PF ? ma[ks] : frag(3, ks, rt), ao = PF ? ma[8 + ks] : frag(3, ks, 2 + rt);
+#pragma unroll
+		for (int c2 = 0; c2 < 2; c2++) {
+			e2[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, T[(4 * ks + g) * LD + 16 * (cb + c2) + j], e2[c2], 0, 0, 0);
+			o2[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, T[(32 + 4 * ks + g) * LD + 16 * (cb + c2) + j], o2[c2], 0, 0, 0);
+		}
+	}
+	double      *op = out + (size_t) p * nn;
+	const double sc = 4.0 / ((double) n * n);
+#pragma unroll
+	for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int yp = 16 * rt + g + 4 * r, x = 16 * (cb + c2) + j;
+			op[yp * n + x]        = (e2[c2][r] + o2[c2][r]) * sc;
+			op[(63 - yp) * n + x] = (e2[c2][r] - o2[c2][r]) * sc;
+		}
 }
 } // namespace te

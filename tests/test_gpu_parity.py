@@ -482,3 +482,30 @@ def test_fused_block_jacobi_cycle_2d(div, neumann):
         g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE, fuse=fuse, cycle_type=1), df, dc)
         outs.append(dc.download())
     assert rel(outs[1], outs[0]) <= 1e-11
+
+
+@pytest.mark.parametrize("div,neumann", [(2, False), (3, True), (0, False), (0, True)])
+def test_half_size_transforms_2d(div, neumann):
+    """k_patch_solve2d_sym (64^2 patches whose two axes close the same way on both sides: half-size transforms on the sums and
+    differences of mirrored entries) against k_patch_solve2d_mfma (TE_2D_NO_SYM) and the oracle: a sweep from a random iterate, a
+    sweep from zero, a V-cycle. Neumann: the boundary patches have a mixed axis and keep the full transforms (two launches per
+    level); one all-Neumann patch: DCT axes, the zero mode."""
+    m, H, levels = util.setup("uniform", 64, div, neumann=neumann, dim=2)
+    g, L = capi.GMG(H), levels[0]
+    u0 = util.rand_vec(L.size, 61)
+    f = util.rand_vec(L.size, 62) / L.a["h"].min() ** 2
+    if neumann and L.P == 1:
+        f -= f.mean()
+    got = {}
+    for mode in (None, "1"):
+        g.set_option("TE_2D_NO_SYM", mode)
+        du, dz, df, dc = g.new_vector(0, u0), g.new_vector(0), g.new_vector(0, f), g.new_vector(0)
+        g.smooth(df, du, smoother=capi.SMOOTH_PATCH_SOLVE)
+        g.smooth(df, dz, smoother=capi.SMOOTH_PATCH_SOLVE)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, dc)
+        got[mode] = (du.download(), dz.download(), dc.download())
+    g.set_option("TE_2D_NO_SYM", None)
+    for a, b in zip(got[None], got["1"]):
+        assert rel(a, b) <= 1e-13 and not np.array_equal(a, b)
+    assert rel(got[None][0], orc.smooth(L, f, u0)) <= 1e-11
+    assert rel(got[None][2], orc.cycle(levels, orc.cycle_opts(smoother=0), f)) <= 1e-10
