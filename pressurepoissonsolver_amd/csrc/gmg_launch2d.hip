@@ -130,19 +130,13 @@ bool patchSolve2dFusable(const te_gmg *g, const LevelHost &L)
 // Cycle.h:57-65 after one block-Jacobi sweep from the zero iterate: inside a patch the residual of an exact patch solve vanishes
 // (up to the solve's rounding: defined as 0), on the edge cells of a face with a neighbour it is -(g + m)/h^2 (the patch operator
 // closed that face with ghost = -m where the operator has the neighbour's g): the coarse right-hand side is zero except along
-// the quadrant edges, which k_restrict_fixup2d<own> fills from the edge values alone -- no pass over u and f (17 B per site).
+// the quadrant edges, which k_restrict_fixup2d<own> writes (zeros and edge terms) from the edge values alone -- no pass over u and f
+// (17 B per site), no memset.
 int interfaceResidRestrict2d(te_gmg *g, LevelHost &L, const double *u, double *coarse, size_t coarse_n)
 {
 	int rc = prepareGhosts2d(g, L, u); // the new edge values of neighbours on other ranks
 	if (rc) return rc;
-	if (coarse_n > 0) {
-		Timed t(g, KC_VECOP, coarse_n);
-		HIPCHK(hipMemsetAsync(coarse, 0, sizeof(double) * coarse_n, g->stream));
-	}
-	if (L.n_up > 0 && L.upbuf.n > 0) { // blocks of children whose parent lives on another rank start from zero as well
-		Timed t(g, KC_VECOP, L.upbuf.n);
-		HIPCHK(hipMemsetAsync(L.upbuf.p, 0, sizeof(double) * L.upbuf.n, g->stream));
-	}
+	(void) coarse_n; // (every coarse block -- local, or on its way to the parent's rank -- is written whole by the kernel)
 	if (L.P > 0) {
 		Timed t(g, KC_FIXUP, (size_t) L.P * 4 * L.nf);
 		hipLaunchKernelGGL(k_restrict_fixup2d, dim3(L.P), dim3(128), 0, g->stream, L.dev2(), u, (const double *) nullptr,

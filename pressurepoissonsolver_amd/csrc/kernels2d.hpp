@@ -619,10 +619,16 @@ static __global__ __launch_bounds__(128) void k_restrict_fixup2d(Level2D L, cons
                                                           Prolong2D dst, double *__restrict__ coarse, double *__restrict__ remote,
                                                           const int64_t *__restrict__ remote_off, bool own = false)
 {
+	// own (interfaceResidRestrict2d): the restricted residual IS these terms -- the block starts from zero, written here (no memset
+	// pass over the coarse vector; the waves of a workgroup see each other's global stores after a barrier)
 	const int n = L.n, nn = n * n, h = n / 2, p = blockIdx.x;
 	const int pa = dst.parent[p], o = dst.orth[p];
 	double   *cb = pa >= 0 ? coarse + (size_t) pa * nn + ((o & 1) ? h : 0) + n * ((o & 2) ? h : 0) : remote + remote_off[-(pa + 2)];
 	const int     cs = pa >= 0 ? n : h;
+	if (own) {
+		for (int i = threadIdx.x; i < h * h; i += blockDim.x) cb[i % h + cs * (i / h)] = 0.0;
+		__syncthreads();
+	}
 	const Fixup2D fx{L, u, e4, p, cb, cs, own};
 	auto          term = [&](int s, int kind, int i) { return fx.term(s, kind, i); };
 	auto          cell = [&](int s, int i) { return fx.cell(s, i); };

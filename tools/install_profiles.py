@@ -10,6 +10,7 @@ tag, commit = sys.argv[1:3]
 W = f"gpurun_out/{tag}f"
 names = {"_bench_512.json": "bench_512_n1.json", "_bench_512_ps.json": "bench_512_n1_patch_solve.json",
          "_bench_256.json": "bench_256_n1.json", "_bench_2d.json": "bench_2d_4096_n1.json",
+         "_bench_2d_ps.json": "bench_2d_4096_n1_patch_solve.json",
          "_bench_c4.json": "bench_c4_2refine_div3_n1.json"}
 for src, dst in names.items():
     d = json.loads(open(W + src).read().strip().splitlines()[-1])

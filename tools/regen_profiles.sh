@@ -25,4 +25,5 @@ python3 bench.py --steps 20 --warmup 5 > ${W}_bench_512.json 2> ${W}_bench_512.e
 python3 bench.py --steps 20 --warmup 5 --smoother patch_solve --no-cpu-baseline > ${W}_bench_512_ps.json 2>> ${W}_bench_512.err && echo ps ok &&
 python3 bench.py --steps 20 --warmup 5 --size 256 --no-cpu-baseline > ${W}_bench_256.json 2>> ${W}_bench_512.err && echo 256 ok &&
 python3 bench.py --steps 20 --warmup 5 --dim 2 --size 4096 --patch 64 --no-cpu-baseline > ${W}_bench_2d.json 2>> ${W}_bench_512.err && echo 2d ok &&
+python3 bench.py --steps 20 --warmup 5 --dim 2 --size 4096 --patch 64 --smoother patch_solve --no-cpu-baseline > ${W}_bench_2d_ps.json 2>> ${W}_bench_512.err && echo 2d ps ok &&
 python3 bench.py --steps 20 --warmup 5 --mesh tests/golden/2refine.bin --divide 3 --no-cpu-baseline > ${W}_bench_c4.json 2>> ${W}_bench_512.err && echo c4 ok
