@@ -556,7 +556,7 @@ def main():
     # tolerance 1e-12) preconditioned with one V-cycle, the drivers' trig problem on the same grid, both smoothers. A first solve
     # warms up (work vectors, code), the second is timed between two synchronisations, a third runs with every kernel class
     # timed and gives the algorithmic bytes per site and iteration.
-    if a.dim == 3 and not a.no_secondary and not a.mesh and os.environ.get("TE_BENCH_NOPROFILE") is None:
+    if not a.no_secondary and not a.mesh and os.environ.get("TE_BENCH_NOPROFILE") is None:
         solve = {}
         sites_local = H.sizes(0)[0] * n ** a.dim
         bb, xx = g.new_vector(0), g.new_vector(0)
@@ -591,7 +591,7 @@ def main():
         g.release_workspace()
         if rank == 0:
             secondary = secondary or {}
-            secondary["solve"] = {"what": f"te_bicgstab + one V(1,1) cycle as preconditioner to 1e-12, trig problem (apps/3d/steady.cpp:253-265) on the benchmarked grid, "
+            secondary["solve"] = {"what": f"te_bicgstab + one V(1,1) cycle as preconditioner to 1e-12, trig problem ({'apps/3d/steady.cpp:253-265' if a.dim == 3 else 'apps/2d/steady.cpp:314-318'}) on the benchmarked grid, "
                                           "second of two solves, wall time between two synchronisations (max over ranks)", **solve}
 
     if rank == 0 and not rows:  # TE_BENCH_NOPROFILE=1 (tooling): wall time only
