@@ -1457,7 +1457,9 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_sym(Level2D L, const int3
 	const double *S  = sym + (size_t) pl * PS2S_PLAN;
 	const double *lm = lam + (size_t) pl * 2 * n;
 	auto          frag = [&](int stage, int ks, int t) { return S[stage * PS2S_STAGE + (ks * 4 + t) * 64 + l]; };
-	double        mb[PF ? 32 : 1], ma[PF ? 16 : 1]; // fragments of a B-side stage (8 k-steps x 4) and of an A-side stage (8, or 2 x 8)
+	// PF: every stage's fragments are fetched a stage ahead; otherwise only those of the A-side stages (8 and 16 values per lane:
+	// 124 -> 140 registers, three workgroups per CU either way), a B-side stage's 32 where it uses them
+	double        mb[PF ? 32 : 1], ma[16]; // fragments of a B-side stage (8 k-steps x 4) and of an A-side stage (8, or 2 x 8)
 	auto          loadB = [&](int stage) {
         if constexpr (PF) {
 #pragma unroll
@@ -1472,13 +1474,11 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_sym(Level2D L, const int3
 	__syncthreads();
 	v4f64_2d d[4];
 	// ---- stage 0: Y1[y][c'] = sum_{x'<32} (X[y][x'] +- X[y][63-x']) Fx[kx(c')][x']: tiles 0, 1 even kx (sums), 2, 3 odd kx (differences)
-	if constexpr (PF) {
 #pragma unroll
-		for (int ks = 0; ks < 8; ks++) ma[ks] = frag(1, ks, w);
-	}
+	for (int ks = 0; ks < 8; ks++) ma[ks] = frag(1, ks, w);
 #pragma unroll
 	for (int ct = 0; ct < 4; ct++) d[ct] = v4f64_2d{0, 0, 0, 0};
-#pragma clang loop unroll_count(PF ? 8 : 2)
+#pragma unroll // (also without PF: the eight k-steps' fragment loads are then in flight together, 586 -> 547 us per C5 cycle)
 	for (int ks = 0; ks < 8; ks++) {
 		const double xl = T[(16 * w + j) * LD + 4 * ks + g], xh = T[(16 * w + j) * LD + 63 - 4 * ks - g];
 		const double ae = xl + xh, ao = xl - xh;
@@ -1494,19 +1494,17 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_sym(Level2D L, const int3
 	// ---- stage 1: Y2[r'][c'] = sum_{y'<32} Fy[ky(r')][y'] (Y1[y'][c'] +- Y1[63-y'][c']): waves 0, 1 even ky, 2, 3 odd ky
 #pragma unroll
 	for (int ct = 0; ct < 4; ct++) d[ct] = v4f64_2d{0, 0, 0, 0};
-#pragma clang loop unroll_count(PF ? 8 : 2)
+#pragma unroll // (also without PF: the eight k-steps' fragment loads are then in flight together, 586 -> 547 us per C5 cycle)
 	for (int ks = 0; ks < 8; ks++) {
-		const double a = PF ? ma[ks] : frag(1, ks, w);
+		const double a = ma[ks];
 #pragma unroll
 		for (int ct = 0; ct < 4; ct++) {
 			const double yl = T[(4 * ks + g) * LD + 16 * ct + j], yh = T[(63 - 4 * ks - g) * LD + 16 * ct + j];
 			d[ct]           = __builtin_amdgcn_mfma_f64_16x16x4f64(a, w < 2 ? yl + yh : yl - yh, d[ct], 0, 0, 0);
 		}
 	}
-	if constexpr (PF) {
 #pragma unroll
-		for (int ks = 0; ks < 8; ks++) ma[ks] = frag(3, ks, w & 1), ma[8 + ks] = frag(3, ks, 2 + (w & 1));
-	}
+	for (int ks = 0; ks < 8; ks++) ma[ks] = frag(3, ks, w & 1), ma[8 + ks] = frag(3, ks, 2 + (w & 1));
 	__syncthreads(); // every wave has read all rows of Y1 before any overwrites its own
 #pragma unroll
 	for (int ct = 0; ct < 4; ct++)
@@ -1523,7 +1521,7 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_sym(Level2D L, const int3
 	v4f64_2d e2[2], o2[2];
 #pragma unroll
 	for (int c2 = 0; c2 < 2; c2++) e2[c2] = o2[c2] = v4f64_2d{0, 0, 0, 0};
-#pragma clang loop unroll_count(PF ? 8 : 2)
+#pragma unroll // (also without PF: the eight k-steps' fragment loads are then in flight together, 586 -> 547 us per C5 cycle)
 	for (int ks = 0; ks < 8; ks++) {
 		const double ae = T[(16 * w + j) * LD + 4 * ks + g], ao = T[(16 * w + j) * LD + 32 + 4 * ks + g];
 #pragma unroll
@@ -1546,9 +1544,9 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_sym(Level2D L, const int3
 	const int rt = w & 1, cb = 2 * (w >> 1);
 #pragma unroll
 	for (int c2 = 0; c2 < 2; c2++) e2[c2] = o2[c2] = v4f64_2d{0, 0, 0, 0};
-#pragma clang loop unroll_count(PF ? 8 : 2)
+#pragma unroll // (also without PF: the eight k-steps' fragment loads are then in flight together, 586 -> 547 us per C5 cycle)
 	for (int ks = 0; ks < 8; ks++) {
-		const double ae = PF ? ma[ks] : frag(3, ks, rt), ao = PF ? ma[8 + ks] : frag(3, ks, 2 + rt);
+		const double ae = ma[ks], ao = ma[8 + ks];
 #pragma unroll
 		for (int c2 = 0; c2 < 2; c2++) {
 			e2[c2] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, T[(4 * ks + g) * LD + 16 * (cb + c2) + j], e2[c2], 0, 0, 0);
