@@ -23,6 +23,7 @@ def main():
                     "real hipIpc mappings between the processes, the attached back-end for everything else")
     ap.add_argument("--cells", type=int, default=8, help="cells per patch axis")
     ap.add_argument("--dim", type=int, default=3)
+    ap.add_argument("--smoother", default="rbgs", help="rbgs | patch_solve (the reference's block Jacobi)")
     ap.add_argument("--push-fault", action="store_true", help="TE_PUSH_FAULT: the direct-store transport never delivers; te_gmg_autotune must "
                     "reject it on all ranks and everything must then run correctly through the attached back-end")
     a = ap.parse_args()
@@ -36,6 +37,7 @@ def main():
     from pressurepoissonsolver_amd import capi, dist as tedist, problems, solver
     n = a.cells
     nc = n ** a.dim
+    SM = capi.SMOOTH_PATCH_SOLVE if a.smoother == "patch_solve" else capi.SMOOTH_RBGS
     mesh = capi.Mesh.uniform(a.dim, a.divides)
     H = capi.Hierarchy(mesh, n, rank=rank, nranks=world)
     g = capi.GMG(H, device=dev)
@@ -46,7 +48,7 @@ def main():
         # the transports are compared on this very machine: identical results, then the faster one; force the direct one afterwards
         if a.push_fault:
             g.set_option("TE_PUSH_FAULT", "1")
-        _, report = g.autotune(g.default_opts(smoother=capi.SMOOTH_RBGS), reps=3)
+        _, report = g.autotune(g.default_opts(smoother=SM), reps=3)
         if a.push_fault:
             assert "REJECTED" in report, report
             try:
@@ -62,7 +64,7 @@ def main():
     b_all, _ = (problems.init_dirichlet if a.dim == 3 else problems.init_dirichlet_2d)(t, n)
     idx = H.l2g(0)
     local = lambda v: v.reshape(-1, nc)[idx].ravel()  # noqa: E731
-    opts = g.default_opts(smoother=capi.SMOOTH_RBGS)
+    opts = g.default_opts(smoother=SM)
 
     def gather(vec):
         mine = torch.zeros(len(t["id"]) * nc, dtype=torch.float64)
@@ -99,10 +101,10 @@ def main():
         f1, u1, au1 = g1.new_vector(0, f_all), g1.new_vector(0), g1.new_vector(0)
         g1.apply(f1, au1)
         assert np.array_equal(got["apply_first"], au1.download()), "sharded apply differs from single-rank"
-        g1.cycle(g1.default_opts(smoother=capi.SMOOTH_RBGS), f1, u1)
+        g1.cycle(g1.default_opts(smoother=SM), f1, u1)
         assert np.array_equal(got["cycle"], u1.download()), "sharded V-cycle differs from single-rank"
         x1 = g1.new_vector(0)
-        its1, rr1 = g1.bicgstab(x1, g1.new_vector(0, b_all), g1.default_opts(smoother=capi.SMOOTH_RBGS))
+        its1, rr1 = g1.bicgstab(x1, g1.new_vector(0, b_all), g1.default_opts(smoother=SM))
         want = x1.download()
         assert abs(its - its1) <= 1 and rr <= 1e-12, (its, its1, rr)
         assert np.linalg.norm(got["bicg"] - want) <= 1e-9 * np.linalg.norm(want), "sharded BiCGStab differs"

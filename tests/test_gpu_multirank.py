@@ -419,6 +419,23 @@ def test_two_processes_gloo(overlap_min):
     assert "MR_WORKER_OK" in r.stdout
 
 
+def test_two_processes_gloo_2d_reference_smoother():
+    """the fused 2D block-Jacobi cycle between real processes (gloo): 64 patches of 64^2 on two ranks -- the post-sweep's neighbours
+    send u + P e (k_pack_faces_prolong2d), the interface residual reads the neighbours' new edges; apply / cycle / BiCGStab / apply
+    equal the single-rank run (mr_worker.py)"""
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", port,
+           os.path.join(root, "tests", "mr_worker.py"), "--backend", "gloo", "--dim", "2", "--cells", "64", "--divides", "3", "--smoother", "patch_solve"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "MR_WORKER_OK" in r.stdout
+
+
 @pytest.mark.parametrize("n,divides,nproc,dim", [(8, 2, 2, 3), (32, 3, 2, 3), (32, 3, 4, 3), (64, 4, 2, 2)],
                          ids=["64x8^3", "512x32^3-fused-path", "512x32^3-4-processes", "2D-256x64^2"])
 def test_two_processes_direct_store_transport(n, divides, nproc, dim):
