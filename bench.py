@@ -230,6 +230,74 @@ def self_launch(ngpus, json_out):
     return p.returncode
 
 
+PROVISIONAL = "#PROVISIONAL "  # worker -> supervisor: the line so far (the headline is measured; a risky secondary block follows)
+
+
+def metric_name(a):
+    if a.size == 512 and a.dim == 3 and not a.mesh and a.patch == 32:
+        return "V-cycle lattice-site updates/sec, 512^3 3D Poisson"
+    if a.mesh:
+        return f"V-cycle lattice-site updates/sec, {os.path.basename(a.mesh)} --divide {a.divide}, {a.dim}D Poisson"
+    return f"V-cycle lattice-site updates/sec, {a.size}^{a.dim} {a.dim}D Poisson"
+
+
+def error_line(a, world, msg):
+    """the one JSON line of a run that produced no number: same keys, value null, the reason in `error`"""
+    return json.dumps({"metric": metric_name(a), "value": None, "unit": "lattice-site updates/s", "n_gpus": world, "steps": a.steps,
+                       "warmup": a.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                       "dtype": "f64", "data": "synthetic", "config": {"workload_key": workload_key(a)}, "error": msg})
+
+
+def supervise(a, json_out):
+    """N > 1 under a launcher (torchrun sets WORLD_SIZE): the process the launcher started never touches the GPU -- it starts the
+    real rank as a CHILD (same arguments, TE_BENCH_WORKER=1), passes its stderr through and reads its stdout. Whatever ends the
+    worker -- an exception, the exchange watchdog's exit 86, a GPU fault's abort, the launcher's SIGTERM after another rank died --
+    rank 0's supervisor still prints ONE JSON line: the worker's final line; or the line the worker had finished before its last
+    optional block (PROVISIONAL) with `error` naming how the worker ended; or an error line with value null. The exit status is
+    the worker's."""
+    import signal
+    import subprocess
+    import threading
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    env = dict(os.environ, TE_BENCH_WORKER="1")
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, text=True)
+    ended_by = []
+
+    def forward(sig, _frm):
+        ended_by.append(signal.Signals(sig).name)
+        try:
+            p.send_signal(signal.SIGTERM)
+        except ProcessLookupError:
+            return
+        threading.Timer(10.0, lambda: p.poll() is None and p.kill()).start()  # (a worker stuck in a device call)
+
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sg, forward)
+    final, prov = None, None
+    for ln in p.stdout:
+        t = ln.strip()
+        if t.startswith(PROVISIONAL):
+            prov = t[len(PROVISIONAL):]
+        elif t.startswith("{"):
+            final = t
+        elif t:
+            print(t, file=sys.stderr, flush=True)
+    rc = p.wait()
+    how = (f"the launcher sent {ended_by[0]} (another rank failed)" if ended_by else
+           "the exchange watchdog ended the worker (exit 86: an exchange never completed)" if rc == 86 else
+           f"worker killed by signal {-rc}" if rc < 0 else f"worker exit status {rc}")
+    if rank == 0:
+        if final is not None:
+            print(final, file=json_out, flush=True)
+        elif prov is not None:
+            d = json.loads(prov)
+            d["error"] = f"the headline was measured; then, inside {d.pop('next_block', 'an optional block')}: {how}"
+            print(json.dumps(d), file=json_out, flush=True)
+        else:
+            print(error_line(a, world, how + "; see stderr"), file=json_out, flush=True)
+    return rc
+
+
 # classes whose launches on a REFINED level move more than on a uniform one: a patch that does not coarsen (AvgRstr.h:103-107,
 # DrctIntp.h:107-111 copy it through) reads its correction, resp. writes its residual, at full size -- 8 B per site where an
 # octant child moves 1 (its eighth of a coarse patch): + 7 B per site of such patches
@@ -294,9 +362,31 @@ def main():
         raise SystemExit(self_launch(a.gpus, json_out))
     if world != a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus} was started with WORLD_SIZE={world}: one rank per GPU")
+    if world > 1 and os.environ.get("TE_BENCH_WORKER") is None and os.environ.get("TE_BENCH_INPROC") is None:
+        raise SystemExit(supervise(a, json_out))  # (this process stays off the GPU; the rank itself runs as its child)
+    die = os.environ.get("TE_BENCH_TEST_DIE")  # test hook (tests/test_bench_launch.py): a worker that ends like a watchdog exit
+    if die is not None and os.environ.get("TE_BENCH_WORKER") is not None:
+        if die == "after-provisional" and rank == 0:
+            print(PROVISIONAL + json.dumps({"metric": metric_name(a), "value": 1.0, "n_gpus": world, "next_block": "a test block"}), file=json_out, flush=True)
+        os._exit(86)
+    try:
+        run(a, json_out, rank, world, local_rank)
+    except BaseException as e:  # noqa: BLE001 -- every failure path ends in a JSON line (rank 0; N > 1: the supervisor's when nothing is left to say here)
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        if rank == 0:
+            print(error_line(a, world, f"{type(e).__name__}: {e}"), file=json_out, flush=True)
+        raise
+
+
+def run(a, json_out, rank, world, local_rank):
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if world > 1:
+        # a wedged exchange must end the run (watchdog: exit 86, the supervisor prints the error line) well inside any driver's
+        # time limit -- the library's own default is 300 s
+        os.environ.setdefault("TE_EXCHANGE_TIMEOUT", "60")
     ndev = torch.cuda.device_count()
     backend = os.environ.get("TE_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of N > 1 on a 1-GPU box only
     if backend == "gloo":
@@ -373,21 +463,11 @@ def main():
              ("gathered<=64-on-rank-0", (64, 64, 0)), ("never-gathered", (0, 64, 0))] if a.dim == 3
             else [("gathered<=64-on-rank-0", (64, 64, 0)), ("gathered<16/rank-on-rank-0", (16, 64, 0)), ("never-gathered", (0, 64, 0))])
         tried, best = [], None
-        push_ok = os.environ.get("TE_BENCH_PUSH", "1") != "0"
-        os.environ.setdefault("TE_PUSH_TIMEOUT", "5")  # (a transport that does not work here is found out within seconds)
+        # (the headline runs on the transport `north_star` names -- RCCL point-to-point groups issued by the library; the
+        # direct-store transport is measured afterwards, as secondary.direct_store, never inside the headline's choice)
         for cname, pl in cands:
             Hc, gc, bname = make(pl)
-            if push_ok:
-                # prepare the direct-store transport (hipIpc-mapped receive buffers); te_gmg_autotune then checks it against the
-                # other one on this machine (identical results on every rank, no wait given up) and keeps the faster
-                try:
-                    gc.use_push(True)
-                except capi.TeError as e:  # (all ranks fail together by construction)
-                    print(f"[rank {rank}] direct-store transport not available: {e}", file=sys.stderr)
-                    push_ok = False
             ms, rep = gc.autotune(gc.default_opts(smoother=smoothers[a.smoother]), reps=10)
-            if "REJECTED" in rep:  # (the same verdict on every rank: it comes out of a reduction) -- not tried again on this machine
-                push_ok = False
             tried.append({"placement": cname, "agglomerate/max/replicate": list(Hc.placement()), "ms_per_cycle_max_over_ranks": ms, "overlap": rep})
             if best is None or ms < best[0]:
                 best = (ms, Hc, gc, bname, cname)
@@ -403,6 +483,7 @@ def main():
     f = g.new_vector(0)
     g.init_problem(f, None, problem=capi.PROBLEM_RANDOM)  # U(-1,1) splitmix64(0x5EED + patch id), generated on the device
     u = g.new_vector(0)
+    g0, f0, u0 = g, f, u
     cells_global = [H.sizes(l)[1] * n ** a.dim for l in range(H.num_levels)]
     # this rank's sites in patches that copy through to the next level, summed over the levels (refined meshes only)
     copy_sites = 0
@@ -422,9 +503,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def measure(o, steps, warmup):
+    def measure(o, steps, warmup, g=None, f=None, u=None):
         """W untimed warm-up cycles with every kernel class timed (per-kernel table; names the dominant class), then
-        exactly K cycles between two barriers with HIP events on the dominant class only; max over ranks"""
+        exactly K cycles between two barriers with HIP events on the dominant class only; max over ranks
+        (g, f, u: another solver and its vectors -- the problem-size block; default: the headline's)"""
+        g, f, u = (g0 if g is None else g), (f0 if f is None else f), (u0 if u is None else u)
         g.profile(True)
         g.profile_select(None)
         # the very first step pays one-time costs (code load, lazy attributes): its events are dropped, so the table
@@ -465,6 +548,20 @@ def main():
             dt = float(tt.item())
         return {"dt": dt, "rows_all": rows_all, "rows": rows, "profiled_warm": profiled_warm}
 
+    def median_cycle_ms(o, steps, g=None, f=None, u=None):
+        """median of per-cycle times: an event pair per cycle on the solver stream"""
+        g, f, u = (g0 if g is None else g), (f0 if f is None else f), (u0 if u is None else u)
+        ext = torch.cuda.ExternalStream(int(g.stream()))
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        with torch.cuda.stream(ext):
+            for e0, e1 in evs:
+                e0.record()
+                g.cycle(o, f, u)
+                e1.record()
+        barrier()
+        return float(np.median([e0.elapsed_time(e1) for e0, e1 in evs]))
+
     def reduction_per_cycle(r):
         """sanity: the cycle must actually reduce the residual (guards against timing a no-op)"""
         g.residual(u, f, r)
@@ -475,22 +572,27 @@ def main():
             rn, fn = tt.tolist()
         return float(np.sqrt(rn / fn))
 
+    def checksum(v):
+        """te_vec_checksum over all ranks: the sum modulo 2^64 of the bit patterns of v's values -- independent of the order of the
+        patches and of how they are cut over ranks, so the lines of N = 1, 2, 4, 8 must print the SAME number for every vector
+        whose computation is order-independent (a cycle's result is; a Krylov solve's is not: its dot products are summed rank
+        by rank). The ranks' parts are added as two 32-bit halves in int64 (no overflow below 2^31 ranks)."""
+        c = v.checksumLocal()
+        if dist is not None:
+            tt = torch.tensor([c & 0xFFFFFFFF, c >> 32], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(tt)
+            lo, hi = (int(x) for x in tt.tolist())
+            c = (lo + (hi << 32)) & 0xFFFFFFFFFFFFFFFF
+        return f"{c:016x}"
+
     m = measure(opts, a.steps, a.warmup)
     dt, rows_all, rows = m["dt"], m["rows_all"], m["rows"]
+    u_checksum = checksum(u)  # (every cycle of the timed region starts from u = 0 on the same f: this is the result of ONE cycle)
     ms_per_step = dt / a.steps * 1e3
     value = cells_global[0] / (dt / a.steps)
     # median of per-cycle times (SURVEY 8(d)): a second, untimed-by-the-contract pass with an event pair per cycle on
     # the solver stream (`value` above stays the contract's K steps between two synchronisations)
-    ext = torch.cuda.ExternalStream(int(g.stream()))
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
-    barrier()
-    with torch.cuda.stream(ext):
-        for e0, e1 in evs:
-            e0.record()
-            g.cycle(opts, f, u)
-            e1.record()
-    barrier()
-    ms_median = float(np.median([e0.elapsed_time(e1) for e0, e1 in evs]))
+    ms_median = median_cycle_ms(opts, a.steps)
 
     # N > 1: what makes a SCALE record diagnosable -- per rank and cycle, the time inside the exchanges as the solver stream
     # sees it (RCCL's kernels plus the wait for the peers), the pack / unpack launches, the kernels, and the host time to
@@ -538,8 +640,10 @@ def main():
     secondary = None
     if a.smoother == "rbgs" and not a.no_secondary and a.dim == 3 and n == 32 and os.environ.get("TE_BENCH_NOPROFILE") is None:
         o2 = g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE)
-        k2 = 12
-        m2 = measure(o2, k2, 3)
+        k2, w2 = 20, 5  # (an MFMA-bound kernel's clock settles over the first cycles: the quoted figure is a MEDIAN of 20 behind 5)
+        m2 = measure(o2, k2, w2)
+        med2 = median_cycle_ms(o2, k2)
+        cs2 = checksum(u)
         red2 = reduction_per_cycle(r)
         if rank == 0 and m2["rows"]:
             name2, st2 = max(((k, v) for k, v in m2["rows"].items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
@@ -547,8 +651,9 @@ def main():
             secondary = {"reference_smoother": {
                 "what": "the same workload with the reference's block-Jacobi smoother (exact patch solves on the fp64 matrix cores), "
                         "default options (fuse = 3)",
-                "steps": k2, "warmup": 3, "ms_per_step": m2["dt"] / k2 * 1e3, "value": cells_global[0] / (m2["dt"] / k2),
-                "unit": "lattice-site updates/s", "residual_reduction_per_cycle": red2,
+                "steps": k2, "warmup": w2, "ms_per_step": m2["dt"] / k2 * 1e3, "ms_per_step_median": med2,
+                "value": cells_global[0] / (m2["dt"] / k2),
+                "unit": "lattice-site updates/s", "residual_reduction_per_cycle": red2, "u_checksum_after_timed_region": cs2,
                 "roofline": roofline_of(name2, st2, ps_key, world), "roofline_mfma": roofline_mfma_of(name2, st2, a.dim, n),
                 "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4)} for k, v in m2["rows_all"].items()}}}
 
@@ -571,6 +676,7 @@ def main():
             its, rr = g.bicgstab(xx, bb, o3)
             barrier()
             dts = time.perf_counter() - t0s
+            x_cs = checksum(xx)
             xx.set(0.0)
             g.profile(True)
             g.profile_select(None)
@@ -586,6 +692,8 @@ def main():
             krylov = sum(ALG_BYTES.get(k, 8.0) * v["cells"] for k, v in prow.items() if k not in cyc and k not in ("exchange", "pack")) / max(its, 1) / max(sites_local, 1)
             allb = sum(ALG_BYTES.get(k, 8.0) * v["cells"] for k, v in prow.items()) / max(its, 1) / max(sites_local, 1)
             solve[sname] = {"iterations": its, "ms": dts * 1e3, "rel_resid": rr, "ms_per_iteration": dts * 1e3 / max(its, 1),
+                            # (equal across N only where the dot products are summed in the same order: informative, not an invariant)
+                            "x_checksum": x_cs,
                             "alg_bytes_per_site_per_iteration": {"outside_the_two_cycles": krylov, "all_kernels": allb}}
         del bb, xx
         g.release_workspace()
@@ -594,34 +702,42 @@ def main():
             secondary["solve"] = {"what": f"te_bicgstab + one V(1,1) cycle as preconditioner to 1e-12, trig problem ({'apps/3d/steady.cpp:253-265' if a.dim == 3 else 'apps/2d/steady.cpp:314-318'}) on the benchmarked grid, "
                                           "second of two solves, wall time between two synchronisations (max over ranks)", **solve}
 
+    def fused_hbm(rows_w, profiled_warm, local_sites, sec_per_step, copy_sites_=0):
+        """whole cycle against the bytes its fused kernels must move (a roofline fraction): the kernels' own algorithmic bytes from
+        the warm-up table, every class that has an ALG_BYTES entry; the others are listed, not silently counted as zero"""
+        counted = sorted(k for k in rows_w if k in ALG_BYTES)
+        uncounted = sorted(k for k in rows_w if k not in ALG_BYTES)
+        fb = sum(ALG_BYTES[k] * rows_w[k]["cells"] for k in counted) / max(1, profiled_warm)
+        fb += 14.0 * copy_sites_  # (refined meshes: the residual down and the correction up of a patch that copies through, at full size)
+        return {"fused_alg_bytes_per_finest_site": fb / local_sites, "fused_achieved_GBs": fb / sec_per_step / 1e9,
+                "fused_frac_of_peak": fb / sec_per_step / 1e9 / HBM_PEAK_GBS, "classes_counted": counted, "classes_without_bytes": uncounted}
+
     if rank == 0 and not rows:  # TE_BENCH_NOPROFILE=1 (tooling): wall time only
         print(json.dumps({"ms_per_step": ms_per_step, "value": value}), file=json_out, flush=True)
+        out = None
     elif rank == 0:
         name, st = max(((k, v) for k, v in rows.items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
         roof = roofline_of(name, st, workload_key(a), world, copy_sites, a.steps)
         roof["measured_triad_GBs"] = triad_gbs
         roof["frac_of_measured_triad"] = roof["achieved"] / triad_gbs
         b_alg = vcycle_alg_bytes_per_finest_cell(cells_global)
-        # what the fused cycle's kernels must move at least: their own algorithmic bytes (warm-up table, every class that has
-        # an ALG_BYTES entry; the others are listed, not silently counted as zero)
-        counted = sorted(k for k in rows_all if k in ALG_BYTES)
-        uncounted = sorted(k for k in rows_all if k not in ALG_BYTES)
-        fused_bytes = sum(ALG_BYTES[k] * rows_all[k]["cells"] for k in counted) / max(1, m["profiled_warm"])
-        fused_bytes += 14.0 * copy_sites  # (refined meshes: the residual down and the correction up of a patch that copies through, at full size)
         local_sites = H.sizes(0)[0] * n ** a.dim
-        default_wl = (a.size == 512 and a.dim == 3 and not a.mesh and n == 32)
         out = {
-            "metric": "V-cycle lattice-site updates/sec, 512^3 3D Poisson" if default_wl else
-                      (f"V-cycle lattice-site updates/sec, {os.path.basename(a.mesh)} --divide {a.divide}, {a.dim}D Poisson" if a.mesh else
-                       f"V-cycle lattice-site updates/sec, {a.size}^{a.dim} {a.dim}D Poisson"),
+            "metric": metric_name(a),
             "value": value, "unit": "lattice-site updates/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            # The result of one cycle of the timed region as te_vec_checksum over all ranks: a sharded cycle is bit-identical to
+            # the single-rank cycle by construction, so the lines of N = 1, 2, 4, 8 on the same workload must carry the SAME value --
+            # SURVEY 8(e)'s equality test, run by whoever runs the scaling bench
+            "u_checksum_after_timed_region": u_checksum,
             "config": {"workload": f"apps/{a.dim}d/steady-equivalent: " + (f"{os.path.basename(a.mesh)} --divide {a.divide}" if a.mesh else f"{a.size}^{a.dim} uniform") + f", {cells_global[0] // n ** a.dim} "
                                    f"patches of {n}^{a.dim}, {H.num_levels} levels, V(1,1), smoother={a.smoother}, "
                                    "Dirichlet, f ~ U(-1,1) splitmix64(0x5EED + patch id)",
                        "workload_key": workload_key(a),
+                       # what carried the exchanges of the timed region (N > 1)
                        "parallelism": f"patch-sharded x{world} (Morton ranges)", "exchange": exchange_backend,
+                       "exchange_timeout_s": float(os.environ.get("TE_EXCHANGE_TIMEOUT", "300")) if world > 1 else None,
                        "levels": H.num_levels,
                        "patches_per_level": [c // n ** a.dim for c in cells_global],
                        # where every level lives (patches per rank): coarse levels gathered on rank 0 show up here
@@ -633,10 +749,7 @@ def main():
             # whole cycle: (i) against the bytes its fused kernels must move (a roofline fraction); (ii) SURVEY 8(d)'s
             # UNFUSED definition (113 B per finest site) divided by the fused cycle's time -- a work-equivalent rate that
             # can exceed the HBM peak because the fused cycle moves about a third of those bytes; not a roofline fraction
-            "vcycle_hbm": {"fused_alg_bytes_per_finest_site": fused_bytes / local_sites,
-                           "fused_achieved_GBs": fused_bytes / (dt / a.steps) / 1e9,
-                           "fused_frac_of_peak": fused_bytes / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
-                           "classes_counted": counted, "classes_without_bytes": uncounted,
+            "vcycle_hbm": {**fused_hbm(rows_all, m["profiled_warm"], local_sites, dt / a.steps, copy_sites),
                            "unfused_definition_bytes_per_finest_site": b_alg,
                            "unfused_definition_equivalent_GBs": b_alg * cells_global[0] / (dt / a.steps) / 1e9,
                            "unfused_definition_equivalent_over_peak": b_alg * cells_global[0] / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world)},
@@ -653,6 +766,105 @@ def main():
             out["roofline_mfma"] = rm
         if secondary:
             out["secondary"] = secondary
+    else:
+        out = None
+
+    def provisional(next_block):
+        """under the supervisor (N > 1): the line as it stands, before a block that may end the process"""
+        if out is not None and os.environ.get("TE_BENCH_WORKER") is not None:
+            print(PROVISIONAL + json.dumps({**out, "next_block": next_block}), file=json_out, flush=True)
+
+    # N > 1: the OTHER transport. One more cycle on the headline's transport is the reference; then the direct-store transport
+    # (te_gmg_use_push: hipIpc-mapped peer buffers, flags, bounded waits) is prepared, must reproduce that result BIT FOR BIT on
+    # every rank -- after a cycle on other data, so that a stale ghost plane would show; three times -- with no check of its
+    # protocol tripped (te_gmg_push_failed), and only then is timed like the headline: secondary.direct_store, a second figure,
+    # never `value`. config.sharded.verified_bit_identical says whether the two transports agreed.
+    if world > 1 and a.dim == 3 and not a.no_secondary and os.environ.get("TE_BENCH_PUSH", "1") != "0" and os.environ.get("TE_BENCH_NOPROFILE") is None:
+        provisional("secondary.direct_store (the direct-store transport between the ranks' GPUs)")
+        ds = {"what": "the same cycles with the face exchanges and the gathers of restricted blocks as direct stores into the peers' "
+                      "hipIpc-mapped buffers (te_gmg_use_push) instead of " + exchange_backend}
+        verified = None
+        try:
+            g.set_option("TE_PUSH_NONFATAL", "1")  # (a wait that gives up is reported below, not turned into exit 86)
+            g.set_option("TE_PUSH_TIMEOUT", os.environ.get("TE_PUSH_TIMEOUT", "10"))
+            g.cycle(opts, f, u)
+            uref = g.new_vector(0)
+            uref.copy(u)
+            ref_cs = checksum(uref)
+            g.use_push(True)  # (collective: succeeds or fails on all ranks together)
+            f2, d = g.new_vector(0), g.new_vector(0)
+            f2.copy(f)
+            f2.scale(-0.625)
+            bad = 0
+            for _trial in range(3):
+                g.cycle(opts, f2, u)
+                g.cycle(opts, f, u)
+                d.copy(u)
+                d.addScaled(-1.0, uref)
+                bad = max(bad, 9 if d.infNorm() != 0.0 else 0, g.push_failed())
+            tt = torch.tensor([bad], dtype=torch.int64, device=red_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            bad = int(tt.item())
+            verified = (bad == 0)
+            ds.update({"verified_bit_identical": verified, "u_checksum": checksum(u), "u_checksum_headline_transport": ref_cs,
+                       "failure_code_max_over_ranks": bad,
+                       "failure_codes": "0 none; 1 a wait gave up; 2 a peer's flag two exchanges ahead; 3 a peer behind when its buffer "
+                                        "was overwritten; 4 epochs out of sequence; 9 result differs"})
+            if verified:
+                m3 = measure(opts, a.steps, a.warmup)
+                ds.update({"steps": a.steps, "warmup": a.warmup, "ms_per_step": m3["dt"] / a.steps * 1e3, "ms_per_step_median": median_cycle_ms(opts, a.steps),
+                           "value": cells_global[0] / (m3["dt"] / a.steps), "unit": "lattice-site updates/s",
+                           "u_checksum_after_timed_region": checksum(u), "push_failed_after_timed_region": g.push_failed()})
+            g.use_push(False)
+            del f2, d, uref
+        except capi.TeError as e:  # (set-up failures come out of reductions: the same on every rank)
+            ds["error"] = str(e)
+        if out is not None:
+            out.setdefault("secondary", {})["direct_store"] = ds
+            if out["config"]["sharded"] is not None:
+                out["config"]["sharded"]["verified_bit_identical"] = {
+                    "headline_transport": exchange_backend, "other_transport": "direct stores (te_gmg_use_push)", "identical": verified,
+                    "note": "one cycle on the same right-hand side through each transport, compared bit for bit on every rank (maximum over the "
+                            "ranks of the differences' infinity norm == 0), three times, each after a cycle on other data; null: the other "
+                            "transport could not be set up here (secondary.direct_store.error)"}
+
+    # N = 1: a problem-size axis (apps/3d/steady.cpp:95 --divide, OctTree.h:119-179): the same cycle at 1024^3 -- 32 768 patches,
+    # 8 GiB per vector, the shape at which eight GPUs would hold 512^3 each (`--size 1024 --gpus 8` is that weak-scaling twin)
+    if world == 1 and a.dim == 3 and a.size == 512 and not a.mesh and n == 32 and not a.no_secondary and os.environ.get("TE_BENCH_NOPROFILE") is None \
+            and os.environ.get("TE_BENCH_NO_1024") is None:
+        try:
+            del r
+            mesh2 = capi.Mesh.uniform(3, 5)
+            H2 = capi.Hierarchy(mesh2, n)
+            g2 = capi.GMG(H2, device=local_rank)
+            fb, ub = g2.new_vector(0), g2.new_vector(0)
+            g2.init_problem(fb, None, problem=capi.PROBLEM_RANDOM)
+            o4 = g2.default_opts(smoother=smoothers[a.smoother])
+            k4, w4 = 10, 3
+            m4 = measure(o4, k4, w4, g2, fb, ub)
+            med4 = median_cycle_ms(o4, k4, g2, fb, ub)
+            cs4 = f"{ub.checksumLocal():016x}"
+            rb = g2.new_vector(0)
+            g2.residual(ub, fb, rb)
+            red4 = float(np.sqrt(rb.twoNormSqLocal() / fb.twoNormSqLocal()))
+            sites4 = H2.sizes(0)[1] * n ** 3
+            name4, st4 = max(((k, v) for k, v in m4["rows"].items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
+            a4 = argparse.Namespace(**{**vars(a), "size": 1024})
+            out["secondary"] = out.get("secondary") or {}
+            out["secondary"]["size_1024"] = {
+                "what": "the headline's cycle on 1024^3 (32 768 patches of 32^3, 6 levels) on this one GPU: 8 GiB per vector; "
+                        "`bench.py --size 1024 --gpus 8` is the weak-scaling twin of the headline (512^3 per GPU)",
+                "steps": k4, "warmup": w4, "ms_per_step": m4["dt"] / k4 * 1e3, "ms_per_step_median": med4, "value": sites4 / (m4["dt"] / k4),
+                "unit": "lattice-site updates/s", "residual_reduction_per_cycle": red4, "u_checksum_after_timed_region": cs4,
+                "patches_per_level": [H2.sizes(l)[1] for l in range(H2.num_levels)],
+                "roofline": roofline_of(name4, st4, workload_key(a4), world),
+                "vcycle_hbm": fused_hbm(m4["rows_all"], m4["profiled_warm"], sites4, m4["dt"] / k4),
+                "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4)} for k, v in m4["rows_all"].items()}}
+            del rb, fb, ub, g2, H2
+        except capi.TeError as e:
+            out.setdefault("secondary", {})["size_1024"] = {"error": str(e)}
+
+    if out is not None:
         if world == 1 and not a.no_cpu_baseline:
             from oracle import build as obuild
             obuild.build_oracle()

@@ -96,19 +96,20 @@ typedef struct {
 	int32_t fuse;         /* 0: one kernel per reference call (apply, scaleThenAdd, restrict, set, ...);
 	                         1: inside te_vcycle use the fused kernels whose results are BIT-IDENTICAL to 0
 	                            (residual+restrict, zero-guess first sweep, sweep on u + P e);
-	                         3 (default): 2, and with exactly one RB-GS pre-sweep and a post-sweep in a V-cycle the
-	                            iterate between them is never stored: the post-sweep kernel recomputes it from f
-	                            (bit-identical to 2). In 2 and 3 the fused pre-sweep forms the residual it restricts on RED
-	                            cells only and takes the black cells' residual as exactly 0: a black cell was relaxed last,
-	                            from the very values its residual is formed with, so what is dropped is the rounding of that
-	                            one update (~1e-16 relative in the coarse right-hand side) -- inside every stated tolerance,
-	                            but not bit-identical to 1;
 	                         2: additionally to 1, with one RB-GS pre-sweep on a uniformly refined 3D level,
 	                            the sweep from the zero iterate, the residual and its restriction are one pass over f;
 	                            the coarse right-hand side differs from 1 by a few ulp along patch faces (the ghost
 	                            term of the residual is added separately), independent of the partition; with one
 	                            block-Jacobi pre-sweep the residual after the exact patch solves is taken on the face
-	                            layers only (it vanishes inside a patch up to the rounding of the solve) */
+	                            layers only (it vanishes inside a patch up to the rounding of the solve);
+	                         3 (default): 2, and with exactly one RB-GS pre-sweep and a post-sweep in a V-cycle the
+	                            iterate between them is never stored: the post-sweep kernel recomputes it from f
+	                            (bit-identical to 2).
+	                         In 2 and 3 the fused pre-sweep forms the residual it restricts on RED cells only and takes
+	                         the black cells' residual as exactly 0: a black cell was relaxed last, from the very values
+	                         its residual is formed with, so what is dropped is the rounding of that one update (~1e-16
+	                         relative in the coarse right-hand side) -- inside every stated tolerance, but not
+	                         bit-identical to 1 */
 } te_cycle_opts;
 
 #define TE_SMOOTH_PATCH_SOLVE 0 /* reference: FFTBlockJacobiSmoother.h:55-58 (block Jacobi, exact patch solves) */
@@ -159,6 +160,14 @@ int te_vec_scale_then_add_scaled2(te_vec *v, double alpha, double beta, const te
 int te_vec_two_norm_sq(const te_vec *v, double *out);
 int te_vec_inf_norm(const te_vec *v, double *out);
 int te_vec_dot(const te_vec *v, const te_vec *b, double *out);
+/* This rank's part of the vector's CHECKSUM: the sum modulo 2^64 of the 64-bit patterns of its values. Integer addition
+ * commutes, so the sum of the ranks' parts (modulo 2^64; the caller adds them, as for the norms) does not depend on the order of
+ * the patches nor on how they are cut over ranks: a sharded run that is bit-identical to the single-rank run -- what every
+ * operation of a cycle is by construction -- prints the same number. How a job on hardware nobody can inspect shows that N
+ * ranks computed the very bits one rank computes (bench.py: u_checksum_after_timed_region). A level that lives on every rank
+ * counts once (rank 0's), as in te_vec_dot. Replaces nothing in the reference; the equality it proves is the one between
+ * `mpirun -np N` and `-np 1` of SchurHelper.h:123-150 / GMG/InterLevelComm.h:169-189 for order-independent operations. */
+int te_vec_checksum(const te_vec *v, uint64_t *out);
 
 /* Operator<D>::apply (Operators/Operator.h:37) as SchurDomainOp / DomainWrapOp implement it:
  * f = A u through SchurHelper::apply (SchurHelper.h:360-376) */

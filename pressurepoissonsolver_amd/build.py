@@ -54,8 +54,29 @@ def _compile_link(out, defines=()):
 
     with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(one, UNITS))
-    _run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-soname," + os.path.basename(out)] + objs + ["-o", out])
+    # linked under another name and moved into place: nobody ever dlopens a half-written library
+    tmp = f"{out}.tmp.{os.getpid()}"
+    _run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-soname," + os.path.basename(out)] + objs + ["-o", tmp])
+    os.replace(tmp, out)
     return out
+
+
+class _BuildLock:
+    """one builder at a time per checkout (the ranks of a torchrun job all import capi at once; the object files have fixed
+    names): an exclusive flock on build/.lock around `is it stale? -> compile -> link`; the others wait and then find it fresh"""
+
+    def __enter__(self):
+        import fcntl
+        d = os.path.join(ROOT, "pressurepoissonsolver_amd", "build")
+        os.makedirs(d, exist_ok=True)
+        self.f = open(os.path.join(d, ".lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
 
 
 def build_hip(force=False):
@@ -64,13 +85,17 @@ def build_hip(force=False):
     deps.append(os.path.join(ROOT, "include", "te_hip.h"))
     if not force and not _newer(LIB_HIP, deps):
         return LIB_HIP
-    return _compile_link(LIB_HIP)
+    with _BuildLock():
+        if not force and not _newer(LIB_HIP, deps):  # (another process built it while this one waited)
+            return LIB_HIP
+        return _compile_link(LIB_HIP)
 
 
 def build_variant(name, defines):
     """tooling: a second library with other compile-time switches (e.g. build_variant("noskew", ["-DTE_LDS_SKEW=0"])) for
     same-box A/B runs: TE_HIP_LIB_PATH=<returned path> python tools/variant_bench.py ..."""
-    return _compile_link(os.path.join(ROOT, "pressurepoissonsolver_amd", f"libte_hip_{name}.so"), defines)
+    with _BuildLock():
+        return _compile_link(os.path.join(ROOT, "pressurepoissonsolver_amd", f"libte_hip_{name}.so"), defines)
 
 
 def build_all(force=False):

@@ -99,6 +99,7 @@ SYMBOLS = {
     "te_vec_two_norm_sq": (_I, [_P, _PD]),
     "te_vec_inf_norm": (_I, [_P, _PD]),
     "te_vec_dot": (_I, [_P, _P, _PD]),
+    "te_vec_checksum": (_I, [_P, C.POINTER(C.c_uint64)]),
     "te_apply": (_I, [_P, _I, _P, _P]),
     "te_patch_apply": (_I, [_P, _I, _P, _P]),
     "te_residual": (_I, [_P, _I, _P, _P, _P]),
@@ -367,6 +368,12 @@ class Vec:
         check(lib().te_vec_dot(self.h, b.h, C.byref(out)))
         return out.value
 
+    def checksumLocal(self):
+        """this rank's part of te_vec_checksum (sum modulo 2^64 of the values' bit patterns); see combine_checksums"""
+        out = C.c_uint64()
+        check(lib().te_vec_checksum(self.h, C.byref(out)))
+        return int(out.value)
+
     def __del__(self):
         if getattr(self, "h", None) and _lib is not None and getattr(self.gmg, "h", None):
             _lib.te_vec_destroy(self.h)
@@ -428,7 +435,9 @@ class GMG:
         check(lib().te_gmg_use_push(self.h, int(bool(enable))))
 
     def push_failed(self):
-        return bool(lib().te_gmg_push_failed(self.h))
+        """0, or the first failure's code of the direct-store transport (1 a wait gave up, 2 a peer's flag two exchanges
+        ahead, 3 a peer behind when its buffer was overwritten, 4 epochs out of sequence)"""
+        return int(lib().te_gmg_push_failed(self.h))
 
     def set_patch_bcgs(self, tol=1e-12, max_it=1000):
         """BiCGStabSolver(op, tol, max_it), PatchSolvers/BiCGStabSolver.h:103-108"""

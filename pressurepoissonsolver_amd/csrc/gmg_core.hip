@@ -13,7 +13,7 @@ const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_j
 const char *optName[O_COUNT] = {"TE_2D_SIMPLE", "TE_2D_NO_MFMA", "TE_2D_NO_PF", "TE_2D_NO_MR_FUSE", "TE_2D_TPB", "TE_NO_FUSE2", "TE_NO_FUSE3",
                                 "TE_NO_FUSE3_CF", "TE_NO_CFP", "TE_NO_XF", "TE_NO_FCORR", "TE_NO_FCORR_CF", "TE_NO_GTAB", "TE_NO_OVERLAP",
                                 "TE_OVERLAP_MIN", "TE_NO_PS_FACES", "TE_PS_MODE", "TE_PS_SLOW", "TE_RBGS_NOSLAB", "TE_ZS_FORCE", "TE_NO_ZS8",
-                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS", "TE_PACK_FACES", "TE_OVERLAP_MODE", "TE_PUSH_TIMEOUT", "TE_NO_BICG_XF", "TE_PUSH_FAULT", "TE_2D_NO_FOLD", "TE_2D_NO_SYM"};
+                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS", "TE_PACK_FACES", "TE_OVERLAP_MODE", "TE_PUSH_TIMEOUT", "TE_NO_BICG_XF", "TE_PUSH_FAULT", "TE_2D_NO_FOLD", "TE_2D_NO_SYM", "TE_PUSH_NONFATAL"};
 
 void drainEvents(te_gmg *g)
 {
@@ -727,12 +727,7 @@ void te_gmg_destroy(te_gmg *g)
 	watchdogStop(g);
 	(void) hipStreamSynchronize(g->stream);
 	if (g->comm_stream) (void) hipStreamSynchronize(g->comm_stream);
-	for (void *m : g->push.opened) (void) hipIpcCloseMemHandle(m);
-	for (size_t l = 0; l + 1 < g->levels.size(); l++) // (the coarse vectors own their first buffer, the level its second)
-		if (g->levels[l]->cf_buf[0]) g->levels[l + 1]->f->d = g->levels[l]->cf_buf[0];
-	if (g->push.flags) (void) hipFree(g->push.flags);
-	if (g->push.err) (void) hipFree(g->push.err);
-	if (g->push.err_host) (void) hipHostFree(g->push.err_host);
+	pushTeardown(g, true); // (the coarse vectors get their own storage back before they are freed below)
 	for (auto &L : g->levels) {
 		for (te_vec *v : {L->u.get(), L->f.get(), L->r.get(), L->t.get()})
 			if (v && v->d) (void) hipFree(v->d);
@@ -1003,6 +998,7 @@ int te_gmg_set_option(te_gmg *g, const char *name, const char *value)
 					if (optStructural(o))
 						return te::fail(TE_ESTATE, std::string("te_gmg_set_option: ") + name + " is read when the solver is created; set it in the environment before te_gmg_create");
 					g->cfg.set(o, value);
+					if (o == O_PUSH_TIMEOUT) g->push.timeout_s = value ? std::max(0.1, atof(value)) : (g->wd.timeout_s > 0 ? g->wd.timeout_s : 300.0);
 					g->verified_opts.clear(); // (an option may change which exchanges a cycle issues)
 					return TE_OK;
 				}

@@ -632,10 +632,12 @@ int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms
 			double t_other = 0, t_push = 0, bad = 0;
 			auto   fail    = [&](int r2) {
                 g->push.fatal.store(true);
-                g->profiling = prof;
+                g->push.trial = false;
+                g->profiling  = prof;
                 return r2;
 			};
 			g->push.fatal.store(false);
+			g->push.trial = true; // (the waits of the trial give up after seconds, not after the production budget)
 			if ((rc = te_gmg_use_push(g, 0)) || (rc = timeIt(&t_other)) || (rc = vcycleWith(g, o, f, ref, nullptr))) return fail(rc);
 			if ((rc = te_vec_copy(f2, f)) || (rc = te_vec_scale(f2, -0.625))) return fail(rc);
 			if ((rc = te_gmg_use_push(g, 1))) return fail(rc);
@@ -645,7 +647,8 @@ int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms
 				double dmax = 0;
 				if (u->n > 0 && (rc = reduce<RED_MAXABS>(u, nullptr, &dmax))) return fail(rc);
 				HIPCHK(hipStreamSynchronize(g->stream));
-				if (dmax != 0.0 || te_gmg_push_failed(g)) bad = 1.0;
+				if (dmax != 0.0) bad = 9.0; // (a result that differs; otherwise the error word's code, pushkernels.hpp PushErr)
+				if (te_gmg_push_failed(g)) bad = (double) te_gmg_push_failed(g);
 			}
 			HIPCHK(hipMemcpyAsync(g->result.p, &bad, sizeof bad, hipMemcpyHostToDevice, g->stream));
 			if ((rc = finishReduce(g, 1, 1, true))) return fail(rc);
@@ -660,7 +663,10 @@ int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms
 				HIPCHK(hipStreamSynchronize(g->stream));
 				HIPCHK(hipMemset(g->push.err, 0, sizeof(int)));
 				*g->push.err_host = 0;
-				snprintf(buf, sizeof buf, "transport: direct-store REJECTED (result differs from the other transport's or a wait gave up) -> %s; ",
+				static const char *why[] = {"", "a wait gave up", "a peer's flag was two exchanges ahead", "a peer was behind when its buffer was overwritten",
+				                            "epochs out of sequence"};
+				const int code = (int) bad;
+				snprintf(buf, sizeof buf, "transport: direct-store REJECTED (%s) -> %s; ", code >= 1 && code <= 4 ? why[code] : "result differs from the other transport's",
 				         g->rccl.comm ? "rccl" : "callback");
 			} else {
 				const bool take = t_push < 0.98 * t_other;
@@ -670,6 +676,7 @@ int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms
 			}
 			tnote = buf;
 			g->push.fatal.store(true);
+			g->push.trial = false;
 		}
 		std::vector<Cand> cands = {{0, 0, "serial"}};
 		if (g->nranks > 1 && g->overlap) {

@@ -23,9 +23,11 @@ template <int N> bool packFaces(te_gmg *g, LevelHost &L, const double *u, const 
 		pp.dst    = L.push_face_dst[L.push_par].p;
 		pp.flags  = L.push_face_flags.p;
 		pp.nflags = (int) L.push_face_flags.n;
-		pp.epoch  = g->cfg.has(O_PUSH_FAULT) ? L.push_ep - 1 : L.push_ep;
+		pp.epoch  = L.push_ep;
+		pp.raise  = pushRaiseValue(g, L.push_ep);
 		pp.done   = L.push_done.p;
 		pp.err    = g->push.err;
+		pp.err_host = g->push.err_host;
 	}
 	if (L.pack_f6) { // the iterate exists only as its face layers
 		ProlongSrc none{nullptr, nullptr, nullptr};

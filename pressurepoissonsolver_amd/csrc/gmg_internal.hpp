@@ -80,7 +80,7 @@ extern const char *kclassName[KC_COUNT]; // (gmg_core.hip)
 enum Opt : int {
 	O_2D_SIMPLE, O_2D_NO_MFMA, O_2D_NO_PF, O_2D_NO_MR_FUSE, O_2D_TPB, O_NO_FUSE2, O_NO_FUSE3, O_NO_FUSE3_CF, O_NO_CFP, O_NO_XF,
 	O_NO_FCORR, O_NO_FCORR_CF, O_NO_GTAB, O_NO_OVERLAP, O_OVERLAP_MIN, O_NO_PS_FACES, O_PS_MODE, O_PS_SLOW, O_RBGS_NOSLAB,
-	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_PUSH_TIMEOUT, O_NO_BICG_XF, O_PUSH_FAULT, O_2D_NO_FOLD, O_2D_NO_SYM, O_COUNT
+	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_PUSH_TIMEOUT, O_NO_BICG_XF, O_PUSH_FAULT, O_2D_NO_FOLD, O_2D_NO_SYM, O_PUSH_NONFATAL, O_COUNT
 };
 extern const char *optName[O_COUNT]; // (gmg_core.hip)
 // options that shape the level tables te_gmg_create builds: fixed for the solver's lifetime
@@ -107,8 +107,10 @@ template <typename T> struct DevBuf {
 	{
 		if (p) (void) hipFree(p);
 	}
-	int alloc(size_t count)
+	int alloc(size_t count) // (an earlier allocation is released first)
 	{
+		if (p) (void) hipFree(p);
+		p = nullptr;
 		n = count;
 		if (count == 0) return TE_OK;
 		HIPCHK(hipMalloc(&p, sizeof(T) * count));
@@ -275,7 +277,7 @@ struct LevelHost {
 	// pack + push in one launch (PackPush): where face i of the send order goes in its receiver's ghost buffer, per parity, and
 	// the flags to raise
 	DevBuf<double *>             push_face_dst[2];
-	DevBuf<unsigned long long *> push_face_flags;
+	DevBuf<PushFlag>             push_face_flags;
 	// an exchange in progress (between pushBegin and pushFinish): its parity, epoch, and what to wait for
 	int                push_par = 0;
 	unsigned long long push_ep  = 0;
@@ -424,7 +426,12 @@ struct te_gmg {
 		std::vector<unsigned long long *> peer_flags; // [nranks] (mine at [rank])
 		int                              *err = nullptr, *err_host = nullptr;
 		std::vector<void *>               opened; // hipIpcOpenMemHandle results, closed in te_gmg_destroy
-		double                            timeout_s = 20.0;
+		unsigned long long               *sent = nullptr; // [nranks][nslot]: the last epoch this rank raised at each peer and slot (PushFlag::sent)
+		// a wait's budget: TE_PUSH_TIMEOUT, by default the watchdog's TE_EXCHANGE_TIMEOUT (a legitimate skew between ranks -- I/O,
+		// first-use allocation -- must not end a job sooner on this transport than on the other); inside te_gmg_autotune's trial of
+		// the transport (`trial`) at most trial_timeout_s: a transport that does not work here is found out within seconds
+		double                            timeout_s = 300.0, trial_timeout_s = 5.0;
+		bool                              trial = false;
 		int                               nslot = 0;
 		std::atomic<bool>                 fatal{true}; // a wait that gave up ends the process (watchdog); false inside te_gmg_autotune's trial
 	} push;
@@ -508,6 +515,15 @@ void pushBegin(te_gmg *g, LevelHost &L, int kind);
 int  pushFinish(te_gmg *g, LevelHost &L, int kind, hipStream_t stream);
 int  pushExchange(te_gmg *g, LevelHost &L, int kind, const double *send, hipStream_t stream = nullptr);
 int  faceExchange(te_gmg *g, LevelHost &L, const double *send, hipStream_t stream = nullptr);
+void pushTeardown(te_gmg *g, bool final = false); // frees what te_gmg_use_push's set-up allocated and mapped (a failed set-up; final: te_gmg_destroy)
+// what a push stores in the peers' flags for epoch `ep`: `ep`, unless TE_PUSH_FAULT (diagnostic) asks for a transport whose data
+// never "arrives" (any value but "overrun": the PREVIOUS epoch, so that the give-up / rejection path can be tested) or for a peer
+// that claims to be two exchanges ahead ("overrun": ep + 2, the receiver's check PUSH_ERR_OVERRUN)
+inline unsigned long long pushRaiseValue(const te_gmg *g, unsigned long long ep)
+{
+	if (!g->cfg.has(O_PUSH_FAULT) || !strcmp(g->cfg.str(O_PUSH_FAULT), "nonce")) return ep;
+	return !strcmp(g->cfg.str(O_PUSH_FAULT), "overrun") ? ep + 2 : ep - 1;
+}
 
 struct WatchdogArm { // around the issue of one exchange: takes a ring slot (issue time now), records its event behind the exchange
 	te_gmg     *g;

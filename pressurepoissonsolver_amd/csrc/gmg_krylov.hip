@@ -35,6 +35,28 @@ int te_vec_two_norm_sq(const te_vec *v, double *out) { return guarded([&]() -> i
 int te_vec_inf_norm(const te_vec *v, double *out) { return guarded([&]() -> int { return reduce<RED_MAXABS>(v, nullptr, out); }); }
 int te_vec_dot(const te_vec *v, const te_vec *b, double *out) { return guarded([&]() -> int { return reduce<RED_DOT>(v, b, out); }); }
 
+// This rank's part of the vector's checksum (te_hip.h): the caller adds the ranks' parts modulo 2^64.
+int te_vec_checksum(const te_vec *v, uint64_t *out)
+{
+	return guarded([&]() -> int {
+		if (!v || !out) return te::fail(TE_EINVAL, "te_vec_checksum: null argument");
+		te_gmg *g = v->g;
+		*out      = 0;
+		if (v->n == 0 || (g->rank != 0 && g->levels[v->level]->replicated)) return TE_OK; // (a level on every rank counts once: rank 0's)
+		static_assert(sizeof(unsigned long long) == sizeof(double), "the result word doubles as the checksum's accumulator");
+		HIPCHK(hipMemsetAsync(g->result.p, 0, sizeof(double), g->stream));
+		{
+			Timed t(g, KC_REDUCE, v->n);
+			hipLaunchKernelGGL(k_checksum, dim3(gridFor(v->n / 2, 256, g->red_blocks)), dim3(256), 0, g->stream, v->n / 2,
+			                   reinterpret_cast<const double2 *>(v->d), reinterpret_cast<unsigned long long *>(g->result.p));
+		}
+		HIPCHK(hipMemcpyAsync(g->result_host, g->result.p, sizeof(double), hipMemcpyDeviceToHost, g->stream));
+		HIPCHK(hipStreamSynchronize(g->stream));
+		memcpy(out, g->result_host, sizeof *out);
+		return TE_OK;
+	});
+}
+
 // BiCGStab.h:45-106, statement for statement, on device vectors. Several ranks: every scalar is summed over the
 // ranks (Vector.h:294,319) -- ncclAllReduce of the one or two doubles on the solver stream with the native RCCL
 // back-end, otherwise the te_gmg_set_allreduce callback -- so all ranks take the same branches.

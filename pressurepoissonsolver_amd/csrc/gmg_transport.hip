@@ -41,11 +41,13 @@ void watchdogLoop(te_gmg *g)
 	auto &w = g->wd;
 	while (!w.stop.load()) {
 		std::this_thread::sleep_for(std::chrono::milliseconds(50));
-		if (g->push.err_host && *g->push.err_host && g->push.fatal.load()) {
+		// (TE_PUSH_NONFATAL: the caller polls te_gmg_push_failed itself -- bench.py's trial of the transport behind its headline)
+		if (g->push.err_host && *g->push.err_host && g->push.fatal.load() && !g->cfg.has(O_PUSH_NONFATAL)) {
 			fprintf(stderr,
-			        "te_hip watchdog: rank %d: a direct-store exchange gave up waiting for a peer's data -- a peer is missing or issued a "
-			        "different exchange sequence; ending the process\n",
-			        g->rank);
+			        "te_hip watchdog: rank %d: a direct-store exchange failed (code %d: 1 gave up waiting for a peer's data, 2 a peer's flag two "
+			        "exchanges ahead, 3 a peer behind when its buffer was overwritten, 4 epochs out of sequence) -- a peer is missing or issued "
+			        "a different exchange sequence; ending the process\n",
+			        g->rank, *g->push.err_host);
 			fflush(stderr);
 			_exit(86);
 		}
@@ -195,18 +197,29 @@ void pushBegin(te_gmg *g, LevelHost &L, int kind)
 	L.push_ep        = ++ep;
 	const int slot   = 2 * L.index + (kind - 1);
 	L.push_wait.n    = 0;
-	for (size_t i = 0; i < pl.peers.size(); i++)
-		if (pl.recv_cnt[i] > 0) L.push_wait.flag[L.push_wait.n++] = g->push.flags + (size_t) pl.peers[i] * g->push.nslot + slot;
+	// every peer of the plan, whatever the counts: the exchange is symmetric (pushkernels.hpp, the no-credit argument)
+	for (size_t i = 0; i < pl.peers.size(); i++) L.push_wait.flag[L.push_wait.n++] = g->push.flags + (size_t) pl.peers[i] * g->push.nslot + slot;
 }
 
 int pushFinish(te_gmg *g, LevelHost &L, int kind, hipStream_t stream)
 {
-	const long long budget = (long long) (g->push.timeout_s * 1e8); // wall_clock64: 100 MHz
+	const double    secs   = g->push.trial ? std::min(g->push.timeout_s, g->push.trial_timeout_s) : g->push.timeout_s;
+	const long long budget = (long long) (secs * 1e8); // wall_clock64: 100 MHz
 	if (L.push_wait.n > 0)
 		hipLaunchKernelGGL(k_push_wait, dim3(1), dim3(64), 0, stream, L.push_wait, L.push_ep, budget, g->push.err, g->push.err_host);
 	if (kind == 1) L.ghost_par = L.push_par; // what the kernels behind this exchange read
 	HIPCHK(hipGetLastError());
 	return TE_OK;
+}
+
+// the flag this rank raises at peer r for `slot`, with the two words its checks need (pushkernels.hpp PushFlag)
+static PushFlag pushFlagFor(te_gmg *g, int r, int slot)
+{
+	PushFlag f;
+	f.flag = g->push.peer_flags[r] + (size_t) g->rank * g->push.nslot + slot;
+	f.back = g->push.flags + (size_t) r * g->push.nslot + slot;
+	f.sent = g->push.sent + (size_t) r * g->push.nslot + slot;
+	return f;
 }
 
 int pushExchange(te_gmg *g, LevelHost &L, int kind, const double *send, hipStream_t stream)
@@ -223,24 +236,17 @@ int pushExchange(te_gmg *g, LevelHost &L, int kind, const double *send, hipStrea
 	PushPlan  pp;
 	int64_t   most = 0;
 	pp.n           = 0;
-	for (size_t i = 0; i < pl.peers.size(); i++) {
-		const int r = pl.peers[i];
-		if (pl.send_cnt[i] > 0) {
-			PushPeer &q = pp.p[pp.n++];
-			q.dst       = (kind == 1 ? L.push_peer_ghost[par][i] : L.push_peer_cf[par][i] + pl.send_off[i]);
-			q.src_off   = pl.send_off[i];
-			q.cnt       = pl.send_cnt[i];
-			q.flag      = g->push.peer_flags[r] + (size_t) g->rank * g->push.nslot + slot;
-			most        = std::max(most, q.cnt);
-		}
+	for (size_t i = 0; i < pl.peers.size(); i++) { // (a peer that gets no data still gets its flag)
+		PushPeer &q = pp.p[pp.n++];
+		q.dst       = (kind == 1 ? L.push_peer_ghost[par][i] : L.push_peer_cf[par][i] + pl.send_off[i]);
+		q.src_off   = pl.send_off[i];
+		q.cnt       = pl.send_cnt[i];
+		q.fl        = pushFlagFor(g, pl.peers[i], slot);
+		most        = std::max(most, q.cnt);
 	}
-	if (pp.n > 0) {
-		const int bx = (int) std::min<int64_t>(64, std::max<int64_t>(1, most / 2 / 256 / 4));
-		// (TE_PUSH_FAULT, diagnostic: the flags are raised to the PREVIOUS epoch -- a transport whose data never "arrives", so that
-		// the give-up / rejection path can be tested)
-		hipLaunchKernelGGL(k_push_ranges, dim3(bx, pp.n), dim3(256), 0, stream, send, pp, g->cfg.has(O_PUSH_FAULT) ? L.push_ep - 1 : L.push_ep,
-		                   L.push_done.p + (kind - 1), (const int *) g->push.err);
-	}
+	const int bx = (int) std::min<int64_t>(64, std::max<int64_t>(1, most / 2 / 256 / 4));
+	hipLaunchKernelGGL(k_push_ranges, dim3(bx, pp.n), dim3(256), 0, stream, send, pp, L.push_ep, pushRaiseValue(g, L.push_ep), L.push_done.p + (kind - 1),
+	                   g->push.err, g->push.err_host);
 	return pushFinish(g, L, kind, stream);
 }
 
@@ -330,10 +336,72 @@ int te_gmg_use_rccl(te_gmg *g, const char *libpath, const char *id128, int rank,
 	});
 }
 
+// one 64-bit word per process, drawn once: tells ranks that live in THIS process (the tests' virtual ranks: their device pointers are
+// valid here as they are) from ranks of other processes that happen to publish the same pid (pids repeat across containers, PID
+// namespaces and nodes) -- those are reached through hipIpcOpenMemHandle or not at all
+static uint64_t processNonce()
+{
+	static const uint64_t nonce = [] {
+		uint64_t v = 0;
+		if (FILE *f = fopen("/dev/urandom", "rb")) {
+			if (fread(&v, sizeof v, 1, f) != 1) v = 0;
+			fclose(f);
+		}
+		v ^= (uint64_t) std::chrono::steady_clock::now().time_since_epoch().count() * 0x9E3779B97F4A7C15ull;
+		v ^= (uint64_t) getpid() << 32;
+		return v ? v : 1;
+	}();
+	return nonce;
+}
+static uint32_t hostHash() // (same node? a mapping across nodes cannot work: said by name instead of by a failing hipIpcOpenMemHandle)
+{
+	char buf[256] = {0};
+	if (FILE *f = fopen("/proc/sys/kernel/random/boot_id", "r")) {
+		if (!fgets(buf, sizeof buf, f)) buf[0] = 0;
+		fclose(f);
+	}
+	if (!buf[0]) (void) gethostname(buf, sizeof buf - 1);
+	uint32_t h = 2166136261u;
+	for (const char *c = buf; *c; c++) h = (h ^ (uint8_t) *c) * 16777619u;
+	return h ? h : 1;
+}
+
+} // extern "C" (resumed below)
+void tei::pushTeardown(te_gmg *g, bool final)
+{
+	auto &P = g->push;
+	for (void *m : P.opened) (void) hipIpcCloseMemHandle(m);
+	P.opened.clear();
+	for (size_t l = 0; l + 1 < g->levels.size(); l++) { // (the coarse vectors own their first buffer, the level its second)
+		LevelHost &L = *g->levels[l];
+		if (L.cf_buf[0]) g->levels[l + 1]->f->d = L.cf_buf[0];
+		L.cf_buf[0] = L.cf_buf[1] = nullptr;
+	}
+	for (auto &Lp : g->levels) {
+		Lp->push_faces = Lp->push_blocks = false;
+		Lp->ghost_par                    = 0;
+	}
+	if (P.flags) (void) hipFree(P.flags);
+	if (P.sent) (void) hipFree(P.sent);
+	// (the error words outlive a failed set-up: the watchdog thread reads err_host without a lock; they go with the solver)
+	if (final) {
+		if (P.err) (void) hipFree(P.err);
+		if (P.err_host) (void) hipHostFree(P.err_host);
+		P.err = P.err_host = nullptr;
+	}
+	P.flags = P.sent = nullptr;
+	P.peer_flags.clear();
+	P.ready = P.on = false;
+}
+extern "C" {
+
 // The direct-store transport (pushkernels.hpp). Collective over the ranks of the hierarchy; needs a working reduction over the
 // ranks (te_gmg_use_rccl or te_gmg_set_allreduce) to publish, once, every rank's IPC handles and receive offsets: a directory of
 // 32-bit words, one slice per rank, summed over the ranks eight words at a time (each word has one contributor).
-// Ranks that live in this very process (the tests' virtual ranks) are reached through their raw pointers.
+// Ranks that live in this very process (the tests' virtual ranks: same pid AND same process nonce) are reached through their raw
+// pointers. Whatever fails on one rank -- an allocation, hipIpcGetMemHandle, a mapping -- that rank still takes part in every
+// reduction of the set-up and the failure travels with them: all ranks return an error together, nobody waits for a peer that
+// has left, and what was allocated or mapped so far is released (pushTeardown), so that a later attempt starts clean.
 static int pushSetup(te_gmg *g)
 {
 	auto &P = g->push;
@@ -344,33 +412,45 @@ static int pushSetup(te_gmg *g)
 	if (R > PUSH_MAX_PEERS) return te::fail(TE_EUNSUPPORTED, "te_gmg_use_push: too many ranks");
 	const bool self = g->cfg.has(O_RCCL_LOOPBACK); // diagnostic: every peer is this rank itself (tools/mr8_budget.py)
 	P.nslot = 2 * NL;
-	const size_t fbytes = sizeof(unsigned long long) * (size_t) R * P.nslot;
-	HIPCHK(hipExtMallocWithFlags((void **) &P.flags, fbytes, hipDeviceMallocFinegrained));
-	HIPCHK(hipMemset(P.flags, 0, fbytes));
-	HIPCHK(hipMalloc((void **) &P.err, 64));
-	HIPCHK(hipMemset(P.err, 0, 64));
-	HIPCHK(hipHostMalloc((void **) &P.err_host, 64, hipHostMallocMapped));
-	*P.err_host = 0;
-	P.timeout_s = std::max(0.1, g->cfg.real(O_PUSH_TIMEOUT, P.timeout_s));
-	int rc;
-	for (int l = 0; l < NL; l++) {
-		LevelHost &L = *g->levels[l];
-		if ((rc = L.push_done.alloc(2))) return rc;
-		HIPCHK(hipMemset(L.push_done.p, 0, 2 * sizeof(unsigned)));
-		if (L.nremote > 0) {
-			if ((rc = L.ghost_alt.alloc(L.ghost.n))) return rc;
-			HIPCHK(hipMemset(L.ghost_alt.p, 0, sizeof(double) * L.ghost.n));
+	P.timeout_s = std::max(0.1, g->cfg.real(O_PUSH_TIMEOUT, g->wd.timeout_s > 0 ? g->wd.timeout_s : 300.0));
+	// ---- this rank's allocations (a failure is carried into the directory, not returned: the peers are already inside the reductions)
+	auto allocate = [&]() -> int {
+		const size_t fbytes = sizeof(unsigned long long) * (size_t) R * P.nslot;
+		HIPCHK(hipExtMallocWithFlags((void **) &P.flags, fbytes, hipDeviceMallocFinegrained));
+		HIPCHK(hipMemset(P.flags, 0, fbytes));
+		HIPCHK(hipMalloc((void **) &P.sent, fbytes));
+		HIPCHK(hipMemset(P.sent, 0, fbytes));
+		if (!P.err) HIPCHK(hipMalloc((void **) &P.err, 64));
+		HIPCHK(hipMemset(P.err, 0, 64));
+		if (!P.err_host) HIPCHK(hipHostMalloc((void **) &P.err_host, 64, hipHostMallocMapped));
+		*P.err_host = 0;
+		int rc;
+		for (int l = 0; l < NL; l++) {
+			LevelHost &L = *g->levels[l];
+			if (!L.push_done.p) {
+				if ((rc = L.push_done.alloc(2))) return rc;
+			}
+			HIPCHK(hipMemset(L.push_done.p, 0, 2 * sizeof(unsigned)));
+			L.face_epoch = L.blk_epoch = 0; // (a set-up after a failed one starts the epochs, like the flags, from zero)
+			if (L.nremote > 0) {
+				if (!L.ghost_alt.p && (rc = L.ghost_alt.alloc(L.ghost.n))) return rc;
+				HIPCHK(hipMemset(L.ghost_alt.p, 0, sizeof(double) * L.ghost.n));
+			}
+			if (L.repl_up && L.repl_direct && l + 1 < NL) {
+				te_vec *cf = g->levels[l + 1]->f.get();
+				if (!L.cf_alt.p && (rc = L.cf_alt.alloc(std::max<size_t>(cf->n, 2)))) return rc;
+				HIPCHK(hipMemset(L.cf_alt.p, 0, sizeof(double) * std::max<size_t>(cf->n, 2)));
+				L.cf_buf[0] = cf->d, L.cf_buf[1] = L.cf_alt.p;
+			}
 		}
-		if (L.repl_up && L.repl_direct && l + 1 < NL) {
-			te_vec *cf = g->levels[l + 1]->f.get();
-			if ((rc = L.cf_alt.alloc(std::max<size_t>(cf->n, 2)))) return rc;
-			HIPCHK(hipMemset(L.cf_alt.p, 0, sizeof(double) * std::max<size_t>(cf->n, 2)));
-			L.cf_buf[0] = cf->d, L.cf_buf[1] = L.cf_alt.p;
-		}
-	}
-	HIPCHK(hipDeviceSynchronize());
-	// ---- the directory: per rank [pid, flags (handle 16 + pointer 2), per level: 4 x (handle 16 + pointer 2), R x recv offset 2]
-	const int      HW = 18, LW = 4 * HW + 2 * R, W = 1 + HW + NL * LW;
+		HIPCHK(hipDeviceSynchronize());
+		return TE_OK;
+	};
+	int         local_rc  = allocate();
+	std::string local_msg = local_rc ? std::string(te_last_error()) : std::string();
+	// ---- the directory: per rank [ok, pid, nonce (2), host, flags (handle 16 + pointer 2), per level: 4 x (handle 16 + pointer 2), R x recv offset 2]
+	const int      D_OK = 0, D_PID = 1, D_NONCE = 2, D_HOST = 4, D_FLAGS = 5;
+	const int      HW = 18, LW = 4 * HW + 2 * R, D_LEVELS = D_FLAGS + HW, W = D_LEVELS + NL * LW;
 	std::vector<double> dir((size_t) R * W, 0.0);
 	auto put = [&](double *dst, const void *devptr) { // handle + raw pointer of one allocation (null: zeros)
 		if (!devptr) return TE_OK;
@@ -385,24 +465,42 @@ static int pushSetup(te_gmg *g)
 		return TE_OK;
 	};
 	double *mine = &dir[(size_t) g->rank * W];
-	mine[0]      = (double) (uint32_t) getpid();
-	if ((rc = put(mine + 1, P.flags))) return rc;
-	for (int l = 0; l < NL; l++) {
-		LevelHost &L = *g->levels[l];
-		double    *q = mine + 1 + HW + (size_t) l * LW;
-		if (L.nremote > 0 && ((rc = put(q, L.ghost.p)) || (rc = put(q + HW, L.ghost_alt.p)))) return rc;
-		if (L.cf_buf[0] && ((rc = put(q + 2 * HW, L.cf_buf[0])) || (rc = put(q + 3 * HW, L.cf_buf[1])))) return rc;
-		for (int r = 0; r < R; r++) q[4 * HW + 2 * r] = q[4 * HW + 2 * r + 1] = 0.0;
-		for (size_t i = 0; i < L.fx.peers.size(); i++) { // where rank fx.peers[i]'s layers land in my ghost buffers (+1: 0 = nothing)
-			const uint64_t o = (uint64_t) L.fx.recv_off[i] + 1;
-			q[4 * HW + 2 * L.fx.peers[i]] = (double) (uint32_t) (o & 0xFFFFFFFFu), q[4 * HW + 2 * L.fx.peers[i] + 1] = (double) (uint32_t) (o >> 32);
+	// (TE_PUSH_FAULT=nonce, diagnostic: this rank publishes another process's nonce under its own pid -- what two containers with
+	// equal pids look like; its in-process peers must then go through hipIpcOpenMemHandle, and fail or work cleanly)
+	const uint64_t my_nonce = processNonce() ^ ((g->cfg.has(O_PUSH_FAULT) && !strcmp(g->cfg.str(O_PUSH_FAULT), "nonce")) ? (uint64_t) (g->rank + 1) << 8 : 0);
+	auto publish = [&]() -> int {
+		int rc;
+		mine[D_PID]       = (double) (uint32_t) getpid();
+		mine[D_NONCE]     = (double) (uint32_t) (my_nonce & 0xFFFFFFFFu);
+		mine[D_NONCE + 1] = (double) (uint32_t) (my_nonce >> 32);
+		mine[D_HOST]      = (double) hostHash();
+		if ((rc = put(mine + D_FLAGS, P.flags))) return rc;
+		for (int l = 0; l < NL; l++) {
+			LevelHost &L = *g->levels[l];
+			double    *q = mine + D_LEVELS + (size_t) l * LW;
+			if (L.nremote > 0 && ((rc = put(q, L.ghost.p)) || (rc = put(q + HW, L.ghost_alt.p)))) return rc;
+			if (L.cf_buf[0] && ((rc = put(q + 2 * HW, L.cf_buf[0])) || (rc = put(q + 3 * HW, L.cf_buf[1])))) return rc;
+			for (size_t i = 0; i < L.fx.peers.size(); i++) { // where rank fx.peers[i]'s layers land in my ghost buffers (+1: 0 = nothing)
+				const uint64_t o = (uint64_t) L.fx.recv_off[i] + 1;
+				q[4 * HW + 2 * L.fx.peers[i]] = (double) (uint32_t) (o & 0xFFFFFFFFu), q[4 * HW + 2 * L.fx.peers[i] + 1] = (double) (uint32_t) (o >> 32);
+			}
 		}
-	}
-	for (size_t i = 0; i < dir.size(); i += 8) {
+		return TE_OK;
+	};
+	if (!local_rc && (local_rc = publish())) local_msg = te_last_error();
+	mine[D_OK] = local_rc ? 0.0 : 1.0;
+	int rc;
+	for (size_t i = 0; i < dir.size(); i += 8) { // (a failed reduction is the transport under this one failing: nothing left to agree through)
 		const int n = (int) std::min<size_t>(8, dir.size() - i);
 		HIPCHK(hipMemcpyAsync(g->result.p, &dir[i], n * sizeof(double), hipMemcpyHostToDevice, g->stream));
 		if ((rc = finishReduce(g, n, 0, true))) return rc;
 		for (int k = 0; k < n; k++) dir[i + k] = g->result_host[k];
+	}
+	for (int r = 0; r < R; r++) {
+		if (dir[(size_t) r * W + D_OK] == 1.0) continue;
+		pushTeardown(g); // every rank sees the same directory: all leave here together
+		if (r == g->rank) return te::fail(local_rc, "te_gmg_use_push: " + local_msg);
+		return te::fail(TE_ESTATE, "te_gmg_use_push: rank " + std::to_string(r) + " could not set up its buffers");
 	}
 	// ---- map the peers
 	const uint32_t mypid = (uint32_t) getpid();
@@ -426,10 +524,13 @@ static int pushSetup(te_gmg *g)
 			*out = own;
 			return TE_OK;
 		}
-		if ((uint32_t) slice[0] == mypid) { // a virtual rank in this process: its pointer as it is
+		const uint64_t nonce = (uint64_t) (uint32_t) slice[D_NONCE] | ((uint64_t) (uint32_t) slice[D_NONCE + 1] << 32);
+		if ((uint32_t) slice[D_PID] == mypid && nonce == processNonce()) { // a virtual rank in this very process: its pointer as it is
 			*out = (void *) (uintptr_t) ((uint64_t) (uint32_t) src[16] | ((uint64_t) (uint32_t) src[17] << 32));
 			return TE_OK;
 		}
+		if ((uint32_t) slice[D_HOST] != hostHash())
+			return te::fail(TE_EUNSUPPORTED, "te_gmg_use_push: rank " + std::to_string(r) + " runs on another node: no direct stores across nodes");
 		return open(src, out);
 	};
 	// (a rank whose mapping fails still takes part in the closing reduction: all ranks succeed, or all fail)
@@ -437,7 +538,7 @@ static int pushSetup(te_gmg *g)
 	P.peer_flags.assign(R, nullptr);
 	for (int r = 0; r < R; r++) {
 		void *m = nullptr;
-		if ((rc = peerPtr(r, &dir[(size_t) r * W + 1], P.flags, &m))) return rc;
+		if ((rc = peerPtr(r, &dir[(size_t) r * W + D_FLAGS], P.flags, &m))) return rc;
 		// loop-back: my own table stands in, shifted so that "my row of the peer's table" is the peer's row of mine
 		P.peer_flags[r] = self ? P.flags + ((ptrdiff_t) r - g->rank) * P.nslot : (unsigned long long *) m;
 		if (!P.peer_flags[r]) return te::fail(TE_ESTATE, "te_gmg_use_push: rank " + std::to_string(r) + " published no flag table");
@@ -449,7 +550,7 @@ static int pushSetup(te_gmg *g)
 			bool ok = true;
 			for (size_t i = 0; i < L.fx.peers.size() && ok; i++) {
 				const int     r = L.fx.peers[i];
-				const double *q = &dir[(size_t) r * W + 1 + HW + (size_t) l * LW];
+				const double *q = &dir[(size_t) r * W + D_LEVELS + (size_t) l * LW];
 				const uint64_t o1 = (uint64_t) (uint32_t) q[4 * HW + 2 * g->rank] | ((uint64_t) (uint32_t) q[4 * HW + 2 * g->rank + 1] << 32);
 				const int64_t off = self ? L.fx.recv_off[i] : (int64_t) o1 - 1;
 				if (off < 0) { // the peer expects nothing from me here although I send: the plans disagree
@@ -466,7 +567,7 @@ static int pushSetup(te_gmg *g)
 			}
 			if (!ok) return te::fail(TE_ESTATE, "te_gmg_use_push: a neighbour rank published no receive buffer for level " + std::to_string(l));
 			// where every face of the send order goes (pack + push in one launch), and the flags that launch raises
-			std::vector<unsigned long long *> fl;
+			std::vector<PushFlag> fl;
 			for (int b = 0; b < 2; b++) {
 				std::vector<double *> dst((size_t) L.nremote, nullptr);
 				for (size_t i = 0; i < L.fx.peers.size(); i++)
@@ -475,8 +576,7 @@ static int pushSetup(te_gmg *g)
 				int rc2 = L.push_face_dst[b].upload(dst);
 				if (rc2) return rc2;
 			}
-			for (size_t i = 0; i < L.fx.peers.size(); i++)
-				if (L.fx.send_cnt[i] > 0) fl.push_back(P.peer_flags[L.fx.peers[i]] + (size_t) g->rank * P.nslot + 2 * l);
+			for (size_t i = 0; i < L.fx.peers.size(); i++) fl.push_back(pushFlagFor(g, L.fx.peers[i], 2 * l)); // (every peer of the plan: symmetric)
 			int rc3 = L.push_face_flags.upload(fl);
 			if (rc3) return rc3;
 			L.push_faces = true;
@@ -485,7 +585,7 @@ static int pushSetup(te_gmg *g)
 			for (int b = 0; b < 2; b++) L.push_peer_cf[b].assign(L.tx_direct.peers.size(), nullptr);
 			for (size_t i = 0; i < L.tx_direct.peers.size(); i++) {
 				const int     r = L.tx_direct.peers[i];
-				const double *q = &dir[(size_t) r * W + 1 + HW + (size_t) l * LW];
+				const double *q = &dir[(size_t) r * W + D_LEVELS + (size_t) l * LW];
 				for (int b = 0; b < 2; b++) {
 					void *m = nullptr;
 					if ((rc = peerPtr(r, q + (2 + b) * HW, L.cf_buf[b ^ 1], &m))) return rc;
@@ -504,8 +604,11 @@ static int pushSetup(te_gmg *g)
 	double failed = map_rc ? 1.0 : 0.0;
 	HIPCHK(hipMemcpyAsync(g->result.p, &failed, sizeof failed, hipMemcpyHostToDevice, g->stream));
 	if ((rc = finishReduce(g, 1, 1, true))) return rc;
-	if (map_rc) return te::fail(map_rc, map_msg);
-	if (g->result_host[0] != 0.0) return te::fail(TE_ESTATE, "te_gmg_use_push: another rank could not map its peers' buffers");
+	if (map_rc || g->result_host[0] != 0.0) {
+		pushTeardown(g);
+		if (map_rc) return te::fail(map_rc, map_msg);
+		return te::fail(TE_ESTATE, "te_gmg_use_push: another rank could not map its peers' buffers");
+	}
 	P.ready = true;
 	return TE_OK;
 }
@@ -546,11 +649,13 @@ int te_gmg_use_push(te_gmg *g, int enable)
 	});
 }
 
-// 0: no direct-store exchange has given up waiting; 1: one has (its data never arrived within TE_PUSH_TIMEOUT seconds: the results
-// since then are garbage, and every later exchange of this solver returns at once). Reads the pinned host copy: no device call.
+// 0: no direct-store exchange has failed; otherwise the first failure's code (pushkernels.hpp PushErr): 1 a wait gave up (its
+// data never arrived within TE_PUSH_TIMEOUT seconds), 2 a peer's flag was two exchanges ahead, 3 a peer was behind when its buffer
+// was overwritten, 4 this rank's own epochs were out of sequence. The results since then are garbage, and every later exchange
+// of this solver returns at once. Reads the pinned host copy: no device call.
 int te_gmg_push_failed(te_gmg *g)
 {
-	return guarded([&]() -> int { return (g && g->push.err_host && *g->push.err_host) ? 1 : 0; });
+	return guarded([&]() -> int { return (g && g->push.err_host) ? *g->push.err_host : 0; });
 }
 
 // moves n doubles from a scratch send buffer to a scratch receive buffer of level 0 through the same

@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "pushkernels.hpp" // PushFlag / pushRaise: the pack kernels raise the peers' flags themselves (PackPush)
 
 namespace te
 {
@@ -281,12 +282,13 @@ __global__ void k_cf_ghost3d(const int32_t *__restrict__ desc, const int32_t *__
 // slot (dst[i]: where face i of the send order goes) and raise the peers' flags when its last workgroup is done -- pack and
 // push in one launch. dst == null: the ordinary pack into the send buffer.
 struct PackPush {
-	double *const             *dst   = nullptr; // [faces]
-	unsigned long long *const *flags = nullptr; // [nflags] the peers' flags to raise
-	int                        nflags = 0;
-	unsigned long long         epoch  = 0;
-	unsigned                  *done   = nullptr; // arrival counter of the workgroups (zero between launches)
-	const int                 *err    = nullptr; // the solver's error word: nothing is stored once a wait has given up
+	double *const  *dst    = nullptr; // [faces]
+	const PushFlag *flags  = nullptr; // [nflags] the peers' flags to raise (pushkernels.hpp: with the checks that go with raising one)
+	int             nflags = 0;
+	unsigned long long epoch = 0, raise = 0; // this exchange's epoch; the value stored in the flags (the same, but for TE_PUSH_FAULT)
+	unsigned       *done     = nullptr; // arrival counter of the workgroups (zero between launches)
+	int            *err      = nullptr; // the solver's error word: nothing is stored once a wait has given up
+	int            *err_host = nullptr;
 };
 __device__ __forceinline__ void packPushTail(const PackPush &pp)
 {
@@ -297,7 +299,7 @@ __device__ __forceinline__ void packPushTail(const PackPush &pp)
 		if (__hip_atomic_fetch_add(pp.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
 			__hip_atomic_store(pp.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			__threadfence_system();
-			for (int k = 0; k < pp.nflags; k++) __hip_atomic_store(pp.flags[k], pp.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			for (int k = 0; k < pp.nflags; k++) pushRaise(pp.flags[k], pp.epoch, pp.raise, pp.err, pp.err_host);
 		}
 	}
 }
@@ -653,6 +655,22 @@ __global__ __launch_bounds__(256) void k_reduce_final(int nparts, const double *
 	for (int i = threadIdx.x; i < nparts; i += blockDim.x) acc = redCombine<OP>(acc, partial[i]);
 	acc = blockReduce<OP>(acc);
 	if (threadIdx.x == 0) result[0] = acc;
+}
+
+// te_vec_checksum: the wrap-around sum of the 64-bit patterns of the values. Integer addition commutes, so the result does
+// not depend on the order of the terms -- nor on how a vector is cut over ranks: two vectors with equal checksums on every
+// partition hold, with overwhelming probability, the same multiset of bits. One atomic add per wave into *out (zeroed before).
+static __global__ __launch_bounds__(256) void k_checksum(size_t n2, const double2 *__restrict__ a, unsigned long long *__restrict__ out)
+{
+	unsigned long long acc = 0;
+	for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += (size_t) gridDim.x * blockDim.x) {
+		const double2 av = a[i];
+		acc += (unsigned long long) __double_as_longlong(av.x);
+		acc += (unsigned long long) __double_as_longlong(av.y);
+	}
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+	if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
 }
 
 // ---- fused BLAS-1 of one BiCGStab iteration (BiCGStab.h:71-104): same expressions, fewer HBM passes ----

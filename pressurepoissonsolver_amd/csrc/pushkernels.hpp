@@ -14,16 +14,52 @@
 // ahead of a peer without a credit message (gmg_transport.hip pushExchange). A wait is bounded: after `budget` ticks of the 100 MHz wall
 // clock it sets *err and returns, and every later push / wait of the solver returns at once -- the host turns that into an error
 // (or, inside te_gmg_autotune, into "this transport is not usable here").
+//
+// The no-credit argument as CHECKS (PushErr): every exchange of a slot (level, kind) is symmetric -- each rank raises a flag at
+// every peer of the plan and waits for every peer's flag, whatever the counts -- so when a rank pushes epoch e it has passed its
+// own wait for e - 1, which needed every peer's flag >= e - 1: the peer's push e - 1 sits, in the peer's stream order, behind every
+// reader of the buffer (e & 1) that push e is about to overwrite. (i) The wait for epoch e therefore never sees a flag beyond e + 1
+// (the peer cannot pass ITS wait for e + 1 before this rank's push e + 1, which comes after this wait): a larger value is
+// PUSH_ERR_OVERRUN. (ii) The kernel that raises epoch e first reads the flag the same peer raises HERE: less than e - 1 is
+// PUSH_ERR_PEER_BEHIND (the stores of this push may have overwritten data the peer had not read). (iii) It keeps the last epoch
+// it raised per peer and slot in its own memory: anything but e - 1 is PUSH_ERR_SEQUENCE (the host skipped or repeated an exchange).
+// All three set the solver's error word like a wait that gave up; te_gmg_push_failed returns the code.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
 namespace te
 {
+enum PushErr : int { PUSH_OK = 0, PUSH_ERR_TIMEOUT = 1, PUSH_ERR_OVERRUN = 2, PUSH_ERR_PEER_BEHIND = 3, PUSH_ERR_SEQUENCE = 4 };
+// one flag this rank raises: `flag` in the peer's table; `back` = the flag the same peer raises in MY table for the same slot (its
+// progress as I can see it); `sent` = my own record of the last epoch I raised there (device memory of this rank)
+struct PushFlag {
+	unsigned long long       *flag;
+	const unsigned long long *back;
+	unsigned long long       *sent;
+};
+__device__ __forceinline__ void pushFail(int *err, int *err_host, int code)
+{
+	int expected = 0; // (the first failure names the cause)
+	if (__hip_atomic_compare_exchange_strong(err, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+		__hip_atomic_store(err_host, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// one thread, after the system-scope fence behind the last workgroup's data: checks (ii) and (iii) above, then the flag.
+// `raise` is `epoch` except under fault injection (TE_PUSH_FAULT).
+__device__ __forceinline__ void pushRaise(const PushFlag &f, unsigned long long epoch, unsigned long long raise, int *err, int *err_host)
+{
+	if (!f.flag) return;
+	if (f.back && __hip_atomic_load(f.back, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) + 1 < epoch) pushFail(err, err_host, PUSH_ERR_PEER_BEHIND);
+	if (f.sent) {
+		if (*f.sent + 1 != epoch) pushFail(err, err_host, PUSH_ERR_SEQUENCE);
+		*f.sent = epoch;
+	}
+	__hip_atomic_store(f.flag, raise, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 struct PushPeer {
-	double             *dst;  // where this peer's range starts in ITS receive buffer (of the current parity)
-	int64_t             src_off, cnt; // the range in my send buffer, doubles
-	unsigned long long *flag; // the flag I raise in the peer's flag table (null: nothing to tell it)
+	double  *dst;          // where this peer's range starts in ITS receive buffer (of the current parity)
+	int64_t  src_off, cnt; // the range in my send buffer, doubles (cnt may be 0: the flag is raised all the same)
+	PushFlag fl;
 };
 constexpr int PUSH_MAX_PEERS = 64;
 struct PushPlan {
@@ -31,8 +67,8 @@ struct PushPlan {
 	int      n;
 };
 // grid (blocks per peer, peers); even counts and 16-byte aligned ranges (face layers and blocks are multiples of 16 doubles)
-static __global__ __launch_bounds__(256) void k_push_ranges(const double *__restrict__ src, PushPlan plan, unsigned long long epoch, unsigned *done,
-                                                     const int *__restrict__ err)
+static __global__ __launch_bounds__(256) void k_push_ranges(const double *__restrict__ src, PushPlan plan, unsigned long long epoch,
+                                                     unsigned long long raise, unsigned *done, int *err, int *err_host)
 {
 	if (*err) return;
 	const PushPeer  pp = plan.p[blockIdx.y];
@@ -49,8 +85,7 @@ static __global__ __launch_bounds__(256) void k_push_ranges(const double *__rest
 		if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) { // every workgroup's data is out
 			__hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			__threadfence_system();
-			for (int k = 0; k < plan.n; k++)
-				if (plan.p[k].flag) __hip_atomic_store(plan.p[k].flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			for (int k = 0; k < plan.n; k++) pushRaise(plan.p[k].fl, epoch, raise, err, err_host);
 		}
 	}
 }
@@ -59,20 +94,21 @@ struct PushWait {
 	int                       n;
 };
 // err: this solver's error word in device memory (what the kernels test); err_host: the same in pinned host memory, written
-// only when a wait gives up (what the host's watchdog reads without touching the device)
+// only on a failure (what the host's watchdog reads without touching the device)
 static __global__ __launch_bounds__(64) void k_push_wait(PushWait w, unsigned long long epoch, long long budget, int *err, int *err_host)
 {
 	const int k = threadIdx.x;
 	if (k < w.n && !*err) {
-		const long long t0 = wall_clock64();
-		while (__hip_atomic_load(w.flag[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+		const long long    t0 = wall_clock64();
+		unsigned long long v;
+		while ((v = __hip_atomic_load(w.flag[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)) < epoch) {
 			if (wall_clock64() - t0 > budget || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-				__hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				pushFail(err, err_host, PUSH_ERR_TIMEOUT);
 				break;
 			}
 			__builtin_amdgcn_s_sleep(4);
 		}
+		if (v > epoch + 1) pushFail(err, err_host, PUSH_ERR_OVERRUN); // check (i): the peer is two exchanges ahead of what it can know
 	}
 	// (no fence here: the loads above are acquires, and the kernels that read the received data start behind this one on the same
 	// stream -- a kernel boundary is a system-scope release / acquire; a fence by all 64 lanes cost 2 us per exchange)

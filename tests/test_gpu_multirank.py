@@ -481,17 +481,35 @@ def test_direct_store_transport_that_never_delivers_is_rejected_everywhere():
     assert "MR_WORKER_OK" in r.stdout and "REJECTED" in r.stdout
 
 
+def run_inner(name, timeout_s="30"):
+    """one test of this file in a process of its own (TE_DIRECT_STORE_INNER=1 enables it there)"""
+    env = dict(os.environ, TE_DIRECT_STORE_INNER="1", TE_PUSH_TIMEOUT=timeout_s)
+    env.pop("TE_OVERLAP_MIN", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", name,
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_direct_store_transport_virtual_ranks():
     """the same transport between two virtual ranks of ONE process (raw pointers instead of hipIpc mappings), in a process of its
     own: a process has few hardware queues, and a kernel that waits for a flag must never sit in the queue in front of the kernel
     that raises it -- true for a fresh process with two solvers (two ranks only), not for a test process that has created dozens of
     streams before (there the wait gives up after TE_PUSH_TIMEOUT and the watchdog ends the process, as it should)."""
-    env = dict(os.environ, TE_DIRECT_STORE_INNER="1", TE_PUSH_TIMEOUT="30")
-    env.pop("TE_OVERLAP_MIN", None)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-k", "direct_store_virtual_ranks_body",
-                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    run_inner("direct_store_virtual_ranks_body")
+
+
+def test_direct_store_overrun_is_caught_by_the_receiver():
+    """the no-credit argument as a check: a peer whose flag is TWO exchanges ahead (TE_PUSH_FAULT=overrun raises epoch + 2) cannot
+    exist under the protocol -- k_push_wait must set the error word to PUSH_ERR_OVERRUN (2) instead of taking it for an arrival"""
+    run_inner("direct_store_overrun_body", "5")
+
+
+def test_direct_store_same_pid_other_process_is_not_taken_for_a_virtual_rank():
+    """pids repeat across containers and nodes: a peer that publishes MY pid but another process nonce (TE_PUSH_FAULT=nonce) must
+    be reached through hipIpcOpenMemHandle, never through its raw pointer -- here (the peer really is in this process) that either
+    fails cleanly on all ranks together or maps the same memory; it must not be treated as an in-process rank by pid alone"""
+    run_inner("direct_store_fake_nonce_body", "5")
 
 
 @pytest.mark.skipif(os.environ.get("TE_DIRECT_STORE_INNER") != "1", reason="runs in a process of its own: test_direct_store_transport_virtual_ranks")
@@ -533,6 +551,100 @@ def test_direct_store_virtual_ranks_body():
     for k in ("v0", "v1", "v2", "off", "on"):
         assert np.array_equal(got[k], want[0]), k
     assert np.array_equal(got["w"], want[1])
+
+
+@pytest.mark.skipif(os.environ.get("TE_DIRECT_STORE_INNER") != "1", reason="runs in a process of its own: test_direct_store_overrun_is_caught_by_the_receiver")
+def test_direct_store_overrun_body():
+    n = 8
+    mesh = util.mesh("uniform", 3)
+
+    def per_rank(r, H, g, fab):
+        g.set_option("TE_PUSH_NONFATAL", "1")  # (the test reads the error word itself; the watchdog must not end the process)
+        df, du = g.new_vector(0, util.rand_vec(H.sizes(0)[0] * n ** 3, 5 + r)), g.new_vector(0)
+        g.use_push(True)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+        g.sync()
+        ok_before = g.push_failed()
+        fab.barrier.wait()
+        g.set_option("TE_PUSH_FAULT", "overrun")
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+        g.sync()
+        return {"before": ok_before, "after": g.push_failed()}
+
+    got = shard_run(mesh, n, 2, per_rank)
+    assert got["before"] == [0, 0]
+    assert got["after"] == [2, 2], got  # PUSH_ERR_OVERRUN on both ranks: each saw the other's flag beyond epoch + 1
+
+
+@pytest.mark.skipif(os.environ.get("TE_DIRECT_STORE_INNER") != "1", reason="runs in a process of its own")
+def test_direct_store_fake_nonce_body():
+    n = 8
+    mesh = util.mesh("uniform", 3)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    f = util.rand_vec(H1.cells(0), 11)
+    d1 = g1.new_vector(0)
+    g1.cycle(g1.default_opts(smoother=capi.SMOOTH_RBGS), g1.new_vector(0, f), d1)
+    want = d1.download()
+    nc = n ** 3
+
+    def per_rank(r, H, g, fab):
+        g.set_option("TE_PUSH_FAULT", "nonce")
+        g.set_option("TE_PUSH_NONFATAL", "1")
+        df, du = g.new_vector(0, f.reshape(-1, nc)[H.l2g(0)].ravel()), g.new_vector(0)
+        try:
+            g.use_push(True)
+            msg = ""
+        except capi.TeError as e:
+            msg = str(e)
+        g.set_option("TE_PUSH_FAULT", None)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)  # through the mapping if there is one, else through the fabric
+        return {"msg": msg, "u": du.download(), "failed": g.push_failed()}
+
+    got = shard_run(mesh, n, 2, per_rank)
+    assert (got["msg"][0] == "") == (got["msg"][1] == ""), got["msg"]  # set up on both ranks, or refused on both
+    if got["msg"][0]:
+        assert all("te_gmg_use_push" in m for m in got["msg"]), got["msg"]
+    assert got["failed"] == [0, 0]
+    assert np.array_equal(got["u"], want)
+
+
+def test_checksum_is_independent_of_order_and_partition():
+    """te_vec_checksum = the sum modulo 2^64 of the values' bit patterns: equal to numpy's on the downloaded vector, unchanged by
+    a permutation of the patches, and the sum of the ranks' parts of a sharded cycle equals the single-rank cycle's (the equality
+    bench.py prints as u_checksum_after_timed_region for N = 1, 2, 4, 8)"""
+    n = 8
+    mesh = util.mesh("uniform", 3)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    f = util.rand_vec(H1.cells(0), 21)
+    f[7] = -0.0  # (the checksum sees bits: -0.0 != +0.0)
+    nc = n ** 3
+    M = (1 << 64) - 1
+
+    def np_sum(a):
+        return int(np.add.reduce(np.ascontiguousarray(a).view(np.uint64), dtype=np.uint64))
+
+    df, du = g1.new_vector(0, f), g1.new_vector(0)
+    assert df.checksumLocal() == np_sum(f)
+    perm = np.random.default_rng(3).permutation(H1.sizes(0)[0])
+    assert g1.new_vector(0, f.reshape(-1, nc)[perm].ravel()).checksumLocal() == np_sum(f)
+    g1.cycle(g1.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+    want = du.checksumLocal()
+    assert want == np_sum(du.download())
+
+    def per_rank(r, H, g, fab):
+        lf, lu = g.new_vector(0, f.reshape(-1, nc)[H.l2g(0)].ravel()), g.new_vector(0)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), lf, lu)
+        coarse = g.new_vector(H.num_levels - 1)  # a level that lives on every rank counts once
+        coarse.set(1.5)
+        return {"c": lu.checksumLocal(), "coarse": coarse.checksumLocal(), "repl": H.replicated(H.num_levels - 1)}
+
+    for nranks in (2, 4):
+        got = shard_run(mesh, n, nranks, per_rank)
+        assert sum(got["c"]) & M == want, nranks
+        if all(got["repl"]):
+            assert [c != 0 for c in got["coarse"]] == [True] + [False] * (nranks - 1)
 
 
 def test_native_rccl_backend_selftest():
