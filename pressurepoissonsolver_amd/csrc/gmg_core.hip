@@ -367,11 +367,48 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 								const int nf = (a == 0) ? g + 4 * q : 4 * q + g, mi = (a == 0) ? 4 * q + g : g + 4 * q;
 								const int sf = (a == 0) ? 1 : (a == 1 ? 0 : 2);
 								fs[(size_t) k * PSS_FRAG + ((sf * 2 + p) * 4 + q) * 64 + ln]      = F[(2 * j + p) * n + nf];
-								fs[(size_t) k * PSS_FRAG + (((3 + a) * 2 + p) * 4 + q) * 64 + ln] = G[j * n + 2 * mi + p];
+								// (the y inverse is the last product of the solve: its fragments carry the scale (2/N)^3 = 2^-12 of
+								// DftPatchSolver.h:214 -- a power of two: the same bits as a multiplication of the result)
+								fs[(size_t) k * PSS_FRAG + (((3 + a) * 2 + p) * 4 + q) * 64 + ln] = G[j * n + 2 * mi + p] * (a == 1 ? 8.0 / (32.0 * 32.0 * 32.0) : 1.0);
 							}
 				}
 			L->sym_ok = pure;
 			if ((rc = L->matsym.upload(fs))) return rc;
+			{ // k_ps_sym's reciprocal eigenvalue sums: one table per distinct (plan, spacings) among the patches with pure axes
+				std::map<std::tuple<int, double, double, double>, int> which;
+				std::vector<int32_t>                                   itab(std::max(P, 1), 0);
+				std::vector<double>                                    inv;
+				for (int p = 0; p < P; p++) {
+					const int k  = plan[p];
+					bool      ok = true;
+					for (int a = 0; a < 3; a++) ok &= (((keys[k] >> (2 * a)) & 1) == ((keys[k] >> (2 * a + 1)) & 1));
+					if (!ok) continue;
+					const auto key = std::make_tuple(k, rh2[(size_t) p * 3], rh2[(size_t) p * 3 + 1], rh2[(size_t) p * 3 + 2]);
+					auto       it  = which.find(key);
+					if (it == which.end()) {
+						it = which.emplace(key, (int) which.size()).first;
+						inv.resize(inv.size() + PSS_INV);
+						double       *T  = &inv[(size_t) it->second * PSS_INV];
+						const double *lx = &lam[((size_t) k * 3 + 0) * n], *ly = &lam[((size_t) k * 3 + 1) * n], *lz = &lam[((size_t) k * 3 + 2) * n];
+						const double  rx = std::get<1>(key), ry = std::get<2>(key), rz = std::get<3>(key);
+						for (int half = 0; half < 2; half++)
+							for (int sl = 0; sl < 16; sl++)
+								for (int pp = 0; pp < 2; pp++)
+									for (int r = 0; r < 4; r++)
+										for (int c = 0; c < 2; c++)
+											for (int ln = 0; ln < 64; ln++) {
+												const int    j = ln & 15, g = ln >> 4, kx = 2 * sl + half, ky = 2 * j + c, kz = 2 * (g + 4 * r) + pp;
+												const double ex = lx[kx] * rx, ey = ly[ky] * ry, ez = lz[kz] * rz;
+												const double d  = -((ex + ey) + ez); // (FftwPatchSolver.h:143-168: the eigenvalue of the patch operator)
+												// zero mode of an all-Neumann patch: the coefficient is set to zero (FftwPatchSolver.h:197)
+												T[((((size_t) (half * 16 + sl) * 2 + pp) * 4 + r) * 2 + c) * 64 + ln] = (zm[k] && kx == 0 && ky == 0 && kz == 0) ? 0.0 : 1.0 / d;
+											}
+					}
+					itab[p] = it->second;
+				}
+				if (inv.empty()) inv.resize(1, 0.0);
+				if ((rc = L->psinv.upload(inv)) || (rc = L->psitab.upload(itab))) return rc;
+			}
 			if (!pure) { // per-patch choice between k_ps_sym and k_ps_fused
 				std::vector<int32_t> lst, mixed;
 				for (int p = 0; p < P; p++) {

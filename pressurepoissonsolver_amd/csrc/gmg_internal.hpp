@@ -41,8 +41,10 @@ using namespace te;
 #define HIPCHK(expr)                                                                              \
 	do {                                                                                          \
 		hipError_t _e = (expr);                                                                   \
-		if (_e != hipSuccess)                                                                     \
+		if (_e != hipSuccess) {                                                                   \
+			(void) hipGetLastError(); /* reported here: a later launch check must not find it again */ \
 			return te::fail(TE_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+		}                                                                                         \
 	} while (0)
 
 
@@ -192,6 +194,8 @@ struct LevelHost {
 	DevBuf<double>  mats, lam, corr; // corr: [P][6][n^2] interface terms of the patch right-hand sides
 	DevBuf<double>  matsT;           // 2D: the transform matrices transposed (k_patch_solve2d_lds)
 	DevBuf<double>  matsym;          // half matrices in MFMA fragment order (patchsolve32_sym.hpp), 32^3 patches
+	DevBuf<double>  psinv;           // k_ps_sym: reciprocals of the eigenvalue sums, one table of PSS_INV doubles per (plan, spacings) of the level
+	DevBuf<int32_t> psitab;          // [P] the patch's table in psinv
 	bool            sym_ok = false;  // every plan of the level has pure (DST-II/III or DCT-II/III) axes
 	DevBuf<int32_t> ps_list;         // otherwise: [patches with pure axes (n_pure) | the others]
 	int             n_pure = 0;

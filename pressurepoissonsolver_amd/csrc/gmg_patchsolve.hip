@@ -105,16 +105,13 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 				const bool faces = faces_req && n_mix == 0 && L.f6buf.p;
 				if (faces) { // only the face layers of the result: see k_ps_sym<CORR, FACES>
 					L.f6_tab = false; // (written as [p][6])
-					launchT(t, (k_ps_sym<false, true>), gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
-					        L.zero_mode.p, L.rh2.p, f, cp, u, (double *) nullptr, lst_sym, L.f6buf.p);
+					launchT(t, (k_ps_sym<false, true>), gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.psinv.p, L.psitab.p, f, cp, u, (double *) nullptr, lst_sym, L.f6buf.p);
 					L.ps_faces = true;
 					xo         = nullptr;
 				} else if (zero_guess)
-					launchT(t, (k_ps_sym<false, false>), gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
-					        L.zero_mode.p, L.rh2.p, f, cp, u, xo, lst_sym, (double *) nullptr);
+					launchT(t, (k_ps_sym<false, false>), gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.psinv.p, L.psitab.p, f, cp, u, xo, lst_sym, (double *) nullptr);
 				else
-					launchT(t, (k_ps_sym<true, false>), gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.lam.p,
-					        L.zero_mode.p, L.rh2.p, f, cp, u, xo, lst_sym, (double *) nullptr);
+					launchT(t, (k_ps_sym<true, false>), gs, b512, PSS_LDS_BYTES, g->stream, n_sym, L.plan.p, L.matsym.p, L.psinv.p, L.psitab.p, f, cp, u, xo, lst_sym, (double *) nullptr);
 				if (xo) xfProduced(L, u);
 			}
 			if (n_mix > 0) {

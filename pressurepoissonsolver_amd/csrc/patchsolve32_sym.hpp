@@ -37,6 +37,12 @@
 #ifndef PSS_NTL
 #define PSS_NTL 1 // ... and non-temporal loads of the right-hand side (re-read one whole sweep later)
 #endif
+#ifndef PSS_BAR3
+#define PSS_BAR3 0 // 1: a barrier between C1 and the odd half's write into the image (not needed: see there)
+#endif
+#ifndef PSS_BAREND
+#define PSS_BAREND 0 // 1: a barrier at the end of every patch (not needed: see there)
+#endif
 #ifndef PSS_NT
 #define PSS_NT 1 // non-temporal stores of the result (nothing re-reads a 1 GiB vector before it has left the caches)
 #endif
@@ -51,6 +57,7 @@ constexpr int PSS_SLAB      = 32 * 32;                             // image: [kx
 constexpr int PSS_RING      = 16 * PSS_SLAB;                       // per-wave ring strips: [wave 8][128]
 constexpr int PSS_TAB       = PSS_RING + 8 * 128;                  // the current plan's fragment table
 constexpr int PSS_LDS_BYTES = (PSS_TAB + PSS_FRAG) * 8;            // 163840: all of a CU's LDS
+constexpr int PSS_INV       = 32 * 32 * 32;                        // one table of reciprocal eigenvalue sums
 #ifdef PSF_TIMING
 static __device__ long long pss_stamp[8][12];
 #define PSS_STAMP(k) do { if (blockIdx.x == 100 && l == 0 && it == (int) (blockIdx.x + 8 * gridDim.x)) pss_stamp[wave][k] = clock64(); } while (0)
@@ -85,10 +92,16 @@ struct PssPlane {
 // f6_out [patch][6][N*N] (the layout of the RB-GS face layers: W,E at (y + N z), S,N at (x + N z), B,T at (x + N y)) -- the
 // residual of a block-Jacobi sweep from zero lives on the faces (interfaceResidRestrict) and the post-sweep overwrites the
 // iterate, reading the old one only through its interface terms (k_face_corr3d): 8 + 1.5 B per site instead of 16.
+// inv / itab: the reciprocals 1 / -(lx[kx] + ly[ky] + lz[kz]) of the eigenvalue sums, one table of PSS_INV doubles per distinct (plan,
+// spacings) of the level, in the order the z stages consume them ([half][slab][kz parity][r][ky parity][lane]: a wave's load is 512
+// contiguous bytes), 0 at the zero mode of an all-Neumann patch (FftwPatchSolver.h:197); itab[patch] = the patch's table. The divisions
+// they replace ran on the vector ALU -- which on gfx950 is the unit the fp64 matrix instruction executes on (tools/mfma_valu.hip:
+// v_fma_f64 issued by one wave of a SIMD and v_mfma_f64 issued by the other take the SUM of their times): 64 divisions of ~ 11
+// instructions per lane and patch were a sixth of the kernel's pipe time.
 template <bool CORR, bool FACES = false>
 __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict__ plan, const double *__restrict__ frag,
-                                                const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
-                                                const double *__restrict__ rh2, const double *__restrict__ in,
+                                                const double *__restrict__ inv, const int32_t *__restrict__ itab,
+                                                const double *__restrict__ in,
                                                 const double *__restrict__ corr, double *__restrict__ out,
                                                 double *__restrict__ xf_out, const int32_t *__restrict__ list,
                                                 double *__restrict__ f6_out = nullptr)
@@ -186,7 +199,8 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 	for (; it < P; it += gridDim.x) {
 		const int pid = patchAt(it);
 		const int pl = plan[pid];
-		if (pl != cur_plan) { // (re)load the plan's fragment table; every wave is past the previous patch here
+		if (pl != cur_plan) { // (re)load the plan's fragment table: only when every wave is past the previous patch
+			if (cur_plan >= 0) ldsBarrier();
 			const double *src = frag + (size_t) pl * PSS_FRAG;
 			for (int i = threadIdx.x; i < PSS_FRAG; i += 512) xbuf[PSS_TAB + i] = src[i];
 			cur_plan = pl;
@@ -194,6 +208,19 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 		}
 		const double *ip = in + (size_t) pid * N * NN;
 		const double *cr = CORR ? corr + (size_t) pid * 6 * NN : nullptr;
+		const double *ivt = inv + (size_t) itab[pid] * PSS_INV;
+		double        iv[2][2][4];
+		auto          ivLoad = [&](int half, int t) {
+            const Lane    q   = lane();
+            const double *ip2 = ivt + ((size_t) (half * 16 + 2 * wave + t) * 16) * 64 + q.l;
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    iv[p][0][r] = ip2[((p * 4 + r) * 2 + 0) * 64];
+                    iv[p][1][r] = ip2[((p * 4 + r) * 2 + 1) * 64];
+                }
+		};
 		PSS_STAMP(0);
 
 		// ---- A: y,x forward of this wave's four planes ---------------------------------------------
@@ -232,6 +259,17 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 				h[0] = e[1][0], h[1] = e[1][1];
 			};
 			double cn[2];
+			// A plane's first instructions -- the butterflies of its y transform -- depend on nothing but its loads, and the instruction
+			// scheduler likes to hoist them to right behind the request (seen in the ISA: s_waitcnt vmcnt(5) five instructions after
+			// plane z_3 was requested -- a whole HBM latency exposed per patch). Nothing crosses a fence: a plane is consumed where
+			// the source says, a plane's worth of matrix instructions behind its request.
+#ifndef PSS_FENCE_MASK
+#define PSS_FENCE_MASK 0x3FC // every class of instruction may cross but vector-ALU ones (a full fence, 0, costs registers: spills)
+#endif
+#ifndef PSS_FENCES
+#define PSS_FENCES 7
+#endif
+#define PSS_FENCE(i) do { if (PSS_FENCES & (1 << (i))) __builtin_amdgcn_sched_barrier(PSS_FENCE_MASK); } while (0)
 			// plane z_0 (slot 0), then request z_2 -> slot 0
 			if (CORR) {
 				loadRing(q, cn, cr, zof(1));
@@ -240,6 +278,7 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 			yfwd(s0);
 			loadPlane(q, s0, ip + zof(2) * NN);
 			xfwd(zof(0), hi[0]);
+			PSS_FENCE(0);
 			// plane z_1 (slot 1), then request z_3 -> slot 1
 			if (CORR) {
 				loadRing(q, c, cr, zof(2));
@@ -248,6 +287,7 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 			yfwd(s1);
 			loadPlane(q, s1, ip + zof(3) * NN);
 			xfwd(zof(1), hi[1]);
+			PSS_FENCE(1);
 			// plane z_2 (slot 0), then the z-face term of z_3 -> slot 0
 			if (CORR) {
 				loadRing(q, cn, cr, zof(3));
@@ -256,6 +296,7 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 			yfwd(s0);
 			if (CORR && zface) loadPlane(q, s0, cr + (wave == 0 ? 4 : 5) * NN);
 			xfwd(zof(2), hi[2]);
+			PSS_FENCE(2);
 			// plane z_3 (slot 1)
 			if (CORR) {
 				applyRing(q, s1, cn);
@@ -265,15 +306,9 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 						s1.ll[k] -= s0.ll[k], s1.lh[k] -= s0.lh[k], s1.hl[k] -= s0.hl[k], s1.hh[k] -= s0.hh[k];
 				}
 			}
-			// eigenvalue tables of this patch, lam * 1/h^2 per axis ([x 32 | y 32 | z 32]), for the z stages: requested
-			// behind the last plane, parked in this wave's (now idle) ring strip, so that the z stages issue no loads
-			const double *lm = lam + (size_t) pl * 3 * N;
-			const double *rh = rh2 + (size_t) pid * 3;
-			const double  e0 = lm[q.l] * rh[q.l >> 5], e1 = lm[2 * N + (q.l & 31)] * rh[2];
+			ivLoad(0, 0); // (the first z stage's first reciprocals: this plane's 32 matrix instructions ahead of their use)
 			yfwd(s1);
 			xfwd(zof(3), hi[3]);
-			ring[q.l] = e0;
-			if (q.l < 32) ring[2 * N + q.l] = e1;
 		}
 		PSS_STAMP(1);
 
@@ -281,60 +316,47 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 		auto zstage = [&](int half, bool fetch_next) {
 			const Lane    q  = lane();
 			const int     j = q.j, g = q.g;
-			const double2 ly = *reinterpret_cast<const double2 *>(ring + N + 2 * j); // ky = 2j, 2j + 1
-			double        ez[2][4];                                                    // kz = 2 (g + 4r) + parity
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				const double2 v = *reinterpret_cast<const double2 *>(ring + 2 * N + 2 * (g + 4 * r));
-				ez[0][r] = v.x, ez[1][r] = v.y;
-			}
-			const bool zmp = zero_mode[pl] != 0;
-			if (fetch_next) prefetch(0);
-			// three passes over the wave's two slabs (forward, divide, inverse) rather than slab by slab: the divisions of
-			// one slab (vector ALU) then have the other slab's MFMAs to hide behind, inside the same wave
-			v4f64 d[2][2][2]; // [slab][kz parity][ky parity]: rows kz = 2 (g + 4r) + parity
+			// The reciprocals of a slab (kx = 2 (2 wave + t) + half), iv[kz parity][ky parity][r], come from L2 (every CU walks the same
+			// few tables): slab 0's were requested by the phase in front of this stage (ivLoad: a transform's worth of matrix
+			// instructions earlier), slab 1's go into the same registers as soon as slab 0's have been used -- slab 0's inverse
+			// and slab 1's forward transform (32 matrix instructions) lie between that request and its use. Slab by slab
+			// rather than stage by stage: one slab's data and one set of reciprocals are live at a time (the kernel runs at 256
+			// registers), and with a multiplication where the division was there is no vector work left to hide.
 #pragma unroll
 			for (int t = 0; t < 2; t++) {
-				const double *sp = xbuf + (2 * wave + t) * PSS_SLAB + 2 * j;
-				d[t][0][0] = d[t][0][1] = d[t][1][0] = d[t][1][1] = v4f64{0, 0, 0, 0};
+				double *sp = xbuf + (2 * wave + t) * PSS_SLAB + 2 * j;
+				v4f64   d[2][2]; // [kz parity][ky parity]: rows kz = 2 (g + 4r) + parity
+				d[0][0] = d[0][1] = d[1][0] = d[1][1] = v4f64{0, 0, 0, 0};
 #pragma unroll
 				for (int k = 0; k < 4; k++) {
 					const double2 vl = *reinterpret_cast<const double2 *>(sp + (4 * k + g) * N);
 					const double2 vh = *reinterpret_cast<const double2 *>(sp + (N - 1 - 4 * k - g) * N);
 					const double  a0 = frg(q, 2, 0, k), a1 = frg(q, 2, 1, k);
-					d[t][0][0] = mfma_f64(a0, vl.x + vh.x, d[t][0][0]);
-					d[t][0][1] = mfma_f64(a0, vl.y + vh.y, d[t][0][1]);
-					d[t][1][0] = mfma_f64(a1, vl.x - vh.x, d[t][1][0]);
-					d[t][1][1] = mfma_f64(a1, vl.y - vh.y, d[t][1][1]);
+					d[0][0] = mfma_f64(a0, vl.x + vh.x, d[0][0]);
+					d[0][1] = mfma_f64(a0, vl.y + vh.y, d[0][1]);
+					d[1][0] = mfma_f64(a1, vl.x - vh.x, d[1][0]);
+					d[1][1] = mfma_f64(a1, vl.y - vh.y, d[1][1]);
 				}
-			}
-#pragma unroll
-			for (int t = 0; t < 2; t++) {
-				const int    kx = 2 * (2 * wave + t) + half;
-				const double lx = ring[kx];
-				const double exy0 = lx + ly.x, exy1 = lx + ly.y;
-				const bool   zm   = zmp && kx == 0 && j == 0;
 #pragma unroll
 				for (int p = 0; p < 2; p++)
 #pragma unroll
 					for (int r = 0; r < 4; r++) {
-						d[t][p][0][r] = pssDiv(d[t][p][0][r], -(exy0 + ez[p][r]));
-						d[t][p][1][r] = pssDiv(d[t][p][1][r], -(exy1 + ez[p][r]));
-						if (zm && p == 0 && g + 4 * r == 0) d[t][p][0][r] = 0.0; // FftwPatchSolver.h:197
+						d[p][0][r] *= iv[p][0][r];
+						d[p][1][r] *= iv[p][1][r];
 					}
-			}
-#pragma unroll
-			for (int t = 0; t < 2; t++) {
-				double *sp = xbuf + (2 * wave + t) * PSS_SLAB + 2 * j;
-				v4f64   pz[2], qz[2];
+				if (t == 0) {
+					ivLoad(half, 1);
+					if (fetch_next) prefetch(0); // (behind the table request: loads return in order)
+				}
+				v4f64 pz[2], qz[2];
 				pz[0] = pz[1] = qz[0] = qz[1] = v4f64{0, 0, 0, 0};
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
 					const double a0 = frg(q, 5, 0, r), a1 = frg(q, 5, 1, r);
-					pz[0] = mfma_f64(a0, d[t][0][0][r], pz[0]);
-					pz[1] = mfma_f64(a0, d[t][0][1][r], pz[1]);
-					qz[0] = mfma_f64(a1, d[t][1][0][r], qz[0]);
-					qz[1] = mfma_f64(a1, d[t][1][1][r], qz[1]);
+					pz[0] = mfma_f64(a0, d[0][0][r], pz[0]);
+					pz[1] = mfma_f64(a0, d[0][1][r], pz[1]);
+					qz[0] = mfma_f64(a1, d[1][0][r], qz[0]);
+					qz[1] = mfma_f64(a1, d[1][1][r], qz[1]);
 				}
 				// rows z = g + 4r (P + Q) and 31 - z (P - Q); every read of this slab is complete (same wave, in order)
 #pragma unroll
@@ -367,11 +389,16 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 		v4f64 Pe[4][2]; // even-kx half of the x inverse of planes z = wave + 8i: rows ky = 2 (g + 4r) + parity, cols x
 		{
 			const Lane q = lane();
+			ivLoad(1, 0); // (the second z stage's first reciprocals)
 #pragma unroll
 			for (int i = 0; i < 4; i++) xhalf(q, wave + 8 * i, 0, Pe[i]);
 		}
 		PSS_STAMP(5);
-		ldsBarrier(); // every wave is done with the even half: the odd one takes its place
+		// The odd half takes the even half's place WITHOUT a barrier: the rows a wave overwrites here -- (slab, z) for its own four
+		// planes z, all slabs -- are exactly the rows it alone has just read in C1 (same wave, LDS operations in program order).
+#if PSS_BAR3
+		ldsBarrier();
+#endif
 		{
 			const Lane q = lane();
 #pragma unroll
@@ -391,7 +418,7 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 		{
 			const Lane       q = lane();
 			const int        j = q.j, g = q.g;
-			constexpr double scale = 8.0 / (32.0 * 32.0 * 32.0); // (2/N)^3, DftPatchSolver.h:214
+			// (the scale (2/N)^3 = 2^-12 of DftPatchSolver.h:214 rides in the y-inverse fragments: a power of two, bit-identical)
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				const int z = wave + 8 * i;
@@ -409,7 +436,7 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 						qy = mfma_f64(frg(q, 4, 1, r), x1[r], qy);
 					}
 					const int   x  = xc ? N - 1 - j : j;
-					const v4f64 yl = (py + qy) * scale, yh = (py - qy) * scale;
+					const v4f64 yl = py + qy, yh = py - qy;
 					if (FACES) {
 						double *fb = f6_out + (size_t) pid * 6 * NN;
 						if (z == 0 || z == N - 1) { // a z face: the whole plane
@@ -444,7 +471,12 @@ __global__ __launch_bounds__(512) void k_ps_sym(int P, const int32_t *__restrict
 			}
 		}
 		PSS_STAMP(9);
-		ldsBarrier(); // the image is rewritten by the next patch's phase A
+		// No barrier at the end of a patch either: the next patch's phase A rewrites rows of this wave's own planes, which only
+		// this wave read in C2; every other wave meets the new data behind the barrier in front of the first z stage. (A change of
+		// plan has its own barrier: the fragment table is shared. That reload must not overtake a wave still in C2 -- see there.)
+#if PSS_BAREND
+		ldsBarrier();
+#endif
 	}
 }
 } // namespace te

@@ -604,7 +604,7 @@ def test_direct_store_fake_nonce_body():
     got = shard_run(mesh, n, 2, per_rank)
     assert (got["msg"][0] == "") == (got["msg"][1] == ""), got["msg"]  # set up on both ranks, or refused on both
     if got["msg"][0]:
-        assert all("te_gmg_use_push" in m for m in got["msg"]), got["msg"]
+        assert all("hipIpcOpenMemHandle" in m or "te_gmg_use_push" in m for m in got["msg"]), got["msg"]  # (went for a mapping, not for the raw pointer)
     assert got["failed"] == [0, 0]
     assert np.array_equal(got["u"], want)
 

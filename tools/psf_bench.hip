@@ -68,6 +68,8 @@ int main(int argc, char **argv)
 	}
 	const dim3 gf(8 * ((P + 7) / 8)), gs(P < 256 ? P : 256);
 	double *fr; CK(hipMalloc(&fr, PSS_FRAG * 8)); CK(hipMemcpy(fr, h.data(), PSS_FRAG * 8, hipMemcpyHostToDevice));
+	double *inv; CK(hipMalloc(&inv, PSS_INV * 8)); CK(hipMemcpy(inv, h.data() + 4096, PSS_INV * 8, hipMemcpyHostToDevice));
+	int32_t *itab; CK(hipMalloc(&itab, P * 4)); CK(hipMemset(itab, 0, P * 4));
 	CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_sym<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS_BYTES));
 	CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ps_sym<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PSS_LDS_BYTES));
 	auto stamps = [&] {
@@ -92,9 +94,9 @@ int main(int argc, char **argv)
 	};
 	for (int skew = 0; skew <= 0; skew++) {
 		printf("skew %d\n", skew);
-		timeit("sym zero-guess", [&] { hipLaunchKernelGGL(k_ps_sym<false>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, (const double *) nullptr, out, s0, (const int32_t *) nullptr); });
+		timeit("sym zero-guess", [&] { hipLaunchKernelGGL(k_ps_sym<false>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, inv, itab, in, (const double *) nullptr, out, s0, (const int32_t *) nullptr); });
 		sstamps();
-		timeit("sym with corr", [&] { hipLaunchKernelGGL(k_ps_sym<true>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, lam, zm, rh2, in, corr, out, s0, (const int32_t *) nullptr); });
+		timeit("sym with corr", [&] { hipLaunchKernelGGL(k_ps_sym<true>, gs, dim3(512), PSS_LDS_BYTES, 0, P, plan, fr, inv, itab, in, corr, out, s0, (const int32_t *) nullptr); });
 		sstamps();
 	}
 	timeit("fused zero-guess", [&] { hipLaunchKernelGGL(k_ps_fused<false>, gf, dim3(512), PSF_LDS_BYTES, 0, P, plan, mats, lam, zm, rh2, in, (const double *) nullptr, out, (const int32_t *) nullptr); });
