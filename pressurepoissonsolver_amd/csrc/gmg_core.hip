@@ -459,6 +459,34 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 							S[3 * PS2S_STAGE + e] = Gy[(16 * (t & 1) + j) * n + 2 * kk + (t >> 1)];
 						}
 			}
+			{ // k_patch_solve2d_sym's reciprocal eigenvalues (times the transforms' scale), one table per distinct (plan, spacings), in the
+			  // kernel's parity-split positions: position c < 32 holds wave number 2c, c >= 32 holds 2 (c - 32) + 1
+				std::map<std::tuple<int, double, double>, int> which;
+				std::vector<int32_t>                           itab(std::max(P, 1), 0);
+				std::vector<double>                            inv;
+				for (int p = 0; p < P; p++) {
+					const int k = plan[p];
+					if (!pure[k]) continue;
+					const auto key = std::make_tuple(k, rh2[(size_t) p * 3], rh2[(size_t) p * 3 + 1]);
+					auto       it  = which.find(key);
+					if (it == which.end()) {
+						it = which.emplace(key, (int) which.size()).first;
+						inv.resize(inv.size() + (size_t) n * n);
+						double       *T  = &inv[(size_t) it->second * n * n];
+						const double *lx = &lam[((size_t) k * 2 + 0) * n], *ly = &lam[((size_t) k * 2 + 1) * n];
+						const double  rx = std::get<1>(key), ry = std::get<2>(key), sc = 4.0 / ((double) n * n);
+						for (int rp = 0; rp < n; rp++)
+							for (int cp = 0; cp < n; cp++) {
+								const int    ky = rp < 32 ? 2 * rp : 2 * (rp - 32) + 1, kx = cp < 32 ? 2 * cp : 2 * (cp - 32) + 1;
+								const double d  = -(lx[kx] * rx + ly[ky] * ry);
+								T[(size_t) rp * n + cp] = (zm[k] && kx == 0 && ky == 0) ? 0.0 : sc / d;
+							}
+					}
+					itab[p] = it->second;
+				}
+				if (inv.empty()) inv.resize(1, 0.0);
+				if ((rc = L->psinv.upload(inv)) || (rc = L->psitab.upload(itab))) return rc;
+			}
 			std::vector<int32_t> lst, mixed;
 			for (int p = 0; p < P; p++) (pure[plan[p]] ? lst : mixed).push_back(p);
 			L->n_pure2 = (int) lst.size();

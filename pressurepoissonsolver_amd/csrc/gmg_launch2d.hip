@@ -183,7 +183,7 @@ int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0
 		};
 		auto launchSym = [&](auto kern) -> int {
 			if (nsym > 0)
-				launchT(t, kern, dim3(nsym), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.mat2sym.p, L.lam.p, L.zero_mode.p, f, u, s1, lst, ps);
+				launchT(t, kern, dim3(nsym), dim3(256), lds, g->stream, L.dev2(), L.plan.p, L.mat2sym.p, L.psinv.p, L.psitab.p, f, u, s1, lst, ps);
 			return TE_OK;
 		};
 		if (!attr) { // all six once, so that the attribute is set whichever runs first

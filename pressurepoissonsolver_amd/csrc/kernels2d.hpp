@@ -1441,8 +1441,8 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_mfma(Level2D L, const int
 // than there: equal to rounding (<= 1e-13).
 constexpr int PS2S_STAGE = 8 * 4 * 64, PS2S_PLAN = 4 * PS2S_STAGE;
 template <bool ZERO, bool PF, bool PROLONG = false>
-__global__ __launch_bounds__(256) void k_patch_solve2d_sym(Level2D L, const int32_t *__restrict__ plan, const double *__restrict__ sym,
-                                                           const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
+__global__ __launch_bounds__(256, PF ? 2 : 4) void k_patch_solve2d_sym(Level2D L, const int32_t *__restrict__ plan, const double *__restrict__ sym,
+                                                           const double *__restrict__ inv, const int32_t *__restrict__ itab,
                                                            const double *__restrict__ f, const double *__restrict__ u,
                                                            double *__restrict__ out, const int32_t *__restrict__ list, Prolong2D ps = Prolong2D())
 {
@@ -1452,10 +1452,14 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_sym(Level2D L, const int3
 	double       *T = tile2d;
 	const int     p = list ? list[blockIdx.x] : blockIdx.x, tid = threadIdx.x, pl = plan[p];
 	const int     w = tid >> 6, l = tid & 63, j = l & 15, g = l >> 4;
-	const double  rhx = L.rh2[p * 3], rhy = L.rh2[p * 3 + 1];
 	const double *fp = f + (size_t) p * nn, *up = u + (size_t) p * nn;
 	const double *S  = sym + (size_t) pl * PS2S_PLAN;
-	const double *lm = lam + (size_t) pl * 2 * n;
+	// inv: per distinct (plan, spacings) of the level one table [position r'][position c'] of scale / -(lx[kx(c')] + ly[ky(r')]), the
+	// reciprocal eigenvalue of the patch operator times the transforms' scale 4 / n^2 = 2^-10 (a power of two: the same bits as a
+	// multiplication of the result), 0 at the zero mode of an all-Neumann patch; itab[p] = the patch's table. The IEEE divisions these
+	// replace (16 per lane, ~ 15 vector instructions each, behind two dependent table loads) ran on the unit the fp64 matrix
+	// instruction executes on (tools/mfma_valu.hip): a sixth of the kernel's pipe time.
+	const double *ivt = inv + (size_t) itab[p] * nn;
 	auto          frag = [&](int stage, int ks, int t) { return S[stage * PS2S_STAGE + (ks * 4 + t) * 64 + l]; };
 	// PF: every stage's fragments are fetched a stage ahead; otherwise only those of the A-side stages (8 and 16 values per lane:
 	// 124 -> 140 registers, three workgroups per CU either way), a B-side stage's 32 where it uses them
@@ -1490,6 +1494,11 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_sym(Level2D L, const int3
 #pragma unroll
 		for (int r = 0; r < 4; r++) T[(16 * w + g + 4 * r) * LD + 16 * ct + j] = d[ct][r]; // (the wave's own rows, in place)
 	loadB(2);
+	double iv[16]; // (requested a stage ahead of their use: they come from L2, every workgroup of the level reads the same few tables)
+#pragma unroll
+	for (int ct = 0; ct < 4; ct++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) iv[ct * 4 + r] = ivt[(16 * w + g + 4 * r) * n + 16 * ct + j];
 	__syncthreads();
 	// ---- stage 1: Y2[r'][c'] = sum_{y'<32} Fy[ky(r')][y'] (Y1[y'][c'] +- Y1[63-y'][c']): waves 0, 1 even ky, 2, 3 odd ky
 #pragma unroll
@@ -1510,11 +1519,8 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_sym(Level2D L, const int3
 	for (int ct = 0; ct < 4; ct++)
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
-			const int rp = 16 * w + g + 4 * r, cp = 16 * ct + j; // positions; the wave numbers behind them:
-			const int ky = rp < 32 ? 2 * rp : 2 * (rp - 32) + 1, kx = cp < 32 ? 2 * cp : 2 * (cp - 32) + 1;
-			double    v  = d[ct][r] / -(lm[kx] * rhx + lm[n + ky] * rhy);
-			if (zero_mode[pl] && kx == 0 && ky == 0) v = 0.0;
-			T[rp * LD + cp] = v;
+			const int rp = 16 * w + g + 4 * r, cp = 16 * ct + j; // positions (the wave numbers behind them: the table's business)
+			T[rp * LD + cp] = d[ct][r] * iv[ct * 4 + r];
 		}
 	__syncthreads();
 	// ---- stage 2: E[r'][x'] = sum_{kx even} Y2 Gx[x'][kx], O[r'][x'] = sum_{kx odd} ...; Y3[r'][x'], Y3[r'][63-x'] = E +- O
@@ -1554,14 +1560,13 @@ __global__ __launch_bounds__(256) void k_patch_solve2d_sym(Level2D L, const int3
 		}
 	}
 	double      *op = out + (size_t) p * nn;
-	const double sc = 4.0 / ((double) n * n);
 #pragma unroll
 	for (int c2 = 0; c2 < 2; c2++)
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			const int yp = 16 * rt + g + 4 * r, x = 16 * (cb + c2) + j;
-			op[yp * n + x]        = (e2[c2][r] + o2[c2][r]) * sc;
-			op[(63 - yp) * n + x] = (e2[c2][r] - o2[c2][r]) * sc;
+			op[yp * n + x]        = e2[c2][r] + o2[c2][r]; // (the scale 4 / n^2 rides in the reciprocal table)
+			op[(63 - yp) * n + x] = e2[c2][r] - o2[c2][r];
 		}
 }
 } // namespace te
