@@ -461,7 +461,8 @@ def run(a, json_out, rank, world, local_rank):
         cands = [("environment", None)] if pinned else (
             [("gathered<=64-on-every-rank", (64, 64, 1)), ("gathered<16/rank-on-every-rank", (16, 64, 1)), ("gathered<4/rank-on-every-rank", (4, 64, 1)),
              ("gathered<=64-on-rank-0", (64, 64, 0)), ("never-gathered", (0, 64, 0))] if a.dim == 3
-            else [("gathered<=64-on-rank-0", (64, 64, 0)), ("gathered<16/rank-on-rank-0", (16, 64, 0)), ("never-gathered", (0, 64, 0))])
+            else [("gathered<=64-on-every-rank", (64, 64, 1)), ("gathered<16/rank-on-every-rank", (16, 64, 1)),
+                  ("gathered<=64-on-rank-0", (64, 64, 0)), ("gathered<16/rank-on-rank-0", (16, 64, 0)), ("never-gathered", (0, 64, 0))])
         tried, best = [], None
         # (the headline runs on the transport `north_star` names -- RCCL point-to-point groups issued by the library; the
         # direct-store transport is measured afterwards, as secondary.direct_store, never inside the headline's choice)

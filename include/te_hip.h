@@ -60,7 +60,7 @@ int te_hier_build(const te_mesh *m, int n, int neumann, int max_levels, double p
 /* The same with the placement of the small levels over the ranks spelled out instead of taken from the environment
  * (te_hier_build reads TE_AGGLOMERATE, TE_AGGLOMERATE_MAX, TE_REPLICATE once per call and comes here): a level with fewer
  * than `agglomerate` patches per rank and at most `agglomerate_max` patches in total, and every level below it, is gathered --
- * on every rank (`replicate` != 0, 3D only) or on rank 0. A negative value = the default (64, 64, 1); agglomerate = 0 never
+ * on every rank (`replicate` != 0; 3D, and since round 5 2D) or on rank 0. A negative value = the default (64, 64, 1); agglomerate = 0 never
  * gathers. What the reference does instead is cut the hierarchy (patches_per_proc, CycleFactory3d.cpp:104). Every rank must
  * pass the same values: te_vcycle / te_bicgstab compare them across the ranks before the first cycle (TE_ESTATE, by name). */
 int te_hier_build_placed(const te_mesh *m, int n, int neumann, int max_levels, double patches_per_proc,
@@ -72,7 +72,7 @@ int te_hier_dim(const te_hier *h);
 int te_hier_n(const te_hier *h);
 /* level 0 = finest. P_local = this rank's patches, P_global = all ranks'. */
 int te_hier_level_sizes(const te_hier *h, int level, int *P_local, int *P_global);
-/* 1: the level lives on EVERY rank (a gathered coarse level of a 3D hierarchy, TE_REPLICATE: each rank holds and computes all
+/* 1: the level lives on EVERY rank (a gathered coarse level, TE_REPLICATE: each rank holds and computes all
  * of it, P_local == P_global, and the `rank` column of te_hier_level_tables names the calling rank for every patch); 0: every
  * patch has one owner; < 0: error. Replaces nothing in the reference (CycleFactory3d.cpp:104 cuts the hierarchy instead). */
 int te_hier_level_replicated(const te_hier *h, int level);

@@ -594,7 +594,7 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 		                      && std::all_of(orth.begin(), orth.end(), [](int32_t o) { return o >= 0; }));
 		L->has_copy           = std::any_of(orth.begin(), orth.end(), [](int32_t o) { return o < 0; });
 		L->prolong_fusable_cf = (D == 3 && parents_local && !g->cfg.has(O_NO_CFP));
-		if (D == 2 && L->lds2d && up.empty() && down.empty()) {
+		if (D == 2 && L->lds2d && parents_local) { // (no transfers, or a coarse level on every rank: its blocks travel behind the kernels)
 			L->fuse2d          = true;
 			// (faces on other ranks are fine: their values of u + P e arrive in ghost slots, packProlongFaces2d)
 			L->prolong_fusable = ((g->cfg.has(O_2D_NO_MR_FUSE) ? L->nslots == 0 : L->ncf == 0)

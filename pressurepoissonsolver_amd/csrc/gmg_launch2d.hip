@@ -98,18 +98,40 @@ int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, doub
 	return TE_OK;
 }
 
-// coarse f = AvgRstr(f - A u) in one pass (levels with L.fuse2d)
-int residRestrict2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse)
+// The restricted blocks the kernels before this have finished -- in upbuf (children whose parent lives on another rank) or, when
+// the coarse level lives on EVERY rank (repl_up, TE_REPLICATE: every parent is local), in the local coarse patches, from where the
+// quadrants are copied out once and sent to everybody -- and the other ranks' blocks into the local coarse patches. The 2D twin of
+// gmg_ghosts3d.hpp shipRestricted (block form). Replaces GMG/InterLevelComm.h:169-189 (scatter / scatterReverse).
+static int shipRestricted2d(te_gmg *g, LevelHost &L, double *coarse)
 {
-	if (L.P == 0) return TE_OK; // a rank without patches on this level (fuse2d: it has no transfers either)
-	int rc = prepareGhosts2d(g, L, u);
+	if (L.repl_up && L.n_up > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_up * L.nc / 4);
+		hipLaunchKernelGGL(k_prolong_pack2d, dim3(L.n_up), dim3(256), 0, g->stream, L.n, L.bc_desc.p, L.up_off.p, coarse, L.upbuf.p);
+	}
+	int rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p);
 	if (rc) return rc;
-	const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
-	Timed        t(g, KC_RESID_RESTRICT, (size_t) L.P * L.nc);
-	hipLaunchKernelGGL(k_resid_restrict2d_lds, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f,
-	                   Prolong2D{L.parent.p, L.orth.p, nullptr}, coarse);
+	if (L.n_down > 0) {
+		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 4);
+		hipLaunchKernelGGL(k_restrict_unpack2d, dim3(L.n_down), dim3(256), 0, g->stream, L.n, L.down_desc.p, L.down_off.p, L.downbuf.p, coarse);
+	}
 	HIPCHK(hipGetLastError());
 	return TE_OK;
+}
+
+// coarse f = AvgRstr(f - A u) in one pass (levels with L.fuse2d: every parent local -- no transfers at all, or the coarse level
+// lives on every rank and the finished blocks travel afterwards)
+int residRestrict2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse)
+{
+	if (L.P > 0) {
+		int rc = prepareGhosts2d(g, L, u);
+		if (rc) return rc;
+		const size_t lds = sizeof(double) * ((size_t) (L.n + 2) * (L.n + 2) + 16);
+		Timed        t(g, KC_RESID_RESTRICT, (size_t) L.P * L.nc);
+		hipLaunchKernelGGL(k_resid_restrict2d_lds, dim3(L.P), dim3(256), lds, g->stream, L.dev2(), u, f,
+		                   Prolong2D{L.parent.p, L.orth.p, nullptr}, coarse);
+		HIPCHK(hipGetLastError());
+	}
+	return L.repl_up ? shipRestricted2d(g, L, coarse) : TE_OK; // (a rank without patches here still receives the others' blocks)
 }
 
 // *swapped: the result went to s1 (= L.t) instead of u: the caller exchanges the two vectors' buffers
@@ -124,7 +146,8 @@ bool ps2dResidFusable(const te_gmg *g, const LevelHost &L)
 }
 bool patchSolve2dFusable(const te_gmg *g, const LevelHost &L)
 {
-	return ps2dResidFusable(g, L) && (L.matsT.p || L.P == 0) && L.fuse2d && L.prolong_fusable && L.tx_up.empty() && L.n_down == 0 && !L.repl_up;
+	// (repl_up: the coarse level lives on every rank -- the blocks that travel serve the restriction only)
+	return ps2dResidFusable(g, L) && (L.matsT.p || L.P == 0) && L.fuse2d && L.prolong_fusable && (L.repl_up || (L.tx_up.empty() && L.n_down == 0));
 }
 
 // Cycle.h:57-65 after one block-Jacobi sweep from the zero iterate: inside a patch the residual of an exact patch solve vanishes
@@ -142,14 +165,9 @@ int interfaceResidRestrict2d(te_gmg *g, LevelHost &L, const double *u, double *c
 		hipLaunchKernelGGL(k_restrict_fixup2d, dim3(L.P), dim3(128), 0, g->stream, L.dev2(), u, (const double *) nullptr,
 		                   Prolong2D{L.parent.p, L.orth.p, nullptr}, coarse, L.upbuf.p, L.up_off.p, true);
 	}
-	// children whose parent lives on another rank: ship the finished blocks (as zeroSweepResid2d)
-	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
-	if (L.n_down > 0) {
-		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 4);
-		hipLaunchKernelGGL(k_restrict_unpack2d, dim3(L.n_down), dim3(256), 0, g->stream, L.n, L.down_desc.p, L.down_off.p, L.downbuf.p, coarse);
-	}
+	// children whose parent lives on another rank, or a coarse level on every rank: ship the finished blocks (as zeroSweepResid2d)
 	HIPCHK(hipGetLastError());
-	return TE_OK;
+	return shipRestricted2d(g, L, coarse);
 }
 
 int patchSolve2d(te_gmg *g, LevelHost &L, const double *f, double *u, double *s0, double *s1, bool zero_guess, bool *swapped,
@@ -332,7 +350,7 @@ int restrict2d(te_gmg *g, LevelHost &L, const double *fine, double *coarse)
 
 int prolong2d(te_gmg *g, LevelHost &L, const double *coarse, double *fine)
 {
-	if (L.n_down > 0) {
+	if (L.n_down > 0 && !L.repl_up) { // (above a level that lives on every rank nothing travels back up: every parent is local)
 		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 4);
 		hipLaunchKernelGGL(k_prolong_pack2d, dim3(L.n_down), dim3(256), 0, g->stream, L.n, L.down_desc.p, L.down_off.p, coarse,
 		                   L.downbuf.p);
@@ -408,14 +426,9 @@ int zeroSweepResid2d(te_gmg *g, LevelHost &L, const double *f, double *out, doub
 		hipLaunchKernelGGL(k_restrict_fixup2d, dim3(L.P), dim3(128), 0, g->stream, L.dev2(), out,
 		                   store_u ? (const double *) nullptr : (const double *) L.e4buf.p, dst, coarse, L.upbuf.p, L.up_off.p);
 	}
-	// children whose parent lives on another rank: ship the finished blocks
-	if ((rc = doExchange(g, 2, L.tx_up, L.upbuf.p, L.downbuf.p))) return rc;
-	if (L.n_down > 0) {
-		Timed t(g, KC_PACK, (size_t) L.n_down * L.nc / 4);
-		hipLaunchKernelGGL(k_restrict_unpack2d, dim3(L.n_down), dim3(256), 0, g->stream, L.n, L.down_desc.p, L.down_off.p, L.downbuf.p, coarse);
-	}
+	// children whose parent lives on another rank, or a coarse level on every rank: ship the finished blocks
 	HIPCHK(hipGetLastError());
-	return TE_OK;
+	return shipRestricted2d(g, L, coarse);
 }
 
 int resweepProlong2d(te_gmg *g, LevelHost &L, const double *f, double *out, const double *prolong_from)

@@ -332,7 +332,7 @@ Hierarchy Hierarchy::build(const Tree &t, int n, bool neumann, int max_levels,
 		// rank in loop-back, profiles/r04_mr8_budget.txt)
 		h.agglomerate     = pl.agglomerate >= 0 ? pl.agglomerate : 64.0;
 		h.agglomerate_max = pl.agglomerate_max >= 0 ? pl.agglomerate_max : 64;
-		h.replicate       = (h.dim == 3 && (pl.replicate < 0 || pl.replicate != 0)) ? 1 : 0;
+		h.replicate       = (pl.replicate < 0 || pl.replicate != 0) ? 1 : 0; // (round 5: 2D hierarchies as well)
 		if (nranks > 1) {
 			const double agg = h.agglomerate;
 			const int    cap = h.agglomerate_max;
