@@ -204,7 +204,7 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
  * caller that has finished solving and wants the memory back (the next te_bicgstab allocates them again). */
 int te_gmg_release_workspace(te_gmg *g);
 
-/* The TE_* switches are read from the environment once, in te_gmg_create. This call sets (value) or
+/* The TE_* switches (docs/SWITCHES.md) are read from the environment once, in te_gmg_create. This call sets (value) or
  * clears (NULL) one of them for this solver afterwards -- how the tests pin one implementation against another. TE_ESTATE
  * for the few that shape the level tables and are therefore fixed at creation; TE_EINVAL for an unknown name. */
 int te_gmg_set_option(te_gmg *g, const char *name, const char *value);

@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libte_hip.so")
+# (TE_HIP_LIB_PATH: tooling -- another build of the library, build.build_variant, for same-box A/B runs)
+LIB_PATH = os.environ.get("TE_HIP_LIB_PATH") or os.path.join(_HERE, "libte_hip.so")
 
 
 class TeError(RuntimeError):

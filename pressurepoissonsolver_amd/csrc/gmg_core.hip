@@ -763,6 +763,10 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 		{ // partial sums: the reduction kernels' blocks, or one pair per work item of a stencil launch with fused sums (<= 8 slabs per patch)
 			size_t items = (size_t) g->red_blocks;
 			for (auto &L : g->levels) items = std::max(items, (size_t) L->P * (L->P <= 64 ? 8 : (L->P < 2048 ? 4 : 1)));
+			// 2D: one pair per workgroup of k_stencil2d's FLAT grid (one x-pair per thread: a capped grid-stride loop streams a third
+			// slower on this chip and cost the fused sums more than the passes they replace)
+			for (auto &L : g->levels)
+				if (L->dim == 2) items = std::max(items, ((size_t) L->P * L->nc / 2 + 255) / 256);
 			if ((rc = g->partial.alloc(2 * items)) || (rc = g->result.alloc(8))) return rc;
 		}
 		HIPCHK(hipHostMalloc((void **) &g->result_host, 8 * sizeof(double), hipHostMallocDefault));
@@ -1051,7 +1055,7 @@ int te_gmg_release_workspace(te_gmg *g)
 	});
 }
 
-// One TE_* switch of this solver: value == NULL clears it (back to the default). te_gmg_create reads all of
+// One TE_* switch (docs/SWITCHES.md) of this solver: value == NULL clears it (back to the default). te_gmg_create reads all of
 // them from the environment once; afterwards this is the only way to change one. Switches that shape the level tables
 // (TE_2D_SIMPLE, TE_NO_CFP, TE_2D_NO_MR_FUSE, TE_NO_OVERLAP, TE_EXCHANGE_TIMEOUT) are fixed at creation: TE_ESTATE.
 int te_gmg_set_option(te_gmg *g, const char *name, const char *value)

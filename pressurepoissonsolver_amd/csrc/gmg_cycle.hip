@@ -447,7 +447,7 @@ int te_residual_norm_sq(te_gmg *g, int level, const te_vec *u, const te_vec *f, 
 			if (L.P == 0) return TE_OK;
 			int blocks = 0;
 			if ((rc = residualSumsq2d(g, L, u->d, f->d, r->d, &blocks))) return rc;
-			hipLaunchKernelGGL(k_reduce_final<RED_SUMSQ>, dim3(1), dim3(256), 0, g->stream, blocks, g->partial.p, g->result.p);
+			hipLaunchKernelGGL(k_reduce_final2, dim3(1), dim3(256), 0, g->stream, blocks, g->partial.p, g->result.p);
 			if ((rc = finishReduce(g, 1, 0, false))) return rc;
 			*norm_sq = g->result_host[0];
 			return TE_OK;

@@ -76,7 +76,7 @@ enum KClass : int {
 };
 extern const char *kclassName[KC_COUNT]; // (gmg_core.hip)
 
-// Every TE_* switch of this library. They are read from the environment ONCE, in te_gmg_create;
+// Every TE_* switch of this library (docs/SWITCHES.md). They are read from the environment ONCE, in te_gmg_create;
 // te_gmg_set_option changes one afterwards (the tests pin one implementation against another that way). Nothing on a
 // launch path looks at the environment.
 enum Opt : int {
@@ -617,10 +617,11 @@ int patchSolve(te_gmg *g, LevelHost &L, const double *f, double *u, bool zero_gu
 int doRestrict(te_gmg *g, int fine_level, const double *fine, double *coarse);
 int doProlong(te_gmg *g, int fine_level, const double *coarse, double *fine);
 // ---- gmg_launch2d.hip
-template <int MODE> int launchStencil2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega);
-extern template int launchStencil2d<MODE_APPLY>(te_gmg *, LevelHost &, const double *, const double *, double *, double);
-extern template int launchStencil2d<MODE_RESID>(te_gmg *, LevelHost &, const double *, const double *, double *, double);
-extern template int launchStencil2d<MODE_JACOBI>(te_gmg *, LevelHost &, const double *, const double *, double *, double);
+template <int MODE> int launchStencil2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega, int redmode = RED_NONE,
+                                        const double *red_a = nullptr, int *red_items = nullptr);
+extern template int launchStencil2d<MODE_APPLY>(te_gmg *, LevelHost &, const double *, const double *, double *, double, int, const double *, int *);
+extern template int launchStencil2d<MODE_RESID>(te_gmg *, LevelHost &, const double *, const double *, double *, double, int, const double *, int *);
+extern template int launchStencil2d<MODE_JACOBI>(te_gmg *, LevelHost &, const double *, const double *, double *, double, int, const double *, int *);
 int residualSumsq2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, int *blocks);
 int launchRbgs2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, bool zero_guess = false, const double *prolong_from = nullptr);
 int residRestrict2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *coarse);

@@ -87,6 +87,10 @@ int te_bicgstab(te_gmg *g, const te_cycle_opts *o, te_vec *x, const te_vec *b, i
 		// (:57-60) are formed by the stencil kernel itself while its result is in registers (k_stencil3d RED, 3D; fixed
 		// summation order per launch geometry): 16 B/site per dot that a separate pass over stored vectors would read.
 		// TE_NO_BICG_FUSE: the separate passes (k_reduce / k_bicg_omega), as before round 3.
+		// 2D: k_stencil2d has the same sums (RED; te_residual_norm_sq uses them) but the solve does not: measured at 4096^2 (round 5,
+		// same box, alternating) the fused form is SLOWER, 9.33 -> 9.60 ms per solve -- the vectors of a 2D problem that size sit in
+		// the Infinity Cache, where a separate dot-product pass costs less than the second operand and the block sums cost the
+		// stencil kernel.
 		const bool   fused = g->dim == 3 && !g->cfg.has(O_NO_BICG_FUSE);
 		g->keep_final_xf   = fused && o != nullptr && !g->cfg.has(O_NO_XF) && !g->cfg.has(O_NO_BICG_XF);
 		LevelHost   &L0    = *g->levels[0];

@@ -21,10 +21,34 @@ int prepareGhosts2d(te_gmg *g, LevelHost &L, const double *u)
 	return TE_OK;
 }
 
-template <int MODE> int launchStencil2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega)
+// redmode != RED_NONE (APPLY, RESID): the kernel leaves one pair of partial sums per workgroup in g->partial (red_a: the second
+// operand of the dot product); *red_items = their number (the caller runs k_reduce_final2 over them) -- the 2D twin of
+// k_stencil3d's RED: te_bicgstab's dot products and the residual norm without passes of their own
+template <int MODE> int launchStencil2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, double omega, int redmode,
+                                        const double *red_a, int *red_items)
 {
+	if (red_items) *red_items = 0;
 	int rc = prepareGhosts2d(g, L, u);
 	if (rc) return rc;
+	if (redmode != RED_NONE && L.P > 0) {
+		if constexpr (MODE == MODE_JACOBI) {
+			return te::fail(TE_EUNSUPPORTED, "fused sums: operator application and residual only");
+		} else {
+			// a FIXED grid per level size (the partial sums' order must not depend on anything else): flat, one x-pair per thread
+			// (g->partial holds a pair per workgroup of the largest 2D level, te_gmg_create)
+			const int blocks = gridFor((size_t) L.P * L.nc / 2, 256, (int) std::min<size_t>((size_t) 1 << 30, g->partial.n / 2));
+			Timed     t(g, MODE == MODE_APPLY ? KC_APPLY_DOT : KC_RESID, (size_t) L.P * L.nc);
+			if (redmode == RED_OUT_A)
+				hipLaunchKernelGGL((k_stencil2d<MODE, RED_OUT_A>), dim3(blocks), dim3(256), 0, g->stream, L.dev2(), u, f, out, omega, g->partial.p, red_a);
+			else if (redmode == RED_OUT_A_OUT)
+				hipLaunchKernelGGL((k_stencil2d<MODE, RED_OUT_A_OUT>), dim3(blocks), dim3(256), 0, g->stream, L.dev2(), u, f, out, omega, g->partial.p, red_a);
+			else
+				hipLaunchKernelGGL((k_stencil2d<MODE, RED_OUT_OUT>), dim3(blocks), dim3(256), 0, g->stream, L.dev2(), u, f, out, omega, g->partial.p, red_a);
+			if (red_items) *red_items = blocks;
+			HIPCHK(hipGetLastError());
+			return TE_OK;
+		}
+	}
 	Timed t(g, MODE == MODE_APPLY ? KC_APPLY : (MODE == MODE_RESID ? KC_RESID : KC_JACOBI), (size_t) L.P * L.nc);
 	hipLaunchKernelGGL(k_stencil2d<MODE>, dim3(gridFor((size_t) L.P * L.nc / 2, 256, 65536)), dim3(256), 0, g->stream, L.dev2(),
 	                   u, f, out, omega);
@@ -32,17 +56,11 @@ template <int MODE> int launchStencil2d(te_gmg *g, LevelHost &L, const double *u
 	return TE_OK;
 }
 
-// r = f - A u together with the partial sums of its squares, one per workgroup, in g->partial (*blocks of them): the residual norm
-// without a second pass over r (the 2D twin of k_stencil3d's RED_OUT_OUT)
+// r = f - A u together with the partial sums of its squares, one PAIR per workgroup, in g->partial (*blocks of them): the residual
+// norm without a second pass over r
 int residualSumsq2d(te_gmg *g, LevelHost &L, const double *u, const double *f, double *out, int *blocks)
 {
-	int rc = prepareGhosts2d(g, L, u);
-	if (rc) return rc;
-	*blocks = gridFor((size_t) L.P * L.nc / 2, 256, (int) std::min<size_t>((size_t) g->red_blocks, g->partial.n));
-	Timed t(g, KC_RESID, (size_t) L.P * L.nc);
-	hipLaunchKernelGGL((k_stencil2d<MODE_RESID, true>), dim3(*blocks), dim3(256), 0, g->stream, L.dev2(), u, f, out, 0.0, g->partial.p);
-	HIPCHK(hipGetLastError());
-	return TE_OK;
+	return launchStencil2d<MODE_RESID>(g, L, u, f, out, 0.0, RED_OUT_OUT, nullptr, blocks);
 }
 
 // 64^2 patches: 512 threads per workgroup (four x-pairs per thread instead of eight: half the registers, twice the waves per
@@ -451,8 +469,8 @@ int resweepProlong2d(te_gmg *g, LevelHost &L, const double *f, double *out, cons
 	return TE_OK;
 }
 
-template int launchStencil2d<MODE_APPLY>(te_gmg *, LevelHost &, const double *, const double *, double *, double);
-template int launchStencil2d<MODE_RESID>(te_gmg *, LevelHost &, const double *, const double *, double *, double);
-template int launchStencil2d<MODE_JACOBI>(te_gmg *, LevelHost &, const double *, const double *, double *, double);
+template int launchStencil2d<MODE_APPLY>(te_gmg *, LevelHost &, const double *, const double *, double *, double, int, const double *, int *);
+template int launchStencil2d<MODE_RESID>(te_gmg *, LevelHost &, const double *, const double *, double *, double, int, const double *, int *);
+template int launchStencil2d<MODE_JACOBI>(te_gmg *, LevelHost &, const double *, const double *, double *, double, int, const double *, int *);
 } // namespace tei
 

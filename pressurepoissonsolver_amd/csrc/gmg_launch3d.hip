@@ -77,11 +77,10 @@ template <int MODE> int launchStencil(te_gmg *g, LevelHost &L, const double *u, 
 	if (red_items) *red_items = 0;
 	if (L.P == 0) return TE_OK;
 	if (L.dim == 2) {
-		if (redmode != RED_NONE) return te::fail(TE_EUNSUPPORTED, "fused sums exist for the 3D stencil kernel only");
 		if constexpr (MODE == MODE_RESID_RESTRICT)
 			return te::fail(TE_EUNSUPPORTED, "fused residual+restrict has no 2D kernel");
 		else
-			return launchStencil2d<MODE>(g, L, u, f, out, omega);
+			return launchStencil2d<MODE>(g, L, u, f, out, omega, redmode, red_a, red_items);
 	}
 	switch (L.n) {
 		case 4: return launchStencilN<4, MODE>(g, L, u, f, out, omega, rd, xf_in, redmode, red_a, red_items);

@@ -60,16 +60,19 @@ __device__ __forceinline__ double offdiag2d(double xl, double xr, double yl, dou
 }
 
 // MODE_APPLY / MODE_RESID / MODE_JACOBI as in k_stencil3d
-// SUMSQ (te_residual_norm_sq, Vector.h:294 twoNorm before its MPI_Allreduce and sqrt): the sum of the squares of the result is formed
-// while it is in registers -- per thread in the order of its grid-stride loop, then wave shuffles -> LDS -> one partial per
-// workgroup in partial[blockIdx.x]; the caller's k_reduce_final adds those in a fixed order (a fixed grid: deterministic).
-template <int MODE, bool SUMSQ = false>
+// RED (march3d.hpp StencilRed; te_residual_norm_sq and te_bicgstab, Vector.h:294,319 before their MPI_Allreduce): sums over the result
+// formed while it is in registers -- RED_OUT_OUT: sum out^2; RED_OUT_A: sum out * a; RED_OUT_A_OUT: sum out * a and sum out^2 --
+// per thread in the order of its grid-stride loop, then wave shuffles -> LDS -> one PAIR per workgroup in partial[2 blockIdx.x],
+// [2 blockIdx.x + 1] (RED_OUT_OUT: (sum, 0)); the caller's k_reduce_final2 adds the pairs in a fixed order (a fixed grid:
+// deterministic). No second pass over the result: 16 B per site and dot product that a k_reduce launch would read.
+template <int MODE, int RED = RED_NONE>
 __global__ __launch_bounds__(256) void k_stencil2d(Level2D L, const double *__restrict__ u, const double *__restrict__ f,
-                                                   double *__restrict__ out, double omega, double *__restrict__ partial = nullptr)
+                                                   double *__restrict__ out, double omega, double *__restrict__ partial = nullptr,
+                                                   const double *__restrict__ a = nullptr)
 {
 	const int    n = L.n, h = n / 2;
 	const size_t total = (size_t) L.P * n * h;
-	double       ssq   = 0.0;
+	double       s0 = 0.0, s1 = 0.0;
 	for (size_t idx = (size_t) blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t) gridDim.x * blockDim.x) {
 		const int     p = (int) (idx / ((size_t) n * h)), q = (int) (idx % ((size_t) n * h));
 		const int     y = q / h, x = 2 * (q % h);
@@ -107,14 +110,23 @@ __global__ __launch_bounds__(256) void k_stencil2d(Level2D L, const double *__re
 			}
 		}
 		*reinterpret_cast<double2 *>(out + (size_t) p * n * n + x + n * y) = r;
-		if (SUMSQ) {
-			ssq += r.x * r.x;
-			ssq += r.y * r.y;
+		if (RED == RED_OUT_OUT) {
+			s0 += r.x * r.x;
+			s0 += r.y * r.y;
+		}
+		if (RED == RED_OUT_A || RED == RED_OUT_A_OUT) {
+			const double2 av = *reinterpret_cast<const double2 *>(a + (size_t) p * n * n + x + n * y);
+			s0 += r.x * av.x;
+			s0 += r.y * av.y;
+			if (RED == RED_OUT_A_OUT) {
+				s1 += r.x * r.x;
+				s1 += r.y * r.y;
+			}
 		}
 	}
-	if (SUMSQ) {
-		ssq = blockReduce<RED_SUMSQ>(ssq);
-		if (threadIdx.x == 0) partial[blockIdx.x] = ssq;
+	if (RED != RED_NONE) {
+		blockReduce2(s0, s1);
+		if (threadIdx.x == 0) partial[2 * blockIdx.x] = s0, partial[2 * blockIdx.x + 1] = s1;
 	}
 }
 

@@ -1707,6 +1707,25 @@ __global__ __launch_bounds__(Tile3<N>::TPB, (V & 32) ? 2 : 3) void k_rbgs_reswee
 	// before its first use (one load per coarse plane instead of one per fine plane).
 	double hA = hs.p[0], hB = chalo[0];
 	double cnx = CFP ? 0.0 : cown[NN * 1 + cq], ccur = 0.0; // N >= 4: planes 2 and 3 share coarse plane 1
+	// CFP: the correction of the own patch's plane p, rows k = 0, 1, WITHOUT a branch in the march (a load under a condition makes
+	// the compiler wait for every request in flight where the branch rejoins -- on every step) and one step ahead of its use, like
+	// the halo operands: one 16-byte load per row from (base, plane stride, offset) chosen once per patch -- a patch that copies
+	// through reads its two cells of the same-size coarse patch; an octant child the aligned pair that holds its coarse cell and
+	// takes the half it needs (two 32-bit selects per value: not fp64 work).
+#ifndef TE_CFP_AHEAD
+#define TE_CFP_AHEAD 0 // 1: the pairs are requested a whole step ahead (8 more registers across the step: spills at 168)
+#endif
+	const double *cfb  = cpo ? yown : cown;
+	const int     cfo0 = cpo ? (2 * Yp + 0) * N + 2 * X : (cq & ~1), cfd = cpo ? N : 0; // (row 1: cfo0 + cfd)
+	const bool    cfy  = !cpo && (cq & 1);
+	auto cfLoad = [&](int p, double2(&dst)[2]) { // (p clamped by the caller)
+		const double *b = cfb + (size_t) NN * (cpo ? p : (p >> 1)) + cfo0;
+		dst[0]          = *reinterpret_cast<const double2 *>(b);
+		dst[1]          = *reinterpret_cast<const double2 *>(b + cfd);
+	};
+	auto cfPick = [&](const double2 &d) { return cpo ? d : (cfy ? double2{d.y, d.y} : double2{d.x, d.x}); };
+	double2 cfn[2]; // the raw pairs of the plane the NEXT step adds its correction to
+	if (CFP && TE_CFP_AHEAD) cfLoad(2, cfn);
 
 	int bz = 0; // z % 3
 	// LAST: the three steps z = N-2, N-1, N, whose plane z+2 is the top neighbour's: code of their own, so that the loads they
@@ -1729,6 +1748,15 @@ __global__ __launch_bounds__(Tile3<N>::TPB, (V & 32) ? 2 : 3) void k_rbgs_reswee
 			ccur = takeReg(cnx);
 			cnx  = (z + 4 < N) ? cown[NN * ((z + 4) >> 1) + cq] : ctop[cq];
 		}
+		if constexpr (CFP && !LAST) {
+			if constexpr (TE_CFP_AHEAD) { // plane z+2's correction arrived a step ago; plane z+3's is requested now
+#pragma unroll
+				for (int k = 0; k < 2; k++) c2v[k] = cfPick(takeRegs(cfn[k]));
+				cfLoad(z + 3 < N ? z + 3 : N - 1, cfn);
+			} else { // requested FIRST in this step, used behind its barrier: the wait leaves the ring's refill (below) in flight
+				cfLoad(z + 2, cfn);
+			}
+		}
 		__builtin_amdgcn_sched_barrier(0);
 		// the right-hand sides move down one plane; plane z+2 leaves the ring and its slot is requested again
 #pragma unroll
@@ -1744,12 +1772,11 @@ __global__ __launch_bounds__(Tile3<N>::TPB, (V & 32) ? 2 : 3) void k_rbgs_reswee
 			fc.apply(fr[S3], ccr[S3]); // plane z+3: first read below
 		}
 		const double c2 = CFP ? 0.0 : (!LAST ? ccur : stop * ccur);
-		if (CFP) {
+		if constexpr (CFP && LAST) { // (the top neighbour's plane: three steps of 34, loaded where it is used)
 #pragma unroll
 			for (int k = 0; k < 2; k++) {
-				const double2 c  = !LAST ? ownC(k, z + 2) : topC(k);
-				const double  cs = !LAST ? 1.0 : stop;
-				c2v[k]           = double2{cs * c.x, cs * c.y};
+				const double2 c = topC(k);
+				c2v[k]          = double2{stop * c.x, stop * c.y};
 			}
 		}
 		double2      tg[2];
@@ -1778,7 +1805,10 @@ __global__ __launch_bounds__(Tile3<N>::TPB, (V & 32) ? 2 : 3) void k_rbgs_reswee
 		if constexpr (!LAST) {
 			fillBlack(zpar, z + 2, tvz, r2, r1, r3, f2);
 #pragma unroll
-			for (int k = 0; k < 2; k++) un2[k] = CFP ? double2{r2[k].x + c2v[k].x, r2[k].y + c2v[k].y} : double2{r2[k].x + c2, r2[k].y + c2};
+			for (int k = 0; k < 2; k++) {
+				if constexpr (CFP && !TE_CFP_AHEAD) c2v[k] = cfPick(cfn[k]);
+				un2[k] = CFP ? double2{r2[k].x + c2v[k].x, r2[k].y + c2v[k].y} : double2{r2[k].x + c2, r2[k].y + c2};
+			}
 		} else {
 #pragma unroll
 			for (int k = 0; k < 2; k++)
