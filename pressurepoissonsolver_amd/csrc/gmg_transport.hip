@@ -497,7 +497,7 @@ static int pushSetup(te_gmg *g)
 		for (int k = 0; k < n; k++) dir[i + k] = g->result_host[k];
 	}
 	for (int r = 0; r < R; r++) {
-		if (dir[(size_t) r * W + D_OK] == 1.0) continue;
+		if (dir[(size_t) r * W + D_OK] == 1.0 || (self && r != g->rank)) continue; // (loop-back: nobody but this rank published anything)
 		pushTeardown(g); // every rank sees the same directory: all leave here together
 		if (r == g->rank) return te::fail(local_rc, "te_gmg_use_push: " + local_msg);
 		return te::fail(TE_ESTATE, "te_gmg_use_push: rank " + std::to_string(r) + " could not set up its buffers");
