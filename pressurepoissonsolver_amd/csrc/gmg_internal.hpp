@@ -525,7 +525,7 @@ void pushTeardown(te_gmg *g, bool final = false); // frees what te_gmg_use_push'
 // that claims to be two exchanges ahead ("overrun": ep + 2, the receiver's check PUSH_ERR_OVERRUN)
 inline unsigned long long pushRaiseValue(const te_gmg *g, unsigned long long ep)
 {
-	if (!g->cfg.has(O_PUSH_FAULT) || !strcmp(g->cfg.str(O_PUSH_FAULT), "nonce")) return ep;
+	if (!g->cfg.has(O_PUSH_FAULT) || !strcmp(g->cfg.str(O_PUSH_FAULT), "nonce") || !strncmp(g->cfg.str(O_PUSH_FAULT), "setup:", 6)) return ep;
 	return !strcmp(g->cfg.str(O_PUSH_FAULT), "overrun") ? ep + 2 : ep - 1;
 }
 

@@ -447,6 +447,10 @@ static int pushSetup(te_gmg *g)
 		return TE_OK;
 	};
 	int         local_rc  = allocate();
+	// (TE_PUSH_FAULT=setup:<rank>, diagnostic: that rank's set-up "fails" after its allocations -- every rank must come back with an
+	// error, nobody may wait for it, and a later attempt must start clean)
+	if (!local_rc && g->cfg.has(O_PUSH_FAULT) && !strncmp(g->cfg.str(O_PUSH_FAULT), "setup:", 6) && atoi(g->cfg.str(O_PUSH_FAULT) + 6) == g->rank)
+		local_rc = te::fail(TE_ENOMEM, "injected set-up failure (TE_PUSH_FAULT)");
 	std::string local_msg = local_rc ? std::string(te_last_error()) : std::string();
 	// ---- the directory: per rank [ok, pid, nonce (2), host, flags (handle 16 + pointer 2), per level: 4 x (handle 16 + pointer 2), R x recv offset 2]
 	const int      D_OK = 0, D_PID = 1, D_NONCE = 2, D_HOST = 4, D_FLAGS = 5;

@@ -609,6 +609,45 @@ def test_direct_store_fake_nonce_body():
     assert np.array_equal(got["u"], want)
 
 
+def test_direct_store_setup_failure_is_collective_and_leaves_nothing_behind():
+    """one rank's set-up of the direct-store transport fails (TE_PUSH_FAULT=setup:1): BOTH ranks come back with an error -- the
+    failing rank still takes part in the directory reductions, so nobody waits for it until a watchdog fires -- and what was
+    allocated or mapped is released: the next attempt, without the fault, succeeds and computes the single-rank result"""
+    run_inner("direct_store_setup_failure_body", "5")
+
+
+@pytest.mark.skipif(os.environ.get("TE_DIRECT_STORE_INNER") != "1", reason="runs in a process of its own")
+def test_direct_store_setup_failure_body():
+    n = 8
+    mesh = util.mesh("uniform", 3)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    f = util.rand_vec(H1.cells(0), 11)
+    d1 = g1.new_vector(0)
+    g1.cycle(g1.default_opts(smoother=capi.SMOOTH_RBGS), g1.new_vector(0, f), d1)
+    want = d1.download()
+    nc = n ** 3
+
+    def per_rank(r, H, g, fab):
+        g.set_option("TE_PUSH_FAULT", "setup:1")
+        try:
+            g.use_push(True)
+            msg = ""
+        except capi.TeError as e:
+            msg = str(e)
+        g.set_option("TE_PUSH_FAULT", None)
+        fab.barrier.wait()
+        g.use_push(True)  # a clean second attempt
+        df, du = g.new_vector(0, f.reshape(-1, nc)[H.l2g(0)].ravel()), g.new_vector(0)
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+        return {"msg": msg, "u": du.download(), "failed": g.push_failed()}
+
+    got = shard_run(mesh, n, 2, per_rank)
+    assert "injected set-up failure" in got["msg"][1] and "rank 1 could not set up" in got["msg"][0], got["msg"]
+    assert got["failed"] == [0, 0]
+    assert np.array_equal(got["u"], want)
+
+
 def test_checksum_is_independent_of_order_and_partition():
     """te_vec_checksum = the sum modulo 2^64 of the values' bit patterns: equal to numpy's on the downloaded vector, unchanged by
     a permutation of the patches, and the sum of the ranks' parts of a sharded cycle equals the single-rank cycle's (the equality
