@@ -259,8 +259,12 @@ int te_gmg_autotune(te_gmg *g, const te_cycle_opts *o, int reps, double *best_ms
  * hipIpcOpenMemHandle -- and raises a flag there; a one-workgroup kernel on the receiver's stream waits for the flags. Two
  * small launches per exchange instead of an RCCL group. enable != 0: prepares it (collective; once; needs te_gmg_use_rccl or
  * te_gmg_set_allreduce, through which the handles and receive offsets are published) and switches it on; 0: switches back.
- * Results are bit-identical either way. A wait is bounded (TE_PUSH_TIMEOUT seconds, default 20): te_gmg_push_failed then
- * returns 1 and the watchdog ends the process as for any exchange that never completes. te_gmg_autotune, when this
+ * Results are bit-identical either way. A wait is bounded (TE_PUSH_TIMEOUT seconds; default: TE_EXCHANGE_TIMEOUT; at most 5 s inside
+ * te_gmg_autotune's trial), and the kernels check the protocol themselves (csrc/pushkernels.hpp): te_gmg_push_failed returns 0, or
+ * the first failure's code -- 1 a wait gave up, 2 a peer's flag was two exchanges ahead, 3 a peer was behind when its buffer was
+ * overwritten, 4 this rank's epochs were out of sequence -- and the watchdog ends the process as for any exchange that never
+ * completes (unless TE_PUSH_NONFATAL leaves that to the caller). A set-up that fails on one rank fails on all (the failure travels
+ * with the directory reductions) and leaves nothing allocated or mapped. te_gmg_autotune, when this
  * transport has been prepared, first checks it against the other one ON THE MACHINE AT HAND (bit-identical result after a
  * cycle on different data, no wait given up, all ranks agreeing) and keeps it only if it passes and is faster.
  * The RCCL point-to-point path stays the default. Same replacement as te_gmg_use_rccl: SchurHelper.h:123-150,
