@@ -79,3 +79,78 @@ def test_march_never_waits_for_its_newest_loads(isa, frag, floor, why):
     w = waits_in(body, s, e)
     assert w and min(w) >= floor, (why, sorted(set(w)))
     assert not any("scratch_" in l for l in body[s:e + 1]), "register spills inside the march"
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# k_ps_sym (the reference smoother's patch solve): a plane is consumed a plane's worth of matrix instructions behind its request.
+# Round 5 found the instruction scheduler hoisting the first instructions of a plane's y transform -- butterflies that depend on
+# nothing but the plane's loads -- to right behind the request: `s_waitcnt vmcnt(5)` six MFMAs after sixteen loads, a whole HBM
+# latency exposed per patch (the zero-guess variant ran 8 % slower); vector-ALU scheduling fences in phase A stopped it.
+PS_SRC = os.path.join(ROOT, "pressurepoissonsolver_amd", "csrc", "gmg_patchsolve.hip")
+
+
+@pytest.fixture(scope="module")
+def ps_isa(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    out = tmp_path_factory.mktemp("isa_ps") / "ps.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip", PS_SRC, "-o", str(out)],
+                   check=True, capture_output=True, timeout=900)
+    lines = out.read_text().split("\n")
+    starts = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_ZN2te8k_ps_sym\w+:", l)]
+    bodies = {}
+    for i, name in starts:
+        end = next(e for e in range(i, len(lines)) if lines[e].startswith(".Lfunc_end"))
+        bodies[name] = lines[i:end]
+    return bodies, out.read_text()
+
+
+def events(body):
+    ev = []
+    for l in body:
+        m = re.search(r"s_waitcnt\s+vmcnt\((\d+)\)", l)
+        if m:
+            ev.append(("W", int(m.group(1))))
+        elif "global_load" in l:
+            ev.append(("L", 0))
+        elif "scratch_load" in l or "scratch_store" in l:
+            ev.append(("X", 0))
+        elif "v_mfma" in l:
+            ev.append(("m", 0))
+        elif "s_barrier" in l:
+            ev.append(("|", 0))
+    return ev
+
+
+@pytest.mark.parametrize("variant", ["ILb0ELb0E", "ILb0ELb1E"], ids=["zero-guess", "zero-guess-faces"])
+def test_patch_solve_planes_are_not_consumed_right_behind_their_request(ps_isa, variant):
+    bodies, text = ps_isa
+    name = next(n for n in bodies if variant in n)
+    ev = events(bodies[name])
+    assert not any(k == "X" for k, _ in ev), "k_ps_sym spills: scratch traffic waits for every plane in flight (in-order memory pipeline)"
+    m = re.search(re.escape(name) + r".*?\.vgpr_spill_count:\s+(\d+)", text, flags=re.S)
+    assert m and int(m.group(1)) == 0
+    # bursts of >= 12 plane loads (a matrix instruction or two may sit inside one); behind each: no wait that needs the burst's own
+    # loads (vmcnt <= 8) within the next 12 matrix instructions
+    i, bursts = 0, 0
+    while i < len(ev):
+        if ev[i][0] != "L":
+            i += 1
+            continue
+        j, loads, inner = i, 0, 0
+        while j < len(ev) and (ev[j][0] == "L" or (ev[j][0] == "m" and inner < 2 and j + 1 < len(ev) and ev[j + 1][0] == "L")):
+            loads += ev[j][0] == "L"
+            inner += ev[j][0] == "m"
+            j += 1
+        if loads >= 12:
+            bursts += 1
+            mf, k = 0, j
+            while k < len(ev) and mf < 12 and ev[k][0] != "|":
+                if ev[k][0] == "m":
+                    mf += 1
+                if ev[k][0] == "W":
+                    assert ev[k][1] > 8, (name, "a wait for loads just requested", [e for e in ev[i:k + 1]][-24:])
+                k += 1
+        i = j
+    assert bursts >= 4  # (the prologue's two planes, the two re-requests of phase A, the reciprocal tables, the prefetches)
