@@ -636,73 +636,6 @@ def run(a, json_out, rank, world, local_rank):
     triad_gbs = 20 * 24.0 * (H.sizes(0)[0] * n ** a.dim) / (time.perf_counter() - t1) / 1e9
     reduction = reduction_per_cycle(r)
 
-    # (f)1 beside the headline: the reference's own smoother (FFTBlockJacobiSmoother.h:55-58, the one cycle with per-V-cycle
-    # parity against the reference) timed by the same driver run, a dozen cycles, both roofs
-    secondary = None
-    if a.smoother == "rbgs" and not a.no_secondary and a.dim == 3 and n == 32 and os.environ.get("TE_BENCH_NOPROFILE") is None:
-        o2 = g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE)
-        k2, w2 = 20, 5  # (an MFMA-bound kernel's clock settles over the first cycles: the quoted figure is a MEDIAN of 20 behind 5)
-        m2 = measure(o2, k2, w2)
-        med2 = median_cycle_ms(o2, k2)
-        cs2 = checksum(u)
-        red2 = reduction_per_cycle(r)
-        if rank == 0 and m2["rows"]:
-            name2, st2 = max(((k, v) for k, v in m2["rows"].items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
-            ps_key = workload_key(argparse.Namespace(**{**vars(a), "smoother": "patch_solve"}))
-            secondary = {"reference_smoother": {
-                "what": "the same workload with the reference's block-Jacobi smoother (exact patch solves on the fp64 matrix cores), "
-                        "default options (fuse = 3)",
-                "steps": k2, "warmup": w2, "ms_per_step": m2["dt"] / k2 * 1e3, "ms_per_step_median": med2,
-                "value": cells_global[0] / (m2["dt"] / k2),
-                "unit": "lattice-site updates/s", "residual_reduction_per_cycle": red2, "u_checksum_after_timed_region": cs2,
-                "roofline": roofline_of(name2, st2, ps_key, world), "roofline_mfma": roofline_mfma_of(name2, st2, a.dim, n),
-                "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4)} for k, v in m2["rows_all"].items()}}}
-
-    # (f)2 in the driver's run: time to solution of the call a user makes (apps/3d/steady.cpp:519-524): BiCGStab (BiCGStab.h:45-106,
-    # tolerance 1e-12) preconditioned with one V-cycle, the drivers' trig problem on the same grid, both smoothers. A first solve
-    # warms up (work vectors, code), the second is timed between two synchronisations, a third runs with every kernel class
-    # timed and gives the algorithmic bytes per site and iteration.
-    if not a.no_secondary and not a.mesh and os.environ.get("TE_BENCH_NOPROFILE") is None:
-        solve = {}
-        sites_local = H.sizes(0)[0] * n ** a.dim
-        bb, xx = g.new_vector(0), g.new_vector(0)
-        g.init_problem(bb, None, problem=capi.PROBLEM_TRIG)
-        for sname in ("rbgs", "patch_solve"):
-            o3 = g.default_opts(smoother=smoothers[sname])
-            xx.set(0.0)
-            its, rr = g.bicgstab(xx, bb, o3)
-            xx.set(0.0)
-            barrier()
-            t0s = time.perf_counter()
-            its, rr = g.bicgstab(xx, bb, o3)
-            barrier()
-            dts = time.perf_counter() - t0s
-            x_cs = checksum(xx)
-            xx.set(0.0)
-            g.profile(True)
-            g.profile_select(None)
-            g.profile_reset()
-            g.bicgstab(xx, bb, o3)
-            prow = g.profile_rows()
-            g.profile(False)
-            if dist is not None:
-                tt = torch.tensor([dts], dtype=torch.float64, device=red_dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dts = float(tt.item())
-            cyc = {k for k in prow if k.startswith(("rbgs_", "stencil_rbgs", "stencil_slabs", "patch_solve", "restrict", "fcorr", "resid_restrict", "prolong", "patch_rhs", "dst_axis", "cf_ghost"))}
-            krylov = sum(ALG_BYTES.get(k, 8.0) * v["cells"] for k, v in prow.items() if k not in cyc and k not in ("exchange", "pack")) / max(its, 1) / max(sites_local, 1)
-            allb = sum(ALG_BYTES.get(k, 8.0) * v["cells"] for k, v in prow.items()) / max(its, 1) / max(sites_local, 1)
-            solve[sname] = {"iterations": its, "ms": dts * 1e3, "rel_resid": rr, "ms_per_iteration": dts * 1e3 / max(its, 1),
-                            # (equal across N only where the dot products are summed in the same order: informative, not an invariant)
-                            "x_checksum": x_cs,
-                            "alg_bytes_per_site_per_iteration": {"outside_the_two_cycles": krylov, "all_kernels": allb}}
-        del bb, xx
-        g.release_workspace()
-        if rank == 0:
-            secondary = secondary or {}
-            secondary["solve"] = {"what": f"te_bicgstab + one V(1,1) cycle as preconditioner to 1e-12, trig problem ({'apps/3d/steady.cpp:253-265' if a.dim == 3 else 'apps/2d/steady.cpp:314-318'}) on the benchmarked grid, "
-                                          "second of two solves, wall time between two synchronisations (max over ranks)", **solve}
-
     def fused_hbm(rows_w, profiled_warm, local_sites, sec_per_step, copy_sites_=0):
         """whole cycle against the bytes its fused kernels must move (a roofline fraction): the kernels' own algorithmic bytes from
         the warm-up table, every class that has an ALG_BYTES entry; the others are listed, not silently counted as zero"""
@@ -765,8 +698,6 @@ def run(a, json_out, rank, world, local_rank):
         rm = roofline_mfma_of(name, st, a.dim, n)
         if rm:
             out["roofline_mfma"] = rm
-        if secondary:
-            out["secondary"] = secondary
     else:
         out = None
 
@@ -774,6 +705,87 @@ def run(a, json_out, rank, world, local_rank):
         """under the supervisor (N > 1): the line as it stands, before a block that may end the process"""
         if out is not None and os.environ.get("TE_BENCH_WORKER") is not None:
             print(PROVISIONAL + json.dumps({**out, "next_block": next_block}), file=json_out, flush=True)
+
+    # from here on every block is optional: the line as it stands is handed to the supervisor (N > 1), and a block that fails
+    # leaves an `error` entry under its own name instead of taking the headline with it
+    provisional("the secondary blocks")
+
+
+    # (f)1 beside the headline: the reference's own smoother (FFTBlockJacobiSmoother.h:55-58, the one cycle with per-V-cycle
+    # parity against the reference) timed by the same driver run, a dozen cycles, both roofs
+    secondary = None
+    if a.smoother == "rbgs" and not a.no_secondary and a.dim == 3 and n == 32 and os.environ.get("TE_BENCH_NOPROFILE") is None:
+      try:
+        o2 = g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE)
+        k2, w2 = 20, 5  # (an MFMA-bound kernel's clock settles over the first cycles: the quoted figure is a MEDIAN of 20 behind 5)
+        m2 = measure(o2, k2, w2)
+        med2 = median_cycle_ms(o2, k2)
+        cs2 = checksum(u)
+        red2 = reduction_per_cycle(r)
+        if rank == 0 and m2["rows"]:
+            name2, st2 = max(((k, v) for k, v in m2["rows"].items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
+            ps_key = workload_key(argparse.Namespace(**{**vars(a), "smoother": "patch_solve"}))
+            secondary = {"reference_smoother": {
+                "what": "the same workload with the reference's block-Jacobi smoother (exact patch solves on the fp64 matrix cores), "
+                        "default options (fuse = 3)",
+                "steps": k2, "warmup": w2, "ms_per_step": m2["dt"] / k2 * 1e3, "ms_per_step_median": med2,
+                "value": cells_global[0] / (m2["dt"] / k2),
+                "unit": "lattice-site updates/s", "residual_reduction_per_cycle": red2, "u_checksum_after_timed_region": cs2,
+                "roofline": roofline_of(name2, st2, ps_key, world), "roofline_mfma": roofline_mfma_of(name2, st2, a.dim, n),
+                "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4)} for k, v in m2["rows_all"].items()}}}
+      except capi.TeError as e:  # (a failure of the library, the same on every rank; anything else ends the run through the supervisor)
+        secondary = {"reference_smoother": {"error": str(e)}}
+
+    # (f)2 in the driver's run: time to solution of the call a user makes (apps/3d/steady.cpp:519-524): BiCGStab (BiCGStab.h:45-106,
+    # tolerance 1e-12) preconditioned with one V-cycle, the drivers' trig problem on the same grid, both smoothers. A first solve
+    # warms up (work vectors, code), the second is timed between two synchronisations, a third runs with every kernel class
+    # timed and gives the algorithmic bytes per site and iteration.
+    if not a.no_secondary and not a.mesh and os.environ.get("TE_BENCH_NOPROFILE") is None:
+      try:
+        solve = {}
+        sites_local = H.sizes(0)[0] * n ** a.dim
+        bb, xx = g.new_vector(0), g.new_vector(0)
+        g.init_problem(bb, None, problem=capi.PROBLEM_TRIG)
+        for sname in ("rbgs", "patch_solve"):
+            o3 = g.default_opts(smoother=smoothers[sname])
+            xx.set(0.0)
+            its, rr = g.bicgstab(xx, bb, o3)
+            xx.set(0.0)
+            barrier()
+            t0s = time.perf_counter()
+            its, rr = g.bicgstab(xx, bb, o3)
+            barrier()
+            dts = time.perf_counter() - t0s
+            x_cs = checksum(xx)
+            xx.set(0.0)
+            g.profile(True)
+            g.profile_select(None)
+            g.profile_reset()
+            g.bicgstab(xx, bb, o3)
+            prow = g.profile_rows()
+            g.profile(False)
+            if dist is not None:
+                tt = torch.tensor([dts], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dts = float(tt.item())
+            cyc = {k for k in prow if k.startswith(("rbgs_", "stencil_rbgs", "stencil_slabs", "patch_solve", "restrict", "fcorr", "resid_restrict", "prolong", "patch_rhs", "dst_axis", "cf_ghost"))}
+            krylov = sum(ALG_BYTES.get(k, 8.0) * v["cells"] for k, v in prow.items() if k not in cyc and k not in ("exchange", "pack")) / max(its, 1) / max(sites_local, 1)
+            allb = sum(ALG_BYTES.get(k, 8.0) * v["cells"] for k, v in prow.items()) / max(its, 1) / max(sites_local, 1)
+            solve[sname] = {"iterations": its, "ms": dts * 1e3, "rel_resid": rr, "ms_per_iteration": dts * 1e3 / max(its, 1),
+                            # (equal across N only where the dot products are summed in the same order: informative, not an invariant)
+                            "x_checksum": x_cs,
+                            "alg_bytes_per_site_per_iteration": {"outside_the_two_cycles": krylov, "all_kernels": allb}}
+        del bb, xx
+        g.release_workspace()
+        if rank == 0:
+            secondary = secondary or {}
+            secondary["solve"] = {"what": f"te_bicgstab + one V(1,1) cycle as preconditioner to 1e-12, trig problem ({'apps/3d/steady.cpp:253-265' if a.dim == 3 else 'apps/2d/steady.cpp:314-318'}) on the benchmarked grid, "
+                                          "second of two solves, wall time between two synchronisations (max over ranks)", **solve}
+      except capi.TeError as e:
+        secondary = secondary or {}
+        secondary["solve"] = {"error": str(e)}
+    if out is not None and secondary:
+        out["secondary"] = secondary
 
     # N > 1: the OTHER transport. One more cycle on the headline's transport is the reference; then the direct-store transport
     # (te_gmg_use_push: hipIpc-mapped peer buffers, flags, bounded waits) is prepared, must reproduce that result BIT FOR BIT on
@@ -820,6 +832,10 @@ def run(a, json_out, rank, world, local_rank):
             del f2, d, uref
         except capi.TeError as e:  # (set-up failures come out of reductions: the same on every rank)
             ds["error"] = str(e)
+            try:
+                g.use_push(False)  # (collective, like the failure that brought every rank here)
+            except capi.TeError:
+                pass
         if out is not None:
             out.setdefault("secondary", {})["direct_store"] = ds
             if out["config"]["sharded"] is not None:
@@ -862,8 +878,8 @@ def run(a, json_out, rank, world, local_rank):
                 "vcycle_hbm": fused_hbm(m4["rows_all"], m4["profiled_warm"], sites4, m4["dt"] / k4),
                 "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4)} for k, v in m4["rows_all"].items()}}
             del rb, fb, ub, g2, H2
-        except capi.TeError as e:
-            out.setdefault("secondary", {})["size_1024"] = {"error": str(e)}
+        except Exception as e:  # noqa: BLE001 -- an optional block never costs the headline its line
+            out.setdefault("secondary", {})["size_1024"] = {"error": f"{type(e).__name__}: {e}"}
 
     if out is not None:
         if world == 1 and not a.no_cpu_baseline:
