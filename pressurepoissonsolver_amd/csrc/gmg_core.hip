@@ -346,6 +346,15 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 				}
 			}
 		}
+		if (D == 3 && n == 32) { // the three-pass kernels' matrices in lane order (patchsolve32.hpp matFragSource)
+			std::vector<double> mf((size_t) np * 6 * 1024);
+			for (int k = 0; k < np; k++)
+				for (int m = 0; m < 6; m++)
+					for (int e = 0; e < 16; e++)
+						for (int ln = 0; ln < 64; ln++)
+							mf[((size_t) k * 6 + m) * 1024 + ((size_t) (e >> 1) * 64 + ln) * 2 + (e & 1)] = mats[((size_t) k * 6 + m) * 1024 + matFragSource(m, ln, e)];
+			if ((rc = L->matfrag.upload(mf))) return rc;
+		}
 		if (D == 3 && n == 32) { // k_ps_sym's tables: [plan][transform 6][parity 2][k-step 4][lane 64]
 			std::vector<double> fs((size_t) np * PSS_FRAG, 0.0);
 			bool                pure = true;
@@ -1040,6 +1049,40 @@ int te_gmg_profile_rows(te_gmg *g, int max_rows, char (*name)[64], int64_t *call
 		return n;
 	});
 }
+
+#if TE_STAMPS
+// diagnostic build only (not in include/te_hip.h): te_stamps_begin clears and arms the collection; te_stamps_read returns the number of
+// instrumented launches since then and copies their stamps ([launch][1024][8] ticks of 10 ns), names and workgroup counts
+int te_stamps_begin(te_gmg *g)
+{
+	return guarded([&]() -> int {
+		auto &S = g->stamps;
+		int   rc;
+		if (!S.buf.p && (rc = S.buf.alloc((size_t) S.MAXL * S.MAXWG * TE_NSTAMP))) return rc;
+		HIPCHK(hipStreamSynchronize(g->stream));
+		HIPCHK(hipMemset(S.buf.p, 0, sizeof(unsigned long long) * S.buf.n));
+		S.names.clear(), S.wgs.clear();
+		S.on = true;
+		return TE_OK;
+	});
+}
+int te_stamps_read(te_gmg *g, unsigned long long *out, char (*names)[64], int *wgs, int max_launches)
+{
+	return guarded([&]() -> int {
+		auto &S = g->stamps;
+		S.on    = false;
+		HIPCHK(hipStreamSynchronize(g->stream));
+		const int n = std::min((int) S.names.size(), max_launches);
+		if (n > 0) HIPCHK(hipMemcpy(out, S.buf.p, sizeof(unsigned long long) * (size_t) n * S.MAXWG * TE_NSTAMP, hipMemcpyDeviceToHost));
+		for (int i = 0; i < n; i++) {
+			strncpy(names[i], S.names[i].c_str(), 63);
+			names[i][63] = 0;
+			wgs[i]       = S.wgs[i];
+		}
+		return n;
+	});
+}
+#endif
 
 // te_bicgstab keeps its eight level-0 work vectors between solves (8 GiB at 512^3); a caller that is done solving hands
 // them back with this call (they are allocated again by the next te_bicgstab)

@@ -193,6 +193,7 @@ struct LevelHost {
 	DevBuf<int32_t> bcgs_its; // [P]: iterations of the last TE_SMOOTH_PATCH_BCGS sweep on this level (allocated on first use)
 	DevBuf<double>  mats, lam, corr; // corr: [P][6][n^2] interface terms of the patch right-hand sides
 	DevBuf<double>  matsT;           // 2D: the transform matrices transposed (k_patch_solve2d_lds)
+	DevBuf<double>  matfrag;         // 32^3 patches: mats in the lane order of the three-pass kernels (patchsolve32.hpp matFragSource)
 	DevBuf<double>  matsym;          // half matrices in MFMA fragment order (patchsolve32_sym.hpp), 32^3 patches
 	DevBuf<double>  psinv;           // k_ps_sym: reciprocals of the eigenvalue sums, one table of PSS_INV doubles per (plan, spacings) of the level
 	DevBuf<int32_t> psitab;          // [P] the patch's table in psinv
@@ -439,6 +440,16 @@ struct te_gmg {
 		int                               nslot = 0;
 		std::atomic<bool>                 fatal{true}; // a wait that gave up ends the process (watchdog); false inside te_gmg_autotune's trial
 	} push;
+#if TE_STAMPS
+	// diagnostic build (kernels3d.hpp Stamps): stamps of up to MAXL launches of at most MAXWG workgroups each
+	struct StampHost {
+		static constexpr int            MAXL = 64, MAXWG = 1024;
+		DevBuf<unsigned long long>      buf;
+		bool                            on = false;
+		std::vector<std::string>        names;
+		std::vector<int>                wgs;
+	} stamps;
+#endif
 	// profiling
 	bool                   profiling = false;
 	int                    prof_only = -1; // >= 0: only this kernel class is timed
@@ -493,6 +504,29 @@ template <typename K, typename... A> void launchT(Timed &t, K kern, dim3 grid, d
 		hipLaunchKernelGGL(kern, grid, blk, shm, s, args...);
 	}
 }
+
+#if TE_STAMPS
+// where the next instrumented launch (`wgs` workgroups) keeps its stamps; null when nobody is collecting
+inline StampDst stampNext(te_gmg *g, const char *name, int wgs)
+{
+	StampDst d;
+	auto    &S = g->stamps;
+	if (!S.on || !S.buf.p || (int) S.names.size() >= S.MAXL || wgs > S.MAXWG || g->recording) return d;
+	d.p = S.buf.p + (size_t) S.names.size() * S.MAXWG * TE_NSTAMP;
+	S.names.push_back(std::string(name) + " L" + std::to_string(g->cur_level));
+	S.wgs.push_back(wgs);
+	return d;
+}
+inline LevelDev stamped(te_gmg *g, LevelDev D, const char *name, int wgs)
+{
+	D.stamp_dst = stampNext(g, name, wgs);
+	return D;
+}
+#define TE_STAMP_ARG(g, name, wgs) , stampNext(g, name, wgs)
+#else
+inline const LevelDev &stamped(te_gmg *, const LevelDev &D, const char *, int) { return D; }
+#define TE_STAMP_ARG(g, name, wgs)
+#endif
 
 inline int gridFor(size_t work_items, int tpb, int cap = 4096)
 {

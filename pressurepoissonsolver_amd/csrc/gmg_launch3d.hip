@@ -5,10 +5,11 @@ namespace tei
 {
 // one launch of k_stencil3d<N, MODE, ZS> with or without fused sums (RED: march3d.hpp StencilRed)
 template <int N, int MODE, int ZS>
-void launchStencilZS(te_gmg *g, dim3 grid, const LevelDev &D, const double *u, const double *f, double *out, double omega,
+void launchStencilZS(te_gmg *g, dim3 grid, const LevelDev &D_, const double *u, const double *f, double *out, double omega,
                      const RestrictDst &rd, int redmode, const RedSrc &rs)
 {
 	const dim3 blk(Tile3<N>::TPB);
+	const LevelDev &D = stamped(g, D_, MODE == MODE_RESID_RESTRICT ? "stencil resid+restrict" : "stencil", grid.x);
 	if constexpr (MODE == MODE_APPLY) {
 		if (redmode == RED_OUT_A) {
 			hipLaunchKernelGGL((k_stencil3d<N, MODE, ZS, RED_OUT_A>), grid, blk, 0, g->stream, D, u, f, out, omega, rd, rs);
@@ -102,10 +103,11 @@ template <int N> inline int rbgsSlabs(const te_gmg *g, int count)
 }
 
 template <int N, bool ZERO, bool PROLONG>
-void launchRbgsKernel(te_gmg *g, const LevelDev &D, const double *u, const double *f, double *out, const ProlongSrc &ps)
+void launchRbgsKernel(te_gmg *g, const LevelDev &D_, const double *u, const double *f, double *out, const ProlongSrc &ps)
 {
-	const int  zs = rbgsSlabs<N>(g, D.count);
-	const dim3 grid(8 * ((D.count * zs + 7) / 8)), blk(Tile3<N>::TPB);
+	const int  zs = rbgsSlabs<N>(g, D_.count);
+	const dim3 grid(8 * ((D_.count * zs + 7) / 8)), blk(Tile3<N>::TPB);
+	const LevelDev &D = stamped(g, D_, ZERO ? "rbgs from zero" : (PROLONG ? "rbgs on u + P e" : "rbgs"), grid.x);
 	if (zs == 8) {
 		if constexpr (N >= 32) hipLaunchKernelGGL((k_rbgs3d<N, ZERO, PROLONG, 8>), grid, blk, 0, g->stream, D, u, f, out, ps);
 	} else if (zs == 4) {

@@ -129,19 +129,19 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 		{
 			Timed t(g, KC_PS_3PASS, total);
 			if (zero_guess)
-				hipLaunchKernelGGL((k_ps_xy<false, false>), gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, f,
-				                   (const double *) nullptr, s1);
+				hipLaunchKernelGGL((k_ps_xy<false, false>), gp, b256, 0, g->stream, L.P, L.plan.p, L.matfrag.p, f,
+				                   (const double *) nullptr, s1 TE_STAMP_ARG(g, "ps xy forward", gp.x * gp.y));
 			else
-				hipLaunchKernelGGL((k_ps_xy<false, true>), gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, f,
-				                   (const double *) L.corr.p, s1);
+				hipLaunchKernelGGL((k_ps_xy<false, true>), gp, b256, 0, g->stream, L.P, L.plan.p, L.matfrag.p, f,
+				                   (const double *) L.corr.p, s1 TE_STAMP_ARG(g, "ps xy forward", gp.x * gp.y));
 		}
 		{
 			Timed t(g, KC_PS_3PASS, total);
-			hipLaunchKernelGGL(k_ps_z, gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, L.lam.p, L.zero_mode.p, L.rh2.p, s1, s0);
+			hipLaunchKernelGGL(k_ps_z, gp, b256, 0, g->stream, L.P, L.plan.p, L.matfrag.p, L.lam.p, L.zero_mode.p, L.rh2.p, s1, s0 TE_STAMP_ARG(g, "ps z", gp.x * gp.y));
 		}
 		{
 			Timed t(g, KC_PS_3PASS, total);
-			hipLaunchKernelGGL(k_ps_xy<true>, gp, b256, 0, g->stream, L.P, L.plan.p, L.mats.p, s0, (const double *) nullptr, u);
+			hipLaunchKernelGGL(k_ps_xy<true>, gp, b256, 0, g->stream, L.P, L.plan.p, L.matfrag.p, s0, (const double *) nullptr, u TE_STAMP_ARG(g, "ps xy inverse", gp.x * gp.y));
 		}
 		HIPCHK(hipGetLastError());
 		return TE_OK;

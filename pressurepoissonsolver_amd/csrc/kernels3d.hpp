@@ -32,6 +32,45 @@ struct RestrictDst {
 	double        *rs6;   // [P][6][(N/2)^2]: 2x2 sums of the patches' face layers (march3d.hpp, k_rbgs_zero_resid3d EXPORT), or null
 };
 
+// Diagnostic build only (-DTE_STAMPS=1, tools/tail_stamps.py; never in libte_hip.so): wave 0 of every workgroup of the small-level
+// kernels keeps wall-clock stamps (s_memrealtime, 100 MHz) of the links of its dependent chain -- entry, tables there, first data
+// there, march begun, last result formed, stores retired -- in scalar registers and writes them out once, at its very end.
+#ifndef TE_STAMPS
+#define TE_STAMPS 0
+#endif
+#if TE_STAMPS
+constexpr int TE_NSTAMP = 8;
+struct StampDst {
+	unsigned long long *p = nullptr; // [workgroup][TE_NSTAMP], or null
+};
+struct Stamps {
+	unsigned long long t[TE_NSTAMP] = {};
+	// DRAIN: everything this wave has requested is there (the link's data has arrived) before the clock is read
+	template <int K, bool DRAIN> __device__ __forceinline__ void at()
+	{
+		if (DRAIN) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+		t[K] = __builtin_amdgcn_s_memrealtime();
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	__device__ __forceinline__ void flush(const StampDst &d, int wg) const
+	{
+		if (d.p && threadIdx.x == 0)
+#pragma unroll
+			for (int k = 0; k < TE_NSTAMP; k++) d.p[(size_t) wg * TE_NSTAMP + k] = t[k];
+	}
+};
+#define TE_STAMP_DECL Stamps stamps_
+#define TE_STAMP(K, DRAIN) stamps_.template at<K, DRAIN>()
+#define TE_STAMP_FLUSH(dst, wg) stamps_.flush(dst, wg)
+#define TE_STAMP_PARAM , StampDst stamp_dst
+#else
+#define TE_STAMP_DECL
+#define TE_STAMP(K, DRAIN)
+#define TE_STAMP_FLUSH(dst, wg)
+#define TE_STAMP_PARAM
+#endif
+
 struct LevelDev {
 	int32_t        P;         // local patches
 	const int32_t *face_kind; // [P*6]
@@ -58,6 +97,9 @@ struct LevelDev {
 	const int32_t *f6off;
 	// ghost terms that still belong to this level's right-hand side (march3d.hpp FCorrSrc), or null
 	const double *fcorr;
+#if TE_STAMPS
+	StampDst stamp_dst;
+#endif
 };
 
 template <int N> __device__ __forceinline__ size_t f6Face(const int32_t *f6off, int p, int s)

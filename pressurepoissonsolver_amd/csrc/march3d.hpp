@@ -128,6 +128,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 	constexpr int TPB  = T::TPB, NP = T::NP, H = T::H;
 	constexpr int NN   = N * N, NNN = N * N * N;
 	constexpr int ZL   = N / ZS; // planes per slab
+	TE_STAMP_DECL;
+	TE_STAMP(0, false);
 	const int nblocks  = L.count * ZS;
 	const int work     = xcdRemap(blockIdx.x, nblocks);
 	if (work >= nblocks) return;
@@ -195,6 +197,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 	const HaloSrc  hs  = haloSrc<N>(tid, fk, fs, u, up, L.ghost, -1.0, 1.0, L.xf);
 	const PlaneSrc bot = zPlaneSrc<N>(fk[4], fs[4], false, u, up, L.ghost, -1.0, 1.0);
 	const PlaneSrc top = zPlaneSrc<N>(fk[5], fs[5], true, u, up, L.ghost, -1.0, 1.0);
+	TE_STAMP(1, true);
 
 	// ---- register pipeline over z ------------------------------------------------------------
 	// um, uc, un = planes z-1, z, z+1 of u (ghost planes scaled). Planes z+2, z+3 of u, z+1, z+2 of the right-hand side (and of
@@ -327,13 +330,18 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 	using B0 = std::integral_constant<int, 0>;
 	using B1 = std::integral_constant<int, 1>;
 	static_assert(ZL % 2 == 0 && ZL >= 4, "the march is unrolled over the two ring slots and ends with two steps of its own");
+	TE_STAMP(2, true);
 #pragma unroll 1
 	for (int zz = 0; zz < ZL - 2; zz += 2) {
 		step(B0{}, std::true_type{}, zz);
 		step(B1{}, std::true_type{}, zz + 1);
 	}
+	TE_STAMP(4, false);
 	step(B0{}, std::false_type{}, ZL - 2);
 	step(B1{}, std::false_type{}, ZL - 1);
+	TE_STAMP(5, false);
+	TE_STAMP(6, true);
+	TE_STAMP_FLUSH(L.stamp_dst, blockIdx.x);
 	if (RED != RED_NONE) {
 		__syncthreads(); // (the LDS of blockReduce2 is its own, but every wave must have left the plane loop's barriers)
 		blockReduce2(acc0, acc1);
@@ -568,6 +576,8 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	constexpr int NN  = N * N, NNN = N * N * N;
 	constexpr int ZL  = N / ZS; // planes per slab (even)
 	static_assert(ZL % 2 == 0 && ZL >= 2, "slabs start on even planes");
+	TE_STAMP_DECL;
+	TE_STAMP(0, false);
 	const int     nwork = L.count * ZS;
 	const int     work  = xcdRemap(blockIdx.x, nwork);
 	if (work >= nwork) return;
@@ -685,6 +695,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		return double2{c, c};
 	};
 
+	TE_STAMP(1, true);
 	// planes: umm = z-2, um = z-1, uc = z, un = z+1, un2 = z+2 (values are updated in place); start at z = zs
 	double2 umm[2], um[2], uc[2], un[2], un2[2], fm[2], fc[2], fn[2];
 #pragma unroll
@@ -715,6 +726,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		fm[k]  = double2{0.0, 0.0};
 	}
 	double hv = ZERO ? 0.0 : hs.s * (hs.p[zs * hs.stride] + (PROLONG ? shalo * chalo[NN * (zs >> hsh)] : 0.0));
+	TE_STAMP(2, true);
 	__syncthreads(); // idiag (and the zeroed tiles)
 
 	int bz = 0; // z % 3
@@ -794,12 +806,17 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 		bz = (bz == 2) ? 0 : bz + 1;
 	};
 	if (ZS > 1 && z0 > 0) step(std::integral_constant<int, 1>{}, z0 - 1); // red values of the plane below the slab
+	TE_STAMP(3, false);
 #pragma unroll 1
 	for (int z = z0; z < z1; z += 2) {
 		step(std::integral_constant<int, 0>{}, z);
 		step(std::integral_constant<int, 1>{}, z + 1);
 	}
+	TE_STAMP(4, false);
 	step(std::integral_constant<int, 0>{}, z1); // black update and store of the last plane (and, inside a patch, the red values above it)
+	TE_STAMP(5, false);
+	TE_STAMP(6, true);
+	TE_STAMP_FLUSH(L.stamp_dst, blockIdx.x);
 }
 
 // ---- ghost terms of the restricted residual without a pass of their own (opts.fuse = 3, two fused levels in a row) ---

@@ -71,36 +71,58 @@ __global__ __launch_bounds__(256) void k_face_corr3d(LevelDev L, const double *_
 }
 
 // mats: [nplans][6][32*32] row-major (forward x,y,z then inverse x,y,z); y_i = sum_j M[i*32+j] x_j
+// mfrag: the same matrices in the order the three-pass kernels' lanes hold them, [nplans][6][chunk 8][lane 64][2]: a lane's 16
+// values of a matrix are 8 coalesced 16-byte loads (from the row-major store they were 16 eight-byte loads touching 16 cache
+// lines each: on the few-patch levels these kernels run on, fetching the 2 x 8 KiB of matrices took longer than the 64 MFMAs --
+// profiles/r06_tail_stamps.txt). Element e = 2 chunk + {0, 1} of lane (j = lane & 15, g = lane >> 4):
+//   matrices 0, 3 (x):       B operand  bx[nb = e >> 3][ks = e & 7]               = M[(2j + nb) * 32 + 4 ks + g]
+//   matrices 1, 4, 5 (y, z): A operand  ay[mo = e >> 3][mb = (e >> 2) & 1][r = e & 3] = M[(16 mo + j) * 32 + 16 mb + g + 4 r]
+//   matrix 2 (z forward):    A operand  af[mb = e >> 3][ks = e & 7]               = M[(16 mb + j) * 32 + 4 ks + g]
+// (matFragIndex below is what gmg_core.hip fills the table with.) The values and the order of the products are unchanged.
+__host__ __device__ inline int matFragSource(int m, int lane, int e)
+{
+	const int j = lane & 15, g = lane >> 4;
+	if (m == 0 || m == 3) return (2 * j + (e >> 3)) * 32 + 4 * (e & 7) + g;
+	if (m == 2) return (16 * (e >> 3) + j) * 32 + 4 * (e & 7) + g;
+	return (16 * (e >> 3) + j) * 32 + 16 * ((e >> 2) & 1) + g + 4 * (e & 3);
+}
+// a lane's 16 values of matrix m of plan pl
+__device__ __forceinline__ void loadMatFrag(const double *__restrict__ mfrag, int pl, int m, int lane, double (&v)[16])
+{
+	const double2 *F = reinterpret_cast<const double2 *>(mfrag + ((size_t) pl * 6 + m) * 1024) + lane;
+#pragma unroll
+	for (int c = 0; c < 8; c++) {
+		const double2 t = F[c * 64];
+		v[2 * c] = t.x, v[2 * c + 1] = t.y;
+	}
+}
 // corr (forward pass only, may be null = zero initial guess, no interface term): see k_face_corr3d.
 template <bool INV, bool CORR = false>
 __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict__ plan,
-                                               const double *__restrict__ mats, const double *__restrict__ in,
-                                               const double *__restrict__ corr, double *__restrict__ out)
+                                               const double *__restrict__ mfrag, const double *__restrict__ in,
+                                               const double *__restrict__ corr, double *__restrict__ out TE_STAMP_PARAM)
 {
 	constexpr int N = 32, NN = N * N;
+	TE_STAMP_DECL;
+	TE_STAMP(0, false);
 	const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, g = l >> 4;
 	// one workgroup per patch and segment: wave w owns planes w + 4 it, it in [it0, it0 + 8 / gridDim.y)
 	// (gridDim.y > 1 spreads the few patches of a coarse level over more CUs)
 	const int pid = blockIdx.x, its = 8 / gridDim.y, it0 = blockIdx.y * its;
 	if (pid >= P) return;
 	const int     pl = plan[pid];
-	const double *Mx = mats + ((size_t) pl * 6 + (INV ? 3 : 0)) * NN;
-	const double *My = mats + ((size_t) pl * 6 + (INV ? 4 : 1)) * NN;
-
+	TE_STAMP(1, true);
 	// matrix fragments, loaded once per wave. Output column kx = 2j + nb (a lane's two columns are
 	// adjacent in memory).
 	double bx[2][8];    // B = Mx^T: B[k = x = 4ks + g][col kx] = Mx[kx][x]
 	double ay[2][2][4]; // A = My: A[i = ky = 16mo + j][k-step (mb, r) = y = 16mb + g + 4r]
+	{
+		double vx[16], vy[16];
+		loadMatFrag(mfrag, pl, INV ? 3 : 0, l, vx);
+		loadMatFrag(mfrag, pl, INV ? 4 : 1, l, vy);
 #pragma unroll
-	for (int nb = 0; nb < 2; nb++)
-#pragma unroll
-		for (int ks = 0; ks < 8; ks++) bx[nb][ks] = Mx[(2 * j + nb) * N + 4 * ks + g];
-#pragma unroll
-	for (int mo = 0; mo < 2; mo++)
-#pragma unroll
-		for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) ay[mo][mb][r] = My[(16 * mo + j) * N + 16 * mb + g + 4 * r];
+		for (int e = 0; e < 16; e++) bx[e >> 3][e & 7] = vx[e], ay[e >> 3][(e >> 2) & 1][e & 3] = vy[e];
+	}
 
 	constexpr double scale = INV ? 8.0 / (32.0 * 32.0 * 32.0) : 1.0; // (2/N)^3, DftPatchSolver.h:214
 	// The data plane is read straight from global memory in the A layout, A[i = y = 16mb + j][k = x =
@@ -140,6 +162,7 @@ __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict_
 	};
 	double nxt[2][8];
 	fetch(nxt, wave + 4 * it0);
+	TE_STAMP(2, true);
 #pragma unroll 1
 	for (int it = it0; it < it0 + its; it++) {
 		const int z = wave + 4 * it;
@@ -179,36 +202,36 @@ __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict_
 			}
 		}
 	}
+	TE_STAMP(5, false);
+	TE_STAMP(6, true);
+	TE_STAMP_FLUSH(stamp_dst, blockIdx.x + gridDim.x * blockIdx.y);
 }
 
 // lam: [nplans][3][32] = 4 sin^2(.), eigenvalue = -(lam_x rh2x + lam_y rh2y + lam_z rh2z)
 // (FftwPatchSolver.h:143-168). One wave = one x-row (fixed y) of a patch, all z.
-static __global__ __launch_bounds__(256) void k_ps_z(int P, const int32_t *__restrict__ plan, const double *__restrict__ mats,
+static __global__ __launch_bounds__(256) void k_ps_z(int P, const int32_t *__restrict__ plan, const double *__restrict__ mfrag,
                                               const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
                                               const double *__restrict__ rh2, const double *__restrict__ in,
-                                              double *__restrict__ out)
+                                              double *__restrict__ out TE_STAMP_PARAM)
 {
 	constexpr int N = 32, NN = N * N, NNN = N * N * N;
+	TE_STAMP_DECL;
+	TE_STAMP(0, false);
 	const int     wave = threadIdx.x >> 6, l = threadIdx.x & 63, j = l & 15, g = l >> 4;
 	const int     pid  = blockIdx.x; // one workgroup per patch and segment (see k_ps_xy); wave w owns rows y = w + 4 it
 	const int     its = 8 / gridDim.y, it0 = blockIdx.y * its;
 	if (pid >= P) return;
 	const int     pl = plan[pid];
-	const double *Mf = mats + ((size_t) pl * 6 + 2) * NN;
-	const double *Mi = mats + ((size_t) pl * 6 + 5) * NN;
-
+	TE_STAMP(1, true);
 	double af[2][8];    // A[i = kz = 16mb + j][k = z = 4ks + g]
 	double ai[2][2][4]; // A[i = z = 16mo + j][k-step (mb, r) = kz = 16mb + g + 4r]
+	{
+		double vf[16], vi[16];
+		loadMatFrag(mfrag, pl, 2, l, vf);
+		loadMatFrag(mfrag, pl, 5, l, vi);
 #pragma unroll
-	for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-		for (int ks = 0; ks < 8; ks++) af[mb][ks] = Mf[(16 * mb + j) * N + 4 * ks + g];
-#pragma unroll
-	for (int mo = 0; mo < 2; mo++)
-#pragma unroll
-		for (int mb = 0; mb < 2; mb++)
-#pragma unroll
-			for (int r = 0; r < 4; r++) ai[mo][mb][r] = Mi[(16 * mo + j) * N + 16 * mb + g + 4 * r];
+		for (int e = 0; e < 16; e++) af[e >> 3][e & 7] = vf[e], ai[e >> 3][(e >> 2) & 1][e & 3] = vi[e];
+	}
 
 	const double *lm = lam + (size_t) pl * 3 * N;
 	const double *rh = rh2 + (size_t) pid * 3;
@@ -226,6 +249,7 @@ static __global__ __launch_bounds__(256) void k_ps_z(int P, const int32_t *__res
 #pragma unroll
 		for (int ks = 0; ks < 8; ks++) nxt[ks] = reinterpret_cast<const double2 *>(ip + (4 * ks + g) * NN)[j];
 	}
+	TE_STAMP(2, true);
 #pragma unroll 1
 	for (int it = it0; it < it0 + its; it++) {
 		const int y = wave + 4 * it;
@@ -272,6 +296,9 @@ static __global__ __launch_bounds__(256) void k_ps_z(int P, const int32_t *__res
 			for (int r = 0; r < 4; r++) reinterpret_cast<double2 *>(op + (16 * mo + g + 4 * r) * NN)[j] = double2{e0[r], e1[r]};
 		}
 	}
+	TE_STAMP(5, false);
+	TE_STAMP(6, true);
+	TE_STAMP_FLUSH(stamp_dst, blockIdx.x + gridDim.x * blockIdx.y);
 }
 
 // ---- single-pass patch solve -------------------------------------------------------------------
