@@ -126,6 +126,30 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 			HIPCHK(hipGetLastError());
 			return TE_OK;
 		}
+		if (seg == 8 && !g->cfg.has(O_PS_NO_HALF)) { // at most 8 patches: one wave per workgroup and half plane (k_ps_xy_half), bit-identical
+			const dim3 gh(L.P, 64), b64(64);
+			{
+				Timed t(g, KC_PS_3PASS, total);
+				if (zero_guess)
+					hipLaunchKernelGGL((k_ps_xy_half<false, false>), gh, b64, 0, g->stream, L.P, L.plan.p, L.matfrag.p, f,
+					                   (const double *) nullptr, s1 TE_STAMP_ARG(g, "ps xy forward (half)", gh.x * gh.y));
+				else
+					hipLaunchKernelGGL((k_ps_xy_half<false, true>), gh, b64, 0, g->stream, L.P, L.plan.p, L.matfrag.p, f,
+					                   (const double *) L.corr.p, s1 TE_STAMP_ARG(g, "ps xy forward (half)", gh.x * gh.y));
+			}
+			{
+				Timed t(g, KC_PS_3PASS, total);
+				hipLaunchKernelGGL(k_ps_z_half, gh, b64, 0, g->stream, L.P, L.plan.p, L.matfrag.p, L.lam.p, L.zero_mode.p, L.rh2.p, s1,
+				                   s0 TE_STAMP_ARG(g, "ps z (half)", gh.x * gh.y));
+			}
+			{
+				Timed t(g, KC_PS_3PASS, total);
+				hipLaunchKernelGGL(k_ps_xy_half<true>, gh, b64, 0, g->stream, L.P, L.plan.p, L.matfrag.p, s0, (const double *) nullptr,
+				                   u TE_STAMP_ARG(g, "ps xy inverse (half)", gh.x * gh.y));
+			}
+			HIPCHK(hipGetLastError());
+			return TE_OK;
+		}
 		{
 			Timed t(g, KC_PS_3PASS, total);
 			if (zero_guess)

@@ -60,11 +60,14 @@ struct Stamps {
 			for (int k = 0; k < TE_NSTAMP; k++) d.p[(size_t) wg * TE_NSTAMP + k] = t[k];
 	}
 };
+// (a value the stamp that follows must find in its register: without it the compiler sinks loads of read-only memory below the stamp)
+#define TE_STAMP_PIN(v) asm volatile("" ::"v"(v))
 #define TE_STAMP_DECL Stamps stamps_
 #define TE_STAMP(K, DRAIN) stamps_.template at<K, DRAIN>()
 #define TE_STAMP_FLUSH(dst, wg) stamps_.flush(dst, wg)
 #define TE_STAMP_PARAM , StampDst stamp_dst
 #else
+#define TE_STAMP_PIN(v)
 #define TE_STAMP_DECL
 #define TE_STAMP(K, DRAIN)
 #define TE_STAMP_FLUSH(dst, wg)
@@ -101,6 +104,18 @@ struct LevelDev {
 	StampDst stamp_dst;
 #endif
 };
+
+// Kernel arguments are fetched with scalar loads where the code first needs them: behind the early exit, behind the `order`
+// branch, behind the position tests -- four or five dependent round trips of 0.3-0.4 us each before the first table load of a
+// small-level kernel can be issued (profiles/r06_tail_stamps.txt: 1.7 us from a workgroup's first instruction to its tables).
+// Naming them as inputs of an empty asm statement at the top of the kernel makes the compiler fetch them there, together.
+__device__ __forceinline__ void argsUpFront(const LevelDev &L, const void *a = nullptr, const void *b = nullptr, const void *c = nullptr,
+                                            const void *d = nullptr, const void *e = nullptr, const void *f = nullptr)
+{
+	asm volatile("" ::"s"(L.P), "s"(L.face_kind), "s"(L.face_src), "s"(L.face_kadj), "s"(L.rh2), "s"(L.ghost), "s"(L.order), "s"(L.first),
+	             "s"(L.count), "s"(L.xf), "s"(L.xf_out), "s"(L.f6), "s"(L.f6_out), "s"(L.f6off), "s"(L.fcorr), "s"(a), "s"(b), "s"(c), "s"(d),
+	             "s"(e), "s"(f));
+}
 
 template <int N> __device__ __forceinline__ size_t f6Face(const int32_t *f6off, int p, int s)
 {

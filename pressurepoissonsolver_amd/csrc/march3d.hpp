@@ -130,6 +130,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 	constexpr int ZL   = N / ZS; // planes per slab
 	TE_STAMP_DECL;
 	TE_STAMP(0, false);
+	if (ZS > 1) argsUpFront(L, u, f, out, rd.parent, rd.orth, rd.coarse);
 	const int nblocks  = L.count * ZS;
 	const int work     = xcdRemap(blockIdx.x, nblocks);
 	if (work >= nblocks) return;
@@ -578,6 +579,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	static_assert(ZL % 2 == 0 && ZL >= 2, "slabs start on even planes");
 	TE_STAMP_DECL;
 	TE_STAMP(0, false);
+	if (ZS > 1) argsUpFront(L, u, f, out, ps.parent, ps.orth, ps.coarse);
 	const int     nwork = L.count * ZS;
 	const int     work  = xcdRemap(blockIdx.x, nwork);
 	if (work >= nwork) return;

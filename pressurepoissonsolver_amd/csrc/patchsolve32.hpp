@@ -162,6 +162,14 @@ __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict_
 	};
 	double nxt[2][8];
 	fetch(nxt, wave + 4 * it0);
+#if TE_STAMPS
+#pragma unroll
+	for (int e = 0; e < 16; e++) {
+		TE_STAMP_PIN(bx[e >> 3][e & 7]);
+		TE_STAMP_PIN(ay[e >> 3][(e >> 2) & 1][e & 3]);
+		TE_STAMP_PIN(nxt[e >> 3][e & 7]);
+	}
+#endif
 	TE_STAMP(2, true);
 #pragma unroll 1
 	for (int it = it0; it < it0 + its; it++) {
@@ -183,6 +191,10 @@ __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict_
 				d1[mb][1] = mfma_f64(a[mb][ks], bx[1][ks], d1[mb][1]);
 			}
 		}
+#if TE_STAMPS
+		TE_STAMP_PIN(d1[0][0][0]); TE_STAMP_PIN(d1[0][1][0]); TE_STAMP_PIN(d1[1][0][0]); TE_STAMP_PIN(d1[1][1][0]);
+		if (it == it0) TE_STAMP(3, false);
+#endif
 		// y transform: D2[row ky = 16mo + g + 4r][col kx] = sum_y My[ky][y] D1[y][kx]
 		double *op = out + ((size_t) pid * N + z) * NN;
 #pragma unroll
@@ -201,6 +213,105 @@ __global__ __launch_bounds__(256) void k_ps_xy(int P, const int32_t *__restrict_
 				reinterpret_cast<double2 *>(op + ky * N)[j] = double2{e0[r] * scale, e1[r] * scale};
 			}
 		}
+	}
+	TE_STAMP(5, false);
+	TE_STAMP(6, true);
+	TE_STAMP_FLUSH(stamp_dst, blockIdx.x + gridDim.x * blockIdx.y);
+}
+
+// The same pass for levels of at most eight patches (the coarsest levels of a cycle: one patch, eight patches), where a launch is
+// one dependent chain per wave -- arguments, plan, matrices + plane, 64 products, stores -- and what bounds it is what ONE compute
+// unit can have in flight (profiles/r06_tail_stamps.txt: 2.1-2.5 us for the 48 KiB a four-wave workgroup requests, then 2 us of
+// products). One wave per workgroup and per HALF plane: the output columns kx = 2j + nb of one nb -- the x products of a column set
+// and the y products that follow are independent of the other set's, so every value is formed by the same instructions in the same
+// order as in k_ps_xy (bit-identical); 64 workgroups per patch instead of 8, 20 KiB requested and 32 products per wave.
+// grid (P, 64): blockIdx.y = 2 z + nb; 64 threads.
+template <bool INV, bool CORR = false>
+__global__ __launch_bounds__(64) void k_ps_xy_half(int P, const int32_t *__restrict__ plan, const double *__restrict__ mfrag,
+                                                   const double *__restrict__ in, const double *__restrict__ corr,
+                                                   double *__restrict__ out TE_STAMP_PARAM)
+{
+	constexpr int N = 32, NN = N * N;
+	TE_STAMP_DECL;
+	TE_STAMP(0, false);
+	const int l = threadIdx.x & 63, j = l & 15, g = l >> 4;
+	const int pid = blockIdx.x, z = blockIdx.y >> 1, nb = blockIdx.y & 1;
+	if (pid >= P) return;
+	const int pl = plan[pid];
+	TE_STAMP(1, true);
+	double bx[8], ay[2][2][4];
+	{
+		// (chunks 4 nb .. 4 nb + 3 of the x matrix are bx[nb][0..7] of k_ps_xy)
+		const double2 *F = reinterpret_cast<const double2 *>(mfrag + ((size_t) pl * 6 + (INV ? 3 : 0)) * 1024) + (size_t) nb * 4 * 64 + l;
+#pragma unroll
+		for (int c = 0; c < 4; c++) {
+			const double2 t = F[c * 64];
+			bx[2 * c] = t.x, bx[2 * c + 1] = t.y;
+		}
+		double vy[16];
+		loadMatFrag(mfrag, pl, INV ? 4 : 1, l, vy);
+#pragma unroll
+		for (int e = 0; e < 16; e++) ay[e >> 3][(e >> 2) & 1][e & 3] = vy[e];
+	}
+	constexpr double scale = INV ? 8.0 / (32.0 * 32.0 * 32.0) : 1.0;
+	static_assert(!(INV && CORR), "interface terms belong to the forward pass");
+	const double *cr = CORR ? corr + (size_t) pid * 6 * NN : nullptr;
+	const double  mW = (g == 0) ? 1.0 : 0.0, mE = (g == 3) ? 1.0 : 0.0, mS = (j == 0) ? 1.0 : 0.0, mN = (j == 15) ? 1.0 : 0.0;
+	double        a[2][8];
+	{ // (k_ps_xy's fetch)
+		const double *ip = in + ((size_t) pid * N + z) * NN + j * N + g;
+#pragma unroll
+		for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+			for (int ks = 0; ks < 8; ks++) {
+				double v = ip[16 * mb * N + 4 * ks];
+				if (CORR) {
+					const int y = 16 * mb + j, x = 4 * ks + g;
+					if (ks == 0) v -= mW * cr[0 * NN + y + N * z];
+					if (ks == 7) v -= mE * cr[1 * NN + y + N * z];
+					if (mb == 0) v -= mS * cr[2 * NN + x + N * z];
+					if (mb == 1) v -= mN * cr[3 * NN + x + N * z];
+				}
+				a[mb][ks] = v;
+			}
+		if (CORR && (z == 0 || z == N - 1)) {
+			const double *cz = cr + (z == 0 ? 4 : 5) * NN;
+#pragma unroll
+			for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+				for (int ks = 0; ks < 8; ks++) a[mb][ks] -= cz[(4 * ks + g) + N * (16 * mb + j)];
+		}
+	}
+#if TE_STAMPS
+#pragma unroll
+	for (int e = 0; e < 16; e++) {
+		TE_STAMP_PIN(bx[e & 7]);
+		TE_STAMP_PIN(ay[e >> 3][(e >> 2) & 1][e & 3]);
+		TE_STAMP_PIN(a[e >> 3][e & 7]);
+	}
+#endif
+	TE_STAMP(2, true);
+	v4f64 d1[2];
+#pragma unroll
+	for (int mb = 0; mb < 2; mb++) {
+		d1[mb] = v4f64{0, 0, 0, 0};
+#pragma unroll
+		for (int ks = 0; ks < 8; ks++) d1[mb] = mfma_f64(a[mb][ks], bx[ks], d1[mb]);
+	}
+#if TE_STAMPS
+	TE_STAMP_PIN(d1[0][0]); TE_STAMP_PIN(d1[1][0]);
+	TE_STAMP(3, false);
+#endif
+	double *op = out + ((size_t) pid * N + z) * NN + nb;
+#pragma unroll
+	for (int mo = 0; mo < 2; mo++) {
+		v4f64 e = v4f64{0, 0, 0, 0};
+#pragma unroll
+		for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) e = mfma_f64(ay[mo][mb][r], d1[mb][r], e);
+#pragma unroll
+		for (int r = 0; r < 4; r++) op[(16 * mo + g + 4 * r) * N + 2 * j] = e[r] * scale;
 	}
 	TE_STAMP(5, false);
 	TE_STAMP(6, true);
@@ -295,6 +406,87 @@ static __global__ __launch_bounds__(256) void k_ps_z(int P, const int32_t *__res
 #pragma unroll
 			for (int r = 0; r < 4; r++) reinterpret_cast<double2 *>(op + (16 * mo + g + 4 * r) * NN)[j] = double2{e0[r], e1[r]};
 		}
+	}
+	TE_STAMP(5, false);
+	TE_STAMP(6, true);
+	TE_STAMP_FLUSH(stamp_dst, blockIdx.x + gridDim.x * blockIdx.y);
+}
+
+// k_ps_z for levels of at most eight patches (see k_ps_xy_half): one wave per workgroup and per half row -- the columns x = 2j + xs
+// of one parity xs; grid (P, 64): blockIdx.y = 2 y + xs; 64 threads. Bit-identical to k_ps_z.
+static __global__ __launch_bounds__(64) void k_ps_z_half(int P, const int32_t *__restrict__ plan, const double *__restrict__ mfrag,
+                                                         const double *__restrict__ lam, const int32_t *__restrict__ zero_mode,
+                                                         const double *__restrict__ rh2, const double *__restrict__ in,
+                                                         double *__restrict__ out TE_STAMP_PARAM)
+{
+	constexpr int N = 32, NN = N * N, NNN = N * N * N;
+	TE_STAMP_DECL;
+	TE_STAMP(0, false);
+	const int l = threadIdx.x & 63, j = l & 15, g = l >> 4;
+	const int pid = blockIdx.x, y = blockIdx.y >> 1, xs = blockIdx.y & 1;
+	if (pid >= P) return;
+	const int pl = plan[pid];
+	TE_STAMP(1, true);
+	double af[2][8], ai[2][2][4];
+	{
+		double vf[16], vi[16];
+		loadMatFrag(mfrag, pl, 2, l, vf);
+		loadMatFrag(mfrag, pl, 5, l, vi);
+#pragma unroll
+		for (int e = 0; e < 16; e++) af[e >> 3][e & 7] = vf[e], ai[e >> 3][(e >> 2) & 1][e & 3] = vi[e];
+	}
+	const double *lm = lam + (size_t) pl * 3 * N;
+	const double *rh = rh2 + (size_t) pid * 3;
+	const double  lx = lm[2 * j + xs] * rh[0];
+	double        ez[2][4];
+#pragma unroll
+	for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+		for (int r = 0; r < 4; r++) ez[mb][r] = lm[2 * N + 16 * mb + g + 4 * r] * rh[2];
+	const bool zm = zero_mode[pl] != 0 && y == 0 && j == 0 && xs == 0;
+	double     v[8];
+	{
+		const double *ip = in + (size_t) pid * NNN + y * N + 2 * j + xs;
+#pragma unroll
+		for (int ks = 0; ks < 8; ks++) v[ks] = ip[(4 * ks + g) * NN];
+	}
+#if TE_STAMPS
+#pragma unroll
+	for (int e = 0; e < 16; e++) {
+		TE_STAMP_PIN(af[e >> 3][e & 7]);
+		TE_STAMP_PIN(ai[e >> 3][(e >> 2) & 1][e & 3]);
+		TE_STAMP_PIN(v[e & 7]);
+	}
+#endif
+	TE_STAMP(2, true);
+	const double ly = lm[N + y] * rh[1];
+	const double exy = lx + ly;
+	v4f64        d[2];
+#pragma unroll
+	for (int mb = 0; mb < 2; mb++) {
+		d[mb] = v4f64{0, 0, 0, 0};
+#pragma unroll
+		for (int ks = 0; ks < 8; ks++) d[mb] = mfma_f64(af[mb][ks], v[ks], d[mb]);
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			d[mb][r] /= -(exy + ez[mb][r]);
+			if (zm && 16 * mb + g + 4 * r == 0) d[mb][r] = 0.0; // FftwPatchSolver.h:197
+		}
+	}
+#if TE_STAMPS
+	TE_STAMP_PIN(d[0][0]); TE_STAMP_PIN(d[1][0]);
+	TE_STAMP(3, false);
+#endif
+	double *op = out + (size_t) pid * NNN + y * N + 2 * j + xs;
+#pragma unroll
+	for (int mo = 0; mo < 2; mo++) {
+		v4f64 e = v4f64{0, 0, 0, 0};
+#pragma unroll
+		for (int mb = 0; mb < 2; mb++)
+#pragma unroll
+			for (int r = 0; r < 4; r++) e = mfma_f64(ai[mo][mb][r], d[mb][r], e);
+#pragma unroll
+		for (int r = 0; r < 4; r++) op[(16 * mo + g + 4 * r) * NN] = e[r];
 	}
 	TE_STAMP(5, false);
 	TE_STAMP(6, true);

@@ -139,7 +139,16 @@ def test_patch_solve_variants_agree(case, monkeypatch):
         g.smooth(df, du, level=0, smoother=capi.SMOOTH_PATCH_SOLVE)
         g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, dc)
         got[mode] = (du.download(), dc.download())
-    for mode in ("3pass", None):
+    # (round 6) levels of at most 8 patches run the three passes with one wave per half plane (k_ps_xy_half / k_ps_z_half: the
+    # default here); TE_PS_NO_HALF puts the four-wave workgroups back
+    g.set_option("TE_PS_MODE", None)
+    g.set_option("TE_PS_NO_HALF", "1")
+    du, df, dc = g.new_vector(0, u), g.new_vector(0, f), g.new_vector(0)
+    g.smooth(df, du, level=0, smoother=capi.SMOOTH_PATCH_SOLVE)
+    g.cycle(g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE), df, dc)
+    got["nohalf"] = (du.download(), dc.download())
+    g.set_option("TE_PS_NO_HALF", None)
+    for mode in ("3pass", None, "nohalf"):
         assert np.array_equal(got["1pass-dense"][0], got[mode][0])
         assert np.array_equal(got["1pass-dense"][1], got[mode][1])
     want = orc.smooth(L, f, u)

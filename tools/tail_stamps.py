@@ -49,7 +49,8 @@ print(f"# tools/tail_stamps.py --size {a.size} --smoother {a.smoother} {' '.join
 print("# per launch, us: gap = first workgroup's entry - last workgroup's end of the previous instrumented launch (other launches may lie between);")
 print("# span = first entry .. last end; then medians over the launch's workgroups of the links of one workgroup's chain:")
 print("# skew = entry after the launch's first entry | tables = entry -> per-patch tables there | data = -> the prologue's requests there |")
-print("# march = -> last result formed | drain = -> stores retired | wg = entry -> end")
+print("# march = -> last result formed (s3, s4: intermediate points of it, from the same origin: slab kernels: first step done / main loop done;")
+print("# ps xy: x products done) | drain = -> stores retired | wg = entry -> end")
 acc = {}
 for c in range(a.cycles):
     capi.check(L.te_stamps_begin(g.h))
@@ -71,14 +72,16 @@ for c in range(a.cycles):
         e0, end = t[:, 0].min(), t[:, 6].max()
         row = dict(wgs=len(t), gap=us(e0 - prev_end) if prev_end is not None else float("nan"), span=us(end - e0),
                    skew=us(np.median(t[:, 0] - e0)), tables=us(np.median(t[:, 1] - t[:, 0])), data=us(np.median(t[:, 2] - t[:, 1])),
+                   s3=us(np.median(t[:, 3] - t[:, 2])) if (t[:, 3] > 0).all() else float("nan"),
+                   s4=us(np.median(t[:, 4] - t[:, 2])) if (t[:, 4] > 0).all() else float("nan"),
                    march=us(np.median(t[:, 5] - t[:, 2])), drain=us(np.median(t[:, 6] - t[:, 5])), wg=us(np.median(t[:, 6] - t[:, 0])))
         prev_end = end
         acc.setdefault((i, name), []).append(row)
 tot_span = tot_gap = 0.0
-print(f"{'launch':34s} {'wgs':>5s} {'gap':>6s} {'span':>6s} | {'skew':>6s} {'tables':>6s} {'data':>6s} {'march':>6s} {'drain':>6s} {'wg':>6s}")
+print(f"{'launch':34s} {'wgs':>5s} {'gap':>6s} {'span':>6s} | {'skew':>6s} {'tables':>6s} {'data':>6s} {'s3':>6s} {'s4':>6s} {'march':>6s} {'drain':>6s} {'wg':>6s}")
 for (i, name), rows in sorted(acc.items()):
     m = {k: float(np.median([r[k] for r in rows])) for k in rows[0]}
-    print(f"{i:2d} {name:31s} {int(m['wgs']):5d} {m['gap']:6.2f} {m['span']:6.2f} | {m['skew']:6.2f} {m['tables']:6.2f} {m['data']:6.2f} {m['march']:6.2f} {m['drain']:6.2f} {m['wg']:6.2f}")
+    print(f"{i:2d} {name:31s} {int(m['wgs']):5d} {m['gap']:6.2f} {m['span']:6.2f} | {m['skew']:6.2f} {m['tables']:6.2f} {m['data']:6.2f} {m['s3']:6.2f} {m['s4']:6.2f} {m['march']:6.2f} {m['drain']:6.2f} {m['wg']:6.2f}")
     tot_span += m["span"]
     if i > 0 and not np.isnan(m["gap"]):
         tot_gap += m["gap"]
