@@ -693,6 +693,20 @@ int buildLevel(te_gmg *g, const Hierarchy &H, int li)
 			L->tx_up   = mergePlan(ups, downs);   // restrict: send child blocks, receive into downbuf
 			L->tx_down = mergePlan(downs, ups);   // prolong: send octants, receive into upbuf
 		}
+		if (L->prolong_fusable && D == 3) { // ProlongSrc::cbase: coarseOctant() of every patch and of its six neighbours, precomputed
+			const int64_t nn = (int64_t) n * n, nnn = nn * n, hh = n / 2;
+			auto          base = [&](int p) {
+                const int o = orth[p];
+                return (int64_t) parent[p] * nnn + ((o & 1) ? hh : 0) + n * ((o & 2) ? hh : 0) + nn * ((o & 4) ? hh : 0);
+			};
+			std::vector<int64_t> cb((size_t) std::max(P, 1) * 7, -1);
+			for (int p = 0; p < P; p++) {
+				cb[(size_t) p * 7] = base(p);
+				for (int s2 = 0; s2 < 6; s2++)
+					if (fk[(size_t) p * 6 + s2] == FACE_LOCAL) cb[(size_t) p * 7 + 1 + s2] = base(fs[(size_t) p * 6 + s2]);
+			}
+			if ((rc = L->cbase.upload(cb))) return rc;
+		}
 		if ((rc = L->parent.upload(parent)) || (rc = L->orth.upload(orth)) || (rc = L->child.upload(child))
 		    || (rc = L->copy.upload(copy)) || (rc = L->up_desc.upload(upd)) || (rc = L->down_desc.upload(downd))
 		    || (rc = L->up_off.upload(upo)) || (rc = L->down_off.upload(downo))

@@ -177,6 +177,7 @@ struct LevelHost {
 	// transfer to level+1
 	int             Pc = 0;
 	DevBuf<int32_t> parent, orth, child, copy;
+	DevBuf<int64_t> cbase; // [P][7] ProlongSrc::cbase (levels with prolong_fusable)
 	// children / parents that live on another rank: blocks of nc/8 (or nc, copy-through) doubles
 	ExPlan          tx_up, tx_down; // child side (sends in restrict), parent side (sends in prolong)
 	int             n_up = 0, n_down = 0;

@@ -127,7 +127,9 @@ template <int N> int launchRbgsN(te_gmg *g, LevelHost &L, const double *u, const
 		ps.parent = L.parent.p;
 		ps.orth   = L.orth.p;
 		ps.coarse = prolong_from;
+		ps.cbase  = L.cbase.p; // (null unless every patch is an octant child of a local parent)
 		const bool cfp = (L.ncf > 0 || L.has_copy); // refined level: copy-through patches / coarse-fine ghost slots
+		if (!cfp && !ps.cbase) return te::fail(TE_ESTATE, "launchRbgs: fused prolongation on a level without its coarse-base table");
 		auto launch = [&](LevelDev D) {
 			if (D.count == 0) return;
 			if (cfp) {

@@ -199,8 +199,27 @@ struct HaloSrc {
 	double        s;
 	int           lds; // slot in the LDS tile, -1 = none
 };
-template <int N>
-__device__ __forceinline__ HaloSrc haloSrc(int tid, const int32_t *fk, const int32_t *fs, const double *u,
+// The six entries of one patch's row of a face table, read together and kept in registers: an index that differs from lane to lane
+// (the halo threads' `side`) picks among them with selects. Taken from memory entry by entry where the code first asks -- under the
+// face-kind tests, in one helper after the other -- the small-level kernels spent five to ten dependent round trips on them before
+// their first plane was requested (profiles/r06_tail_stamps.txt).
+struct Reg6 {
+	int32_t v[6];
+	__device__ __forceinline__ explicit Reg6(const int32_t *p)
+	{
+#pragma unroll
+		for (int s = 0; s < 6; s++) v[s] = p[s];
+	}
+	__device__ __forceinline__ int32_t operator[](int i) const
+	{
+		int32_t r = v[0];
+#pragma unroll
+		for (int s = 1; s < 6; s++) r = (i == s) ? v[s] : r;
+		return r;
+	}
+};
+template <int N, class FK>
+__device__ __forceinline__ HaloSrc haloSrc(int tid, const FK &fk, const FK &fs, const double *u,
                                            const double *up, const double *ghost, double dir_sign, double neu_sign,
                                            const double *xf = nullptr)
 {

@@ -59,7 +59,7 @@ __device__ __forceinline__ double takeReg(double src)
 // are three dependent waits at the start of every workgroup, and a slab kernel is six plane steps long.
 struct FaceKinds {
 	int32_t k[6];
-	__device__ __forceinline__ explicit FaceKinds(const int32_t *fk)
+	template <class FK> __device__ __forceinline__ explicit FaceKinds(const FK &fk)
 	{
 #pragma unroll
 		for (int s = 0; s < 6; s++) k[s] = fk[s];
@@ -141,8 +141,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 	__shared__ __attribute__((aligned(16))) double tile[2][T::LSZ];
 	__shared__ double idiag[27];
 
-	const int32_t *fk  = L.face_kind + (size_t) pid * 6;
-	const int32_t *fs  = L.face_src + (size_t) pid * 6;
+	const Reg6     fk(L.face_kind + (size_t) pid * 6), fs(L.face_src + (size_t) pid * 6);
 	const double   rhx = L.rh2[(size_t) pid * 3], rhy = L.rh2[(size_t) pid * 3 + 1], rhz = L.rh2[(size_t) pid * 3 + 2];
 	const double  *up  = u + (size_t) pid * NNN;
 	const double2 *up2 = reinterpret_cast<const double2 *>(up);
@@ -368,6 +367,11 @@ struct ProlongSrc {
 	// no second exchange (nor its pack kernel) runs. gparent / gorth [ghost slot]: that coarse patch and orthant; null
 	// when the slots hold v + P e already (sent that way: k_pack_faces6_3d)
 	const int32_t *gparent = nullptr, *gorth = nullptr;
+	// [patch][7]: offset inside `coarse` of the octant base (coarseOctant) of the patch itself and of its W, E, S, N, B, T
+	// neighbours (-1: no neighbour patch on this rank behind that face), or null. The z-slab sweeps of the small levels take
+	// their seven bases from here in one round trip; followed through face_src -> orth / parent, face by face under the
+	// face-kind tests, they were ten dependent ones (profiles/r06_tail_stamps.txt: 2.4 us before the first plane is requested)
+	const int64_t *cbase = nullptr;
 };
 // coarseOctant for the patch behind ghost slot `slot` (see ProlongSrc::gparent)
 template <int N> __device__ __forceinline__ const double *coarseOctantSlot(const ProlongSrc &ps, int slot)
@@ -592,8 +596,12 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	__shared__ __attribute__((aligned(16))) double tile[3][T::LSZ]; // planes z-1, z, z+1 rotate
 	__shared__ double idiag[27]; // 1/diag per (x,y,z) position class
 
-	const int32_t *fk  = L.face_kind + (size_t) pid * 6;
-	const int32_t *fs  = L.face_src + (size_t) pid * 6;
+	const Reg6     fk(L.face_kind + (size_t) pid * 6), fs(L.face_src + (size_t) pid * 6);
+	int64_t        cb[7] = {0, -1, -1, -1, -1, -1, -1}; // ProlongSrc::cbase (the host passes it with every launch of this variant)
+	if (PROLONG && !CFP) {
+#pragma unroll
+		for (int i = 0; i < 7; i++) cb[i] = ps.cbase[(size_t) pid * 7 + i];
+	}
 	const double   rhx = L.rh2[(size_t) pid * 3], rhy = L.rh2[(size_t) pid * 3 + 1], rhz = L.rh2[(size_t) pid * 3 + 2];
 	const double  *up  = u + (size_t) pid * NNN;
 	const double2 *up2 = reinterpret_cast<const double2 *>(up);
@@ -638,7 +646,22 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	const double *yown = nullptr, *ybot = nullptr, *ytop = nullptr;
 	int           hsh = 1;
 	static_assert(!CFP || (PROLONG && ZS == 1), "CFP is a variant of the fused-prolongation sweep without z-slabs");
-	if (PROLONG) {
+	if (PROLONG && !CFP) { // (the seven bases were requested with the face tables; the same addresses as below)
+		cown  = ps.coarse + cb[0];
+		chalo = cbot = ctop = cown;
+		if (tid < 4 * N) {
+			const int     side = tid / N, t = tid % N;
+			const int64_t b    = side == 0 ? cb[1] : (side == 1 ? cb[2] : (side == 2 ? cb[3] : cb[4]));
+			if (b >= 0) {
+				const int cx = (side == 0) ? H - 1 : (side == 1 ? 0 : t / 2);
+				const int cy = (side == 2) ? H - 1 : (side == 3 ? 0 : t / 2);
+				chalo        = ps.coarse + b + cx + N * cy;
+				shalo        = 1.0;
+			}
+		}
+		if (cb[5] >= 0) cbot = ps.coarse + cb[5] + NN * (H - 1), sbot = 1.0;
+		if (cb[6] >= 0) ctop = ps.coarse + cb[6], stop = 1.0;
+	} else if (PROLONG) {
 		if (CFP && ps.orth[pid] < 0) {
 			cpo  = true;
 			yown = ps.coarse + (size_t) ps.parent[pid] * NNN;
