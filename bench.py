@@ -231,6 +231,9 @@ def self_launch(ngpus, json_out):
 
 
 PROVISIONAL = "#PROVISIONAL "  # worker -> supervisor: the line so far (the headline is measured; a risky secondary block follows)
+# the line as far as it is built (rank 0, once the headline is measured): whatever ends run() afterwards -- ANY exception, not only the
+# library's -- main() prints THIS with an `error` entry, never a value-null line in its place
+HEADLINE = {"out": None, "block": None}
 
 
 def metric_name(a):
@@ -287,7 +290,16 @@ def supervise(a, json_out):
            "the exchange watchdog ended the worker (exit 86: an exchange never completed)" if rc == 86 else
            f"worker killed by signal {-rc}" if rc < 0 else f"worker exit status {rc}")
     if rank == 0:
-        if final is not None:
+        final_null = False
+        if final is not None and prov is not None:
+            try:  # (a worker whose last words are a value-null error line, behind a provisional line that carries the measured headline)
+                fd = json.loads(final)
+                final_null = fd.get("value") is None
+                if final_null:
+                    how = f"{fd.get('error', how)} ({how})"
+            except ValueError:
+                final_null = False
+        if final is not None and not final_null:
             print(final, file=json_out, flush=True)
         elif prov is not None:
             d = json.loads(prov)
@@ -366,16 +378,28 @@ def main():
         raise SystemExit(supervise(a, json_out))  # (this process stays off the GPU; the rank itself runs as its child)
     die = os.environ.get("TE_BENCH_TEST_DIE")  # test hook (tests/test_bench_launch.py): a worker that ends like a watchdog exit
     if die is not None and os.environ.get("TE_BENCH_WORKER") is not None:
-        if die == "after-provisional" and rank == 0:
+        if die in ("after-provisional", "raise-after-provisional") and rank == 0:
             print(PROVISIONAL + json.dumps({"metric": metric_name(a), "value": 1.0, "n_gpus": world, "next_block": "a test block"}), file=json_out, flush=True)
-        os._exit(86)
+        if not die.startswith("raise-"):
+            os._exit(86)
     try:
+        if die == "raise-after-provisional":  # (a worker that ends in an exception which is not the library's, behind its provisional line)
+            raise ValueError("max() arg is an empty sequence")
+        if die == "raise-in-optional-block":  # (in-process: the headline is built, then something that is not a TeError is raised)
+            HEADLINE["out"] = {"metric": metric_name(a), "value": 1.0, "n_gpus": world}
+            HEADLINE["block"] = "a test block"
+            raise ValueError("max() arg is an empty sequence")
         run(a, json_out, rank, world, local_rank)
     except BaseException as e:  # noqa: BLE001 -- every failure path ends in a JSON line (rank 0; N > 1: the supervisor's when nothing is left to say here)
         if isinstance(e, SystemExit) and e.code in (0, None):
             raise
         if rank == 0:
-            print(error_line(a, world, f"{type(e).__name__}: {e}"), file=json_out, flush=True)
+            if HEADLINE["out"] is not None:  # the headline was measured: it keeps its line, the failure goes beside it
+                d = dict(HEADLINE["out"])
+                d["error"] = f"the headline was measured; then, inside {HEADLINE['block'] or 'an optional block'}: {type(e).__name__}: {e}"
+                print(json.dumps(d), file=json_out, flush=True)
+            else:
+                print(error_line(a, world, f"{type(e).__name__}: {e}"), file=json_out, flush=True)
         raise
 
 
@@ -702,9 +726,21 @@ def run(a, json_out, rank, world, local_rank):
         out = None
 
     def provisional(next_block):
-        """under the supervisor (N > 1): the line as it stands, before a block that may end the process"""
+        """the line as it stands, before a block that may end the process: kept for main()'s handler (any exception from here on
+        prints it with `error`), and under the supervisor (N > 1) handed over as well (a worker that dies without a word)"""
+        HEADLINE["out"], HEADLINE["block"] = out, next_block
         if out is not None and os.environ.get("TE_BENCH_WORKER") is not None:
             print(PROVISIONAL + json.dumps({**out, "next_block": next_block}), file=json_out, flush=True)
+
+    def optional_failed(name, e):
+        """an optional block raised: its error under its own name. A library error (TeError) comes out of reductions -- the same on every
+        rank, the run goes on; anything else at N > 1 may be this rank's alone, and the collectives of the blocks that follow would
+        wait for it: the line is finished as it stands and the exception ends the run (main() prints the line with `error`)"""
+        if out is not None:
+            out.setdefault("secondary", {})[name] = {"error": f"{type(e).__name__}: {e}"}
+        if world > 1 and not isinstance(e, capi.TeError):
+            HEADLINE["out"], HEADLINE["block"] = out, f"secondary.{name}"
+            raise e
 
     # from here on every block is optional: the line as it stands is handed to the supervisor (N > 1), and a block that fails
     # leaves an `error` entry under its own name instead of taking the headline with it
@@ -713,9 +749,11 @@ def run(a, json_out, rank, world, local_rank):
 
     # (f)1 beside the headline: the reference's own smoother (FFTBlockJacobiSmoother.h:55-58, the one cycle with per-V-cycle
     # parity against the reference) timed by the same driver run, a dozen cycles, both roofs
-    secondary = None
     if a.smoother == "rbgs" and not a.no_secondary and a.dim == 3 and n == 32 and os.environ.get("TE_BENCH_NOPROFILE") is None:
+      HEADLINE["block"] = "secondary.reference_smoother"
       try:
+        if os.environ.get("TE_BENCH_TEST_RAISE") == "reference_smoother":  # test hook: an exception that is not the library's
+            raise ValueError("max() arg is an empty sequence")
         o2 = g.default_opts(smoother=capi.SMOOTH_PATCH_SOLVE)
         k2, w2 = 20, 5  # (an MFMA-bound kernel's clock settles over the first cycles: the quoted figure is a MEDIAN of 20 behind 5)
         m2 = measure(o2, k2, w2)
@@ -725,22 +763,23 @@ def run(a, json_out, rank, world, local_rank):
         if rank == 0 and m2["rows"]:
             name2, st2 = max(((k, v) for k, v in m2["rows"].items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
             ps_key = workload_key(argparse.Namespace(**{**vars(a), "smoother": "patch_solve"}))
-            secondary = {"reference_smoother": {
+            out.setdefault("secondary", {})["reference_smoother"] = {
                 "what": "the same workload with the reference's block-Jacobi smoother (exact patch solves on the fp64 matrix cores), "
                         "default options (fuse = 3)",
                 "steps": k2, "warmup": w2, "ms_per_step": m2["dt"] / k2 * 1e3, "ms_per_step_median": med2,
                 "value": cells_global[0] / (m2["dt"] / k2),
                 "unit": "lattice-site updates/s", "residual_reduction_per_cycle": red2, "u_checksum_after_timed_region": cs2,
                 "roofline": roofline_of(name2, st2, ps_key, world), "roofline_mfma": roofline_mfma_of(name2, st2, a.dim, n),
-                "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4)} for k, v in m2["rows_all"].items()}}}
-      except capi.TeError as e:  # (a failure of the library, the same on every rank; anything else ends the run through the supervisor)
-        secondary = {"reference_smoother": {"error": str(e)}}
+                "kernels_warmup": {k: {"calls": v["calls"], "ms": round(v["ms"], 4)} for k, v in m2["rows_all"].items()}}
+      except Exception as e:  # noqa: BLE001 -- an optional block never costs the headline its line
+        optional_failed("reference_smoother", e)
 
     # (f)2 in the driver's run: time to solution of the call a user makes (apps/3d/steady.cpp:519-524): BiCGStab (BiCGStab.h:45-106,
     # tolerance 1e-12) preconditioned with one V-cycle, the drivers' trig problem on the same grid, both smoothers. A first solve
     # warms up (work vectors, code), the second is timed between two synchronisations, a third runs with every kernel class
     # timed and gives the algorithmic bytes per site and iteration.
     if not a.no_secondary and not a.mesh and os.environ.get("TE_BENCH_NOPROFILE") is None:
+      HEADLINE["block"] = "secondary.solve"
       try:
         solve = {}
         sites_local = H.sizes(0)[0] * n ** a.dim
@@ -778,14 +817,10 @@ def run(a, json_out, rank, world, local_rank):
         del bb, xx
         g.release_workspace()
         if rank == 0:
-            secondary = secondary or {}
-            secondary["solve"] = {"what": f"te_bicgstab + one V(1,1) cycle as preconditioner to 1e-12, trig problem ({'apps/3d/steady.cpp:253-265' if a.dim == 3 else 'apps/2d/steady.cpp:314-318'}) on the benchmarked grid, "
+            out.setdefault("secondary", {})["solve"] = {"what": f"te_bicgstab + one V(1,1) cycle as preconditioner to 1e-12, trig problem ({'apps/3d/steady.cpp:253-265' if a.dim == 3 else 'apps/2d/steady.cpp:314-318'}) on the benchmarked grid, "
                                           "second of two solves, wall time between two synchronisations (max over ranks)", **solve}
-      except capi.TeError as e:
-        secondary = secondary or {}
-        secondary["solve"] = {"error": str(e)}
-    if out is not None and secondary:
-        out["secondary"] = secondary
+      except Exception as e:  # noqa: BLE001
+        optional_failed("solve", e)
 
     # N > 1: the OTHER transport. One more cycle on the headline's transport is the reference; then the direct-store transport
     # (te_gmg_use_push: hipIpc-mapped peer buffers, flags, bounded waits) is prepared, must reproduce that result BIT FOR BIT on
@@ -836,6 +871,13 @@ def run(a, json_out, rank, world, local_rank):
                 g.use_push(False)  # (collective, like the failure that brought every rank here)
             except capi.TeError:
                 pass
+        except Exception as e:  # noqa: BLE001 -- (this rank's alone, possibly: the line as it stands, then the end of the run)
+            optional_failed("direct_store", e)
+        finally:
+            try:
+                g.set_option("TE_PUSH_NONFATAL", None)  # (the headline solver goes back to a watchdog that ends the process on a failed exchange)
+            except Exception:  # noqa: BLE001
+                pass
         if out is not None:
             out.setdefault("secondary", {})["direct_store"] = ds
             if out["config"]["sharded"] is not None:
@@ -849,6 +891,7 @@ def run(a, json_out, rank, world, local_rank):
     # 8 GiB per vector, the shape at which eight GPUs would hold 512^3 each (`--size 1024 --gpus 8` is that weak-scaling twin)
     if world == 1 and a.dim == 3 and a.size == 512 and not a.mesh and n == 32 and not a.no_secondary and os.environ.get("TE_BENCH_NOPROFILE") is None \
             and os.environ.get("TE_BENCH_NO_1024") is None:
+        HEADLINE["block"] = "secondary.size_1024"
         try:
             del r
             mesh2 = capi.Mesh.uniform(3, 5)
@@ -883,9 +926,14 @@ def run(a, json_out, rank, world, local_rank):
 
     if out is not None:
         if world == 1 and not a.no_cpu_baseline:
-            from oracle import build as obuild
-            obuild.build_oracle()
-            out["cpu_baseline"] = cpu_baseline(a.cpu_size or a.size, a.dim, n, a.smoother)
+            HEADLINE["block"] = "cpu_baseline"
+            try:
+                from oracle import build as obuild
+                obuild.build_oracle()
+                out["cpu_baseline"] = cpu_baseline(a.cpu_size or a.size, a.dim, n, a.smoother)
+            except Exception as e:  # noqa: BLE001 -- the reported baseline never costs the headline its line
+                out["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        HEADLINE["out"] = None  # (printed here)
         print(json.dumps(out), file=json_out, flush=True)
     if dist is not None:
         dist.barrier()

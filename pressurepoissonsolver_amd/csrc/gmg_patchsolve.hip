@@ -126,7 +126,7 @@ template <int N> int patchSolveN(te_gmg *g, LevelHost &L, const double *f, doubl
 			HIPCHK(hipGetLastError());
 			return TE_OK;
 		}
-		if (seg == 8 && !g->cfg.has(O_PS_NO_HALF)) { // at most 8 patches: one wave per workgroup and half plane (k_ps_xy_half), bit-identical
+		if (!one_pass && !mode && L.P <= g->cfg.num(O_PS_HALF_MAX, 8) && !g->cfg.has(O_PS_NO_HALF)) { // at most 8 patches: one wave per workgroup and half plane (k_ps_xy_half), bit-identical
 			const dim3 gh(L.P, 64), b64(64);
 			{
 				Timed t(g, KC_PS_3PASS, total);

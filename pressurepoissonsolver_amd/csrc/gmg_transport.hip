@@ -42,7 +42,7 @@ void watchdogLoop(te_gmg *g)
 	while (!w.stop.load()) {
 		std::this_thread::sleep_for(std::chrono::milliseconds(50));
 		// (TE_PUSH_NONFATAL: the caller polls te_gmg_push_failed itself -- bench.py's trial of the transport behind its headline)
-		if (g->push.err_host && *g->push.err_host && g->push.fatal.load() && !g->cfg.has(O_PUSH_NONFATAL)) {
+		if (g->push.err_host && *g->push.err_host && g->push.fatal.load() && g->cfg.num(O_PUSH_NONFATAL, 0) == 0) { // (TE_PUSH_NONFATAL=0 is "fatal", like the switch unset)
 			fprintf(stderr,
 			        "te_hip watchdog: rank %d: a direct-store exchange failed (code %d: 1 gave up waiting for a peer's data, 2 a peer's flag two "
 			        "exchanges ahead, 3 a peer behind when its buffer was overwritten, 4 epochs out of sequence) -- a peer is missing or issued "
@@ -496,8 +496,16 @@ static int pushSetup(te_gmg *g)
 	int rc;
 	for (size_t i = 0; i < dir.size(); i += 8) { // (a failed reduction is the transport under this one failing: nothing left to agree through)
 		const int n = (int) std::min<size_t>(8, dir.size() - i);
-		HIPCHK(hipMemcpyAsync(g->result.p, &dir[i], n * sizeof(double), hipMemcpyHostToDevice, g->stream));
-		if ((rc = finishReduce(g, n, 0, true))) return rc;
+		if (hipMemcpyAsync(g->result.p, &dir[i], n * sizeof(double), hipMemcpyHostToDevice, g->stream) != hipSuccess) {
+			(void) hipGetLastError();
+			pushTeardown(g);
+			return te::fail(TE_EHIP, "te_gmg_use_push: hipMemcpyAsync(directory)");
+		}
+		if ((rc = finishReduce(g, n, 0, true))) { // (what this set-up allocated and mapped so far does not outlive it: a later attempt starts clean)
+			const std::string m = te_last_error();
+			pushTeardown(g);
+			return te::fail(rc, m);
+		}
 		for (int k = 0; k < n; k++) dir[i + k] = g->result_host[k];
 	}
 	for (int r = 0; r < R; r++) {
@@ -606,8 +614,16 @@ static int pushSetup(te_gmg *g)
 	const std::string map_msg = map_rc ? std::string(te_last_error()) : std::string();
 	// nobody pushes before everybody has finished mapping (and zeroing): one more reduction, which also carries "somebody failed"
 	double failed = map_rc ? 1.0 : 0.0;
-	HIPCHK(hipMemcpyAsync(g->result.p, &failed, sizeof failed, hipMemcpyHostToDevice, g->stream));
-	if ((rc = finishReduce(g, 1, 1, true))) return rc;
+	if (hipMemcpyAsync(g->result.p, &failed, sizeof failed, hipMemcpyHostToDevice, g->stream) != hipSuccess) {
+		(void) hipGetLastError();
+		pushTeardown(g);
+		return te::fail(TE_EHIP, "te_gmg_use_push: hipMemcpyAsync(failed)");
+	}
+	if ((rc = finishReduce(g, 1, 1, true))) {
+		const std::string m = te_last_error();
+		pushTeardown(g);
+		return te::fail(rc, m);
+	}
 	if (map_rc || g->result_host[0] != 0.0) {
 		pushTeardown(g);
 		if (map_rc) return te::fail(map_rc, map_msg);

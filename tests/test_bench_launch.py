@@ -60,6 +60,39 @@ def test_supervisor_prints_a_line_when_the_worker_dies(die):
     assert q.returncode == 86 and json_lines(q.stdout) == []
 
 
+def test_supervisor_prefers_the_provisional_line_to_a_value_null_last_line():
+    """(round 5 advisor) a worker that has handed over its measured headline (PROVISIONAL) and then ends in an exception that is not the
+    library's prints a value-null error line on its way out: rank 0's supervisor must keep the measured headline and put the
+    exception beside it, not the other way round"""
+    env = {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "TE_BENCH_TEST_DIE": "raise-after-provisional"}
+    p = run_bench(["--gpus", "2", "--size", "64"], env)
+    assert p.returncode != 0
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    assert lines[0]["value"] == 1.0 and "ValueError" in lines[0]["error"] and "a test block" in lines[0]["error"], lines[0]
+
+
+def test_in_process_headline_survives_any_exception_behind_it():
+    """N = 1 (no supervisor, no provisional line on stdout): once the headline is built, an exception of ANY type in what follows
+    ends in that line with `error`, not in a value-null line"""
+    p = run_bench(["--gpus", "1", "--size", "64"], {"TE_BENCH_TEST_DIE": "raise-in-optional-block", "TE_BENCH_WORKER": "1"})
+    assert p.returncode != 0
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1 and lines[0]["value"] == 1.0 and "ValueError" in lines[0]["error"], p.stdout
+
+
+@pytest.mark.gpu
+def test_optional_block_that_raises_leaves_its_error_under_its_own_name():
+    """on the GPU box, the real thing at N = 1: secondary.reference_smoother raises a ValueError; the line keeps its value, carries
+    secondary.reference_smoother.error, and the blocks behind it (secondary.solve) still ran"""
+    p = run_bench(["--gpus", "1", "--size", "128", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"], {"TE_BENCH_TEST_RAISE": "reference_smoother"})
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json_lines(p.stdout)[-1]
+    assert out["value"] > 0 and "error" not in out
+    assert "ValueError" in out["secondary"]["reference_smoother"]["error"]
+    assert out["secondary"]["solve"]["rbgs"]["iterations"] > 0
+
+
 @pytest.mark.gpu
 def test_self_launch_two_ranks_gloo_rehearsal():
     """two ranks on the one GPU of the test box, gloo for the exchanges: one JSON line, n_gpus 2 -- and the line proves what it
