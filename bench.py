@@ -453,7 +453,9 @@ def run(a, json_out, rank, world, local_rank):
         t1 = time.perf_counter()
         g = capi.GMG(H, device=local_rank)                  # te_gmg_create: tables, plans, scratch (synchronised on return)
         t2 = time.perf_counter()
-        setup_ms.update({"te_hier_build": (t1 - t0) * 1e3, "te_gmg_create": (t2 - t1) * 1e3})
+        setup_ms.update({"te_hier_build": (t1 - t0) * 1e3, "te_gmg_create": (t2 - t1) * 1e3,
+                         # (te_gmg_setup_ms; the FIRST solver of a process pays the HIP runtime's start and the code-object load in context_streams)
+                         "te_gmg_create_parts": g.setup_ms()})
         name = "none"
         if world > 1:
             # RCCL point-to-point issued by the native library itself (no Python per exchange); the
@@ -886,6 +888,20 @@ def run(a, json_out, rank, world, local_rank):
                     "note": "one cycle on the same right-hand side through each transport, compared bit for bit on every rank (maximum over the "
                             "ranks of the differences' infinity norm == 0), three times, each after a cycle on other data; null: the other "
                             "transport could not be set up here (secondary.direct_store.error)"}
+
+    # the reference's "GMG Setup" timer (apps/3d/steady.cpp:480-484) is the cost of building a cycle in a process that already runs:
+    # a SECOND solver on the same hierarchy, created and destroyed here (rank-local; no collective inside te_gmg_create)
+    if out is not None and world == 1 and not a.no_secondary and os.environ.get("TE_BENCH_NOPROFILE") is None:
+        HEADLINE["block"] = "setup_ms.te_gmg_create_second"
+        try:
+            t0c = time.perf_counter()
+            gs = capi.GMG(H, device=local_rank)
+            t1c = time.perf_counter()
+            out["setup_ms"]["te_gmg_create_second"] = (t1c - t0c) * 1e3
+            out["setup_ms"]["te_gmg_create_second_parts"] = gs.setup_ms()
+            del gs
+        except Exception as e:  # noqa: BLE001
+            out["setup_ms"]["te_gmg_create_second"] = {"error": f"{type(e).__name__}: {e}"}
 
     # N = 1: a problem-size axis (apps/3d/steady.cpp:95 --divide, OctTree.h:119-179): the same cycle at 1024^3 -- 32 768 patches,
     # 8 GiB per vector, the shape at which eight GPUs would hold 512^3 each (`--size 1024 --gpus 8` is that weak-scaling twin)

@@ -322,6 +322,14 @@ int te_gmg_profile_reset(te_gmg *g);
  * a dozen launches: bench.py times only the dominant class inside its timed region. */
 int te_gmg_profile_select(te_gmg *g, const char *name);
 
+/* Where te_gmg_create spent its time -- the "GMG Setup" timer of apps/3d/steady.cpp:480-484 around GMG/CycleFactory3d.cpp:69-134,
+ * broken down (milliseconds, host clock): out[0] device selection, context, streams, events (the first solver of a process also pays
+ * the HIP runtime's start and the load of this library's code object here); out[1] the level tables, plans and transform matrices
+ * built on the host; out[2] device allocations (hipMalloc), out[3] their number; out[4] uploads of the tables (hipMemcpy);
+ * out[5] the work vectors of every level (allocation + zero fill queued); out[6] the final synchronisation; out[7] the whole call.
+ * n <= 8 values are written; returns TE_OK. */
+int te_gmg_setup_ms(const te_gmg *g, double *out, int n);
+
 #ifdef __cplusplus
 }
 #endif

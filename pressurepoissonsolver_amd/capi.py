@@ -125,6 +125,7 @@ SYMBOLS = {
     "te_gmg_patch_bcgs_iterations": (_I, [_P, _I, _P]),
     "te_gmg_exchange_selftest": (_I, [_P, _I]),
     "te_gmg_watchdog_selftest": (_I, [_P, _D]),
+    "te_gmg_setup_ms": (_I, [_P, _PD, _I]),
     "te_gmg_profile": (_I, [_P, _I]),
     "te_gmg_profile_rows": (_I, [_P, _I, _P, _P, _P, _P]),
     "te_gmg_profile_reset": (_I, [_P]),
@@ -507,6 +508,13 @@ class GMG:
         out = C.c_double()
         check(lib().te_volume(self.h, level, C.byref(out)))
         return out.value
+
+    def setup_ms(self):
+        """where te_gmg_create spent its time (include/te_hip.h te_gmg_setup_ms), by name"""
+        v = (C.c_double * 8)()
+        check(lib().te_gmg_setup_ms(self.h, v, 8))
+        names = ("context_streams", "host_tables", "device_allocations", "device_allocation_count", "table_uploads", "work_vectors", "final_sync", "total")
+        return {k: (int(x) if k.endswith("count") else round(float(x), 3)) for k, x in zip(names, v)}
 
     def profile(self, enable=True): check(lib().te_gmg_profile(self.h, int(enable)))
     def profile_reset(self): check(lib().te_gmg_profile_reset(self.h))

@@ -758,6 +758,14 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 {
 	return guarded([&]() -> int {
 		if (!h || !out) return te::fail(TE_EINVAL, "te_gmg_create: null argument");
+		using clk = std::chrono::steady_clock;
+		auto ms   = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+		const auto t_begin = clk::now();
+		SetupAcc   acc;
+		struct AccScope { // (the allocations and uploads of THIS call, whichever way it ends)
+			explicit AccScope(SetupAcc *a) { g_setup_acc = a; }
+			~AccScope() { g_setup_acc = nullptr; }
+		} acc_scope(&acc);
 		int ndev = 0;
 		if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
 			return te::fail(TE_EHIP, "te_gmg_create: no HIP device visible (this library has no CPU fallback)");
@@ -780,9 +788,12 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 		HIPCHK(hipEventCreateWithFlags(&g->ev_recv, hipEventDisableTiming));
 		g->cfg.fromEnv();
 		g->overlap = !g->cfg.has(O_NO_OVERLAP);
+		const auto t_ctx = clk::now();
 		int rc;
 		for (int li = 0; li < (int) h->h.levels.size(); li++)
 			if ((rc = buildLevel(g.get(), h->h, li))) return rc;
+		const auto     t_levels = clk::now();
+		const SetupAcc acc_levels = acc;
 		{ // partial sums: the reduction kernels' blocks, or one pair per work item of a stencil launch with fused sums (<= 8 slabs per patch)
 			size_t items = (size_t) g->red_blocks;
 			for (auto &L : g->levels) items = std::max(items, (size_t) L->P * (L->P <= 64 ? 8 : (L->P < 2048 ? 4 : 1)));
@@ -807,8 +818,27 @@ int te_gmg_create(const te_hier *h, int device, te_gmg **out)
 				L.f.reset(v);
 			}
 		}
+		const auto t_vecs = clk::now();
 		HIPCHK(hipStreamSynchronize(g->stream));
+		const auto t_end = clk::now();
+		g->setup_ms[0]   = ms(t_begin, t_ctx);
+		g->setup_ms[1]   = ms(t_ctx, t_levels) - acc_levels.malloc_ms - acc_levels.copy_ms;
+		g->setup_ms[2]   = acc.malloc_ms;
+		g->setup_ms[3]   = acc.nmalloc;
+		g->setup_ms[4]   = acc.copy_ms;
+		g->setup_ms[5]   = ms(t_levels, t_vecs) - (acc.malloc_ms - acc_levels.malloc_ms) - (acc.copy_ms - acc_levels.copy_ms);
+		g->setup_ms[6]   = ms(t_vecs, t_end);
+		g->setup_ms[7]   = ms(t_begin, t_end);
 		*out = g.release();
+		return TE_OK;
+	});
+}
+
+int te_gmg_setup_ms(const te_gmg *g, double *out, int n)
+{
+	return guarded([&]() -> int {
+		if (!g || !out || n < 0) return te::fail(TE_EINVAL, "te_gmg_setup_ms: bad argument");
+		for (int i = 0; i < std::min(n, 8); i++) out[i] = g->setup_ms[i];
 		return TE_OK;
 	});
 }

@@ -102,6 +102,21 @@ struct Cfg {
 	double      real(int o, double dflt) const { return on[o] ? atof(val[o].c_str()) : dflt; }
 };
 
+// te_gmg_setup_ms: hipMalloc / hipMemcpy time of the te_gmg_create in progress on this thread (null outside of one)
+struct SetupAcc {
+	double malloc_ms = 0, copy_ms = 0, nmalloc = 0;
+};
+inline thread_local SetupAcc *g_setup_acc = nullptr;
+struct SetupClock {
+	double                               *dst;
+	std::chrono::steady_clock::time_point t0;
+	explicit SetupClock(double *d) : dst(d), t0(std::chrono::steady_clock::now()) {}
+	~SetupClock()
+	{
+		if (dst) *dst += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	}
+};
+
 template <typename T> struct DevBuf {
 	T     *p = nullptr;
 	size_t n = 0;
@@ -115,6 +130,8 @@ template <typename T> struct DevBuf {
 		p = nullptr;
 		n = count;
 		if (count == 0) return TE_OK;
+		SetupClock c(g_setup_acc ? &g_setup_acc->malloc_ms : nullptr);
+		if (g_setup_acc) g_setup_acc->nmalloc += 1;
 		HIPCHK(hipMalloc(&p, sizeof(T) * count));
 		return TE_OK;
 	}
@@ -122,6 +139,7 @@ template <typename T> struct DevBuf {
 	{
 		int rc = alloc(h.size());
 		if (rc) return rc;
+		SetupClock c(g_setup_acc ? &g_setup_acc->copy_ms : nullptr);
 		if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
 		return TE_OK;
 	}
@@ -451,6 +469,7 @@ struct te_gmg {
 		std::vector<int>                wgs;
 	} stamps;
 #endif
+	double setup_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // te_gmg_setup_ms
 	// profiling
 	bool                   profiling = false;
 	int                    prof_only = -1; // >= 0: only this kernel class is timed
