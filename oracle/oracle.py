@@ -50,6 +50,7 @@ def lib():
             "orc_bicgstab": (C.c_int, [pl, C.c_int, C.POINTER(OrcCycleOpts), C.c_int, pd, pd, C.c_int,
                                         C.c_double, C.POINTER(C.c_double)]),
             "orc_set_threads": (None, [C.c_int]),
+            "orc_set_fast_transforms": (None, [C.c_int]),
         }
         for k, (r, a) in sig.items():
             f = getattr(L, k)
@@ -210,3 +211,8 @@ def bicgstab(levels, opts, b, x0=None, use_prec=True, max_it=1000, tol=1e-12):
 
 def set_threads(n):
     lib().orc_set_threads(int(n))
+
+
+def set_fast_transforms(on=True):
+    """the patch solve's transforms in O(n log n) (FftwPatchSolver's way) instead of dense products (DftPatchSolver's): timing only"""
+    lib().orc_set_fast_transforms(int(bool(on)))

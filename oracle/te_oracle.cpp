@@ -299,8 +299,165 @@ void transformAxis(const Geo &G, const std::vector<double> &M, int ax, const dou
 		}
 	}
 }
+// ---- the same six transforms in O(n log n) (n a power of two): what the reference's DEFAULT patch solver does through FFTW's r2r
+// plans (PatchSolvers/FftwPatchSolver.h:93-141: RODFT10/01, REDFT10/01, RODFT11, REDFT11; apps/3d/steady.cpp:126 --patch_solver fftw),
+// where the dense products above are its DftPatchSolver (one dgemv per line). Own code (FFTW is not in the image): a radix-2 complex
+// FFT over a batch of lines (every butterfly is a loop over contiguous lines: the compiler vectorises it) and the classic reductions
+//   DCT-II : v_j = x_2j, v_{n-1-j} = x_{2j+1};  y_k = Re(e^{-i pi k / 2n} FFT_n(v)_k)                       (Makhoul 1980)
+//   DCT-III: a_k = c_k x_k e^{+i pi k / 2n} (c_0 = 1/2); v = Re(conj-FFT_n(a)); y_2j = v_j, y_{2j+1} = v_{n-1-j}
+//   DCT-IV : b_j = x_j e^{+i pi j / 2n} zero-padded to 2n; y_i = Re(e^{+i pi (2i+1) / 4n} conj-FFT_2n(b)_i)
+//   DST-II(x)_i = DCT-II((-1)^j x_j)_{n-1-i};  DST-III(x)_i = (-1)^i DCT-III(reversed x)_i;  DST-IV(x)_i = (-1)^i DCT-IV(reversed x)_i
+// with the matrices' own (unnormalised) scaling, so that either path can stand in transformAxis' place. Used by the TIMED baseline
+// only (orc_set_fast_transforms, bench.py's cpu_baseline row "patch_solve_fft"); parity tests keep the dense products
+// (tests/test_oracle_fast_transforms.py holds the two together to 1e-12).
+int g_fast_transforms = 0;
+struct FftTables {
+	int                 n = 0;
+	std::vector<int>    rev;
+	std::vector<double> wr, wi; // e^{-2 pi i k / n}, k < n/2
+};
+const FftTables &fftTables(int n)
+{
+	static std::map<int, FftTables> cache;
+	FftTables                      *t;
+#pragma omp critical(orc_fft_tables)
+	{
+		auto it = cache.find(n);
+		if (it == cache.end()) {
+			FftTables T;
+			T.n = n;
+			T.rev.resize(n);
+			int bits = 0;
+			while ((1 << bits) < n) bits++;
+			for (int i = 0; i < n; i++) {
+				int r = 0;
+				for (int b = 0; b < bits; b++)
+					if (i & (1 << b)) r |= 1 << (bits - 1 - b);
+				T.rev[i] = r;
+			}
+			T.wr.resize(n / 2 + 1), T.wi.resize(n / 2 + 1);
+			for (int k = 0; k <= n / 2; k++) T.wr[k] = cos(2 * M_PI * k / n), T.wi[k] = -sin(2 * M_PI * k / n);
+			it = cache.emplace(n, std::move(T)).first;
+		}
+		t = &it->second;
+	}
+	return *t;
+}
+// in-place DFT of length n over m lines: re/im[j * m + x]; sign -1: e^{-2 pi i jk/n}, +1: the conjugate kernel; unnormalised
+void fftBatch(int n, int m, double *re, double *im, int sign)
+{
+	const FftTables &T = fftTables(n);
+	for (int i = 0; i < n; i++) {
+		const int r = T.rev[i];
+		if (r > i)
+			for (int x = 0; x < m; x++) std::swap(re[(size_t) i * m + x], re[(size_t) r * m + x]), std::swap(im[(size_t) i * m + x], im[(size_t) r * m + x]);
+	}
+	for (int len = 2; len <= n; len <<= 1) {
+		const int half = len / 2, step = n / len;
+		for (int base = 0; base < n; base += len)
+			for (int k = 0; k < half; k++) {
+				const double wr = T.wr[k * step], wi = sign < 0 ? T.wi[k * step] : -T.wi[k * step];
+				double *ar = re + (size_t) (base + k) * m, *ai = im + (size_t) (base + k) * m;
+				double *br = re + (size_t) (base + k + half) * m, *bi = im + (size_t) (base + k + half) * m;
+				for (int x = 0; x < m; x++) {
+					const double tr = br[x] * wr - bi[x] * wi, ti = br[x] * wi + bi[x] * wr;
+					br[x] = ar[x] - tr, bi[x] = ai[x] - ti;
+					ar[x] += tr, ai[x] += ti;
+				}
+			}
+	}
+}
+// y[i * m + x] = sum_j M_t[i][j] x[j * m + x] for m lines at once (x, y: n x m, distinct); re, im: scratch of 2n x m each
+void fastTransformBatch(DftType t, int n, int m, const double *x, double *y, double *re, double *im)
+{
+	const bool sine = (t == DST_II || t == DST_III || t == DST_IV);
+	// the input a cosine transform of the same kind sees: sign-alternated (DST-II) or reversed (DST-III, DST-IV)
+	auto in = [&](int j, int xx) -> double {
+		if (t == DST_II) return (j & 1) ? -x[(size_t) j * m + xx] : x[(size_t) j * m + xx];
+		if (sine) return x[(size_t) (n - 1 - j) * m + xx];
+		return x[(size_t) j * m + xx];
+	};
+	if (t == DCT_II || t == DST_II) {
+		for (int j = 0; j < n / 2; j++)
+			for (int xx = 0; xx < m; xx++) {
+				re[(size_t) j * m + xx]           = in(2 * j, xx);
+				re[(size_t) (n - 1 - j) * m + xx] = in(2 * j + 1, xx);
+			}
+		std::fill(im, im + (size_t) n * m, 0.0);
+		fftBatch(n, m, re, im, -1);
+		for (int k = 0; k < n; k++) {
+			const double c = cos(M_PI * k / (2.0 * n)), sn = sin(M_PI * k / (2.0 * n));
+			double      *o = y + (size_t) (sine ? n - 1 - k : k) * m;
+			for (int xx = 0; xx < m; xx++) o[xx] = re[(size_t) k * m + xx] * c + im[(size_t) k * m + xx] * sn;
+		}
+	} else if (t == DCT_III || t == DST_III) {
+		for (int k = 0; k < n; k++) {
+			const double c = (k == 0 ? 0.5 : 1.0) * cos(M_PI * k / (2.0 * n)), sn = (k == 0 ? 0.5 : 1.0) * sin(M_PI * k / (2.0 * n));
+			for (int xx = 0; xx < m; xx++) {
+				const double v            = in(k, xx);
+				re[(size_t) k * m + xx] = v * c, im[(size_t) k * m + xx] = v * sn;
+			}
+		}
+		fftBatch(n, m, re, im, +1);
+		for (int j = 0; j < n / 2; j++)
+			for (int xx = 0; xx < m; xx++) {
+				const double a = re[(size_t) j * m + xx], b = re[(size_t) (n - 1 - j) * m + xx];
+				y[(size_t) (2 * j) * m + xx]     = a;                                   // ((-1)^i = +1 on even rows)
+				y[(size_t) (2 * j + 1) * m + xx] = sine ? -b : b;
+			}
+	} else { // DCT_IV, DST_IV
+		for (int j = 0; j < n; j++) {
+			const double c = cos(M_PI * j / (2.0 * n)), sn = sin(M_PI * j / (2.0 * n));
+			for (int xx = 0; xx < m; xx++) {
+				const double v            = in(j, xx);
+				re[(size_t) j * m + xx] = v * c, im[(size_t) j * m + xx] = v * sn;
+			}
+		}
+		std::fill(re + (size_t) n * m, re + (size_t) 2 * n * m, 0.0);
+		std::fill(im + (size_t) n * m, im + (size_t) 2 * n * m, 0.0);
+		fftBatch(2 * n, m, re, im, +1);
+		for (int i = 0; i < n; i++) {
+			const double ph = M_PI * (2 * i + 1) / (4.0 * n), c = cos(ph), sn = sin(ph), sg = (sine && (i & 1)) ? -1.0 : 1.0;
+			for (int xx = 0; xx < m; xx++) y[(size_t) i * m + xx] = sg * (re[(size_t) i * m + xx] * c - im[(size_t) i * m + xx] * sn);
+		}
+	}
+}
+// transformAxis through the fast transforms: lines along an axis of stride > 1 are already a batch (the `st` contiguous cells);
+// the x axis goes through a transpose of n x n tiles
+void fastTransformAxis(const Geo &G, DftType t, int ax, const double *in, double *out)
+{
+	const int           n = G.n, st = G.stride[ax];
+	constexpr int       MB = 64; // lines per batch: 2n x MB scratch stays in the first cache levels
+	static thread_local std::vector<double> re, im, xin, yout; // (one set per OpenMP thread, grown once)
+	if (re.size() < (size_t) 2 * n * MB) re.resize((size_t) 2 * n * MB), im.resize((size_t) 2 * n * MB), xin.resize((size_t) n * MB), yout.resize((size_t) n * MB);
+	if (st == 1) {
+		const int lines = G.nc / n;
+		for (int l0 = 0; l0 < lines; l0 += MB) {
+			const int m = std::min(MB, lines - l0);
+			for (int x = 0; x < m; x++)
+				for (int j = 0; j < n; j++) xin[(size_t) j * m + x] = in[(size_t) (l0 + x) * n + j];
+			fastTransformBatch(t, n, m, xin.data(), yout.data(), re.data(), im.data());
+			for (int x = 0; x < m; x++)
+				for (int i = 0; i < n; i++) out[(size_t) (l0 + x) * n + i] = yout[(size_t) i * m + x];
+		}
+		return;
+	}
+	const int outer = G.nc / (n * st);
+	for (int o = 0; o < outer; o++)
+		for (int x0 = 0; x0 < st; x0 += MB) {
+			const int     m   = std::min(MB, st - x0);
+			const double *src = in + (size_t) o * n * st + x0;
+			double       *dst = out + (size_t) o * n * st + x0;
+			for (int j = 0; j < n; j++)
+				for (int x = 0; x < m; x++) xin[(size_t) j * m + x] = src[(size_t) j * st + x];
+			fastTransformBatch(t, n, m, xin.data(), yout.data(), re.data(), im.data());
+			for (int i = 0; i < n; i++)
+				for (int x = 0; x < m; x++) dst[(size_t) i * st + x] = yout[(size_t) i * m + x];
+		}
+}
 struct SolvePlan {
 	std::vector<double> fwd[3], inv[3], eig;
+	DftType             ftype[3], itype[3];
 };
 SolvePlan makePlan(const orc_level *L, const Geo &G, int p)
 {
@@ -327,6 +484,7 @@ SolvePlan makePlan(const orc_level *L, const Geo &G, int p)
 		}
 		pl.fwd[ax] = transformMatrix(f, n);
 		pl.inv[ax] = transformMatrix(i, n);
+		pl.ftype[ax] = f, pl.itype[ax] = i;
 		// eigenvalues, FftwPatchSolver.h:143-168 == DftPatchSolver.h:150-166
 		for (int c = 0; c < G.nc; c++) {
 			int    xi = (c / G.stride[ax]) % n;
@@ -377,8 +535,12 @@ void solvePatch(const orc_level *L, const Geo &G, const Ifaces &I, const PlanCac
 	}
 	const SolvePlan &pl = *PC.of_patch[p];
 	double   *src = a.data(), *dst = b.data();
+	const bool fast = g_fast_transforms && (n & (n - 1)) == 0 && n >= 4;
 	for (int ax = 0; ax < G.dim; ax++) {
-		transformAxis(G, pl.fwd[ax], ax, src, dst);
+		if (fast)
+			fastTransformAxis(G, pl.ftype[ax], ax, src, dst);
+		else
+			transformAxis(G, pl.fwd[ax], ax, src, dst);
 		std::swap(src, dst);
 	}
 	for (int c = 0; c < G.nc; c++) src[c] /= pl.eig[c];
@@ -388,7 +550,10 @@ void solvePatch(const orc_level *L, const Geo &G, const Ifaces &I, const PlanCac
 	// reference tests neumann.all() (DftPatchSolver.h:208); identical for a 1-patch domain
 	if (all_neu) src[0] = 0;
 	for (int ax = 0; ax < G.dim; ax++) {
-		transformAxis(G, pl.inv[ax], ax, src, dst);
+		if (fast)
+			fastTransformAxis(G, pl.itype[ax], ax, src, dst);
+		else
+			transformAxis(G, pl.inv[ax], ax, src, dst);
 		std::swap(src, dst);
 	}
 	double scale = pow(2.0 / n, G.dim);
@@ -411,6 +576,7 @@ inline double faceDiagCoef(int kind, bool neu)
 
 extern "C" {
 void orc_set_threads(int nthreads) { g_threads = nthreads < 1 ? 1 : nthreads; }
+void orc_set_fast_transforms(int on) { g_fast_transforms = on != 0; }
 
 int orc_num_ifaces(const orc_level *L) { return buildIfaces(L).count; }
 

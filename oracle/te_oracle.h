@@ -92,6 +92,10 @@ int orc_bicgstab(const orc_level *levels, int nlevels, const orc_cycle_opts *o, 
                  const double *b, double *x, int max_it, double tol, double *final_rel_resid);
 
 void orc_set_threads(int nthreads);
+/* the exact patch solve's transforms in O(n log n) (own radix-2 FFT: what PatchSolvers/FftwPatchSolver.h:93-206 does through FFTW, the
+ * reference's default --patch_solver) instead of the dense products of DftPatchSolver.h:295-347; for the TIMED CPU baseline only: the
+ * parity oracle keeps the dense products (the two agree to 1e-12: tests/test_oracle_fast_transforms.py) */
+void orc_set_fast_transforms(int on);
 #ifdef __cplusplus
 }
 #endif
