@@ -249,6 +249,7 @@ PROVISIONAL = "#PROVISIONAL "  # worker -> supervisor: the line so far (the head
 # the line as far as it is built (rank 0, once the headline is measured): whatever ends run() afterwards -- ANY exception, not only the
 # library's -- main() prints THIS with an `error` entry, never a value-null line in its place
 HEADLINE = {"out": None, "block": None}
+DIRECT_STORE_BLOCK = "secondary.direct_store (the direct-store transport between the ranks' GPUs)"
 
 
 def metric_name(a):
@@ -395,6 +396,11 @@ def main():
     if die is not None and os.environ.get("TE_BENCH_WORKER") is not None:
         if die in ("after-provisional", "raise-after-provisional") and rank == 0:
             print(PROVISIONAL + json.dumps({"metric": metric_name(a), "value": 1.0, "n_gpus": world, "next_block": "a test block"}), file=json_out, flush=True)
+        if die == "killed-in-direct-store":  # (a GPU fault's abort / the kernel's OOM killer inside the one block that talks to other GPUs)
+            if rank == 0:
+                print(PROVISIONAL + json.dumps({"metric": metric_name(a), "value": 1.0, "n_gpus": world, "next_block": DIRECT_STORE_BLOCK}), file=json_out, flush=True)
+            import signal
+            os.kill(os.getpid(), signal.SIGKILL)
         if not die.startswith("raise-"):
             os._exit(86)
     try:
@@ -845,7 +851,7 @@ def run(a, json_out, rank, world, local_rank):
     # protocol tripped (te_gmg_push_failed), and only then is timed like the headline: secondary.direct_store, a second figure,
     # never `value`. config.sharded.verified_bit_identical says whether the two transports agreed.
     if world > 1 and a.dim == 3 and not a.no_secondary and os.environ.get("TE_BENCH_PUSH", "1") != "0" and os.environ.get("TE_BENCH_NOPROFILE") is None:
-        provisional("secondary.direct_store (the direct-store transport between the ranks' GPUs)")
+        provisional(DIRECT_STORE_BLOCK)
         ds = {"what": "the same cycles with the face exchanges and the gathers of restricted blocks as direct stores into the peers' "
                       "hipIpc-mapped buffers (te_gmg_use_push) instead of " + exchange_backend}
         verified = None

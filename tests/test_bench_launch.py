@@ -60,6 +60,18 @@ def test_supervisor_prints_a_line_when_the_worker_dies(die):
     assert q.returncode == 86 and json_lines(q.stdout) == []
 
 
+def test_worker_killed_inside_the_direct_store_block_keeps_the_headline():
+    """the one block of the N > 1 line that has never met two GPUs is secondary.direct_store: a worker that is KILLED in it (SIGKILL: no
+    handler runs, nothing more is printed) leaves rank 0's supervisor with the provisional line -- the measured headline -- and the
+    error names the block and the signal"""
+    env = {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "TE_BENCH_TEST_DIE": "killed-in-direct-store"}
+    p = run_bench(["--gpus", "2", "--size", "64"], env)
+    assert p.returncode != 0
+    lines = json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    assert lines[0]["value"] == 1.0 and "secondary.direct_store" in lines[0]["error"] and "signal 9" in lines[0]["error"], lines[0]
+
+
 def test_supervisor_prefers_the_provisional_line_to_a_value_null_last_line():
     """(round 5 advisor) a worker that has handed over its measured headline (PROVISIONAL) and then ends in an exception that is not the
     library's prints a value-null error line on its way out: rank 0's supervisor must keep the measured headline and put the
