@@ -17,9 +17,12 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	rd.coarse     = coarse;
 	rd.remote     = L.upbuf.p;
 	rd.remote_off = L.up_off.p;
-	// the patches export their 2x2 face sums only on uniformly refined levels; a refined level's terms are formed by the
-	// gather kernel from the face layers
-	const bool export_rs6 = fcorr_out && L.prolong_fusable;
+	// the patches export the 2x2 sums of their face layers (rs6); what lies behind a ghost slot, and a copy-through patch's own faces,
+	// the gather kernel forms from the slot / the face layers
+	// (round 6: on refined levels too -- the kernel's export does not look at what a patch is, a same-level neighbour's finished sums
+	// are what the gather needs behind every FACE_LOCAL face, and they are a quarter of the face layers it read instead:
+	// 141 -> 107 (descriptors) -> ... us per launch on `2refine --divide 3`; TE_NO_RS6_CF: as before)
+	const bool export_rs6 = fcorr_out && L.rs6.p && (L.prolong_fusable || !g->cfg.has(O_NO_RS6_CF));
 	rd.rs6                = export_rs6 ? L.rs6.p : nullptr;
 	int rc;
 	if (L.P > 0) {
@@ -70,7 +73,23 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	L.ghost_has_v = !store_u; // (the slots of neighbours on other ranks hold their face layers of v until the next exchange of the level)
 	if (fcorr_out) { // the ghost terms were formed by the patches that own the face values: sort them into the coarse
 		// level's side array (a permutation copy of 6/128 of a vector instead of the fix-up pass)
-		if (L.Pc > 0) {
+		if (L.Pc > 0 && !g->cfg.has(O_NO_GTAB2) && !g->cfg.has(O_NO_GTAB)) { // descriptors once per level, then 16-byte data loads only (k_fcorr_gather3d_v2)
+			LevelDev  D   = L.dev();
+			const int key = (export_rs6 ? 1 : 0) | (D.f6off ? 2 : 0);
+			if (L.gdesc_key != key) { // (built once; again if the face layers change their layout: TE_PACK_FACES)
+				int rc2 = L.gdesc.p ? TE_OK : L.gdesc.alloc((size_t) L.Pc * 48);
+				if (rc2) return rc2;
+				hipLaunchKernelGGL(k_gather_desc3d<N>, dim3(L.Pc), dim3(64), 0, g->stream, D, L.child.p, L.copy.p, export_rs6 ? 1 : 0, L.gdesc.p);
+				L.gdesc_key = key;
+			}
+			if (L.fcorr_zeroed_for != fcorr_out) { // (planes without a term are never stored: k_fcorr_gather3d_v2; the other gathers store every entry)
+				HIPCHK(hipMemsetAsync(fcorr_out, 0, sizeof(double) * (size_t) L.Pc * 4 * N * N, g->stream));
+				L.fcorr_zeroed_for = fcorr_out;
+			}
+			Timed t(g, KC_FCORR_GATHER, (size_t) L.P * 6 * L.nf / 4);
+			hipLaunchKernelGGL(k_fcorr_gather3d_v2<N>, dim3(L.Pc * 12), dim3(256), 0, g->stream, D, (const GatherDesc *) L.gdesc.p,
+			                   export_rs6 ? (const double *) L.rs6.p : (const double *) nullptr, (const double *) L.f6buf.p, coarse, fcorr_out);
+		} else if (L.Pc > 0) {
 			const bool use_gtab = export_rs6 && !g->cfg.has(O_NO_GTAB);
 			if (use_gtab && !L.gtab.p && (size_t) L.P * 6 * (N / 2) * (N / 2) < ((size_t) 1 << 31)) { // once per level
 				int rc2 = L.gtab.alloc((size_t) L.Pc * 48);

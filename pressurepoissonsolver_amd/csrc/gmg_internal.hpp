@@ -82,7 +82,7 @@ extern const char *kclassName[KC_COUNT]; // (gmg_core.hip)
 enum Opt : int {
 	O_2D_SIMPLE, O_2D_NO_MFMA, O_2D_NO_PF, O_2D_NO_MR_FUSE, O_2D_TPB, O_NO_FUSE2, O_NO_FUSE3, O_NO_FUSE3_CF, O_NO_CFP, O_NO_XF,
 	O_NO_FCORR, O_NO_FCORR_CF, O_NO_GTAB, O_NO_OVERLAP, O_OVERLAP_MIN, O_NO_PS_FACES, O_PS_MODE, O_PS_SLOW, O_RBGS_NOSLAB,
-	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_PUSH_TIMEOUT, O_NO_BICG_XF, O_PUSH_FAULT, O_2D_NO_FOLD, O_2D_NO_SYM, O_PUSH_NONFATAL, O_PS_NO_HALF, O_PS_HALF_MAX, O_COUNT
+	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_PUSH_TIMEOUT, O_NO_BICG_XF, O_PUSH_FAULT, O_2D_NO_FOLD, O_2D_NO_SYM, O_PUSH_NONFATAL, O_PS_NO_HALF, O_PS_HALF_MAX, O_NO_GTAB2, O_NO_RS6_CF, O_COUNT
 };
 extern const char *optName[O_COUNT]; // (gmg_core.hip)
 // options that shape the level tables te_gmg_create builds: fixed for the solver's lifetime
@@ -316,7 +316,10 @@ struct LevelHost {
 	bool           f_has_corr = false;
 	Fold2DHost     fold_pending; // (2D) belongs to the current L.f, inside te_vcycle: see Fold2DHost
 	DevBuf<double> rs6; // [P][6][(n/2)^2]: the 2x2 sums of the face layers, as the producer of the next level's fcorr
-	DevBuf<int32_t> gtab; // 3D: [Pc][48] block starts in rs6 for k_fcorr_gather3d (built at its first launch)
+	DevBuf<int32_t> gtab; // 3D: [Pc][48] block starts in rs6 for k_fcorr_gather3d (built at its first launch; TE_NO_GTAB2)
+	DevBuf<GatherDesc> gdesc; // 3D: [Pc][48] k_fcorr_gather3d_v2's descriptors; gdesc_key: what they were built for (rs6 there? f6 through the table?)
+	int                gdesc_key = -1;
+	const double      *fcorr_zeroed_for = nullptr; // the coarse level's side array this level's gather has zeroed once (its all-zero planes are never written)
 	DevBuf<double> e4buf; // 2D: [P][4][n] edge layers of an iterate that is never stored (the 2D twin of f6buf)
 	const double  *pack_f6 = nullptr; // set while that iterate is the one whose faces travel to other ranks
 	// reference smoother, opts.fuse = 3: the zero-guess pre-sweep is asked to store only the face layers of its result (ps_faces_req,

@@ -1044,6 +1044,159 @@ __global__ __launch_bounds__(256) void k_fcorr_gather3d(LevelDev L, const int32_
 	}
 }
 
+// k_fcorr_gather3d, round 6. The kernel above walks child -> face kind / source -> f6 offset -> values for EVERY entry in EVERY thread:
+// on a refined fine level (no rs6, no table) each entry costs five dependent loads and ~9 load instructions of which 4 fetch data --
+// 150 us per launch at 0.97 TB/s on `2refine --divide 3` (profiles/r05_bench_c4_2refine_div3_n1.json) -- and on a uniform one a table
+// word per entry. But the walk depends on the (coarse patch, axis, plane, quadrant) only: 48 answers per coarse patch. k_gather_desc3d
+// writes them down once per level as descriptors -- what to read (finished sums of a neighbour / a 2x2 sum over a face layer or a
+// ghost slot / a copy-through patch's own face, cell by cell), where, and the weight -- and the gather keeps the (at most 12)
+// descriptors of its plane in LDS: a thread issues nothing but 16-byte data loads, two adjacent entries at a time. The values,
+// the order of the additions and the stores are those of k_fcorr_gather3d (bit-identical; TE_NO_GTAB runs the kernel above).
+struct GatherDesc {
+	int32_t mode, pad;
+	int64_t off; // doubles, inside rs6 / f6 / the ghost planes
+	double  w;   // -1/h^2 of the axis
+};
+enum GatherMode : int32_t { GD_ZERO = 0, GD_RS6 = 1, GD_SUM_F6 = 2, GD_SUM_GHOST = 3, GD_COPY_F6 = 4, GD_COPY_GHOST = 5 };
+template <int N>
+__global__ void k_gather_desc3d(LevelDev L, const int32_t *__restrict__ child, const int32_t *__restrict__ copy, int has_rs6,
+                                GatherDesc *__restrict__ gd)
+{
+	constexpr int NN = N * N, HH = (N / 2) * (N / 2);
+	const int     pc = blockIdx.x, e = threadIdx.x;
+	if (e >= 48) return;
+	const int  ax = e / 16, j = (e / 4) % 4, oa = e & 1, ob = (e >> 1) & 1;
+	GatherDesc d;
+	d.mode = GD_ZERO, d.pad = 0, d.off = 0, d.w = 0.0;
+	if (copy && copy[pc]) { // the coarse patch IS a fine patch that does not coarsen: its own two faces of the axis, cell by cell (w g)
+		if (j == 0 || j == 3) {
+			const int p = child[(size_t) pc * 8], sp = 2 * ax + (j == 3);
+			if (p >= 0) {
+				const int kind = L.face_kind[(size_t) p * 6 + sp], src = L.face_src[(size_t) p * 6 + sp];
+				if (kind >= FACE_LOCAL) {
+					d.w    = -L.rh2[(size_t) p * 3 + ax];
+					d.mode = kind == FACE_GHOST ? GD_COPY_GHOST : GD_COPY_F6;
+					d.off  = kind == FACE_GHOST ? (int64_t) src * NN : (int64_t) f6Face<N>(L.f6off, src, sp ^ 1);
+				}
+			}
+		}
+	} else {
+		const int a0 = (ax == 0) ? 1 : 0, a1 = (ax == 2) ? 1 : 2;
+		const int s = 2 * ax + (j & 1), hi = j >> 1;
+		const int p = child[(size_t) pc * 8 + ((hi << ax) | (oa << a0) | (ob << a1))];
+		if (p >= 0) {
+			const int kind = L.face_kind[(size_t) p * 6 + s], src = L.face_src[(size_t) p * 6 + s];
+			if (kind == FACE_LOCAL && has_rs6) {
+				d.mode = GD_RS6;
+				d.off  = ((int64_t) src * 6 + (s ^ 1)) * HH;
+			} else if (kind >= FACE_LOCAL) {
+				d.w    = -L.rh2[(size_t) p * 3 + ax];
+				d.mode = kind == FACE_GHOST ? GD_SUM_GHOST : GD_SUM_F6;
+				d.off  = kind == FACE_GHOST ? (int64_t) src * NN : (int64_t) f6Face<N>(L.f6off, src, s ^ 1);
+			}
+		}
+	}
+	gd[(size_t) pc * 48 + e] = d;
+}
+// the terms of the two adjacent entries (a, b), (a + 1, b) of a plane, a even (they share a quadrant)
+template <int N>
+__device__ __forceinline__ double2 gatherPair(const GatherDesc &d, int a, int b, const double *__restrict__ rs6, const double *__restrict__ f6,
+                                              const double *__restrict__ ghost)
+{
+	constexpr int H = N / 2;
+	const int     oa = a >= H, ob = b >= H, ha = a - oa * H, hb = b - ob * H;
+	if (d.mode == GD_ZERO) return double2{0.0, 0.0};
+	if (d.mode == GD_RS6) return *reinterpret_cast<const double2 *>(rs6 + d.off + ha + H * hb);
+	const double *gp = ((d.mode == GD_SUM_GHOST || d.mode == GD_COPY_GHOST) ? ghost : f6) + d.off;
+	if (d.mode == GD_COPY_F6 || d.mode == GD_COPY_GHOST) {
+		const double2 g = *reinterpret_cast<const double2 *>(gp + a + N * b);
+		return double2{d.w * g.x, d.w * g.y};
+	}
+	// the sum of k_restrict_fixup3d over the 2x2 block, first face coordinate fastest
+	const double2 r00 = *reinterpret_cast<const double2 *>(gp + 2 * ha + N * (2 * hb)), r10 = *reinterpret_cast<const double2 *>(gp + 2 * ha + 2 + N * (2 * hb));
+	const double2 r01 = *reinterpret_cast<const double2 *>(gp + 2 * ha + N * (2 * hb + 1)), r11 = *reinterpret_cast<const double2 *>(gp + 2 * ha + 2 + N * (2 * hb + 1));
+	double2       v   = double2{0.0, 0.0};
+	v.x += (d.w * r00.x) / 8, v.x += (d.w * r00.y) / 8, v.x += (d.w * r01.x) / 8, v.x += (d.w * r01.y) / 8;
+	v.y += (d.w * r10.x) / 8, v.y += (d.w * r10.y) / 8, v.y += (d.w * r11.x) / 8, v.y += (d.w * r11.y) / 8;
+	return v;
+}
+template <int N>
+__global__ __launch_bounds__(256) void k_fcorr_gather3d_v2(LevelDev L, const GatherDesc *__restrict__ gd, const double *__restrict__ rs6,
+                                                           const double *__restrict__ f6, double *__restrict__ coarse, double *__restrict__ fcorr)
+{
+	constexpr int NN = N * N, NNN = N * N * N, H = N / 2;
+	constexpr int NPAIR = NN / 2, QN = (NPAIR + 255) / 256; // pairs of adjacent entries per plane / per thread
+	constexpr int coord[4] = {0, H - 1, H, N - 1};
+	const int     pc = blockIdx.x / 12, blk = blockIdx.x % 12, j = blk & 3; // 0..3: the x planes; 4..7: the y planes; 8..11: the z planes
+	__shared__ GatherDesc sd[12];
+	if (threadIdx.x < 12) {
+		const int q = threadIdx.x;
+		if (q < 4)
+			sd[q] = gd[(size_t) pc * 48 + (blk >> 2) * 16 + j * 4 + q];
+		else if (blk >= 8) // the y terms of the rows of this z plane that lie on a y plane too: plane jy, quadrant (x half, this plane's z half)
+			sd[q] = gd[(size_t) pc * 48 + 16 + ((q - 4) >> 1) * 4 + ((q - 4) & 1) + 2 * (j >> 1)];
+	}
+	__syncthreads();
+	// a plane none of whose descriptors has anything to add (the inner octant planes of a copy-through patch, faces on the physical
+	// boundary): nothing to read, and nothing to write -- the side array is zeroed when the descriptors are built, and only this
+	// kernel writes it afterwards, the same entries every time
+	bool any = false;
+#pragma unroll
+	for (int q = 0; q < 12; q++) any = any || (q < (blk >= 8 ? 12 : 4) && sd[q].mode != GD_ZERO);
+	if (!any) return;
+	double  *cv = coarse + (size_t) pc * NNN;
+	double2 v[QN], vy[QN], f[QN];
+	if (blk < 4) { // an x plane: into the side array
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = 2 * (threadIdx.x + 256 * k), a = i % N, b = i / N;
+			v[k]        = i < NN ? gatherPair<N>(sd[(a >= H) + 2 * (b >= H)], a, b, rs6, f6, L.ghost) : double2{0.0, 0.0};
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = 2 * (threadIdx.x + 256 * k);
+			if (i < NN) *reinterpret_cast<double2 *>(fcorr + ((size_t) pc * 4 + j) * NN + i) = v[k];
+		}
+	} else if (blk < 8) { // a y plane: entry (x, z) -> cell (x, coord[j], z); the cells that also lie on a z plane are that plane's
+#pragma clang fp contract(off)
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int  i = 2 * (threadIdx.x + 256 * k), a = i % N, b = i / N;
+			const bool in = i < NN && octPlane<N>(b) < 0;
+			v[k]          = in ? gatherPair<N>(sd[(a >= H) + 2 * (b >= H)], a, b, rs6, f6, L.ghost) : double2{0.0, 0.0};
+			f[k]          = in ? *reinterpret_cast<const double2 *>(cv + a + N * coord[j] + NN * b) : double2{0.0, 0.0};
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = 2 * (threadIdx.x + 256 * k), a = i % N, b = i / N;
+			double2   t = f[k];
+			if (v[k].x != 0.0) t.x = t.x + v[k].x;
+			if (v[k].y != 0.0) t.y = t.y + v[k].y;
+			if (v[k].x != 0.0 || v[k].y != 0.0) *reinterpret_cast<double2 *>(cv + a + N * coord[j] + NN * b) = t;
+		}
+	} else { // a z plane: entry (x, y) -> cell (x, y, coord[j]); a cell that lies on a y plane too takes its y term first
+#pragma clang fp contract(off)
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int  i = 2 * (threadIdx.x + 256 * k), a = i % N, b = i / N, jy = octPlane<N>(b);
+			const bool in = i < NN;
+			f[k]          = in ? *reinterpret_cast<const double2 *>(cv + a + N * b + NN * coord[j]) : double2{0.0, 0.0};
+			vy[k]         = (in && jy >= 0) ? gatherPair<N>(sd[4 + 2 * jy + (a >= H)], a, coord[j], rs6, f6, L.ghost) : double2{0.0, 0.0};
+			v[k]          = in ? gatherPair<N>(sd[(a >= H) + 2 * (b >= H)], a, b, rs6, f6, L.ghost) : double2{0.0, 0.0};
+		}
+#pragma unroll
+		for (int k = 0; k < QN; k++) {
+			const int i = 2 * (threadIdx.x + 256 * k), a = i % N, b = i / N;
+			double2   t = f[k];
+			if (vy[k].x != 0.0) t.x = t.x + vy[k].x;
+			if (vy[k].y != 0.0) t.y = t.y + vy[k].y;
+			if (v[k].x != 0.0) t.x = t.x + v[k].x;
+			if (v[k].y != 0.0) t.y = t.y + v[k].y;
+			if (vy[k].x != 0.0 || vy[k].y != 0.0 || v[k].x != 0.0 || v[k].y != 0.0) *reinterpret_cast<double2 *>(cv + a + N * b + NN * coord[j]) = t;
+		}
+	}
+}
+
 // ---- pre-smoothing sweep from a zero iterate + residual + restriction in one pass (opts.fuse = 2) --------------
 // Cycle.h:57-65 for the first sweep of a cycle: u = S(0, f); coarse f = AvgRstr(f - A u). The sweep of a patch
 // needs no neighbour data at all (every ghost of a zero iterate is zero), and the residual of every cell that

@@ -157,6 +157,34 @@ def test_patch_solve_variants_agree(case, monkeypatch):
     assert rel(got["1pass"][1], got["3pass"][1]) <= 1e-13
 
 
+@pytest.mark.parametrize("mesh,n,div,neumann", [("uniform", 8, 4, False), ("uniform", 32, 4, True), ("2refine.bin", 8, 3, False), ("2refine.bin", 4, 3, True),
+                                                ("2refine.bin", 16, 3, False)])
+def test_exported_ghost_terms_gather_variants_bit_identical(mesh, n, div, neumann):
+    """Two fused levels in a row: the ghost terms of the restricted residual reach the coarse level through k_fcorr_gather3d_v2
+    (round 6: per-level descriptors, 16-byte data loads only), through the kernel it replaces (TE_NO_GTAB2: a table word per entry on
+    uniform levels, the walk child -> face -> offset per entry on refined ones) or through the fix-up pass (TE_NO_FCORR): the same
+    bits. Uniform (finished sums of the neighbours) and refined (2x2 sums over face layers, copy-through patches) fine levels."""
+    m, H, levels = util.setup(mesh, n, div, neumann=neumann, dim=3)
+    g = capi.GMG(H)
+    f = util.rand_vec(H.cells(0), 77) / levels[0].a["h"].min() ** 2
+    got = {}
+    for name, opt in (("v2", None), ("v1", "TE_NO_GTAB2"), ("walk", "TE_NO_GTAB"), ("layers", "TE_NO_RS6_CF"), ("fixup", "TE_NO_FCORR")):
+        if opt:
+            g.set_option(opt, "1")
+        df, du = g.new_vector(0, f), g.new_vector(0)
+        g.profile(True)
+        g.profile_reset()
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+        rows = g.profile_rows()
+        g.profile(False)
+        if opt:
+            g.set_option(opt, None)
+        assert ("fcorr_gather" in rows) == (name != "fixup"), (name, sorted(rows))
+        got[name] = du.download()
+    for name in ("v1", "walk", "layers", "fixup"):
+        assert np.array_equal(got["v2"], got[name]), name
+
+
 @pytest.mark.parametrize("n,neumann,mesh,div", [(4, False, "uniform", 3), (8, False, "uniform", 3), (8, True, "uniform", 3),
                                                 (16, False, "uniform", 3), (32, False, "uniform", 3),
                                                 # refined: patches that copy through, coarse/fine faces (960 patches)
