@@ -10,8 +10,11 @@ smoother) so that the GPU tests can compare at full size without repeating it:
     checksum                wrap-around uint64 sum of the bit patterns of x (order-independent)
 
 Smoothers: 0 = the reference's block-Jacobi patch solve (FFTBlockJacobiSmoother.h:55-58), 2 = patch-local red-black
-Gauss-Seidel (the headline smoother; the builder's restatement). Usage: python oracle/gen_c3_solve.py [div] [n]
-(defaults 4, 32 = C3; `3 32` writes the C2 twin used to cross-check the fixture format against a live run)."""
+Gauss-Seidel (the headline smoother; the builder's restatement). Usage: python oracle/gen_c3_solve.py [div] [n] [mesh] [tag]
+(defaults 4, 32 = C3; `3 32` writes the C2 twin used to cross-check the fixture format against a live run; round 6:
+`2 32 2refine.bin c4` = C4 at the parity tests' size (960 patches) and `4 16 uniform d16` = 256^3 in 16^3 patches, whose live
+oracle solves were 45 s of every GPU test run -- for these two the oracle's level tables come from oracle/levels_bfs.py, not from
+the product's hierarchy)."""
 import os
 import sys
 import time
@@ -35,18 +38,25 @@ def sample_index(P, nc, seed=0xC3):
 def main():
     div = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-    m = capi.Mesh.unit_root(3)
+    mesh = sys.argv[3] if len(sys.argv) > 3 else "uniform"
+    m = capi.Mesh.unit_root(3) if mesh == "uniform" else capi.Mesh.read(os.path.join(ROOT, "tests", "golden", mesh), 3)
     for _ in range(div):
         m.refine_leaves()
     H = capi.Hierarchy(m, n)
-    levels = orc.levels_from_hierarchy(H)
+    if len(sys.argv) > 4:  # (the fixtures of round 6: level tables independent of the product's)
+        from oracle import levels_bfs
+        nodes = m.nodes()
+        tabs = levels_bfs.tables_in_order(levels_bfs.extract_levels(nodes, 3), nodes, 3, [H.tables(l)["id"] for l in range(H.num_levels)])
+        levels = [orc.Level.from_tables(t, 3, n, False) for t in tabs]
+    else:
+        levels = orc.levels_from_hierarchy(H)
     t0 = H.tables(0)
     ids = np.asarray(t0["id"])
     orc.set_threads(os.cpu_count() or 1)
     b, exact = problems.init_dirichlet(t0, n)
     nc = n ** 3
     pp, cc = sample_index(levels[0].P, nc)
-    tag = {4: "c3", 3: "c2"}.get(div, f"div{div}") + ("" if n == 32 else f"_n{n}")
+    tag = sys.argv[4] if len(sys.argv) > 4 else {4: "c3", 3: "c2"}.get(div, f"div{div}") + ("" if n == 32 else f"_n{n}")
     for sm, name in ((0, "patch_solve"), (2, "rbgs")):
         t = time.time()
         x, its, rr = orc.bicgstab(levels, orc.cycle_opts(smoother=sm), b)

@@ -155,15 +155,18 @@ def test_default_bicgstab_against_oracle_at_full_size(full, smoother):
     its, rr = g.bicgstab(dx, db, g.default_opts(smoother=smoother))
     x = dx.download()
     name = "rbgs" if smoother == capi.SMOOTH_RBGS else "patch_solve"
-    if full["name"] in ("C3-512^3", "C2-256^3"):
-        # (C2 both ways: the fixture format is itself checked against the live oracle below)
-        fx = solve_fixture("c3" if full["name"].startswith("C3") else "c2", name)
+    tag = {"C3-512^3": "c3", "C2-256^3": "c2", "C4-2refine-div2": "c4", "256^3-in-16^3": "d16"}.get(full["name"])
+    if tag:
+        # the oracle's solve from its committed fixture (oracle/gen_c3_solve.py, run once in the build container: minutes of host time
+        # per configuration that every GPU test run used to repeat). C2 with RB-GS goes both ways: the fixture format is itself checked
+        # against the live oracle below
+        fx = solve_fixture(tag, name)
         assert int(fx["n"]) == full["n"] and int(fx["smoother"]) == smoother
         assert rr <= 1e-12 and float(fx["rr"]) <= 1e-12 and abs(its - int(fx["its"])) <= 1
         against_fixture(x, H.tables(0)["id"], full["n"] ** 3, fx, 1e-8)
         e = rel(x, exact)
         assert abs(e - float(fx["err_rel"])) <= 1e-3 * float(fx["err_rel"])
-        if full["name"].startswith("C3"):
+        if not (tag == "c2" and smoother == capi.SMOOTH_RBGS):
             return
     x_ref, its_ref, rr_ref = orc.bicgstab(levels, orc.cycle_opts(smoother=smoother), b)
     assert rr <= 1e-12 and rr_ref <= 1e-12 and abs(its - its_ref) <= 1

@@ -22,9 +22,26 @@ def mesh(name, divides=0, dim=3):
     return m
 
 
-def setup(name, n, divides=0, neumann=False, dim=3, **kw):
+def independent_levels(m, H):
+    """The oracle's level tables WITHOUT the product's: the tree's node table (pinned node for node to the reference's Tree<D> by
+    tests/golden/ref_tree_*.npz) through oracle/levels_bfs.py, the breadth-first walk of ThundereggDomGen.h:127-222 restated in
+    Python. Only the ORDER of the patches inside a level is taken from the hierarchy (the implementation's choice, not semantics): a
+    neighbour, parent or orthant the product's csrc/mesh.cpp got wrong no longer cancels between the two sides of a parity test."""
+    from oracle import levels_bfs
+    nodes = m.nodes()
+    nl = H.num_levels
+    tabs = levels_bfs.tables_in_order(levels_bfs.extract_levels(nodes, H.dim)[:nl], nodes, H.dim, [H.tables(l)["id"] for l in range(nl)])
+    return [orc.Level.from_tables(t, H.dim, H.n, H.neumann) for t in tabs]
+
+
+def setup(name, n, divides=0, neumann=False, dim=3, independent=True, **kw):
+    """mesh, hierarchy and the oracle's levels. independent (default): the levels come from oracle/levels_bfs.py, not from the
+    hierarchy under test (round 5 review, parity 1c); False: orc.levels_from_hierarchy (hierarchies the walk does not model:
+    patches_per_proc cut-offs)"""
     m = mesh(name, divides, dim)
     H = capi.Hierarchy(m, n, neumann=neumann, **kw)
+    if independent and not kw.get("patches_per_proc"):
+        return m, H, independent_levels(m, H)
     return m, H, orc.levels_from_hierarchy(H)
 
 
