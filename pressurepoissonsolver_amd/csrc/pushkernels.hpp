@@ -24,6 +24,12 @@
 // PUSH_ERR_PEER_BEHIND (the stores of this push may have overwritten data the peer had not read). (iii) It keeps the last epoch
 // it raised per peer and slot in its own memory: anything but e - 1 is PUSH_ERR_SEQUENCE (the host skipped or repeated an exchange).
 // All three set the solver's error word like a wait that gave up; te_gmg_push_failed returns the code.
+// ASSUMPTION the three checks rest on: the exchanges of ONE slot are ordered on the device -- push e + 1 of a slot is issued behind
+// the wait for e of the same slot. pushExchange runs on whichever stream the level's overlap form hands it (the communication
+// stream under the interior patches, or the solver stream), and the host orders the two with events around every exchange
+// (withGhosts: ev_pack in front, ev_recv behind), so the order holds whatever form a level takes and when the form changes between
+// cycles; tests/test_gpu_multirank.py::test_direct_store_transport_under_every_overlap_form runs every form and every change of form.
+// A caller that issued exchanges of one slot on two streams WITHOUT such events would trip PUSH_ERR_SEQUENCE (by design).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

@@ -499,6 +499,15 @@ def test_direct_store_transport_virtual_ranks():
     run_inner("direct_store_virtual_ranks_body")
 
 
+def test_direct_store_transport_under_every_overlap_form():
+    """(round 5 advisor) the protocol's checks (overrun, peer behind, sequence) rest on per-slot stream order: push e + 1 of a slot
+    sits behind wait e. pushExchange runs on the communication stream or on the solver stream depending on how a level meets its
+    exchange (in line / exchange under the interior patches / interior patches on the second stream): every form te_gmg_autotune
+    can choose, and changes of form from one cycle to the next on the same slots, must leave push_failed() == 0 and the single-rank
+    bits"""
+    run_inner("direct_store_overlap_forms_body")
+
+
 def test_direct_store_overrun_is_caught_by_the_receiver():
     """the no-credit argument as a check: a peer whose flag is TWO exchanges ahead (TE_PUSH_FAULT=overrun raises epoch + 2) cannot
     exist under the protocol -- k_push_wait must set the error word to PUSH_ERR_OVERRUN (2) instead of taking it for an arrival"""
@@ -551,6 +560,41 @@ def test_direct_store_virtual_ranks_body():
     for k in ("v0", "v1", "v2", "off", "on"):
         assert np.array_equal(got[k], want[0]), k
     assert np.array_equal(got["w"], want[1])
+
+
+@pytest.mark.skipif(os.environ.get("TE_DIRECT_STORE_INNER") != "1", reason="runs in a process of its own: test_direct_store_transport_under_every_overlap_form")
+def test_direct_store_overlap_forms_body():
+    n = 8
+    mesh = util.mesh("uniform", 3)
+    H1 = capi.Hierarchy(mesh, n)
+    g1 = capi.GMG(H1)
+    f = util.rand_vec(H1.cells(0), 12)
+    nc = n ** 3
+    d1 = g1.new_vector(0)
+    g1.cycle(g1.default_opts(smoother=capi.SMOOTH_RBGS), g1.new_vector(0, f), d1)
+    want = d1.download()
+    # (TE_OVERLAP_MIN, TE_OVERLAP_MODE): in line; exchange on the communication stream under the interior patches; interior patches on
+    # the second stream, exchange on the solver stream -- and back and forth between them, so that consecutive exchanges of one slot
+    # are issued on different streams
+    forms = [("1000000", None), ("0", None), ("0", "2"), ("0", None), ("1000000", None), ("0", "2"), ("0", "2"), ("0", None)]
+
+    def per_rank(r, H, g, fab):
+        df, du = g.new_vector(0, f.reshape(-1, nc)[H.l2g(0)].ravel()), g.new_vector(0)
+        out = {}
+        g.use_push(True)
+        for k, (omin, omode) in enumerate(forms):
+            g.set_option("TE_OVERLAP_MIN", omin)
+            g.set_option("TE_OVERLAP_MODE", omode)
+            g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+            out[f"c{k}"] = du.download()
+        out["failed"] = g.push_failed()
+        g.use_push(False)
+        return out
+
+    got = shard_run(mesh, n, 2, per_rank)
+    assert not any(got["failed"]), got["failed"]
+    for k in range(len(forms)):
+        assert np.array_equal(got[f"c{k}"], want), (k, forms[k])
 
 
 @pytest.mark.skipif(os.environ.get("TE_DIRECT_STORE_INNER") != "1", reason="runs in a process of its own: test_direct_store_overrun_is_caught_by_the_receiver")
