@@ -22,7 +22,7 @@ CLASS = [(r"k_rbgs_zero_resid3d<\d+, false, \w+, true", "rbgs_zero_resid_restric
          (r"k_rbgs_zero_resid3d<\d+, false", "rbgs_zero_resid_restrict_faces"),
          (r"k_rbgs_resweep_prolong3d<\d+, \d+, true", "rbgs_resweep_prolong_fcorr"), (r"k_rbgs_resweep_prolong3d", "rbgs_resweep_prolong"),
          (r"k_rbgs_zero_resid3d", "rbgs_zero_resid_restrict"), (r"k_restrict_fixup3d", "restrict_fixup"), (r"k_fcorr_gather3d", "fcorr_gather"),
-         (r"k_rbgs3d<\d+, \w+, \w+, [24][,>]", "stencil_rbgs_slabs"), (r"k_stencil3d<\d+, \d, [24]>", "stencil_slabs"),
+         (r"k_rbgs3d<\d+, \w+, \w+, [248][,>]", "stencil_rbgs_slabs"), (r"k_stencil3d<\d+, \d, [248][,>]", "stencil_slabs"),
          (r"k_rbgs3d<\d+, true", "stencil_rbgs_zero"), (r"k_rbgs3d<\d+, false, true", "stencil_rbgs_prolong"),
          (r"k_rbgs3d<", "stencil_rbgs"), (r"k_stencil3d<\d+, 0,", "stencil_apply"), (r"k_stencil3d<\d+, 1,", "stencil_resid"),
          (r"k_stencil3d<\d+, 2,", "stencil_jacobi"), (r"k_stencil3d<\d+, 3,", "resid_restrict"),
