@@ -6,10 +6,14 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
 C=$1
+PART=${2:-all}   # base | extra | all (one gpurun call is at most 20 minutes: base and extra fit one each)
 T=r06
 W=gpurun_out/${T}f
+if [ "$PART" != "extra" ]; then
 bash tools/regen_profiles.sh $C $T || exit 1
 echo "base regen done"
+fi
+[ "$PART" = "base" ] && exit 0
 bash tools/profile_round.sh ${T}f_c4 $C --mesh tests/golden/2refine.bin --divide 3 > ${W}_c4_profile.log 2>&1 || { tail -5 ${W}_c4_profile.log; exit 1; }
 python3 tools/prof_summary.py ${W}_c4 ${W}_c4/summary $C "bench.py --steps 20 --warmup 5 --mesh tests/golden/2refine.bin --divide 3" "3d:2refine.bin+3:p32:rbgs" 1 > /dev/null
 echo "c4 counters done"
