@@ -20,6 +20,7 @@ csrc/ travels with it); otherwise it is null.
 import argparse
 import hashlib
 import json
+import math
 import os
 import platform
 import sys
@@ -576,10 +577,20 @@ def run(a, json_out, rank, world, local_rank):
             dom_name = names[0]
         # timed region: HIP events around the dominant class only (an event pair per launch costs a few
         # microseconds of stream time; a V-cycle is a dozen launches)
+        stride = 1
         if os.environ.get("TE_BENCH_NOPROFILE") is not None:  # tooling: wall time only
             g.profile(False)
         else:
             g.profile_select(dom_name)  # (--warmup 0: no candidate yet, every class is timed)
+            # an event pair on a dispatch costs microseconds of stream time on this runtime (profiles/r06_event_cost.txt: 24-28 us of a
+            # 210-us 4096^2 cycle with its six timed launches, 0-20 us of a 512^3 cycle with its one): inside the timed
+            # region every FOURTH launch of the dominant class carries one (a stride without a common factor with the class's launches
+            # per cycle, so that the sample walks over all its levels; TE_BENCH_EVENT_STRIDE=1: every launch, as before round 6)
+            if dom_name is not None and steps >= 8 and profiled_warm > 0:
+                per_cycle = max(1, round(rows_all[dom_name]["calls"] / profiled_warm)) if dom_name in rows_all else 1
+                want = int(os.environ.get("TE_BENCH_EVENT_STRIDE", "4"))
+                stride = next((c for c in (want, want + 1, want - 1, want + 3) if c >= 1 and math.gcd(c, per_cycle) == 1), 1)
+            g.profile_stride(stride)
         g.profile_reset()
         barrier()
         t0 = time.perf_counter()
@@ -590,11 +601,12 @@ def run(a, json_out, rank, world, local_rank):
         rows = g.profile_rows()
         g.profile(False)
         g.profile_select(None)
+        g.profile_stride(1)
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return {"dt": dt, "rows_all": rows_all, "rows": rows, "profiled_warm": profiled_warm}
+        return {"dt": dt, "rows_all": rows_all, "rows": rows, "profiled_warm": profiled_warm, "event_stride": stride}
 
     def median_cycle_ms(o, steps, g=None, f=None, u=None):
         """median of per-cycle times: an event pair per cycle on the solver stream"""
@@ -698,7 +710,9 @@ def run(a, json_out, rank, world, local_rank):
         out = None
     elif rank == 0:
         name, st = max(((k, v) for k, v in rows.items() if k in ALG_BYTES), key=lambda kv: kv[1]["ms"])
-        roof = roofline_of(name, st, workload_key(a), world, copy_sites, a.steps)
+        roof = roofline_of(name, st, workload_key(a), world, copy_sites, a.steps / m["event_stride"])
+        # (every event_stride-th launch of the class inside the timed region carried an event pair: `launches` of them)
+        roof["event_stride"] = m["event_stride"]
         roof["measured_triad_GBs"] = triad_gbs
         roof["frac_of_measured_triad"] = roof["achieved"] / triad_gbs
         b_alg = vcycle_alg_bytes_per_finest_cell(cells_global)

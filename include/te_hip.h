@@ -321,6 +321,11 @@ int te_gmg_profile_reset(te_gmg *g);
  * A HIP event pair around a launch costs a few microseconds of stream time, which matters for a V-cycle of
  * a dozen launches: bench.py times only the dominant class inside its timed region. */
 int te_gmg_profile_select(te_gmg *g, const char *name);
+/* ... and only every `stride`-th launch of a timed class carries its event pair (stride <= 1: every launch). On this runtime an
+ * event pair on a dispatch costs microseconds of stream time (profiles/r06_event_cost.txt: 24-28 us of a 210-us 4096^2 cycle with six
+ * timed launches per cycle, 0-20 us of a 512^3 cycle with one): bench.py times every fourth launch of the dominant class inside its timed region; calls / cells / total_ms of
+ * te_gmg_profile_rows count the timed launches only, so averages stay what they were. */
+int te_gmg_profile_stride(te_gmg *g, int stride);
 
 /* Where te_gmg_create spent its time -- the "GMG Setup" timer of apps/3d/steady.cpp:480-484 around GMG/CycleFactory3d.cpp:69-134,
  * broken down (milliseconds, host clock): out[0] device selection, context, streams, events (the first solver of a process also pays

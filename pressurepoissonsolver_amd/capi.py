@@ -130,6 +130,7 @@ SYMBOLS = {
     "te_gmg_profile_rows": (_I, [_P, _I, _P, _P, _P, _P]),
     "te_gmg_profile_reset": (_I, [_P]),
     "te_gmg_profile_select": (_I, [_P, C.c_char_p]),
+    "te_gmg_profile_stride": (_I, [_P, _I]),
     "te_init_problem": (_I, [_P, _I, _I, _I, _P, _P]),
     "te_integrate": (_I, [_P, _I, _P, _P]),
     "te_volume": (_I, [_P, _I, _P]),
@@ -519,6 +520,7 @@ class GMG:
     def profile(self, enable=True): check(lib().te_gmg_profile(self.h, int(enable)))
     def profile_reset(self): check(lib().te_gmg_profile_reset(self.h))
     def profile_select(self, name=None): check(lib().te_gmg_profile_select(self.h, (name or "").encode()))
+    def profile_stride(self, stride=1): check(lib().te_gmg_profile_stride(self.h, int(stride)))
 
     def profile_rows(self):
         names = (C.c_char * 64 * 64)()

@@ -1062,6 +1062,17 @@ int te_gmg_profile_select(te_gmg *g, const char *name)
 	});
 }
 
+int te_gmg_profile_stride(te_gmg *g, int stride)
+{
+	return guarded([&]() -> int {
+		if (!g) return te::fail(TE_EINVAL, "te_gmg_profile_stride: null");
+		drainEvents(g);
+		g->prof_stride = stride > 1 ? stride : 1;
+		memset(g->prof_seq, 0, sizeof(g->prof_seq));
+		return TE_OK;
+	});
+}
+
 int te_gmg_profile_reset(te_gmg *g)
 {
 	return guarded([&]() -> int {

@@ -476,6 +476,8 @@ struct te_gmg {
 	// profiling
 	bool                   profiling = false;
 	int                    prof_only = -1; // >= 0: only this kernel class is timed
+	int                    prof_stride = 1; // > 1: only every prof_stride-th launch of a timed class carries events (te_gmg_profile_stride)
+	uint32_t               prof_seq[KC_COUNT] = {}; // launches of each class seen since the stride was set
 	std::vector<EventPair> ev_pool;
 	size_t                 ev_used = 0;
 	int64_t                calls[KC_COUNT];
@@ -495,6 +497,7 @@ struct Timed {
 	Timed(te_gmg *g_, int kc, size_t ncells = 0, bool ext_ = false) : g(g_), ext(ext_)
 	{
 		if (!g->profiling || (g->prof_only >= 0 && g->prof_only != kc)) return;
+		if (g->prof_stride > 1 && (g->prof_seq[kc]++ % (uint32_t) g->prof_stride) != 0) return;
 		g->cells[kc] += (int64_t) ncells;
 		if (g->ev_used == g->ev_pool.size()) {
 			EventPair e;
