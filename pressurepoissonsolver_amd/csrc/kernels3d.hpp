@@ -212,9 +212,18 @@ struct Reg6 {
 	}
 	__device__ __forceinline__ int32_t operator[](int i) const
 	{
-		int32_t r = v[0];
+		// (each candidate passes through an empty asm first: over plain array elements the compiler turns the chain of selects back into
+		// ONE load at a selected address -- from a copy of the array in scratch memory, 52 bytes per lane and a dependent round trip of
+		// its own; tests/test_isa_waits.py checks that no slab kernel touches scratch)
+		int32_t c[6];
 #pragma unroll
-		for (int s = 1; s < 6; s++) r = (i == s) ? v[s] : r;
+		for (int s = 0; s < 6; s++) {
+			c[s] = v[s];
+			asm volatile("" : "+v"(c[s]));
+		}
+		int32_t r = c[0];
+#pragma unroll
+		for (int s = 1; s < 6; s++) r = (i == s) ? c[s] : r;
 		return r;
 	}
 };

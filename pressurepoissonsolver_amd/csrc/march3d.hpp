@@ -130,7 +130,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_stencil3d(LevelDev L, const d
 	constexpr int ZL   = N / ZS; // planes per slab
 	TE_STAMP_DECL;
 	TE_STAMP(0, false);
-	if (ZS > 1) argsUpFront(L, u, f, out, rd.parent, rd.orth, rd.coarse);
+	if (ZS > 1) argsUpFront(L, u, f, out, rd.parent, rd.orth, MODE == MODE_RESID_RESTRICT ? (const void *) rd.remote_off : (const void *) rd.coarse);
 	const int nblocks  = L.count * ZS;
 	const int work     = xcdRemap(blockIdx.x, nblocks);
 	if (work >= nblocks) return;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 	static_assert(ZL % 2 == 0 && ZL >= 2, "slabs start on even planes");
 	TE_STAMP_DECL;
 	TE_STAMP(0, false);
-	if (ZS > 1) argsUpFront(L, u, f, out, ps.parent, ps.orth, ps.coarse);
+	if (ZS > 1) argsUpFront(L, u, f, out, PROLONG ? (const void *) ps.cbase : (const void *) ps.parent, ps.orth, ps.coarse);
 	const int     nwork = L.count * ZS;
 	const int     work  = xcdRemap(blockIdx.x, nwork);
 	if (work >= nwork) return;
@@ -734,7 +734,10 @@ __global__ __launch_bounds__(Tile3<N>::TPB) void k_rbgs3d(LevelDev L, const doub
 			un[k]     = up2[(zs + 1) * NP + q[k]];
 			if (PROLONG && !CFP) {
 				const double c0 = cown[NN * (zs >> 1) + cq], c1 = cown[NN * ((zs + 1) >> 1) + cq];
-				const double cb = (zs > 0) ? cown[NN * ((zs - 1) >> 1) + cq] : sbot * cbot[cq];
+				// (one load from a selected address, not a load under a branch: the compiler waits for EVERYTHING in flight where such a
+				// branch rejoins -- a whole memory latency in the middle of the prologue's requests; 1.0 * x is x)
+				const double *cbp = (zs > 0) ? cown + NN * ((zs - 1) >> 1) : cbot;
+				const double  cb  = ((zs > 0) ? 1.0 : sbot) * cbp[cq];
 				uc[k].x += c0, uc[k].y += c0, un[k].x += c1, un[k].y += c1;
 				um[k].x += sm * cb, um[k].y += sm * cb;
 			}

@@ -154,3 +154,54 @@ def test_patch_solve_planes_are_not_consumed_right_behind_their_request(ps_isa, 
                 k += 1
         i = j
     assert bursts >= 4  # (the prologue's two planes, the two re-requests of phase A, the reciprocal tables, the prefetches)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The z-slab kernels of the small levels (round 6, profiles/r06_tail_stamps.txt): a launch there is ONE dependent chain per workgroup,
+# and what the stamps found in front of the first plane request was five to ten round trips -- kernel arguments fetched by scalar loads
+# in four or five batches (behind the early exit, behind the `order` branch, ...), face tables entry by entry under the face-kind tests,
+# a load under a branch in the middle of the prologue's data requests. Kept out by: argsUpFront (one batch), Reg6 (tables once, in
+# registers), ProlongSrc::cbase, addresses selected instead of loads branched around. The ISA shows whether they are still out.
+SLAB_SRC = os.path.join(ROOT, "pressurepoissonsolver_amd", "csrc", "gmg_launch3d.hip")
+SLABS = [  # mangled-name fragment, most `s_waitcnt vmcnt(0)` allowed before the first barrier (the `order` entry + the tables; None: not counted)
+    ("k_rbgs3dILi32ELb1ELb0ELi8E", 2, "sweep from zero"),
+    ("k_rbgs3dILi32ELb0ELb1ELi8E", 2, "sweep on u + P e"),
+    ("k_rbgs3dILi32ELb0ELb0ELi8E", 2, "plain sweep"),
+    ("k_stencil3dILi32ELi3ELi8ELi0E", None, "residual + restriction (the blocks of a parent on another rank are fetched under a branch of their own)"),
+    ("k_stencil3dILi32ELi1ELi8ELi0E", 2, "residual"),
+]
+
+
+@pytest.fixture(scope="module")
+def slab_isa(tmp_path_factory):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    out = tmp_path_factory.mktemp("isa_slab") / "l3d.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-x", "hip", SLAB_SRC, "-o", str(out)],
+                   check=True, capture_output=True, timeout=900)
+    lines = out.read_text().split("\n")
+    bodies = {}
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN2te\d*k_(?:rbgs3d|stencil3d)\w+):", l)
+        if m:
+            end = next(e for e in range(i, len(lines)) if lines[e].startswith(".Lfunc_end"))
+            bodies[m.group(1)] = [x for x in lines[i:end] if not x.lstrip().startswith(";")]
+    return bodies
+
+
+@pytest.mark.parametrize("frag,max_drains,what", SLABS, ids=[s[2].split(" (")[0] for s in SLABS])
+def test_slab_kernels_fetch_arguments_once_and_tables_once(slab_isa, frag, max_drains, what):
+    name = next((n for n in slab_isa if frag in n), None)
+    assert name is not None, f"kernel {frag} is not instantiated any more"
+    body = slab_isa[name]
+    first_branch = next(i for i, l in enumerate(body) if re.search(r"\bs_c?branch", l))
+    first_barrier = next(i for i, l in enumerate(body) if "s_barrier" in l)
+    # kernel arguments come through s[0:1] (the kernarg segment pointer): every scalar load from it sits in front of the first branch
+    late = [l.strip() for l in body[first_branch:] if re.search(r"s_load_dword\w*\s+s\S+,\s*s\[0:1\]", l)]
+    assert not late, (what, "kernel arguments fetched behind a branch", late[:4])
+    assert sum(bool(re.search(r"s_load_dword\w*\s+s\S+,\s*s\[0:1\]", l)) for l in body[:first_branch]) >= 4
+    if max_drains is not None:
+        drains = sum("vmcnt(0)" in l for l in body[:first_barrier])
+        assert drains <= max_drains, (what, f"{drains} full drains of the memory pipeline before the first plane step")
+    assert not any("scratch_" in l for l in body), "register spills"
