@@ -20,10 +20,10 @@ echo "c4 counters done"
 bash tools/profile_round.sh ${T}f_2dps $C --dim 2 --size 4096 --patch 64 --smoother patch_solve > ${W}_2dps_profile.log 2>&1 || { tail -5 ${W}_2dps_profile.log; exit 1; }
 echo "2d patch_solve counters done"
 cp profiles/traffic.json ${W}_traffic.json
-python3 tools/mr8_budget.py --size 512 --smoother rbgs --out ${W}_mr8_budget_rccl.txt > /dev/null 2> ${W}_mr8.err && echo "mr8 rccl ok"
-python3 tools/mr8_budget.py --size 512 --smoother rbgs --push --ranks 2,4,8 --out ${W}_mr8_budget_push.txt > /dev/null 2>> ${W}_mr8.err && echo "mr8 push ok"
-python3 tools/mr8_budget.py --size 512 --smoother patch_solve --ranks 1,8 --out ${W}_mr8_budget_ps.txt > /dev/null 2>> ${W}_mr8.err && echo "mr8 ps ok"
-python3 tools/mr8_budget.py --dim 2 --size 4096 --ranks 1,8 --out ${W}_mr8_budget_2d.txt > /dev/null 2>> ${W}_mr8.err && echo "mr8 2d ok"
+python3 tools/mr8_budget.py --size 512 --smoother rbgs --agg 64 --out ${W}_mr8_budget_rccl.txt > /dev/null 2> ${W}_mr8.err && echo "mr8 rccl ok"
+python3 tools/mr8_budget.py --size 512 --smoother rbgs --agg 64 --push --ranks 2,4,8 --out ${W}_mr8_budget_push.txt > /dev/null 2>> ${W}_mr8.err && echo "mr8 push ok"
+python3 tools/mr8_budget.py --size 512 --smoother patch_solve --agg 64 --ranks 1,8 --out ${W}_mr8_budget_ps.txt > /dev/null 2>> ${W}_mr8.err && echo "mr8 ps ok"
+python3 tools/mr8_budget.py --dim 2 --size 4096 --agg 64 --ranks 1,8 --out ${W}_mr8_budget_2d.txt > /dev/null 2>> ${W}_mr8.err && echo "mr8 2d ok"
 python3 bench.py --steps 10 --warmup 3 --size 1024 --no-cpu-baseline > ${W}_bench_1024.json 2>> ${W}_bench_512.err && echo "1024 ok"
 TE_BENCH_BACKEND=gloo timeout -k 10 600 python3 bench.py --gpus 4 --size 512 > ${W}_rehearsal_512_n4.json 2> ${W}_rehearsal.err && echo "rehearsal 512 ok"
 TE_BENCH_BACKEND=gloo timeout -k 10 600 python3 bench.py --gpus 4 --size 1024 --no-cpu-baseline > ${W}_rehearsal_1024_n4.json 2>> ${W}_rehearsal.err && echo "rehearsal 1024 ok"
