@@ -133,3 +133,35 @@ def test_host_mesh_code_is_clean_under_sanitizers():
         r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
         assert r.returncode == 0 and "SANITIZE_OK" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_setup_breakdown_and_event_stride():
+    """te_gmg_setup_ms: the parts of te_gmg_create add up to its total, and a second solver in the same process costs a small
+    fraction of the first (whose context part carries the HIP runtime's start and the code-object load);
+    te_gmg_profile_stride: only every n-th launch of a class is timed and counted, the averages stay what they are"""
+    H = capi.Hierarchy(util.mesh("uniform", 3), 8)
+    g1 = capi.GMG(H)
+    g2 = capi.GMG(H)
+    for g in (g1, g2):
+        p = g.setup_ms()
+        assert p["device_allocation_count"] > 20 and p["total"] > 0
+        parts = sum(p[k] for k in ("context_streams", "host_tables", "device_allocations", "table_uploads", "work_vectors", "final_sync"))
+        assert abs(parts - p["total"]) <= 0.05 * p["total"] + 0.05
+    assert g2.setup_ms()["total"] < 100.0  # (milliseconds: nothing of a process's first HIP call is in a second create)
+    f, u = g2.new_vector(0, util.rand_vec(H.cells(0), 3)), g2.new_vector(0)
+    o = g2.default_opts(smoother=capi.SMOOTH_RBGS)
+    rows = {}
+    for stride in (1, 4):
+        g2.profile(True)
+        g2.profile_stride(stride)
+        g2.profile_reset()
+        for _ in range(8):
+            g2.cycle(o, f, u)
+        rows[stride] = g2.profile_rows()
+        g2.profile(False)
+    g2.profile_stride(1)
+    for k, v in rows[1].items():
+        assert v["calls"] % 8 == 0
+        assert rows[4][k]["calls"] == v["calls"] // 4, (k, v["calls"], rows[4][k]["calls"])
+        assert rows[4][k]["cells"] * v["calls"] == v["cells"] * rows[4][k]["calls"] or len({rows[4][k]["cells"] // rows[4][k]["calls"], v["cells"] // v["calls"]}) <= 2
