@@ -22,7 +22,13 @@ int zeroSweepResidN(te_gmg *g, LevelHost &L, const double *f, double *out, doubl
 	// (round 6: on refined levels too -- the kernel's export does not look at what a patch is, a same-level neighbour's finished sums
 	// are what the gather needs behind every FACE_LOCAL face, and they are a quarter of the face layers it read instead:
 	// 141 -> 107 (descriptors) -> ... us per launch on `2refine --divide 3`; TE_NO_RS6_CF: as before)
-	const bool export_rs6 = fcorr_out && L.rs6.p && (L.prolong_fusable || !g->cfg.has(O_NO_RS6_CF));
+	// ... and (round 6, last) also when a fix-up pass follows instead of the gather (the coarser level is not a fused one): it reads the
+	// finished sums of same-level neighbours instead of their face layers (TE_NO_RS6_FIXUP: the layers, as before). Not on a level that
+	// itself reads exported terms (fcorr_in): the kernel variant that does both is slower by more than the fix-up gains (measured at
+	// 512^3, level 1: +3.5 us per cycle; 256^3, level 0, without fcorr_in: -2.3 us)
+	const bool export_rs6 = L.rs6.p && !store_u
+	                        && (fcorr_out ? (L.prolong_fusable || !g->cfg.has(O_NO_RS6_CF))
+	                                      : (L.Pc > 0 || L.n_up > 0) && !fcorr_in && !g->cfg.has(O_NO_RS6_FIXUP));
 	rd.rs6                = export_rs6 ? L.rs6.p : nullptr;
 	int rc;
 	if (L.P > 0) {

@@ -1597,11 +1597,15 @@ __global__ __launch_bounds__(256) void k_restrict_fixup3d(LevelDev L, const doub
 			const int    sa = (ax == 0) ? N : 1, sb = (ax == 2) ? N : NN, sn = (ax == 0) ? 1 : (ax == 1 ? N : NN);
 			const int    oth = (s & 1) ? 0 : (N - 1) * sn;             // the neighbour's facing layer
 			const double w   = -L.rh2[(size_t) p * 3 + ax];
+			// (round 6) the neighbour's FINISHED sum where the pre-sweep exported it (rd.rs6: the same products added in the same order
+			// by the patch that owns the values, k_rbgs_zero_resid3d EXPORT): a quarter of the bytes of the face layer
+			const double *fin = (!OWN && rd.rs6 && kind == FACE_LOCAL) ? rd.rs6 + ((size_t) src * 6 + (s ^ 1)) * (H * H) : nullptr;
 			for (int i = threadIdx.x; i < H * H; i += blockDim.x) {
 				const int ha = i % H, hb = i / H;
 				double    acc = 0.0;
+				if (fin) acc = fin[i];
 #pragma unroll
-				for (int db = 0; db < 2; db++)
+				for (int db = 0; db < 2 && !fin; db++)
 #pragma unroll
 					for (int da = 0; da < 2; da++) {
 						const int a = 2 * ha + da, b = 2 * hb + db;

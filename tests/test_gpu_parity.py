@@ -168,20 +168,21 @@ def test_exported_ghost_terms_gather_variants_bit_identical(mesh, n, div, neuman
     g = capi.GMG(H)
     f = util.rand_vec(H.cells(0), 77) / levels[0].a["h"].min() ** 2
     got = {}
-    for name, opt in (("v2", None), ("v1", "TE_NO_GTAB2"), ("walk", "TE_NO_GTAB"), ("layers", "TE_NO_RS6_CF"), ("fixup", "TE_NO_FCORR")):
-        if opt:
-            g.set_option(opt, "1")
+    for name, opt in (("v2", None), ("v1", "TE_NO_GTAB2"), ("walk", "TE_NO_GTAB"), ("layers", "TE_NO_RS6_CF"), ("fixup", "TE_NO_FCORR"),
+                      ("fixup-layers", "TE_NO_FCORR,TE_NO_RS6_FIXUP")):  # (the fix-up pass from exported sums / from the face layers)
+        for o1 in (opt.split(",") if opt else ()):
+            g.set_option(o1, "1")
         df, du = g.new_vector(0, f), g.new_vector(0)
         g.profile(True)
         g.profile_reset()
         g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
         rows = g.profile_rows()
         g.profile(False)
-        if opt:
-            g.set_option(opt, None)
-        assert ("fcorr_gather" in rows) == (name != "fixup"), (name, sorted(rows))
+        for o1 in (opt.split(",") if opt else ()):
+            g.set_option(o1, None)
+        assert ("fcorr_gather" in rows) == (not name.startswith("fixup")), (name, sorted(rows))
         got[name] = du.download()
-    for name in ("v1", "walk", "layers", "fixup"):
+    for name in ("v1", "walk", "layers", "fixup", "fixup-layers"):
         assert np.array_equal(got["v2"], got[name]), name
 
 
