@@ -13,7 +13,7 @@ const char *kclassName[KC_COUNT] = {"stencil_apply", "stencil_resid", "stencil_j
 const char *optName[O_COUNT] = {"TE_2D_SIMPLE", "TE_2D_NO_MFMA", "TE_2D_NO_PF", "TE_2D_NO_MR_FUSE", "TE_2D_TPB", "TE_NO_FUSE2", "TE_NO_FUSE3",
                                 "TE_NO_FUSE3_CF", "TE_NO_CFP", "TE_NO_XF", "TE_NO_FCORR", "TE_NO_FCORR_CF", "TE_NO_GTAB", "TE_NO_OVERLAP",
                                 "TE_OVERLAP_MIN", "TE_NO_PS_FACES", "TE_PS_MODE", "TE_PS_SLOW", "TE_RBGS_NOSLAB", "TE_ZS_FORCE", "TE_NO_ZS8",
-                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS", "TE_PACK_FACES", "TE_OVERLAP_MODE", "TE_PUSH_TIMEOUT", "TE_NO_BICG_XF", "TE_PUSH_FAULT", "TE_2D_NO_FOLD", "TE_2D_NO_SYM", "TE_PUSH_NONFATAL", "TE_PS_NO_HALF", "TE_PS_HALF_MAX", "TE_NO_GTAB2", "TE_NO_RS6_CF", "TE_NO_RS6_FIXUP"};
+                                "TE_RESWEEP_V", "TE_EXCHANGE_TIMEOUT", "TE_NO_VERIFY", "TE_RCCL_LOOPBACK", "TE_ZR_AHEAD", "TE_NO_BICG_FUSE", "TE_POST_EXCHANGE", "TE_REPL_BLOCKS", "TE_PACK_FACES", "TE_OVERLAP_MODE", "TE_PUSH_TIMEOUT", "TE_NO_BICG_XF", "TE_PUSH_FAULT", "TE_2D_NO_FOLD", "TE_2D_NO_SYM", "TE_PUSH_NONFATAL", "TE_PS_NO_HALF", "TE_PS_HALF_MAX", "TE_NO_GTAB2", "TE_NO_RS6_CF", "TE_NO_RS6_FIXUP", "TE_NO_CFP59"};
 
 void drainEvents(te_gmg *g)
 {

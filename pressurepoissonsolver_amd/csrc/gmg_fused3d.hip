@@ -150,6 +150,8 @@ int resweepProlongN(te_gmg *g, LevelHost &L, const double *f, double *out, const
 			if (L.ncf > 0 || L.has_copy) { // refined level: copy-through patches / coarse-fine ghost slots
 				if (v == 3)
 					launchT(t, (k_rbgs_resweep_prolong3d<N, 3, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
+				else if (v == 59 && !g->cfg.has(O_NO_CFP59))
+					launchT(t, (k_rbgs_resweep_prolong3d<N, 59, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
 				else
 					launchT(t, (k_rbgs_resweep_prolong3d<N, 27, false, true>), grid, blk, 0, g->stream, D, f, out, ps);
 			} else if (fcorr_in) {

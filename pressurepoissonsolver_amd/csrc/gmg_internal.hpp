@@ -82,7 +82,7 @@ extern const char *kclassName[KC_COUNT]; // (gmg_core.hip)
 enum Opt : int {
 	O_2D_SIMPLE, O_2D_NO_MFMA, O_2D_NO_PF, O_2D_NO_MR_FUSE, O_2D_TPB, O_NO_FUSE2, O_NO_FUSE3, O_NO_FUSE3_CF, O_NO_CFP, O_NO_XF,
 	O_NO_FCORR, O_NO_FCORR_CF, O_NO_GTAB, O_NO_OVERLAP, O_OVERLAP_MIN, O_NO_PS_FACES, O_PS_MODE, O_PS_SLOW, O_RBGS_NOSLAB,
-	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_PUSH_TIMEOUT, O_NO_BICG_XF, O_PUSH_FAULT, O_2D_NO_FOLD, O_2D_NO_SYM, O_PUSH_NONFATAL, O_PS_NO_HALF, O_PS_HALF_MAX, O_NO_GTAB2, O_NO_RS6_CF, O_NO_RS6_FIXUP, O_COUNT
+	O_ZS_FORCE, O_NO_ZS8, O_RESWEEP_V, O_EXCHANGE_TIMEOUT, O_NO_VERIFY, O_RCCL_LOOPBACK, O_ZR_AHEAD, O_NO_BICG_FUSE, O_POST_EXCHANGE, O_REPL_BLOCKS, O_PACK_FACES, O_OVERLAP_MODE, O_PUSH_TIMEOUT, O_NO_BICG_XF, O_PUSH_FAULT, O_2D_NO_FOLD, O_2D_NO_SYM, O_PUSH_NONFATAL, O_PS_NO_HALF, O_PS_HALF_MAX, O_NO_GTAB2, O_NO_RS6_CF, O_NO_RS6_FIXUP, O_NO_CFP59, O_COUNT
 };
 extern const char *optName[O_COUNT]; // (gmg_core.hip)
 // options that shape the level tables te_gmg_create builds: fixed for the solver's lifetime

@@ -15,6 +15,9 @@
 #include "kernels3d.hpp"
 #include <type_traits>
 
+#ifndef TE_ZR_WIDE
+#define TE_ZR_WIDE 1 // (0: tooling -- every variant of the fused pre-sweep at three workgroups per CU, as before round 6's end)
+#endif
 #ifndef TE_ZR_NT
 #define TE_ZR_NT 0 // (non-temporal loads of f in the pre-sweep cost more in the post-sweep, which finds less of f in the Infinity Cache)
 #endif
@@ -1242,7 +1245,7 @@ template <int FS> __device__ __forceinline__ double2 fsrcCombine(const FSrc &fs,
 	return double2{__builtin_fma(fs.s2, tx, c.x), __builtin_fma(fs.s2, ty, c.y)};
 }
 template <int N, bool STORE_U, bool EXPORT = false, bool FCORR = false, int AH = 4, int FS = 0>
-__global__ __launch_bounds__(Tile3<N>::TPB, 3) void k_rbgs_zero_resid3d(LevelDev L, const double *__restrict__ f,
+__global__ __launch_bounds__(Tile3<N>::TPB, (TE_ZR_WIDE && EXPORT && (FS == 2 || FCORR)) ? 2 : 3) void k_rbgs_zero_resid3d(LevelDev L, const double *__restrict__ f,
                                                                      double *__restrict__ out, RestrictDst rd, FSrc fs = FSrc())
 {
 	static_assert(FS == 0 || (!FCORR && !STORE_U && AH >= 2), "the fused right-hand sides exist for the level-0 path of te_bicgstab");

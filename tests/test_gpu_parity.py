@@ -488,6 +488,32 @@ def test_post_sweep_tuning_variants_bit_identical():
             assert np.array_equal(x, ref), k
 
 
+def test_refined_post_sweep_variants_bit_identical():
+    """the recomputing post-sweep of a REFINED level (copy-through patches, coarse/fine ghost slots: k_rbgs_resweep_prolong3d<..., CFP>) in
+    its three-workgroups-per-CU form (TE_RESWEEP_V=27; it spills nine registers) and in the two-workgroup form a large finest level
+    takes since round 6 (59: no spill; 1107 -> 1072 us per launch on `2refine --divide 3`; TE_NO_CFP59 = the former choice): same bits"""
+    m, H, levels = util.setup("2refine.bin", 32, 2)
+    g = capi.GMG(H)
+    f = util.rand_vec(levels[0].size, 89) / levels[0].a["h"].min() ** 2
+    got = {}
+    for name, opts in (("default", {}), ("v59", {"TE_RESWEEP_V": "59"}), ("v27", {"TE_RESWEEP_V": "27"}), ("no59", {"TE_RESWEEP_V": "59", "TE_NO_CFP59": "1"})):
+        for k, v in opts.items():
+            g.set_option(k, v)
+        df, du = g.new_vector(0, f), g.new_vector(0)
+        g.profile(True)
+        g.profile_reset()
+        g.cycle(g.default_opts(smoother=capi.SMOOTH_RBGS), df, du)
+        rows = g.profile_rows()
+        g.profile(False)
+        for k in opts:
+            g.set_option(k, None)
+        assert "rbgs_resweep_prolong" in rows, sorted(rows)
+        got[name] = du.download()
+    for name in ("v59", "v27", "no59"):
+        assert np.array_equal(got["default"], got[name]), name
+    assert np.linalg.norm(got["default"] - orc.cycle(levels, orc.cycle_opts(smoother=capi.SMOOTH_RBGS), f)) <= 1e-10 * np.linalg.norm(got["default"])
+
+
 @pytest.mark.parametrize("div,neumann", [(2, False), (3, False), (2, True)])
 def test_fused_block_jacobi_cycle_2d(div, neumann):
     """The reference smoother's V-cycle on uniform 2D levels of 64^2 patches (config C5's shape): fuse = 1 adds the prolongation

@@ -81,6 +81,25 @@ def test_march_never_waits_for_its_newest_loads(isa, frag, floor, why):
     assert not any("scratch_" in l for l in body[s:e + 1]), "register spills inside the march"
 
 
+NO_SPILL = [  # every instantiation a default-option cycle or te_bicgstab launches on 32^3 patches (round 6: two of them spilled --
+    # the pre-sweep that forms te_bicgstab's pending p and exports ghost terms, and the one that reads AND exports them -- with their
+    # reloads inside the march, in the in-order queue of the planes in flight; they run two workgroups per CU now)
+    "k_rbgs_zero_resid3dILi32ELb0ELb1ELb0ELi4ELi0E", "k_rbgs_zero_resid3dILi32ELb0ELb1ELb0ELi4ELi1E", "k_rbgs_zero_resid3dILi32ELb0ELb1ELb0ELi4ELi2E",
+    "k_rbgs_zero_resid3dILi32ELb0ELb0ELb0ELi4ELi0E", "k_rbgs_zero_resid3dILi32ELb0ELb0ELb0ELi4ELi1E", "k_rbgs_zero_resid3dILi32ELb0ELb0ELb0ELi4ELi2E",
+    "k_rbgs_zero_resid3dILi32ELb0ELb0ELb1ELi4ELi0E", "k_rbgs_zero_resid3dILi32ELb0ELb1ELb1ELi4ELi0E", "k_rbgs_zero_resid3dILi32ELb1ELb0ELb0ELi4ELi0E",
+    "k_rbgs_resweep_prolong3dILi32ELi59ELb0ELb0E", "k_rbgs_resweep_prolong3dILi32ELi59ELb0ELb1E", "k_rbgs_resweep_prolong3dILi32ELi19ELb0ELb0E",
+    "k_rbgs_resweep_prolong3dILi32ELi27ELb0ELb0E", "k_rbgs_resweep_prolong3dILi32ELi3ELb1ELb0E",
+]
+
+
+@pytest.mark.parametrize("frag", NO_SPILL, ids=[f[7:48] for f in NO_SPILL])
+def test_default_path_kernels_do_not_spill(isa, frag):
+    name = next((n for n in isa if frag in n), None)
+    assert name is not None, f"kernel {frag} is not instantiated any more"
+    spills = [l.strip() for l in isa[name] if "scratch_" in l]
+    assert not spills, (frag, len(spills), spills[:3])
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # k_ps_sym (the reference smoother's patch solve): a plane is consumed a plane's worth of matrix instructions behind its request.
 # Round 5 found the instruction scheduler hoisting the first instructions of a plane's y transform -- butterflies that depend on
